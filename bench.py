@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — forward-PBR hot path on MI355X (BASELINE.json metric: Mpixels/s forward-PBR @4K, 64 lights).
+
+A "step" is one pass of BASELINE config 3 over one synthetic frame tile that is already resident in HBM:
+    forward lighting (64 point lights + IBL sample)  -> RGBA16F scene colour   [vqhip_forward_lighting]
+    21-tap Gaussian blur X, Y                        -> RGBA16F                 [vqhip_gaussian_blur_x/_y]
+    tonemap (Reinhard + sRGB OETF)                   -> RGBA8_UNORM             [vqhip_tonemap]
+N = 1: one 3840x2160 frame. N > 1 (weak scaling): the frame is 3840 x (2160*N), row-tiled one tile per GPU, with
+the RCCL halo exchange before the Y blur and the all-gather composite of the RGBA8 tiles inside the timed region.
+`value` = pixels of the whole frame / max-over-ranks wall time. Prints ONE JSON line on rank 0."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from vqengine_amd import abi, capi, synth, tiling  # noqa: E402
+
+W, TILE_H, N_LIGHTS = 3840, 2160, 64
+HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec); 6290 measured copy ceiling
+VALU_PEAK_TFLOPS = 157.3        # :40
+SHADE_BYTES_PER_PX = 64 + 8     # 4 float4 G-buffer planes in + RGBA16F out
+SHADE_FLOPS_PER_PX = 170 * N_LIGHTS + 160
+
+
+def build_ibl(ctx):
+    """Load-time inputs (outside the timed region): BASELINE config 4 — 2048^2 equirect -> min-filter mips ->
+    diffuse 64^2 (step 0.010) + blur + 7-mip specular 128^2, and the 1024^2 x 2048 BRDF LUT."""
+    eq = torch.from_numpy(synth.equirect(2048, 2048)).cuda()
+    chain, n = ctx.mip_chain(eq)
+    pre = ctx.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_WAVE64)
+    lut = ctx.brdf_lut(1024, 2048, abi.FMT_RG16F)
+    torch.cuda.synchronize()
+    return pre, lut
+
+
+def upload_tile(frame_h, row0, row1):
+    gb = [torch.empty((row1 - row0, W, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
+    for r in range(row0, row1, 240):
+        part = synth.gbuffer_rows(W, frame_h, r, min(r + 240, row1), seed=0x6400)
+        for k in range(4):
+            gb[k][r - row0:r - row0 + part[k].shape[0]].copy_(torch.from_numpy(part[k]))
+    return gb
+
+
+def cpu_baseline(pre, lut, pf, pv, frame_h, target_s=12.0):
+    """The CPU oracle (a scalar C++ port of the HLSL, OpenMP over rows) timed on the host cores on a bounded row
+    band of the SAME workload. Reported baseline only — never the thing measured as `value`."""
+    from tests import oracle_lib as O
+    lib = O.load()
+    cores = lib.vqo_max_threads()
+    env = O.host_envmap(pre["diffuse_blurred"].cpu().numpy(), pre["specular"].cpu().numpy(), 128, pre["spec_mips"], lut.cpu().numpy())
+    keep = (env,)
+
+    def run(rows):
+        gb = synth.gbuffer_rows(W, frame_h, 1000, 1000 + rows, seed=0x6400)
+        t0 = time.perf_counter()
+        sc = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F, env=env)
+        x = O.blur_pass(sc, abi.FMT_RGBA16F, 0)
+        y = O.blur_pass(x, abi.FMT_RGBA16F, 1)
+        O.tonemap(y, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
+        return time.perf_counter() - t0
+    t_probe = run(32)
+    rows = int(max(32, min(TILE_H - 1000, 32 * target_s / max(t_probe, 1e-6))))
+    t = run(rows)
+    del keep
+    return {"value": round(W * rows / t / 1e6, 4), "unit": "Mpix/s", "cores": int(cores), "kind": "port",
+            "sample": f"oracle (C++ port of the HLSL, OpenMP) on a {W}x{rows}-row band of the same frame: shade 64 lights + IBL, blur X/Y, tonemap; {t:.2f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--halo", choices=["p2p", "allgather"], default="p2p")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    ctx = capi.Context(local_rank)
+
+    frame_h = TILE_H * world
+    tl = tiling.RowTiling(W, frame_h, world, rank)
+    pre, lut = build_ibl(ctx)
+    env = capi.make_envmap(pre["diffuse_blurred"], pre["specular"], 128, pre["spec_mips"], lut)
+    pf, extra = synth.per_frame(points=synth.point_lights(N_LIGHTS, seed=0x6400), hdri_offset=0.3)
+    pv = synth.per_view(W, frame_h, max_env_lod=pre["spec_mips"])
+    gb = upload_tile(frame_h, tl.row0, tl.row1)
+
+    F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
+    scene = capi.empty_image(TILE_H, W, F16, ctx.device)
+    xblur = capi.empty_image(TILE_H, W, F16, ctx.device)
+    yblur = capi.empty_image(TILE_H, W, F16, ctx.device)
+    sdr = [capi.empty_image(TILE_H, W, R8, ctx.device) for _ in range(2)]
+    frame = [torch.empty((frame_h, W, 4), dtype=torch.uint8, device=ctx.device) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+    halo_fn = tiling.exchange_halos_p2p if args.halo == "p2p" else tiling.exchange_halos_allgather
+
+    def step(i, ev=None):
+        b = i & 1
+        if world > 1 and pending[b] is not None:      # composite of step i-2 must have drained before sdr[b]/frame[b] are reused
+            pending[b].wait()
+            pending[b] = None
+        if ev:
+            ev[0].record()
+        ctx.forward_lighting(gb, pf, pv, out=scene, out_fmt=F16, extra_point=extra, env=env)
+        if ev:
+            ev[1].record()
+        ctx.gaussian_blur_x(scene, F16, out=xblur)
+        top = bottom = None
+        if world > 1:
+            top, bottom = halo_fn(xblur)
+        ctx.gaussian_blur_y(xblur, F16, out=yblur, halo_top=top, halo_bottom=bottom)
+        if ev:
+            ev[2].record()
+        ctx.tonemap(yblur, F16, R8, out=sdr[b])
+        if ev:
+            ev[3].record()
+        if world > 1:                                  # overlaps the next frame's shading on RCCL's own stream
+            _, pending[b] = tiling.composite(sdr[b], out=frame[b], async_op=True)
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, evs[i])
+    drain()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        px_tile, px_frame = W * TILE_H, W * frame_h
+        t_shade = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) * 1e-3
+        t_blur = float(np.mean([e[1].elapsed_time(e[2]) for e in evs])) * 1e-3
+        t_tm = float(np.mean([e[2].elapsed_time(e[3]) for e in evs])) * 1e-3
+        ach = SHADE_BYTES_PER_PX * px_tile / t_shade / 1e9
+        out = {
+            "metric": "Mpixels/s forward-PBR @4K,64 lights", "value": round(px_frame * args.steps / dt / 1e6, 2), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg3: 3840x2160 float4 G-buffer tile per GPU, 64 point lights + IBL sample -> RGBA16F, "
+                                   "21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8" + ("" if world == 1 else f"; frame 3840x{frame_h} row-tiled, RCCL halo ({args.halo}) + all-gather composite"),
+                       "width": W, "frame_height": frame_h, "lights": N_LIGHTS, "parallelism": f"rows{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_forward_lighting<env,nocasters,RGBA16F>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "bytes_per_px": SHADE_BYTES_PER_PX, "ms": round(t_shade * 1e3, 4),
+                         "note": "64-light shading is VALU-bound by construction (SURVEY.md 8d): see valu"},
+            "valu": {"achieved_tflops_model": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
+                     "frac": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12 / VALU_PEAK_TFLOPS, 4), "flops_per_px_model": SHADE_FLOPS_PER_PX},
+            "stages": {"shade_Mpix_s": round(px_tile / t_shade / 1e6, 1), "shade_ms": round(t_shade * 1e3, 4),
+                       "blur_xy_ms": round(t_blur * 1e3, 4), "blur_xy_GBps": round(px_tile * 32 / t_blur / 1e9, 1),
+                       "tonemap_ms": round(t_tm * 1e3, 4), "tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pre, lut, pf, pv, frame_h)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,331 @@
+/*
+ * vqhip.h — C ABI of the MI355X-native offscreen PBR-shading / IBL / post path.
+ *
+ * This is the drop-in boundary: plain C, pointers + sizes, no torch / HIP types.
+ * Every entry point cites the reference call it replaces (paths relative to the VQEngine tree).
+ *
+ * Conventions
+ *   - every `const void* / void*` image argument is a DEVICE pointer owned by the caller;
+ *   - every `VQ_*` struct pointer is a HOST pointer (the reference fills these on the CPU and
+ *     bump-allocates them into an upload heap: Source/Renderer/Rendering/SceneRendering.cpp:429-467);
+ *   - every call enqueues on `stream` (a hipStream_t passed as void*; NULL = the null stream) and
+ *     returns without synchronising, mirroring "record into a command list";
+ *   - return value: VQHIP_OK (0) or a negative vqhip_status; vqhip_last_error() gives the text.
+ *     (The reference returns void and asserts/logs: e.g. EnvironmentMapRendering.cpp:139, Renderer.cpp:871.)
+ *   - images are dense row-major, `row_pitch_px` pixels between rows where stated, otherwise == width.
+ *
+ * Struct layouts are byte-for-byte those of Shaders/LightingConstantBufferData.h (namespace
+ * VQ_SHADER_DATA); the static asserts below pin the offsets derived in SURVEY.md §8(b).
+ */
+#ifndef VQHIP_H
+#define VQHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__cplusplus)
+#define VQHIP_STATIC_ASSERT(c, m) static_assert(c, m)
+#define VQHIP_ALIGNAS(n) alignas(n)
+#else
+#define VQHIP_STATIC_ASSERT(c, m) _Static_assert(c, m)
+#define VQHIP_ALIGNAS(n) _Alignas(n)
+#endif
+
+#define VQHIP_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------------
+ * status / formats
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum vqhip_status {
+    VQHIP_OK                = 0,
+    VQHIP_ERR_INVALID_ARG   = -1,
+    VQHIP_ERR_HIP           = -2,   /* a HIP runtime call failed; see vqhip_last_error()            */
+    VQHIP_ERR_UNSUPPORTED   = -3,   /* format / parameter combination not implemented              */
+    VQHIP_ERR_NO_DEVICE     = -4    /* no gfx950 device visible — there is NO CPU fallback          */
+} vqhip_status;
+
+/* Storage formats of the reference render targets:
+ *   scene colour / blur / env cubemaps : DXGI_FORMAT_R16G16B16A16_FLOAT  (RenderResources.cpp:40,144-161,221-243;
+ *                                                                          EnvironmentMapRendering.cpp:32-53)
+ *   SDR tonemapper output              : DXGI_FORMAT_R8G8B8A8_UNORM      (RenderResources.cpp:41,245-261)
+ *   BRDF integration LUT               : DXGI_FORMAT_R16G16_FLOAT        (Renderer.cpp:1026-1032)
+ *   HDRI equirect                      : DXGI_FORMAT_R32G32B32A32_FLOAT  (TextureManager.cpp:590-592)
+ * RGBA32F / RG32F variants are offered for every output so parity can also be judged before the
+ * storage rounding. fp32 -> fp16 is round-to-nearest-even, fp32 -> UNORM8 is trunc(sat(x)*255 + 0.5). */
+typedef enum vqhip_format {
+    VQHIP_FMT_RGBA32F     = 0,
+    VQHIP_FMT_RGBA16F     = 1,
+    VQHIP_FMT_RGBA8_UNORM = 2,
+    VQHIP_FMT_RG16F       = 3,
+    VQHIP_FMT_RG32F       = 4
+} vqhip_format;
+
+/* ------------------------------------------------------------------------------------------------
+ * VQ_SHADER_DATA mirror  (Shaders/LightingConstantBufferData.h:39-186, Shaders/VQPlatform.h:21-41)
+ * ---------------------------------------------------------------------------------------------- */
+#define VQ_NUM_LIGHTS__POINT                 100   /* LightingConstantBufferData.h:39 */
+#define VQ_NUM_LIGHTS__SPOT                  20    /* :40 */
+#define VQ_NUM_SHADOWING_LIGHTS__POINT       5     /* :42 */
+#define VQ_NUM_SHADOWING_LIGHTS__SPOT        5     /* :43 */
+#define VQ_NUM_SHADOWING_LIGHTS__DIRECTIONAL 1     /* :44 */
+
+typedef struct VQ_float2 { float x, y; } VQ_float2;
+typedef struct VQ_float3 { float x, y, z; } VQ_float3;
+typedef struct VQ_float4 { float x, y, z, w; } VQ_float4;
+/* DirectX::XMMATRIX: 4 rows of 4 floats, 16-byte aligned, row-major on the CPU. HLSL reads a cbuffer
+ * `matrix` column-major, so HLSL `mul(M, v)` == row-vector v * M_cpu  (SURVEY.md §8b). */
+typedef struct VQ_matrix { VQHIP_ALIGNAS(16) float m[4][4]; } VQ_matrix;
+
+typedef struct VQ_PointLight {          /* LightingConstantBufferData.h:50-61 */
+    VQ_float3 position;    float range;
+    VQ_float3 color;       float brightness;
+    VQ_float3 attenuation; float depthBias;
+} VQ_PointLight;
+
+typedef struct VQ_SpotLight {           /* :63-78 (its "48 bytes" comment is wrong: 64) */
+    VQ_float3 position;    float outerConeAngle;
+    VQ_float3 color;       float brightness;
+    VQ_float3 spotDir;     float depthBias;
+    float innerConeAngle;  float range; float dummy1; float dummy2;
+} VQ_SpotLight;
+
+typedef struct VQ_DirectionalLight {    /* :80-90 */
+    VQ_float3 lightDirection; float brightness;
+    VQ_float3 color;          float depthBias;
+    int32_t shadowing;        int32_t enabled;
+} VQ_DirectionalLight;
+
+typedef struct VQ_SceneLighting {       /* :92-109 */
+    int32_t numPointLights, numSpotLights, numPointCasters, numSpotCasters;
+    VQ_DirectionalLight directional;
+    VQ_matrix     shadowViewDirectional;
+    VQ_PointLight point_lights [VQ_NUM_LIGHTS__POINT];
+    VQ_PointLight point_casters[VQ_NUM_SHADOWING_LIGHTS__POINT];
+    VQ_SpotLight  spot_lights  [VQ_NUM_LIGHTS__SPOT];
+    VQ_SpotLight  spot_casters [VQ_NUM_SHADOWING_LIGHTS__SPOT];
+    VQ_matrix     shadowViews  [VQ_NUM_SHADOWING_LIGHTS__SPOT];
+} VQ_SceneLighting;
+
+typedef struct VQ_PerFrameData {        /* :164-172 ; filled at SceneRendering.cpp:429-450 */
+    VQ_SceneLighting Lights;
+    VQ_float2 f2PointLightShadowMapDimensions;
+    VQ_float2 f2SpotLightShadowMapDimensions;
+    VQ_float2 f2DirectionalLightShadowMapDimensions;
+    float fAmbientLightingFactor;
+    float fHDRIOffsetInRadians;
+} VQ_PerFrameData;
+
+typedef struct VQ_PerViewLightingData { /* :173-186 ; filled at SceneRendering.cpp:452-467 */
+    VQ_matrix matView, matViewToWorld, matProjInverse;
+    VQ_float4 WorldFrustumPlanes[6];
+    VQ_float3 CameraPosition; float MaxEnvMapLODLevels;
+    VQ_float2 ScreenDimensions;
+    int32_t   EnvironmentMapDiffuseOnlyIllumination;
+    float     pad1;
+} VQ_PerViewLightingData;
+
+typedef struct VQ_MaterialData {        /* :126-143 ; Material::GetCBufferData Material.h:120-127 */
+    VQHIP_ALIGNAS(16) VQ_float3 diffuse; float alpha;
+    VQ_float3 emissiveColor;  float emissiveIntensity;
+    VQ_float3 specular;       float normalMapMipBias;
+    VQ_float4 uvScaleOffset;
+    float roughness, metalness, displacement, textureConfig;
+} VQ_MaterialData;
+
+/* Tonemapper.hlsl:98-104 cbuffer == first 16 bytes of FPostProcessParameters::FTonemapper
+ * (Source/Engine/PostProcess/PostProcess.h:84-91). Enums: Source/Renderer/Rendering/HDR.h:78-95. */
+typedef enum VQ_EColorSpace   { VQ_COLOR_SPACE_REC_709 = 0, VQ_COLOR_SPACE_REC_2020 = 1 } VQ_EColorSpace;
+typedef enum VQ_EDisplayCurve { VQ_DISPLAY_CURVE_SRGB = 0, VQ_DISPLAY_CURVE_ST2084 = 1, VQ_DISPLAY_CURVE_LINEAR = 2 } VQ_EDisplayCurve;
+typedef struct VQ_TonemapperParams {
+    int32_t ContentColorSpaceEnum;            /* default REC_709 */
+    int32_t OutputDisplayCurveEnum;           /* default sRGB    */
+    float   DisplayReferenceBrightnessLevel;  /* default 200.0f  */
+    int32_t ToggleGammaCorrection;            /* default 1       */
+} VQ_TonemapperParams;
+
+/* GaussianBlur.hlsl:65-68 cbuffer == FPostProcessParameters::FBlurParams (PostProcess.h:92-96). */
+typedef struct VQ_BlurParams { int32_t iImageSizeX, iImageSizeY; } VQ_BlurParams;
+
+VQHIP_STATIC_ASSERT(sizeof(VQ_PointLight) == 48, "PointLight");
+VQHIP_STATIC_ASSERT(offsetof(VQ_PointLight, range) == 12 && offsetof(VQ_PointLight, color) == 16 &&
+                    offsetof(VQ_PointLight, brightness) == 28 && offsetof(VQ_PointLight, attenuation) == 32 &&
+                    offsetof(VQ_PointLight, depthBias) == 44, "PointLight offsets");
+VQHIP_STATIC_ASSERT(sizeof(VQ_SpotLight) == 64, "SpotLight");
+VQHIP_STATIC_ASSERT(offsetof(VQ_SpotLight, outerConeAngle) == 12 && offsetof(VQ_SpotLight, spotDir) == 32 &&
+                    offsetof(VQ_SpotLight, depthBias) == 44 && offsetof(VQ_SpotLight, innerConeAngle) == 48 &&
+                    offsetof(VQ_SpotLight, range) == 52, "SpotLight offsets");
+VQHIP_STATIC_ASSERT(sizeof(VQ_DirectionalLight) == 40, "DirectionalLight");
+VQHIP_STATIC_ASSERT(offsetof(VQ_DirectionalLight, shadowing) == 32 && offsetof(VQ_DirectionalLight, enabled) == 36, "DirectionalLight offsets");
+VQHIP_STATIC_ASSERT(sizeof(VQ_SceneLighting) == 7088, "SceneLighting");
+VQHIP_STATIC_ASSERT(offsetof(VQ_SceneLighting, directional) == 16 && offsetof(VQ_SceneLighting, shadowViewDirectional) == 64 &&
+                    offsetof(VQ_SceneLighting, point_lights) == 128 && offsetof(VQ_SceneLighting, point_casters) == 4928 &&
+                    offsetof(VQ_SceneLighting, spot_lights) == 5168 && offsetof(VQ_SceneLighting, spot_casters) == 6448 &&
+                    offsetof(VQ_SceneLighting, shadowViews) == 6768, "SceneLighting offsets");
+VQHIP_STATIC_ASSERT(sizeof(VQ_PerFrameData) == 7120, "PerFrameData");
+VQHIP_STATIC_ASSERT(offsetof(VQ_PerFrameData, f2PointLightShadowMapDimensions) == 7088 &&
+                    offsetof(VQ_PerFrameData, f2SpotLightShadowMapDimensions) == 7096 &&
+                    offsetof(VQ_PerFrameData, f2DirectionalLightShadowMapDimensions) == 7104 &&
+                    offsetof(VQ_PerFrameData, fAmbientLightingFactor) == 7112 &&
+                    offsetof(VQ_PerFrameData, fHDRIOffsetInRadians) == 7116, "PerFrameData offsets");
+VQHIP_STATIC_ASSERT(sizeof(VQ_PerViewLightingData) == 320, "PerViewLightingData");
+VQHIP_STATIC_ASSERT(offsetof(VQ_PerViewLightingData, WorldFrustumPlanes) == 192 && offsetof(VQ_PerViewLightingData, CameraPosition) == 288 &&
+                    offsetof(VQ_PerViewLightingData, MaxEnvMapLODLevels) == 300 && offsetof(VQ_PerViewLightingData, ScreenDimensions) == 304 &&
+                    offsetof(VQ_PerViewLightingData, EnvironmentMapDiffuseOnlyIllumination) == 312, "PerViewLightingData offsets");
+VQHIP_STATIC_ASSERT(sizeof(VQ_MaterialData) == 80, "MaterialData");
+VQHIP_STATIC_ASSERT(offsetof(VQ_MaterialData, uvScaleOffset) == 48 && offsetof(VQ_MaterialData, roughness) == 64 &&
+                    offsetof(VQ_MaterialData, textureConfig) == 76, "MaterialData offsets");
+VQHIP_STATIC_ASSERT(sizeof(VQ_TonemapperParams) == 16, "TonemapperParams");
+VQHIP_STATIC_ASSERT(sizeof(VQ_BlurParams) == 8, "BlurParams");
+
+/* ------------------------------------------------------------------------------------------------
+ * resource descriptors (replace the SRV tables bound at SceneRendering.cpp:1687-1717)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Image-based-lighting inputs of ForwardLighting.hlsl:93-95 (t10 texEnvMapDiff, t11 texEnvMapSpec,
+ * t12 texBRDFIntegral). Layouts:
+ *   diffuse_cube  : [6][diffuse_res][diffuse_res] RGBA16F (Tex_IrradianceDiffBlurred, 1 mip; EnvironmentMapRendering.cpp:32-43)
+ *   specular_cube : mip-major, [mip][6][res>>mip][res>>mip] RGBA16F, densely packed, spec_mips levels
+ *                   (Tex_IrradianceSpec; MIPS = CalculateMipLevelCount(res,res) - 1, EnvironmentMapRendering.cpp:55-63)
+ *   brdf_lut      : [lut_size][lut_size] RG16F, u = NdotV along x, v = roughness along y (Renderer.cpp:1026-1032)
+ * Face order +X,-X,+Y,-Y,+Z,-Z (CubemapUtility.h:26-36). */
+typedef struct vqhip_envmap {
+    const void* diffuse_cube;   int32_t diffuse_res;
+    const void* specular_cube;  int32_t spec_res0;  int32_t spec_mips;
+    const void* brdf_lut;       int32_t lut_size;
+} vqhip_envmap;
+
+/* Shadow maps of ForwardLighting.hlsl:97-99 as linear R32F arrays (depth targets are D32; point
+ * casters store distance/far, Lighting.hlsl:161-163):
+ *   directional : [dir_dim][dir_dim]                 (2048 in the reference, SceneRendering.cpp:441)
+ *   spot        : [VQ_NUM_SHADOWING_LIGHTS__SPOT][spot_dim][spot_dim]      (1024, :440)
+ *   point       : [VQ_NUM_SHADOWING_LIGHTS__POINT][6][point_dim][point_dim] (1024, :439)
+ * Any pointer may be NULL when the matching caster count is 0 / directional.shadowing == 0. */
+typedef struct vqhip_shadowmaps {
+    const float* directional;  int32_t dir_dim;
+    const float* spot;         int32_t spot_dim;
+    const float* point;        int32_t point_dim;
+} vqhip_shadowmaps;
+
+/* Linear float4 G-buffer = the state of ForwardLighting.hlsl:PSMain at :284-293.
+ * Four SoA planes of float4, row-major:
+ *   gb0 = (P.xyz world position, ao)        ao = fAmbientLightingFactor*localAO*ssao   (:247,269,281)
+ *   gb1 = (Surface.N.xyz raw (not renormalised), Surface.roughness)                     (:267,272-277)
+ *   gb2 = (Surface.diffuseColor.rgb linear, Surface.metalness)                          (:249,253)
+ *   gb3 = (Surface.emissiveColor.rgb, Surface.emissiveIntensity)                        (:250-251) */
+typedef struct vqhip_gbuffer {
+    const void* gb0; const void* gb1; const void* gb2; const void* gb3;
+    int32_t width, height, row_pitch_px;
+} vqhip_gbuffer;
+
+/* Output of the load-time environment-map prefilter (FEnvironmentMapRenderingResources,
+ * EnvironmentMapRendering.h:30-64): caller-allocated device buffers, same layouts as vqhip_envmap. */
+typedef struct vqhip_envmap_out {
+    void* diffuse_unblurred;    /* Tex_IrradianceDiff        [6][dres][dres] RGBA16F (optional, may be NULL) */
+    void* diffuse_blurred;      /* Tex_IrradianceDiffBlurred [6][dres][dres] RGBA16F                          */
+    void* blur_tmp;             /* Tex_BlurTemp              [dres][dres]    RGBA16F (scratch)                */
+    void* specular;             /* Tex_IrradianceSpec        mip-major RGBA16F                                */
+} vqhip_envmap_out;
+
+typedef struct vqhip_ctx vqhip_ctx;
+
+/* summation order of the convolution integrals (DESIGN.md "Convolution order"):
+ *   SEQUENTIAL : one lane per texel, taps accumulated in the HLSL loop order (CubemapConvolution.hlsl:132-159,183-219)
+ *   WAVE64     : one 64-lane wave per texel; lane l accumulates taps l, l+64, ... in order, then a fixed
+ *                xor-butterfly (32,16,8,4,2,1) combines the 64 partial sums. Default; the oracle implements both. */
+typedef enum vqhip_conv_order { VQHIP_CONV_SEQUENTIAL = 0, VQHIP_CONV_WAVE64 = 1 } vqhip_conv_order;
+
+/* ------------------------------------------------------------------------------------------------
+ * entry points
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Replaces VQRenderer::Initialize device/queue creation (Source/Renderer/Renderer.cpp:204) for this path:
+ * binds the context to HIP device `device_ordinal`. Fails with VQHIP_ERR_NO_DEVICE when no GPU is visible. */
+VQHIP_API int  vqhip_create(int device_ordinal, vqhip_ctx** out_ctx);
+VQHIP_API void vqhip_destroy(vqhip_ctx* ctx);
+VQHIP_API const char* vqhip_last_error(const vqhip_ctx* ctx);   /* ctx may be NULL: process-wide last error */
+VQHIP_API int  vqhip_abi_version(void);                          /* == VQHIP_ABI_VERSION */
+#define VQHIP_ABI_VERSION 1
+
+/* Replaces VQRenderer::RenderSceneColor's lit draw loop (SceneRendering.cpp:1619-1785, hot part :1730-1784)
+ * == ForwardLighting.hlsl:PSMain :289-380 evaluated for every pixel of the G-buffer.
+ *   perFrame / perView : the cbuffers b0 / b1 of ForwardLighting.hlsl:76-77.
+ *   extraPoint[numExtraPoint] : extension — point lights beyond the 100-slot cbuffer array (BASELINE cfg5);
+ *                               accumulated right after point_lights[0..numPointLights) in index order.
+ *   env  : NULL => NullCubemap / NullTex2D path (SceneRendering.cpp:1698-1709): IBL contributes 0.
+ *   sm   : NULL allowed iff numPointCasters == numSpotCasters == 0 and !directional.shadowing.
+ *   out  : float4(I_total, roughness) per pixel (ForwardLighting.hlsl:380), outFmt RGBA16F (reference RT0,
+ *          PipelineStateObjects.cpp:1454) or RGBA32F; out_row_pitch_px pixels per row. */
+VQHIP_API int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream,
+        const vqhip_gbuffer* gbuf,
+        const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+        const VQ_PointLight* extraPoint, int numExtraPoint,
+        const vqhip_envmap* env, const vqhip_shadowmaps* sm,
+        void* out, int out_row_pitch_px, vqhip_format outFmt);
+
+/* Replaces the GaussianBlur.hlsl CSMain_X / CSMain_Y dispatches (EnvironmentMapRendering.cpp:279-373,
+ * SceneRendering.cpp:2582-2638): 21-tap separable Gaussian, clamp-to-edge, alpha := 1.
+ * fmt (RGBA16F = reference, or RGBA32F) applies to in, tmp and out alike; the intermediate is rounded
+ * to `fmt` between the passes exactly like the reference's Tex_BlurTemp / BlurIntermediate. */
+VQHIP_API int vqhip_gaussian_blur(vqhip_ctx* ctx, void* stream, const void* in, void* tmp, void* out,
+        const VQ_BlurParams* params, vqhip_format fmt);
+VQHIP_API int vqhip_gaussian_blur_x(vqhip_ctx* ctx, void* stream, const void* in, void* out,
+        const VQ_BlurParams* params, vqhip_format fmt);
+/* Y pass over a row tile. halo_top = the `halo_rows` rows just above row 0 of `in` (row -halo_rows first),
+ * halo_bottom = the rows just below the tile; NULL => that side is the image border (clamp).
+ * halo_rows must be 0 (both NULL) or >= 10 (= KERNEL_RANGE-1, GaussianBlur.hlsl:54-55). Used by the
+ * row-tiled multi-GPU mode where neighbours exchange X-blurred rows over RCCL. */
+VQHIP_API int vqhip_gaussian_blur_y(vqhip_ctx* ctx, void* stream, const void* in, void* out,
+        const void* halo_top, const void* halo_bottom, int halo_rows,
+        const VQ_BlurParams* params, vqhip_format fmt);
+
+/* Replaces the Tonemapper.hlsl:CSMain dispatch (SceneRendering.cpp:2640-2656).
+ * inFmt RGBA16F|RGBA32F; outFmt RGBA8_UNORM (SDR swapchain path) | RGBA16F (HDR path) | RGBA32F. */
+VQHIP_API int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
+        const VQ_TonemapperParams* params, vqhip_format inFmt, vqhip_format outFmt);
+
+/* Replaces VQRenderer::ComputeBRDFIntegrationLUT (Renderer.cpp:871-909) == CubemapConvolution.hlsl:
+ * CSMain_BRDFIntegration :225-240. Reference values: size 1024, samples 2048, RG16F. */
+VQHIP_API int vqhip_brdf_lut(vqhip_ctx* ctx, void* stream, void* outRG, int size, int samples, vqhip_format fmt);
+
+/* Replaces VQ_DXGI_UTILS::MipImage's 16-byte branch (Source/Renderer/Resources/DXGIUtils.cpp:289-317) as
+ * driven by TextureManager::GenerateMips (TextureManager.cpp:643-738): per-channel MIN of each 2x2 block,
+ * alpha := 1. `mips` = device buffer holding level 0 (w0 x h0 RGBA32F) followed by space for all further
+ * levels, densely packed; levels 1..nMips-1 are written. vqhip_mip_chain_bytes() sizes the buffer and
+ * vqhip_mip_level_count() == Image::CalculateMipLevelCount == floor(log2(max(w,h)))+1. */
+VQHIP_API int    vqhip_mip_level_count(int w, int h);
+VQHIP_API size_t vqhip_mip_chain_bytes(int w0, int h0, int nMips);
+VQHIP_API size_t vqhip_mip_level_offset_bytes(int w0, int h0, int level);
+VQHIP_API int    vqhip_mip_chain_min_rgba32f(vqhip_ctx* ctx, void* stream, void* mips, int w0, int h0, int nMips);
+
+/* Cube-map helpers: number of mips of the specular cube == CalculateMipLevelCount(res,res) - 1
+ * (EnvironmentMapRendering.cpp:63) and byte sizes of the packed RGBA16F cubes. */
+VQHIP_API int    vqhip_specular_mip_count(int spec_res0);
+VQHIP_API size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt);
+
+/* Replaces the diffuse-irradiance draws (EnvironmentMapRendering.cpp:181-277) ==
+ * CubemapConvolution.hlsl:PSMain_DiffuseIrradiance :112-163 over all 6 faces.
+ * equirect_mips = RGBA32F mip chain (layout of vqhip_mip_chain_min_rgba32f); the shader samples mip 3
+ * with a TRILINEAR_WRAP sampler (RootSignatures.cpp:402). step = INTEGRATION_STEP_DIFFUSE_IRRADIANCE
+ * (0.050 / 0.025 / 0.010, PipelineStateObjects.cpp:1298-1306). */
+VQHIP_API int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
+        int diffuseRes, float step, vqhip_conv_order order, void* outCube, vqhip_format fmt);
+
+/* Replaces the specular-prefilter draws (EnvironmentMapRendering.cpp:386-472) ==
+ * CubemapConvolution.hlsl:PSMain_SpecularIrradiance :168-223 for every (mip, face); roughness =
+ * mip/(MIPS-1), TextureDimensionsLOD0 = (w0,h0) of the equirect (:431-435). */
+VQHIP_API int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
+        int specRes0, vqhip_conv_order order, void* outCubeMips, vqhip_format fmt);
+
+/* Replaces VQRenderer::PreFilterEnvironmentMap (EnvironmentMapRendering.cpp:139-486): diffuse
+ * convolution -> per-face blur X,Y -> specular mips, all outputs RGBA16F like the reference. */
+VQHIP_API int vqhip_envmap_prefilter(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
+        int diffuseRes, float diffuseStep, int specRes0, vqhip_conv_order order, const vqhip_envmap_out* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQHIP_H */

@@ -1,0 +1,274 @@
+// vqo_math.h — scalar float32 "lowering table" of the HLSL intrinsics used by the hot path.
+//
+// ORACLE / TEST INFRASTRUCTURE ONLY. Nothing under vqengine_amd/ may include, link or call this.
+// PARITY UNPINNED: the reference (vilbeyli/VQEngine) has no numeric tests, golden images or
+// known-answer vectors for this path and D3D12/WARP/DXC cannot run here, so
+// the exact bits of the reference's intrinsics (DXC's HL->DXIL lowering + WARP's JIT) are not
+// observable. This file fixes ONE legal D3D-precision lowering per intrinsic; the HIP kernels
+// implement the same lowering independently (vqengine_amd/csrc/vq_devmath.h) and must match these
+// bits exactly.
+//
+// Lowering rules (each cites the HLSL construct it stands for):
+//   a + b, a - b, a * b      IEEE-754 binary32, round-to-nearest-even, NO contraction into FMA
+//                            (compile with -ffp-contract=off).
+//   a / b                    a * rcp(b), rcp(b) = correctly rounded 1/b.  (What D3D drivers emit for
+//                            HLSL '/'; within the D3D 1-ULP 'div' allowance per factor.)
+//   sqrt(x)                  correctly rounded.
+//   rsqrt(x)                 rcp(sqrt(x)).
+//   dot(a,b)                 left-to-right FMA chain: fma(az,bz, fma(ay,by, ax*bx)) (DXIL dot2/3/4 are
+//                            opaque intrinsics; GPUs evaluate them as mul + mad chains). mul(vec,matrix)
+//                            and mul(matrix,vec) are dots of the same form.
+//   normalize(v)             v * rsqrt(dot(v,v))          (DXC lowers normalize this way)
+//   length(v)                sqrt(dot(v,v))
+//   lerp(a,b,t)              a + t*(b-a)
+//   reflect(i,n)             i - (2*dot(n,i))*n           written as i - n*(2*dot(n,i)) per component
+//   cross(a,b)               (ay*bz - az*by, az*bx - ax*bz, ax*by - ay*bx), no FMA
+//   saturate(x)              min(max(x,0),1) with NaN -> 0
+//   max/min                  IEEE maxNum/minNum (fmaxf/fminf)
+//   pow(x, 2)                x*x          (DXC HLOperationLower: only the literal exponent 2 becomes a mul
+//                                          outside FXC-compat mode — recalled from DXC sources, unverifiable here)
+//   pow(x, y)                exp2(y * log2(x))   => pow(0,y>0) = 0, pow(neg,y) = NaN
+//   exp2/log2/sin/cos/tan/asin/acos/atan2   the explicit polynomial algorithms below (classic
+//                            Cephes-style single-precision kernels, evaluated with explicit FMA Horner
+//                            steps; accuracy vs libm double is measured in tests/test_oracle_math.py).
+//   (int)x                   truncation toward zero; NaN -> 0; saturating.
+#ifndef VQO_MATH_H
+#define VQO_MATH_H
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace vqo {
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+
+static inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+static inline float    u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+static inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static inline float rcp(float b) { return 1.0f / b; }
+static inline float div_(float a, float b) { return a * rcp(b); }
+static inline float sqrt_(float x) { return __builtin_sqrtf(x); }
+static inline float rsqrt(float x) { return rcp(sqrt_(x)); }
+static inline float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+static inline float min_(float a, float b) { return __builtin_fminf(a, b); }
+static inline float saturate(float x) { return (x > 0.0f) ? ((x < 1.0f) ? x : 1.0f) : 0.0f; }   // NaN -> 0
+static inline float abs_(float x) { return __builtin_fabsf(x); }
+
+static inline f3 add(f3 a, f3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+static inline f3 sub(f3 a, f3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+static inline f3 mul(f3 a, f3 b) { return { a.x * b.x, a.y * b.y, a.z * b.z }; }
+static inline f3 mul(f3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+static inline f3 neg(f3 a) { return { -a.x, -a.y, -a.z }; }
+static inline float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+static inline float dot4(f4 a, f4 b) { return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x))); }
+static inline f3 normalize(f3 v) { return mul(v, rsqrt(dot(v, v))); }
+static inline float length(f3 v) { return sqrt_(dot(v, v)); }
+static inline f3 cross(f3 a, f3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
+static inline float lerp(float a, float b, float t) { return a + t * (b - a); }
+static inline f3 reflect(f3 i, f3 n) { float t = 2.0f * dot(n, i); return { i.x - n.x * t, i.y - n.y * t, i.z - n.z * t }; }
+
+// float -> int, truncation toward zero, NaN -> 0, saturating (HLSL (int)x; also used for texel addressing)
+static inline int f2i_trunc(float x) {
+    if (!(x == x)) return 0;
+    if (x >=  2147483520.0f) return  2147483520;
+    if (x <= -2147483520.0f) return -2147483520;
+    return (int)x;
+}
+static inline int f2i_floor(float x) { return f2i_trunc(__builtin_floorf(x)); }
+
+// ---------------------------------------------------------------------------------------------
+// log2(x): x = m * 2^e, m in [sqrt(1/2), sqrt(2)), f = m - 1,
+//   ln(1+f) ~ f - f^2/2 + f^3 * P(f)   (9-term minimax, Cephes logf),  log2 = e + ln(1+f)*log2(e)
+//   with log2(e) split as 1 + 0.4426950408889634.  x<0 -> NaN, x==0 -> -inf, denormals are scaled.
+// ---------------------------------------------------------------------------------------------
+static inline float log2_(float x) {
+    if (!(x == x)) return x;
+    if (x < 0.0f) return u2f(0x7fc00000u);
+    if (x == 0.0f) return -INFINITY;
+    if (x == INFINITY) return x;
+    int e = 0;
+    uint32_t u = f2u(x);
+    if (u < 0x00800000u) { x = x * 8388608.0f; u = f2u(x); e = -23; }     // denormal
+    e += (int)(u >> 23) - 126;                                             // x = m * 2^e, m in [0.5,1)
+    float m = u2f((u & 0x007fffffu) | 0x3f000000u);
+    float f;
+    if (m < 0.70710678118654752440f) { e -= 1; f = (m + m) - 1.0f; } else { f = m - 1.0f; }
+    float z = f * f;
+    float p = 7.0376836292E-2f;
+    p = fma_(p, f, -1.1514610310E-1f);
+    p = fma_(p, f,  1.1676998740E-1f);
+    p = fma_(p, f, -1.2420140846E-1f);
+    p = fma_(p, f,  1.4249322787E-1f);
+    p = fma_(p, f, -1.6668057665E-1f);
+    p = fma_(p, f,  2.0000714765E-1f);
+    p = fma_(p, f, -2.4999993993E-1f);
+    p = fma_(p, f,  3.3333331174E-1f);
+    float y = (p * f) * z;
+    y = fma_(-0.5f, z, y);
+    const float L2EA = 0.44269504088896340736f;   // log2(e) - 1
+    float r = y * L2EA;
+    r = fma_(f, L2EA, r);
+    r = r + y;
+    r = r + f;
+    r = r + (float)e;
+    return r;
+}
+
+// exp2(x): n = nearest integer, f = x - n in [-0.5, 0.5], 2^f ~ 1 + f*P(f) (Cephes exp2f), scale by 2^n.
+// x >= 128 -> +inf; x < -126 -> 0 (denormal results flush to zero like D3D); NaN -> NaN.
+static inline float exp2_(float x) {
+    if (!(x == x)) return x;
+    if (x >= 128.0f) return INFINITY;
+    if (x < -126.0f) return 0.0f;
+    float n = __builtin_floorf(x);
+    float f = x - n;
+    if (f > 0.5f) { n += 1.0f; f -= 1.0f; }
+    float p = 1.535336188319500E-4f;
+    p = fma_(p, f, 1.339887440266574E-3f);
+    p = fma_(p, f, 9.618437357674640E-3f);
+    p = fma_(p, f, 5.550332471162809E-2f);
+    p = fma_(p, f, 2.402264791363012E-1f);
+    p = fma_(p, f, 6.931472028550421E-1f);
+    float r = fma_(p, f, 1.0f);
+    int ni = (int)n;                              // in [-126, 128]
+    if (ni > 127) { r = r * 2.0f; ni = 127; }     // f rounding can give n = 128 for x just below 128
+    return r * u2f((uint32_t)(ni + 127) << 23);
+}
+
+static inline float pow_(float x, float y) { return exp2_(y * log2_(x)); }
+
+// sin/cos: Cody-Waite reduction by pi/4 octants (3-part constant), Cephes sinf/cosf kernels on
+// [-pi/4, pi/4]. |x| > 2^20 or non-finite -> NaN.
+static inline void sincos_(float x, float* s, float* c) {
+    float ax = abs_(x);
+    if (!(ax <= 1048576.0f)) { *s = *c = u2f(0x7fc00000u); return; }
+    int j = (int)(ax * 1.27323954473516f);        // 4/pi
+    j = (j + 1) & ~1;
+    float y = (float)j;
+    float r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = r * r;
+    float ps = -1.9515295891E-4f;
+    ps = fma_(ps, z, 8.3321608736E-3f);
+    ps = fma_(ps, z, -1.6666654611E-1f);
+    float sn = fma_(ps * z, r, r);
+    float pc = 2.443315711809948E-5f;
+    pc = fma_(pc, z, -1.388731625493765E-3f);
+    pc = fma_(pc, z, 4.166664568298827E-2f);
+    float cs = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
+    int q = (j >> 1) & 3;
+    float ss, cc;
+    switch (q) {
+        case 0:  ss =  sn; cc =  cs; break;
+        case 1:  ss =  cs; cc = -sn; break;
+        case 2:  ss = -sn; cc = -cs; break;
+        default: ss = -cs; cc =  sn; break;
+    }
+    *s = (x < 0.0f) ? -ss : ss;
+    *c = cc;
+}
+static inline float sin_(float x) { float s, c; sincos_(x, &s, &c); return s; }
+static inline float cos_(float x) { float s, c; sincos_(x, &s, &c); return c; }
+static inline float tan_(float x) { float s, c; sincos_(x, &s, &c); return div_(s, c); }
+
+// asin on [-1,1] (Cephes asinf): |x| > 0.5 uses pi/2 - 2*asin(sqrt((1-|x|)/2)). |x| > 1 -> NaN.
+static inline float asin_poly(float x, float z) {   // x + x*z*P(z)
+    float p = 4.2163199048E-2f;
+    p = fma_(p, z, 2.4181311049E-2f);
+    p = fma_(p, z, 4.5470025998E-2f);
+    p = fma_(p, z, 7.4953002686E-2f);
+    p = fma_(p, z, 1.6666752422E-1f);
+    return fma_(p * z, x, x);
+}
+static inline float asin_(float x) {
+    float a = abs_(x);
+    if (!(a <= 1.0f)) return u2f(0x7fc00000u);
+    float r;
+    if (a > 0.5f) {
+        float z = 0.5f * (1.0f - a);
+        float s = sqrt_(z);
+        float t = asin_poly(s, z);
+        r = 1.5707963267948966192f - (t + t);
+    } else {
+        r = asin_poly(a, a * a);
+    }
+    return (x < 0.0f) ? -r : r;
+}
+static inline float acos_(float x) {
+    if (!(abs_(x) <= 1.0f)) return u2f(0x7fc00000u);
+    if (x < -0.5f) { float z = 0.5f * (1.0f + x); float s = sqrt_(z); float t = asin_poly(s, z); return 3.14159265358979323846f - (t + t); }
+    if (x >  0.5f) { float z = 0.5f * (1.0f - x); float s = sqrt_(z); float t = asin_poly(s, z); return t + t; }
+    return 1.5707963267948966192f - asin_poly(x, x * x);
+}
+
+// atan (Cephes atanf): reduce with tan(3pi/8), tan(pi/8); odd polynomial in x.
+static inline float atan_(float xx) {
+    float x = abs_(xx);
+    float y;
+    if (x > 2.414213562373095f)       { y = 1.5707963267948966192f; x = -rcp(x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483096f; x = div_(x - 1.0f, x + 1.0f); }
+    else                              { y = 0.0f; }
+    float z = x * x;
+    float p = 8.05374449538e-2f;
+    p = fma_(p, z, -1.38776856032E-1f);
+    p = fma_(p, z,  1.99777106478E-1f);
+    p = fma_(p, z, -3.33329491539E-1f);
+    y = y + fma_(p * z, x, x);
+    return (xx < 0.0f) ? -y : y;
+}
+// atan2(y,x) with HLSL/C quadrant conventions; atan2(0,0) = 0.
+static inline float atan2_(float y, float x) {
+    if (!(x == x) || !(y == y)) return u2f(0x7fc00000u);
+    const float PI_F = 3.14159265358979323846f, PIO2_F = 1.5707963267948966192f;
+    if (x == 0.0f) { if (y > 0.0f) return PIO2_F; if (y < 0.0f) return -PIO2_F; return 0.0f; }
+    if (y == 0.0f) return (x < 0.0f) ? PI_F : 0.0f;
+    float w = 0.0f;
+    if (x < 0.0f) w = (y < 0.0f) ? -PI_F : PI_F;
+    return w + atan_(div_(y, x));
+}
+
+// ---------------------------------------------------------------------------------------------
+// storage conversions
+// ---------------------------------------------------------------------------------------------
+// fp32 -> fp16 round-to-nearest-even, denormals kept, overflow -> inf, NaN -> quiet NaN.
+static inline uint16_t f32_to_f16(float f) {
+    uint32_t u = f2u(f);
+    uint32_t sign = (u >> 16) & 0x8000u;
+    uint32_t a = u & 0x7fffffffu;
+    if (a >= 0x7f800000u) return (uint16_t)(sign | (a > 0x7f800000u ? 0x7e00u : 0x7c00u));
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);            // >= 65520 rounds to inf
+    if (a < 0x33000001u) return (uint16_t)sign;                          // <= 2^-25 rounds to 0
+    int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x007fffffu) | 0x00800000u;
+    int shift = (e < -14) ? (13 + (-14 - e)) : 13;                       // bits to drop
+    uint32_t h = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1u))) h += 1;
+    uint32_t out;
+    if (e < -14) out = h;                                                // denormal (may carry into normal)
+    else         out = ((uint32_t)(e + 15) << 10) + (h - 0x400u);        // h has the implicit bit at 0x400
+    return (uint16_t)(sign | out);
+}
+static inline float f16_to_f32(uint16_t h) {
+    uint32_t sign = ((uint32_t)h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    if (e == 0) {
+        if (m == 0) return u2f(sign);
+        float v = (float)m * 5.9604644775390625e-8f;                     // m * 2^-24
+        return (sign ? -v : v);
+    }
+    if (e == 31) return u2f(sign | 0x7f800000u | (m << 13));
+    return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+// fp32 -> UNORM8: NaN -> 0, clamp to [0,1], scale by 255, add 0.5, truncate (D3D FLOAT -> UNORM rule).
+static inline uint8_t f32_to_unorm8(float f) {
+    float c = saturate(f);
+    return (uint8_t)(int)(c * 255.0f + 0.5f);
+}
+
+} // namespace vqo
+#endif

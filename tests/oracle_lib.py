@@ -1,0 +1,193 @@
+"""ctypes loader for the CPU oracle (oracle/libvqoracle.so). TEST INFRASTRUCTURE: imported only by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg — never by vqengine_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from vqengine_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SO = os.path.join(ROOT, "oracle", "libvqoracle.so")
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO):
+        build()
+    lib = C.CDLL(SO)
+    vp, i32, f32, sz, lg = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_long
+    lib.vqo_math_array.argtypes = [i32, vp, vp, vp, sz]
+    lib.vqo_f32_to_f16.argtypes = [vp, vp, sz]
+    lib.vqo_f16_to_f32.argtypes = [vp, vp, sz]
+    lib.vqo_f32_to_unorm8.argtypes = [vp, vp, sz]
+    lib.vqo_brdf.argtypes = [vp, f32, vp, f32, vp, vp, vp]
+    lib.vqo_cube_texel_dir.argtypes = [i32, i32, i32, i32, vp]
+    lib.vqo_cube_face_uv.argtypes = [vp, vp]
+    lib.vqo_cube_edge_neighbor.argtypes = [i32, i32, i32, i32, vp]
+    lib.vqo_sample_cube_rgba16f.argtypes = [vp, i32, vp, vp]
+    lib.vqo_direction_to_equirect_uv.argtypes = [vp, vp]
+    lib.vqo_sample_equirect_lod.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp]
+    lib.vqo_forward_lighting.argtypes = [C.POINTER(abi.GBuffer), C.POINTER(abi.PerFrameData), C.POINTER(abi.PerViewLightingData),
+                                         vp, i32, C.POINTER(abi.EnvMap), C.POINTER(abi.ShadowMaps), vp, i32, i32, i32]
+    lib.vqo_gaussian_blur_pass.argtypes = [vp, vp, i32, i32, i32, i32, vp, vp, i32, i32]
+    lib.vqo_tonemap.argtypes = [vp, vp, i32, i32, C.POINTER(abi.TonemapperParams), i32, i32, i32]
+    lib.vqo_brdf_lut.argtypes = [vp, i32, i32, i32, i32]
+    lib.vqo_brdf_lut_rows.argtypes = [vp, i32, i32, i32, i32, i32, i32]
+    lib.vqo_mip_chain_min_rgba32f.argtypes = [vp, i32, i32, i32]
+    lib.vqo_mip_chain_floats.restype = sz
+    lib.vqo_mip_chain_floats.argtypes = [i32, i32, i32]
+    lib.vqo_cube_halfs.restype = sz
+    lib.vqo_cube_halfs.argtypes = [i32, i32]
+    lib.vqo_loop_count.argtypes = [f32, f32]
+    lib.vqo_conv_diffuse.argtypes = [vp, i32, i32, i32, i32, f32, i32, vp, i32, lg, lg, i32]
+    lib.vqo_conv_specular.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, i32]
+    lib.vqo_envmap_prefilter.argtypes = [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32]
+    if not lib.vqo_has_fma():
+        raise RuntimeError("oracle needs a host CPU with FMA (it is compiled -mfma)")
+    _lib = lib
+    return lib
+
+
+_NP = {abi.FMT_RGBA32F: (np.float32, 4), abi.FMT_RGBA16F: (np.float16, 4), abi.FMT_RGBA8_UNORM: (np.uint8, 4),
+       abi.FMT_RG16F: (np.float16, 2), abi.FMT_RG32F: (np.float32, 2)}
+
+
+def np_image(h, w, fmt):
+    dt, ch = _NP[fmt]
+    return np.empty((h, w, ch), dt)
+
+
+def _p(a):
+    return a.ctypes.data if a is not None else None
+
+
+def math_array(fn, a, b=None):
+    lib = load()
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    bb = np.ascontiguousarray(b, np.float32) if b is not None else None
+    lib.vqo_math_array(fn, _p(a), _p(bb), _p(out), a.size)
+    return out
+
+
+def forward_lighting(gb, per_frame, per_view, out_fmt=abi.FMT_RGBA16F, extra_point=None, env=None, shadow=None, nthreads=0):
+    """gb: 4 float32 numpy arrays [H,W,4]; env: abi.EnvMap with HOST pointers (use host_envmap)."""
+    lib = load()
+    gb = [np.ascontiguousarray(g, np.float32) for g in gb]
+    h, w = gb[0].shape[:2]
+    out = np_image(h, w, out_fmt)
+    g = abi.GBuffer(_p(gb[0]), _p(gb[1]), _p(gb[2]), _p(gb[3]), w, h, w)
+    n_extra = len(extra_point) if extra_point is not None else 0
+    ep = C.cast(extra_point, C.c_void_p) if n_extra else None
+    rc = lib.vqo_forward_lighting(C.byref(g), C.byref(per_frame), C.byref(per_view), ep, n_extra,
+                                  C.byref(env) if env is not None else None, C.byref(shadow) if shadow is not None else None,
+                                  _p(out), w, out_fmt, nthreads)
+    assert rc == 0, rc
+    return out
+
+
+def host_envmap(diffuse_cube, spec_cube, spec_res0, spec_mips, lut):
+    """abi.EnvMap over numpy float16 arrays (caller keeps them alive)."""
+    return abi.EnvMap(_p(diffuse_cube), diffuse_cube.shape[1], _p(spec_cube), spec_res0, spec_mips, _p(lut), lut.shape[0])
+
+
+def blur_pass(img, fmt, direction, halo_top=None, halo_bottom=None, nthreads=0):
+    lib = load()
+    h, w = img.shape[:2]
+    out = np.empty_like(img)
+    rows = 0
+    for hh in (halo_top, halo_bottom):
+        if hh is not None:
+            rows = hh.shape[0]
+    rc = lib.vqo_gaussian_blur_pass(_p(img), _p(out), w, h, fmt, direction, _p(halo_top), _p(halo_bottom), rows, nthreads)
+    assert rc == 0, rc
+    return out
+
+
+def gaussian_blur(img, fmt, nthreads=0):
+    return blur_pass(blur_pass(img, fmt, 0, nthreads=nthreads), fmt, 1, nthreads=nthreads)
+
+
+def tonemap(img, in_fmt, out_fmt=abi.FMT_RGBA8_UNORM, params=None, nthreads=0):
+    lib = load()
+    h, w = img.shape[:2]
+    out = np_image(h, w, out_fmt)
+    params = params if params is not None else abi.TonemapperParams.default()
+    rc = lib.vqo_tonemap(_p(img), _p(out), w, h, C.byref(params), in_fmt, out_fmt, nthreads)
+    assert rc == 0, rc
+    return out
+
+
+def brdf_lut(size, samples, fmt=abi.FMT_RG16F, rows=None, nthreads=0):
+    lib = load()
+    if rows is None:
+        out = np_image(size, size, fmt)
+        rc = lib.vqo_brdf_lut(_p(out), size, samples, fmt, nthreads)
+    else:
+        out = np_image(rows[1] - rows[0], size, fmt)
+        rc = lib.vqo_brdf_lut_rows(_p(out), size, samples, fmt, rows[0], rows[1], nthreads)
+    assert rc == 0, rc
+    return out
+
+
+def mip_chain(level0):
+    lib = load()
+    h, w = level0.shape[:2]
+    n = abi.mip_level_count(w, h)
+    chain = np.empty((abi.mip_chain_px(w, h, n), 4), np.float32)
+    chain[: w * h] = level0.reshape(-1, 4)
+    assert lib.vqo_mip_chain_min_rgba32f(_p(chain), w, h, n) == 0
+    return chain, n
+
+
+def conv_diffuse(chain, w0, h0, n_mips, res, step, order, fmt=abi.FMT_RGBA16F, t0=0, t1=-1, nthreads=0):
+    lib = load()
+    dt, ch = _NP[fmt]
+    out = np.zeros((6, res, res, ch), dt)
+    rc = lib.vqo_conv_diffuse(_p(chain), w0, h0, n_mips, res, step, order, _p(out), fmt, t0, t1, nthreads)
+    assert rc == 0, rc
+    return out
+
+
+def conv_specular(chain, w0, h0, n_mips, res0, order, fmt=abi.FMT_RGBA16F, nthreads=0):
+    lib = load()
+    dt, ch = _NP[fmt]
+    mips = abi.specular_mip_count(res0)
+    out = np.empty((abi.cube_px(res0, mips), ch), dt)
+    rc = lib.vqo_conv_specular(_p(chain), w0, h0, n_mips, res0, order, _p(out), fmt, nthreads)
+    assert rc == 0, rc
+    return out, mips
+
+
+def envmap_prefilter(chain, w0, h0, n_mips, diffuse_res, diffuse_step, spec_res0, order, nthreads=0):
+    lib = load()
+    mips = abi.specular_mip_count(spec_res0)
+    d0 = np.empty((6, diffuse_res, diffuse_res, 4), np.float16)
+    d1 = np.empty_like(d0)
+    sp = np.empty((abi.cube_px(spec_res0, mips), 4), np.float16)
+    rc = lib.vqo_envmap_prefilter(_p(chain), w0, h0, n_mips, diffuse_res, diffuse_step, spec_res0, order, _p(d0), _p(d1), _p(sp), nthreads)
+    assert rc == 0, rc
+    return {"diffuse_unblurred": d0, "diffuse_blurred": d1, "specular": sp, "spec_mips": mips}
+
+
+def bits_equal(a, b):
+    """Bit-exact comparison of two same-dtype arrays treating any-NaN == any-NaN. Returns (#mismatch, first indices)."""
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
+    if a.dtype.kind == "f":
+        it = {2: np.uint16, 4: np.uint32}[a.dtype.itemsize]
+        ne = (a.view(it) != b.view(it)) & ~(np.isnan(a) & np.isnan(b))
+    else:
+        ne = a != b
+    idx = np.argwhere(ne)
+    return int(ne.sum()), idx[:5]

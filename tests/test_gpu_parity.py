@@ -1,0 +1,348 @@
+"""GPU parity: every HIP kernel, called through the C ABI (libvqhip.so), against the CPU oracle on the same
+seeded inputs. Bar: BIT-EXACT in every output format (fp32 before storage rounding, and the reference's
+RGBA16F / RG16F / RGBA8 storage formats) — which implies the north-star tolerance of <= 1 ULP per channel in
+the reference storage format with margin. NaNs compare equal to NaNs."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle_lib as O
+from vqengine_amd import abi, capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def assert_bits(gpu_t, ref_np, what):
+    got = gpu_t.cpu().numpy()
+    n, idx = O.bits_equal(got, ref_np)
+    assert n == 0, f"{what}: {n} mismatching elements of {got.size}; first at {idx.tolist()}: " \
+                   f"gpu={[got[tuple(i)] for i in idx]} ref={[ref_np[tuple(i)] for i in idx]}"
+
+
+# ---------------------------------------------------------------------------------------------------
+# small shared IBL inputs (equirect -> mips -> prefilter -> LUT), computed once by the ORACLE and once by the GPU
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def env_small(ctx):
+    eq = synth.equirect(128, 64)
+    chain_o, n = O.mip_chain(eq)
+    chain_g, n_g = ctx.mip_chain(dev(eq))
+    assert n == n_g
+    pre_o = O.envmap_prefilter(chain_o, 128, 64, n, 16, 0.05, 32, abi.CONV_WAVE64)
+    pre_g = ctx.envmap_prefilter(chain_g, 128, 64, n, 16, 0.05, 32, abi.CONV_WAVE64)
+    lut_o = O.brdf_lut(64, 128, abi.FMT_RG16F)
+    lut_g = ctx.brdf_lut(64, 128, abi.FMT_RG16F)
+    return dict(eq=eq, n=n, chain_o=chain_o, chain_g=chain_g, pre_o=pre_o, pre_g=pre_g, lut_o=lut_o, lut_g=lut_g)
+
+
+def test_mip_chain_min(env_small):
+    assert_bits(env_small["chain_g"], env_small["chain_o"], "min-filter mip chain")
+
+
+def test_brdf_lut(ctx, env_small):
+    assert_bits(env_small["lut_g"], env_small["lut_o"], "BRDF LUT RG16F 64^2 x128")
+    assert_bits(ctx.brdf_lut(32, 256, abi.FMT_RG32F), O.brdf_lut(32, 256, abi.FMT_RG32F), "BRDF LUT RG32F 32^2 x256")
+
+
+def test_brdf_lut_reference_size_rows(ctx):
+    """1024^2 x 2048 (the reference's size, Renderer.cpp:895-900,1026-1032): full LUT on the GPU, 6 rows checked."""
+    lut = ctx.brdf_lut(1024, 2048, abi.FMT_RG16F).cpu().numpy()
+    for y in (0, 1, 511, 777, 1023):
+        ref = O.brdf_lut(1024, 2048, abi.FMT_RG16F, rows=(y, y + 1))
+        n, idx = O.bits_equal(lut[y:y + 1], ref)
+        assert n == 0, (y, n, idx)
+    f = lut.astype(np.float32)
+    assert np.isfinite(f).all() and (f >= 0).all() and (f[..., 0] + f[..., 1] <= 1.001).all()
+
+
+def test_envmap_prefilter(env_small):
+    for k in ("diffuse_unblurred", "diffuse_blurred", "specular"):
+        assert_bits(env_small["pre_g"][k], env_small["pre_o"][k], f"prefilter {k}")
+
+
+@pytest.mark.parametrize("order", [abi.CONV_SEQUENTIAL, abi.CONV_WAVE64])
+@pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+def test_conv_orders(ctx, env_small, order, fmt):
+    e = env_small
+    d_g = ctx.conv_diffuse(e["chain_g"], 128, 64, e["n"], 8, 0.05, order, fmt)
+    d_o = O.conv_diffuse(e["chain_o"], 128, 64, e["n"], 8, 0.05, order, fmt)
+    assert_bits(d_g, d_o, f"conv_diffuse order={order} fmt={fmt}")
+    s_g, _ = ctx.conv_specular(e["chain_g"], 128, 64, e["n"], 16, order, fmt)
+    s_o, _ = O.conv_specular(e["chain_o"], 128, 64, e["n"], 16, order, fmt)
+    assert_bits(s_g, s_o, f"conv_specular order={order} fmt={fmt}")
+
+
+# ---------------------------------------------------------------------------------------------------
+# forward lighting
+# ---------------------------------------------------------------------------------------------------
+def _envs(e):
+    pre_o, pre_g = e["pre_o"], e["pre_g"]
+    env_o = O.host_envmap(pre_o["diffuse_blurred"], pre_o["specular"], 32, pre_o["spec_mips"], e["lut_o"])
+    env_g = capi.make_envmap(pre_g["diffuse_blurred"], pre_g["specular"], 32, pre_g["spec_mips"], e["lut_g"])
+    return env_o, env_g
+
+
+@pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+def test_forward_point_lights_cfg2_shape(ctx, fmt):
+    """BASELINE cfg2 shape at reduced size: 16 point lights, no IBL, no casters, ragged width (not a multiple of 256)."""
+    W, H = 333, 61
+    gb = synth.gbuffer(W, H)
+    pf, extra = synth.per_frame(points=synth.point_lights(16))
+    pv = synth.per_view(W, H)
+    ref = O.forward_lighting(gb, pf, pv, fmt)
+    got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=fmt)
+    assert_bits(got, ref, f"forward 16 point lights fmt={fmt}")
+
+
+def test_forward_all_light_types_and_ibl(ctx, env_small):
+    """cfg3 shape at reduced size: 64 point + 6 spot + directional + IBL (specular mips, LUT, diffuse cube)."""
+    W, H = 256, 48
+    gb = synth.gbuffer(W, H, seed=0x6400)
+    pf, extra = synth.per_frame(points=synth.point_lights(64, seed=0x6400), spots=synth.spot_lights(6),
+                                directional=synth.directional_light(), hdri_offset=0.3)
+    env_o, env_g = _envs(env_small)
+    pv = synth.per_view(W, H, max_env_lod=env_small["pre_o"]["spec_mips"])
+    for fmt in (abi.FMT_RGBA32F, abi.FMT_RGBA16F):
+        ref = O.forward_lighting(gb, pf, pv, fmt, env=env_o)
+        got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=fmt, env=env_g)
+        assert_bits(got, ref, f"forward all lights + IBL fmt={fmt}")
+    pv.EnvironmentMapDiffuseOnlyIllumination = 1          # GFXSettings.Reflections == SSR path, SceneRendering.cpp:464
+    ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F, env=env_o)
+    got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F, env=env_g)
+    assert_bits(got, ref, "forward diffuse-only IBL")
+
+
+def test_forward_cube_seams_and_directions(ctx, env_small):
+    """IBL-only shading with normals/view vectors aimed at cube edges and corners (seamless filtering paths)."""
+    rng = np.random.default_rng(5)
+    n = 4096
+    d = rng.choice([-1.0, 1.0], (n, 3)) * np.where(rng.random((n, 3)) < 0.5, 1.0, rng.random((n, 3)))
+    d += rng.normal(0, 0.02, (n, 3))
+    gb = [np.zeros((1, n, 4), np.float32) for _ in range(4)]
+    gb[0][0, :, :3] = rng.normal(0, 1, (n, 3)); gb[0][0, :, 3] = 0.03
+    gb[1][0, :, :3] = d / np.linalg.norm(d, axis=1, keepdims=True); gb[1][0, :, 3] = rng.random(n)
+    gb[2][0] = rng.random((n, 4)); gb[3][0] = 0
+    pf, _ = synth.per_frame(hdri_offset=0.0)
+    env_o, env_g = _envs(env_small)
+    pv = synth.per_view(n, 1, camera=(0.0, 0.0, 0.0), max_env_lod=env_small["pre_o"]["spec_mips"])
+    ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F, env=env_o)
+    got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F, env=env_g)
+    assert_bits(got, ref, "forward IBL cube seams")
+
+
+def test_forward_extra_point_lights_cfg5_shape(ctx):
+    """cfg5 shape: 256 point lights = 100 in the cbuffer array + 156 through the extension array."""
+    W, H = 192, 16
+    gb = synth.gbuffer(W, H, seed=0x25600)
+    pf, extra = synth.per_frame(points=synth.point_lights(256, seed=0x25600))
+    assert pf.Lights.numPointLights == 100 and len(extra) == 156
+    pv = synth.per_view(W, H)
+    ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F, extra_point=extra)
+    got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA16F, extra_point=extra)
+    assert_bits(got, ref, "forward 256 point lights")
+
+
+def _shadow_setup(W, H):
+    """Default-scene-like caster set (cfg1 substitute): shadowing directional + 2 spot casters + 1 point
+    caster with synthetic shadow maps: half-plane occluders so both lit and shadowed PCF taps occur."""
+    rng = np.random.default_rng(11)
+    pf, _ = synth.per_frame(points=synth.point_lights(3), directional=synth.directional_light(shadowing=1))
+    L = pf.Lights
+    spots = synth.spot_lights(2, seed=77)
+    L.numSpotCasters = 2
+    for i in range(2):
+        L.spot_casters[i] = spots[i]
+    pc = synth.point_lights(1, seed=99)
+    pc[0].depthBias = 5e-5
+    L.numPointCasters = 1
+    L.point_casters[0] = pc[0]
+
+    def mat(scale, tz):       # simple "orthographic" light-space matrix: xz plane -> clip xy, y -> depth
+        m = abi.matrix()
+        m.m[0][0] = scale; m.m[2][1] = scale; m.m[1][2] = -0.02; m.m[3][2] = tz; m.m[3][3] = 1.0
+        return m
+    L.shadowViewDirectional = mat(1 / 60.0, 0.5)
+    L.shadowViews[0] = mat(1 / 45.0, 0.45)
+    L.shadowViews[1] = mat(1 / 70.0, 0.55)
+    dmap = rng.random((64, 64), dtype=np.float32) * 0.2 + 0.4
+    dmap[:, 32:] = 1.0
+    smap = rng.random((5, 32, 32), dtype=np.float32) * 0.3 + 0.35
+    smap[:, 16:, :] = 1.0
+    pmap = rng.random((5, 6, 16, 16), dtype=np.float32) * 0.5 + 0.05
+    pf.f2DirectionalLightShadowMapDimensions = abi.float2(64.0, 64.0)
+    pf.f2SpotLightShadowMapDimensions = abi.float2(32.0, 32.0)
+    pf.f2PointLightShadowMapDimensions = abi.float2(16.0, 16.0)
+    return pf, dmap, smap, pmap
+
+
+def test_forward_shadow_casters_pcf(ctx):
+    W, H = 200, 40
+    gb = synth.gbuffer(W, H, seed=0x5AD0)
+    pf, dmap, smap, pmap = _shadow_setup(W, H)
+    pv = synth.per_view(W, H)
+    sm_o = abi.ShadowMaps(dmap.ctypes.data, 64, smap.ctypes.data, 32, pmap.ctypes.data, 16)
+    dg, sg, pg = dev(dmap), dev(smap), dev(pmap)
+    sm_g = abi.ShadowMaps(dg.data_ptr(), 64, sg.data_ptr(), 32, pg.data_ptr(), 16)
+    ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F, shadow=sm_o)
+    got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F, shadow=sm_g)
+    assert_bits(got, ref, "forward with PCF shadow casters")
+    unshadowed = O.forward_lighting(gb, synth.per_frame(points=synth.point_lights(3), directional=synth.directional_light())[0], pv, abi.FMT_RGBA32F)
+    assert (np.abs(ref[..., :3] - unshadowed[..., :3]) > 1e-6).mean() > 0.05, "shadow maps had no effect: the PCF path was not exercised"
+
+
+def test_forward_edge_cases(ctx):
+    """Degenerate inputs: zero lights, zero normal (NaN propagation), light exactly at the pixel, roughness 0/1, 1x1 image."""
+    pf0, _ = synth.per_frame()
+    pv = synth.per_view(1, 1)
+    gb = [np.zeros((1, 1, 4), np.float32) for _ in range(4)]
+    gb[1][0, 0] = (0, 1, 0, 0.5); gb[2][0, 0] = (0.5, 0.25, 0.125, 0.0); gb[0][0, 0, 3] = 0.05; gb[3][0, 0] = (1, 2, 3, 0.5)
+    got = ctx.forward_lighting([dev(g) for g in gb], pf0, pv, out_fmt=abi.FMT_RGBA32F).cpu().numpy()
+    np.testing.assert_array_equal(got[0, 0], np.array([0.5 * 0.05 + 0.5, 0.25 * 0.05 + 1.0, 0.125 * 0.05 + 1.5, 0.5], np.float32))
+    W = 64
+    gb = synth.gbuffer(W, 2, seed=3)
+    pts = synth.point_lights(4, seed=3)
+    gb[1][0, 0, :3] = 0.0                                   # zero normal -> normalize gives NaN
+    gb[0][0, 1, :3] = (pts[0].position.x, pts[0].position.y, pts[0].position.z)   # D == 0
+    gb[1][0, 2, 3] = 0.0; gb[1][0, 3, 3] = 1.0              # roughness extremes
+    gb[2][0, 4, 3] = 1.0; gb[2][0, 5, 3] = 0.0              # metalness extremes
+    pf, _ = synth.per_frame(points=pts)
+    pv = synth.per_view(W, 2)
+    ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F)
+    got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F)
+    assert_bits(got, ref, "forward edge cases")
+    assert np.isnan(ref[0, 0, :3]).all()
+
+
+def test_forward_full_size_properties(ctx):
+    """BASELINE cfg3 size 3840x2160, 64 lights: (i) a 24-row crop is bit-exact vs the oracle; (ii) additivity of lights
+    in a size-independent form: shading with lights A then B separately sums to shading with A+B within fp32 rounding;
+    (iii) RGBA16F output == RNE(fp32 output)."""
+    W, H = 3840, 2160
+    rows = (1000, 1024)
+    gb_crop = synth.gbuffer_rows(W, H, rows[0], rows[1], seed=0x6400)
+    pts = synth.point_lights(64, seed=0x6400)
+    pf, _ = synth.per_frame(points=pts)
+    pv = synth.per_view(W, H)
+    gb_full = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
+    for r0 in range(0, H, 240):
+        part = synth.gbuffer_rows(W, H, r0, r0 + 240, seed=0x6400)
+        for k in range(4):
+            gb_full[k][r0:r0 + 240].copy_(torch.from_numpy(part[k]))
+    out32 = ctx.forward_lighting(gb_full, pf, pv, out_fmt=abi.FMT_RGBA32F)
+    ref = O.forward_lighting(gb_crop, pf, pv, abi.FMT_RGBA32F)
+    assert_bits(out32[rows[0]:rows[1]], ref, "4K crop")
+    out16 = ctx.forward_lighting(gb_full, pf, pv, out_fmt=abi.FMT_RGBA16F)
+    assert torch.equal(out16.view(torch.int16), out32.to(torch.float16).view(torch.int16))
+    pfA, _ = synth.per_frame(points=[pts[i] for i in range(32)], ambient=0.055)
+    pfB, _ = synth.per_frame(points=[pts[i] for i in range(32, 64)])
+    a = ctx.forward_lighting(gb_full, pfA, pv, out_fmt=abi.FMT_RGBA32F)
+    b = ctx.forward_lighting(gb_full, pfB, pv, out_fmt=abi.FMT_RGBA32F)
+    base = ctx.forward_lighting(gb_full, synth.per_frame()[0], pv, out_fmt=abi.FMT_RGBA32F)
+    s = (a[..., :3].double() + b[..., :3].double() - base[..., :3].double())
+    rel = ((s - out32[..., :3].double()).abs() / out32[..., :3].double().abs().clamp_min(1e-6))
+    assert torch.isfinite(out32).all()
+    assert rel.max().item() < 2e-5, rel.max().item()
+
+
+# ---------------------------------------------------------------------------------------------------
+# post chain
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+@pytest.mark.parametrize("shape", [(97, 301), (1, 5), (64, 64), (40, 1)])
+def test_blur(ctx, fmt, shape):
+    h, w = shape
+    img = synth.hdr_image(w, h).astype(O._NP[fmt][0])
+    x_o = O.blur_pass(img, fmt, 0)
+    x_g = ctx.gaussian_blur_x(dev(img), fmt)
+    assert_bits(x_g, x_o, f"blur X {shape} fmt={fmt}")
+    y_o = O.blur_pass(x_o, fmt, 1)
+    y_g = ctx.gaussian_blur_y(x_g, fmt)
+    assert_bits(y_g, y_o, f"blur Y {shape} fmt={fmt}")
+    assert_bits(ctx.gaussian_blur(dev(img), fmt), y_o, f"blur XY {shape} fmt={fmt}")
+    assert (y_o[..., 3] == 1).all()
+
+
+def test_blur_y_row_tiles_with_halos(ctx):
+    """Row-tiled Y pass (multi-GPU mode): tiles blurred with neighbour halos == the full-frame blur."""
+    fmt = abi.FMT_RGBA16F
+    h, w, tiles = 96, 130, 3
+    x = O.blur_pass(synth.hdr_image(w, h).astype(np.float16), fmt, 0)
+    full = O.blur_pass(x, fmt, 1)
+    th = h // tiles
+    xg = dev(x)
+    for t in range(tiles):
+        top = xg[t * th - 10:t * th].contiguous() if t > 0 else None
+        bot = xg[(t + 1) * th:(t + 1) * th + 10].contiguous() if t < tiles - 1 else None
+        got = ctx.gaussian_blur_y(xg[t * th:(t + 1) * th].contiguous(), fmt, halo_top=top, halo_bottom=bot)
+        assert_bits(got, full[t * th:(t + 1) * th], f"tile {t}")
+        ref_t = O.blur_pass(x[t * th:(t + 1) * th], fmt, 1, halo_top=x[t * th - 10:t * th] if t > 0 else None,
+                            halo_bottom=x[(t + 1) * th:(t + 1) * th + 10] if t < tiles - 1 else None)
+        n, _ = O.bits_equal(ref_t, full[t * th:(t + 1) * th])
+        assert n == 0
+
+
+@pytest.mark.parametrize("in_fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+@pytest.mark.parametrize("out_fmt", [abi.FMT_RGBA8_UNORM, abi.FMT_RGBA16F, abi.FMT_RGBA32F])
+@pytest.mark.parametrize("curve", [abi.DISPLAY_CURVE_SRGB, abi.DISPLAY_CURVE_ST2084, abi.DISPLAY_CURVE_LINEAR, 7])
+def test_tonemap(ctx, in_fmt, out_fmt, curve):
+    img = synth.hdr_image(257, 33, scale=50.0).astype(O._NP[in_fmt][0])
+    img[0, :8, 0] = (0.0, 1e-6, 0.0031308, 0.0031309, 1.0, 65504.0, 0.18, 0.5)     # curve knee + extremes
+    for gamma, cs in ((1, abi.COLOR_SPACE_REC_709), (0, abi.COLOR_SPACE_REC_2020)):
+        p = abi.TonemapperParams(cs, curve, 200.0, gamma)
+        ref = O.tonemap(img, in_fmt, out_fmt, p)
+        got = ctx.tonemap(dev(img), in_fmt, out_fmt, p)
+        assert_bits(got, ref, f"tonemap in={in_fmt} out={out_fmt} curve={curve} gamma={gamma}")
+
+
+def test_post_chain_full_size_properties(ctx):
+    """cfg3-sized post chain (3840x2160 RGBA16F): blur of a constant image is that constant times the summed weights;
+    a 32-row band of blur->tonemap matches the oracle bit-exactly; tonemap output is monotone in input."""
+    W, H = 3840, 2160
+    img = torch.from_numpy(synth.hdr_image(W, H).astype(np.float16)).cuda()
+    blurred = ctx.gaussian_blur(img, abi.FMT_RGBA16F)
+    sdr = ctx.tonemap(blurred, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
+    band = (1200, 1232)
+    src = img[band[0] - 10:band[1] + 10].cpu().numpy()
+    x_o = O.blur_pass(src, abi.FMT_RGBA16F, 0)
+    y_o = O.blur_pass(x_o, abi.FMT_RGBA16F, 1)[10:-10]
+    assert_bits(blurred[band[0]:band[1]], y_o, "4K blur band")
+    assert_bits(sdr[band[0]:band[1]], O.tonemap(y_o, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM), "4K tonemap band")
+    const = torch.full((64, 512, 4), 0.75, dtype=torch.float16, device="cuda")
+    cb = ctx.gaussian_blur(const, abi.FMT_RGBA16F).float()
+    assert (cb[..., :3] - 0.75).abs().max().item() < 2e-3 and (cb[..., 3] == 1).all()
+    ramp = torch.linspace(0, 8, 4096, device="cuda").half().reshape(1, 4096, 1).repeat(1, 1, 4).contiguous()
+    tm = ctx.tonemap(ramp, abi.FMT_RGBA16F, abi.FMT_RGBA32F)[0, :, 0]
+    assert (tm[1:] >= tm[:-1]).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# C-ABI error behaviour (the reference asserts/logs; the ABI returns negative codes and never falls back)
+# ---------------------------------------------------------------------------------------------------
+def test_abi_errors(ctx):
+    lib = ctx.lib
+    g = synth.gbuffer(8, 2)
+    pf, _ = synth.per_frame()
+    pv = synth.per_view(8, 2)
+    t = [dev(x) for x in g]
+    with pytest.raises(capi.VQHipError) as e:
+        pf.Lights.numPointLights = 101
+        ctx.forward_lighting(t, pf, pv)
+    assert e.value.code == abi.VQHIP_ERR_INVALID_ARG and "light count" in str(e.value)
+    pf.Lights.numPointLights = 0
+    pf.Lights.numSpotCasters = 1
+    with pytest.raises(capi.VQHipError):
+        ctx.forward_lighting(t, pf, pv)                       # casters without shadow maps
+    pf.Lights.numSpotCasters = 0
+    out8 = torch.empty((2, 8, 4), dtype=torch.uint8, device="cuda")
+    gb = abi.GBuffer(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), 8, 2, 8)
+    rc = lib.vqhip_forward_lighting(ctx._h, None, C.byref(gb), C.byref(pf), C.byref(pv), None, 0, None, None, out8.data_ptr(), 8, abi.FMT_RGBA8_UNORM)
+    assert rc == abi.VQHIP_ERR_UNSUPPORTED
+    rc = lib.vqhip_tonemap(ctx._h, None, None, out8.data_ptr(), 8, 2, C.byref(abi.TonemapperParams.default()), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
+    assert rc == abi.VQHIP_ERR_INVALID_ARG
+    assert lib.vqhip_forward_lighting(None, None, None, None, None, None, 0, None, None, None, 0, 0) == abi.VQHIP_ERR_INVALID_ARG

@@ -1,0 +1,230 @@
+"""Thin ctypes binding over the C ABI (include/vqhip.h, vqengine_amd/lib/libvqhip.so).
+
+torch is used only as plumbing: device memory (tensor.data_ptr()) and the current HIP stream.
+There is NO fallback: if the library is missing, or no gfx950 device is visible, this raises."""
+import ctypes as C
+import os
+
+import torch
+
+from . import abi
+from .abi import (FMT_RGBA32F, FMT_RGBA16F, FMT_RGBA8_UNORM, FMT_RG16F, FMT_RG32F, CONV_WAVE64)
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvqhip.so")
+_lib = None
+
+
+class VQHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vqhip error {code}: {msg}")
+        self.code = code
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen libvqhip.so and declare every entry point of include/vqhip.h. Loud failure if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise FileNotFoundError(f"{_LIB_PATH} not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for this path.")
+    lib = C.CDLL(_LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    sig = {
+        "vqhip_abi_version": (i32, []),
+        "vqhip_create": (i32, [i32, C.POINTER(vp)]),
+        "vqhip_destroy": (None, [vp]),
+        "vqhip_last_error": (C.c_char_p, [vp]),
+        "vqhip_forward_lighting": (i32, [vp, vp, C.POINTER(abi.GBuffer), C.POINTER(abi.PerFrameData), C.POINTER(abi.PerViewLightingData),
+                                         vp, i32, C.POINTER(abi.EnvMap), C.POINTER(abi.ShadowMaps), vp, i32, i32]),
+        "vqhip_gaussian_blur": (i32, [vp, vp, vp, vp, vp, C.POINTER(abi.BlurParams), i32]),
+        "vqhip_gaussian_blur_x": (i32, [vp, vp, vp, vp, C.POINTER(abi.BlurParams), i32]),
+        "vqhip_gaussian_blur_y": (i32, [vp, vp, vp, vp, vp, vp, i32, C.POINTER(abi.BlurParams), i32]),
+        "vqhip_tonemap": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.TonemapperParams), i32, i32]),
+        "vqhip_brdf_lut": (i32, [vp, vp, vp, i32, i32, i32]),
+        "vqhip_mip_level_count": (i32, [i32, i32]),
+        "vqhip_mip_chain_bytes": (sz, [i32, i32, i32]),
+        "vqhip_mip_level_offset_bytes": (sz, [i32, i32, i32]),
+        "vqhip_mip_chain_min_rgba32f": (i32, [vp, vp, vp, i32, i32, i32]),
+        "vqhip_specular_mip_count": (i32, [i32]),
+        "vqhip_cube_bytes": (sz, [i32, i32, i32]),
+        "vqhip_conv_diffuse": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, i32]),
+        "vqhip_conv_specular": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32]),
+        "vqhip_envmap_prefilter": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, C.POINTER(abi.EnvMapOut)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    if lib.vqhip_abi_version() != 1:
+        raise RuntimeError("libvqhip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "vqhip_abi_version", "vqhip_create", "vqhip_destroy", "vqhip_last_error", "vqhip_forward_lighting",
+    "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_tonemap", "vqhip_brdf_lut",
+    "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
+    "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
+]
+
+_TORCH_DTYPE = {FMT_RGBA32F: (torch.float32, 4), FMT_RGBA16F: (torch.float16, 4), FMT_RGBA8_UNORM: (torch.uint8, 4),
+                FMT_RG16F: (torch.float16, 2), FMT_RG32F: (torch.float32, 2)}
+
+
+def empty_image(h, w, fmt, device):
+    dt, ch = _TORCH_DTYPE[fmt]
+    return torch.empty((h, w, ch), dtype=dt, device=device)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _check_img(t, fmt, name):
+    dt, ch = _TORCH_DTYPE[fmt]
+    if not (t.is_cuda and t.is_contiguous() and t.dtype == dt and t.shape[-1] == ch):
+        raise ValueError(f"{name}: expected contiguous cuda tensor [...,{ch}] of {dt}, got {tuple(t.shape)} {t.dtype} {t.device}")
+
+
+class Context:
+    """One vqhip_ctx bound to one GPU. Calls enqueue on torch's current stream for that device."""
+
+    def __init__(self, device_ordinal=0):
+        self.lib = load_library()
+        self.device = torch.device("cuda", device_ordinal)
+        h = C.c_void_p()
+        rc = self.lib.vqhip_create(device_ordinal, C.byref(h))
+        if rc != 0:
+            raise VQHipError(rc, (self.lib.vqhip_last_error(None) or b"").decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vqhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self, stream=None):
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        return C.c_void_p(s.cuda_stream)
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise VQHipError(rc, (self.lib.vqhip_last_error(self._h) or b"").decode())
+
+    # ---- forward lighting (RenderSceneColor, SceneRendering.cpp:1619) --------------------------------------
+    def forward_lighting(self, gb, per_frame, per_view, out=None, out_fmt=FMT_RGBA16F, extra_point=None, env=None, shadow=None, stream=None):
+        """gb: tuple of 4 float32 cuda tensors [H,W,4] (gb0..gb3). env: abi.EnvMap or None. Returns out tensor."""
+        g0, g1, g2, g3 = gb
+        for i, g in enumerate(gb):
+            _check_img(g, FMT_RGBA32F, f"gb{i}")
+        h, w = g0.shape[0], g0.shape[1]
+        if out is None:
+            out = empty_image(h, w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out")
+        gbuf = abi.GBuffer(g0.data_ptr(), g1.data_ptr(), g2.data_ptr(), g3.data_ptr(), w, h, w)
+        n_extra = 0
+        extra_ptr = C.c_void_p(None)
+        if extra_point is not None and len(extra_point):
+            n_extra = len(extra_point)
+            extra_ptr = C.cast(extra_point, C.c_void_p)
+        rc = self.lib.vqhip_forward_lighting(self._h, self._stream(stream), C.byref(gbuf), C.byref(per_frame), C.byref(per_view),
+                                             extra_ptr, n_extra, C.byref(env) if env is not None else None,
+                                             C.byref(shadow) if shadow is not None else None, _ptr(out), out.shape[1], out_fmt)
+        self._ck(rc)
+        return out
+
+    # ---- post-process (RenderPostProcess, SceneRendering.cpp:2507) ------------------------------------------
+    def gaussian_blur(self, src, fmt, tmp=None, out=None, stream=None):
+        _check_img(src, fmt, "src")
+        h, w = src.shape[0], src.shape[1]
+        tmp = tmp if tmp is not None else torch.empty_like(src)
+        out = out if out is not None else torch.empty_like(src)
+        p = abi.BlurParams(w, h)
+        self._ck(self.lib.vqhip_gaussian_blur(self._h, self._stream(stream), _ptr(src), _ptr(tmp), _ptr(out), C.byref(p), fmt))
+        return out
+
+    def gaussian_blur_x(self, src, fmt, out=None, stream=None):
+        _check_img(src, fmt, "src")
+        out = out if out is not None else torch.empty_like(src)
+        p = abi.BlurParams(src.shape[1], src.shape[0])
+        self._ck(self.lib.vqhip_gaussian_blur_x(self._h, self._stream(stream), _ptr(src), _ptr(out), C.byref(p), fmt))
+        return out
+
+    def gaussian_blur_y(self, src, fmt, out=None, halo_top=None, halo_bottom=None, stream=None):
+        _check_img(src, fmt, "src")
+        out = out if out is not None else torch.empty_like(src)
+        rows = 0
+        for hh in (halo_top, halo_bottom):
+            if hh is not None:
+                _check_img(hh, fmt, "halo")
+                rows = hh.shape[0]
+        p = abi.BlurParams(src.shape[1], src.shape[0])
+        self._ck(self.lib.vqhip_gaussian_blur_y(self._h, self._stream(stream), _ptr(src), _ptr(out), _ptr(halo_top), _ptr(halo_bottom), rows, C.byref(p), fmt))
+        return out
+
+    def tonemap(self, src, in_fmt, out_fmt=FMT_RGBA8_UNORM, params=None, out=None, stream=None):
+        _check_img(src, in_fmt, "src")
+        h, w = src.shape[0], src.shape[1]
+        out = out if out is not None else empty_image(h, w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out")
+        params = params if params is not None else abi.TonemapperParams.default()
+        self._ck(self.lib.vqhip_tonemap(self._h, self._stream(stream), _ptr(src), _ptr(out), w, h, C.byref(params), in_fmt, out_fmt))
+        return out
+
+    # ---- load-time IBL (ComputeBRDFIntegrationLUT Renderer.cpp:871, PreFilterEnvironmentMap EnvironmentMapRendering.cpp:139)
+    def brdf_lut(self, size=1024, samples=2048, fmt=FMT_RG16F, stream=None):
+        out = empty_image(size, size, fmt, self.device)
+        self._ck(self.lib.vqhip_brdf_lut(self._h, self._stream(stream), _ptr(out), size, samples, fmt))
+        return out
+
+    def mip_chain(self, level0, stream=None):
+        """level0: float32 cuda [H,W,4]. Returns (flat float32 chain [px,4], n_mips) incl. level 0 (min-filter mips)."""
+        _check_img(level0, FMT_RGBA32F, "level0")
+        h, w = level0.shape[0], level0.shape[1]
+        n = abi.mip_level_count(w, h)
+        chain = torch.empty((abi.mip_chain_px(w, h, n), 4), dtype=torch.float32, device=self.device)
+        chain[: w * h].copy_(level0.reshape(-1, 4))
+        self._ck(self.lib.vqhip_mip_chain_min_rgba32f(self._h, self._stream(stream), _ptr(chain), w, h, n))
+        return chain, n
+
+    def conv_diffuse(self, chain, w0, h0, n_mips, res=64, step=0.010, order=CONV_WAVE64, fmt=FMT_RGBA16F, stream=None):
+        dt, ch = _TORCH_DTYPE[fmt]
+        out = torch.empty((6, res, res, ch), dtype=dt, device=self.device)
+        self._ck(self.lib.vqhip_conv_diffuse(self._h, self._stream(stream), _ptr(chain), w0, h0, n_mips, res, step, order, _ptr(out), fmt))
+        return out
+
+    def conv_specular(self, chain, w0, h0, n_mips, res0=128, order=CONV_WAVE64, fmt=FMT_RGBA16F, stream=None):
+        dt, ch = _TORCH_DTYPE[fmt]
+        mips = abi.specular_mip_count(res0)
+        out = torch.empty((abi.cube_px(res0, mips), ch), dtype=dt, device=self.device)
+        self._ck(self.lib.vqhip_conv_specular(self._h, self._stream(stream), _ptr(chain), w0, h0, n_mips, res0, order, _ptr(out), fmt))
+        return out, mips
+
+    def envmap_prefilter(self, chain, w0, h0, n_mips, diffuse_res=64, diffuse_step=0.010, spec_res0=128, order=CONV_WAVE64, stream=None):
+        """Returns dict(diffuse_unblurred, diffuse_blurred, specular, spec_mips) of float16 tensors (reference formats)."""
+        mips = abi.specular_mip_count(spec_res0)
+        d0 = torch.empty((6, diffuse_res, diffuse_res, 4), dtype=torch.float16, device=self.device)
+        d1 = torch.empty_like(d0)
+        tmp = torch.empty((diffuse_res, diffuse_res, 4), dtype=torch.float16, device=self.device)
+        sp = torch.empty((abi.cube_px(spec_res0, mips), 4), dtype=torch.float16, device=self.device)
+        o = abi.EnvMapOut(d0.data_ptr(), d1.data_ptr(), tmp.data_ptr(), sp.data_ptr())
+        self._ck(self.lib.vqhip_envmap_prefilter(self._h, self._stream(stream), _ptr(chain), w0, h0, n_mips, diffuse_res, diffuse_step,
+                                                 spec_res0, order, C.byref(o)))
+        return {"diffuse_unblurred": d0, "diffuse_blurred": d1, "specular": sp, "spec_mips": mips, "_tmp": tmp}
+
+
+def make_envmap(diffuse_cube, spec_cube, spec_res0, spec_mips, lut):
+    """abi.EnvMap over device tensors (keeps no references — the caller owns the tensors)."""
+    return abi.EnvMap(diffuse_cube.data_ptr(), diffuse_cube.shape[1], spec_cube.data_ptr(), spec_res0, spec_mips,
+                      lut.data_ptr(), lut.shape[0])

@@ -1,0 +1,322 @@
+// capi.hip — the C ABI of include/vqhip.h: argument validation, the per-call constant ring (the
+// analogue of the reference's DynamicBufferHeap upload heap) and kernel dispatch. There is no CPU
+// fallback anywhere in this library: without a gfx950 device vqhip_create() fails and every other
+// entry point needs a context.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "vq_internal.h"
+
+using namespace vqk;
+
+struct vqhip_ctx {
+    int device = 0;
+    static constexpr int kSlots = 32;
+    char* hostRing = nullptr;      // pinned
+    char* devRing = nullptr;
+    hipEvent_t slotEvent[kSlots] = {};
+    bool slotBusy[kSlots] = {};
+    int nextSlot = 0;
+    void* scratch = nullptr; size_t scratchBytes = 0;
+    std::string lastError;
+};
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(vqhip_ctx* ctx, int code, const std::string& msg) {
+    g_lastError = msg;
+    if (ctx) ctx->lastError = msg;
+    return code;
+}
+int failHip(vqhip_ctx* ctx, hipError_t e, const char* what) {
+    return fail(ctx, VQHIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return failHip(ctx, e_, #call); } while (0)
+
+bool isImageFmt(int f) { return f == VQHIP_FMT_RGBA32F || f == VQHIP_FMT_RGBA16F; }
+
+// Acquire the next constant-ring slot (waits for the kernel that last read it, if still in flight).
+int acquireSlot(vqhip_ctx* ctx, int* slot) {
+    const int s = ctx->nextSlot;
+    ctx->nextSlot = (s + 1) % vqhip_ctx::kSlots;
+    if (ctx->slotBusy[s]) { HIP_TRY(ctx, hipEventSynchronize(ctx->slotEvent[s])); ctx->slotBusy[s] = false; }
+    *slot = s;
+    return VQHIP_OK;
+}
+int commitSlot(vqhip_ctx* ctx, int slot, size_t bytes, hipStream_t st) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->devRing + (size_t)slot * kConstSlotBytes, ctx->hostRing + (size_t)slot * kConstSlotBytes, bytes, hipMemcpyHostToDevice, st));
+    return VQHIP_OK;
+}
+int releaseSlot(vqhip_ctx* ctx, int slot, hipStream_t st) {
+    HIP_TRY(ctx, hipEventRecord(ctx->slotEvent[slot], st));
+    ctx->slotBusy[slot] = true;
+    return VQHIP_OK;
+}
+
+int ensureScratch(vqhip_ctx* ctx, size_t bytes) {
+    if (ctx->scratchBytes >= bytes) return VQHIP_OK;
+    if (ctx->scratch) { HIP_TRY(ctx, hipDeviceSynchronize()); HIP_TRY(ctx, hipFree(ctx->scratch)); ctx->scratch = nullptr; ctx->scratchBytes = 0; }
+    HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratchBytes = bytes;
+    return VQHIP_OK;
+}
+
+int mipDim(int d0, int l) { int d = d0 >> l; return d < 1 ? 1 : d; }
+
+} // namespace
+
+extern "C" {
+
+int vqhip_abi_version(void) { return VQHIP_ABI_VERSION; }
+
+const char* vqhip_last_error(const vqhip_ctx* ctx) { return ctx ? ctx->lastError.c_str() : g_lastError.c_str(); }
+
+int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
+    if (!out_ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "vqhip_create: out_ctx is NULL");
+    *out_ctx = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, VQHIP_ERR_NO_DEVICE, "vqhip_create: no HIP device visible (this library has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= n) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "vqhip_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, VQHIP_ERR_NO_DEVICE, std::string("vqhip_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    HIP_TRY(nullptr, hipSetDevice(device_ordinal));
+    vqhip_ctx* ctx = new vqhip_ctx();
+    ctx->device = device_ordinal;
+    const size_t ringBytes = kConstSlotBytes * vqhip_ctx::kSlots;
+    if ((e = hipHostMalloc((void**)&ctx->hostRing, ringBytes, hipHostMallocDefault)) != hipSuccess ||
+        (e = hipMalloc((void**)&ctx->devRing, ringBytes)) != hipSuccess) {
+        int rc = failHip(nullptr, e, "vqhip_create: constant ring allocation");
+        vqhip_destroy(ctx);
+        return rc;
+    }
+    for (int i = 0; i < vqhip_ctx::kSlots; ++i)
+        if ((e = hipEventCreateWithFlags(&ctx->slotEvent[i], hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "hipEventCreate"); vqhip_destroy(ctx); return rc; }
+    *out_ctx = ctx;
+    return VQHIP_OK;
+}
+
+void vqhip_destroy(vqhip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < vqhip_ctx::kSlots; ++i) if (ctx->slotEvent[i]) (void)hipEventDestroy(ctx->slotEvent[i]);
+    if (ctx->hostRing) (void)hipHostFree(ctx->hostRing);
+    if (ctx->devRing) (void)hipFree(ctx->devRing);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    delete ctx;
+}
+
+int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb,
+        const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+        const VQ_PointLight* extraPoint, int numExtraPoint,
+        const vqhip_envmap* env, const vqhip_shadowmaps* sm,
+        void* out, int out_row_pitch_px, vqhip_format outFmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "forward_lighting: ctx is NULL");
+    if (!gb || !perFrame || !perView || !out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: NULL argument");
+    if (!gb->gb0 || !gb->gb1 || !gb->gb2 || !gb->gb3) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: NULL G-buffer plane");
+    if (gb->width <= 0 || gb->height <= 0 || gb->row_pitch_px < gb->width || out_row_pitch_px < gb->width)
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: bad dimensions / pitch");
+    if (!isImageFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "forward_lighting: outFmt must be RGBA32F or RGBA16F");
+    const VQ_SceneLighting& L = perFrame->Lights;
+    if (L.numPointLights < 0 || L.numPointLights > VQ_NUM_LIGHTS__POINT || L.numSpotLights < 0 || L.numSpotLights > VQ_NUM_LIGHTS__SPOT ||
+        L.numPointCasters < 0 || L.numPointCasters > VQ_NUM_SHADOWING_LIGHTS__POINT || L.numSpotCasters < 0 || L.numSpotCasters > VQ_NUM_SHADOWING_LIGHTS__SPOT)
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: light count exceeds the cbuffer array (LightingConstantBufferData.h:39-44)");
+    if (numExtraPoint < 0 || numExtraPoint > kMaxExtraPointLights || (numExtraPoint > 0 && !extraPoint))
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: bad extraPoint / numExtraPoint");
+    const bool casters = L.numPointCasters > 0 || L.numSpotCasters > 0 || (L.directional.enabled && L.directional.shadowing);
+    if (casters) {
+        if (!sm) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: shadow casters present but sm is NULL");
+        if ((L.numPointCasters > 0 && (!sm->point || sm->point_dim <= 0)) || (L.numSpotCasters > 0 && (!sm->spot || sm->spot_dim <= 0)) ||
+            (L.directional.enabled && L.directional.shadowing && (!sm->directional || sm->dir_dim <= 0)))
+            return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: missing shadow map for a caster");
+    }
+    if (env) {
+        if (!env->diffuse_cube || env->diffuse_res <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: env->diffuse_cube missing");
+        if (!perView->EnvironmentMapDiffuseOnlyIllumination &&
+            (!env->specular_cube || env->spec_res0 <= 0 || env->spec_mips <= 0 || (env->spec_res0 >> (env->spec_mips - 1)) < 1 || !env->brdf_lut || env->lut_size <= 0))
+            return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: env specular cube / BRDF LUT missing");
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int slot;
+    int rc = acquireSlot(ctx, &slot);
+    if (rc) return rc;
+    FrameConstants* fc = (FrameConstants*)(ctx->hostRing + (size_t)slot * kConstSlotBytes);
+    std::memset(fc, 0, sizeof(FrameConstants));
+    fc->perFrame = *perFrame;
+    fc->perView = *perView;
+    if (env) fc->env = *env;
+    if (sm) fc->sm = *sm;
+    fc->hasEnv = env ? 1 : 0;
+    fc->numExtraPoint = numExtraPoint;
+    if (numExtraPoint) std::memcpy(fc + 1, extraPoint, (size_t)numExtraPoint * sizeof(VQ_PointLight));
+    rc = commitSlot(ctx, slot, sizeof(FrameConstants) + (size_t)numExtraPoint * sizeof(VQ_PointLight), st);
+    if (rc) return rc;
+    ShadeArgs a;
+    a.gb0 = (const float4*)gb->gb0; a.gb1 = (const float4*)gb->gb1; a.gb2 = (const float4*)gb->gb2; a.gb3 = (const float4*)gb->gb3;
+    a.out = out;
+    a.fc = (const FrameConstants*)(ctx->devRing + (size_t)slot * kConstSlotBytes);
+    a.width = gb->width; a.height = gb->height; a.pitch = gb->row_pitch_px; a.outPitch = out_row_pitch_px;
+    hipError_t e = launch_forward_lighting(st, a, env != nullptr, casters, outFmt);
+    if (e != hipSuccess) return failHip(ctx, e, "forward_lighting launch");
+    return releaseSlot(ctx, slot, st);
+}
+
+int vqhip_gaussian_blur_x(vqhip_ctx* ctx, void* stream, const void* in, void* out, const VQ_BlurParams* p, vqhip_format fmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur_x: ctx is NULL");
+    if (!in || !out || !p || p->iImageSizeX <= 0 || p->iImageSizeY <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_x: bad argument");
+    if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_x: fmt must be RGBA32F or RGBA16F");
+    if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_x: in-place blur is not supported");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_blur_x((hipStream_t)stream, in, out, p->iImageSizeX, p->iImageSizeY, fmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "blur_x launch");
+}
+
+int vqhip_gaussian_blur_y(vqhip_ctx* ctx, void* stream, const void* in, void* out, const void* halo_top, const void* halo_bottom, int halo_rows,
+                          const VQ_BlurParams* p, vqhip_format fmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y: ctx is NULL");
+    if (!in || !out || !p || p->iImageSizeX <= 0 || p->iImageSizeY <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y: bad argument");
+    if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_y: fmt must be RGBA32F or RGBA16F");
+    if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y: in-place blur is not supported");
+    if ((halo_top || halo_bottom) && halo_rows < 10) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y: halo_rows must be >= 10 (KERNEL_RANGE-1)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_blur_y((hipStream_t)stream, in, out, halo_top, halo_bottom, halo_rows, p->iImageSizeX, p->iImageSizeY, fmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "blur_y launch");
+}
+
+int vqhip_gaussian_blur(vqhip_ctx* ctx, void* stream, const void* in, void* tmp, void* out, const VQ_BlurParams* p, vqhip_format fmt) {
+    if (!tmp) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur: tmp is NULL");
+    int rc = vqhip_gaussian_blur_x(ctx, stream, in, tmp, p, fmt);
+    if (rc) return rc;
+    return vqhip_gaussian_blur_y(ctx, stream, tmp, out, nullptr, nullptr, 0, p, fmt);
+}
+
+int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
+                  const VQ_TonemapperParams* p, vqhip_format inFmt, vqhip_format outFmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "tonemap: ctx is NULL");
+    if (!in || !out || !p || width <= 0 || height <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "tonemap: bad argument");
+    if (!isImageFmt(inFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "tonemap: inFmt must be RGBA32F or RGBA16F");
+    if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "tonemap: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_tonemap((hipStream_t)stream, in, out, width, height, *p, inFmt, outFmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "tonemap launch");
+}
+
+int vqhip_brdf_lut(vqhip_ctx* ctx, void* stream, void* outRG, int size, int samples, vqhip_format fmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "brdf_lut: ctx is NULL");
+    if (!outRG || size <= 0 || samples <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "brdf_lut: bad argument");
+    if (fmt != VQHIP_FMT_RG16F && fmt != VQHIP_FMT_RG32F) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "brdf_lut: fmt must be RG16F or RG32F");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_brdf_lut((hipStream_t)stream, outRG, size, samples, fmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "brdf_lut launch");
+}
+
+int vqhip_mip_level_count(int w, int h) { int m = w > h ? w : h; if (m < 1) return 0; int n = 1; while (m > 1) { m >>= 1; ++n; } return n; }
+size_t vqhip_mip_level_offset_bytes(int w0, int h0, int level) {
+    size_t off = 0;
+    for (int l = 0; l < level; ++l) off += (size_t)mipDim(w0, l) * mipDim(h0, l) * 16;
+    return off;
+}
+size_t vqhip_mip_chain_bytes(int w0, int h0, int nMips) { return vqhip_mip_level_offset_bytes(w0, h0, nMips); }
+
+int vqhip_mip_chain_min_rgba32f(vqhip_ctx* ctx, void* stream, void* mips, int w0, int h0, int nMips) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "mip_chain: ctx is NULL");
+    if (!mips || w0 <= 0 || h0 <= 0 || nMips <= 0 || nMips > vqhip_mip_level_count(w0, h0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "mip_chain: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int l = 1; l < nMips; ++l) {
+        const float4* src = (const float4*)((const char*)mips + vqhip_mip_level_offset_bytes(w0, h0, l - 1));
+        float4* dst = (float4*)((char*)mips + vqhip_mip_level_offset_bytes(w0, h0, l));
+        hipError_t e = launch_mip_min((hipStream_t)stream, src, dst, mipDim(w0, l - 1), mipDim(h0, l - 1), mipDim(w0, l), mipDim(h0, l));
+        if (e != hipSuccess) return failHip(ctx, e, "mip_min launch");
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_specular_mip_count(int spec_res0) { return vqhip_mip_level_count(spec_res0, spec_res0) - 1; }
+size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt) {
+    const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;
+    size_t px = 0;
+    for (int m = 0; m < nMips; ++m) { size_t r = (size_t)(res0 >> m); px += 6 * r * r; }
+    return px * bpp;
+}
+
+static int checkChain(vqhip_ctx* ctx, const void* chain, int w0, int h0, int nMips, const char* who) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, std::string(who) + ": ctx is NULL");
+    if (!chain || w0 <= 0 || h0 <= 0 || nMips <= 0 || nMips > vqhip_mip_level_count(w0, h0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, std::string(who) + ": bad equirect chain");
+    return VQHIP_OK;
+}
+
+int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
+                       int diffuseRes, float step, vqhip_conv_order order, void* outCube, vqhip_format fmt) {
+    int rc = checkChain(ctx, equirect_mips, w0, h0, nMips, "conv_diffuse");
+    if (rc) return rc;
+    if (!outCube || diffuseRes <= 0 || !(step > 0.0f)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_diffuse: bad argument");
+    if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_diffuse: fmt must be RGBA32F or RGBA16F");
+    if (order != VQHIP_CONV_SEQUENTIAL && order != VQHIP_CONV_WAVE64) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_diffuse: bad order");
+    // fp32 sequences of `for (phi = 0; phi < TWO_PI; phi += step)` / `for (theta = 0; theta < PI_OVER_TWO; theta += step)`
+    // (CubemapConvolution.hlsl:132-136): plain IEEE adds, identical on any host.
+    const size_t maxFloats = kConstSlotBytes / sizeof(float);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int slot;
+    rc = acquireSlot(ctx, &slot);
+    if (rc) return rc;
+    float* tab = (float*)(ctx->hostRing + (size_t)slot * kConstSlotBytes);
+    size_t n = 0; int nPhi = 0, nTheta = 0;
+    for (float phi = 0.0f; phi < 6.28318530718f; phi += step) { if (n >= maxFloats) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_diffuse: step too small"); tab[n++] = phi; ++nPhi; }
+    for (float th = 0.0f; th < 1.5707963268f; th += step) { if (n >= maxFloats) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_diffuse: step too small"); tab[n++] = th; ++nTheta; }
+    if ((size_t)nTheta * 2 * sizeof(float) > 60 * 1024) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_diffuse: step too small for the LDS theta table");
+    rc = commitSlot(ctx, slot, n * sizeof(float), st);
+    if (rc) return rc;
+    const float* dtab = (const float*)(ctx->devRing + (size_t)slot * kConstSlotBytes);
+    hipError_t e = launch_conv_diffuse_tables(st, (const float4*)equirect_mips, w0, h0, nMips, diffuseRes, dtab, nPhi, dtab + nPhi, nTheta, order, outCube, fmt);
+    if (e != hipSuccess) return failHip(ctx, e, "conv_diffuse launch");
+    return releaseSlot(ctx, slot, st);
+}
+
+int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
+                        int specRes0, vqhip_conv_order order, void* outCubeMips, vqhip_format fmt) {
+    int rc = checkChain(ctx, equirect_mips, w0, h0, nMips, "conv_specular");
+    if (rc) return rc;
+    const int MIPS = vqhip_specular_mip_count(specRes0);
+    if (!outCubeMips || specRes0 < 4 || (specRes0 & (specRes0 - 1)) || MIPS < 2) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_specular: specRes0 must be a power of two >= 4");
+    if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_specular: fmt must be RGBA32F or RGBA16F");
+    if (order != VQHIP_CONV_SEQUENTIAL && order != VQHIP_CONV_WAVE64) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_specular: bad order");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;
+    size_t off = 0;
+    for (int mip = 0; mip < MIPS; ++mip) {                                   // EnvironmentMapRendering.cpp:413-464
+        const int r = specRes0 >> mip;
+        hipError_t e = launch_conv_specular((hipStream_t)stream, (const float4*)equirect_mips, w0, h0, nMips, r, mip, MIPS, order, (char*)outCubeMips + off, fmt);
+        if (e != hipSuccess) return failHip(ctx, e, "conv_specular launch");
+        off += (size_t)6 * r * r * bpp;
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_envmap_prefilter(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
+                           int diffuseRes, float diffuseStep, int specRes0, vqhip_conv_order order, const vqhip_envmap_out* out) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "envmap_prefilter: ctx is NULL");
+    if (!out || !out->diffuse_blurred || !out->blur_tmp || !out->specular) return fail(ctx, VQHIP_ERR_INVALID_ARG, "envmap_prefilter: missing output buffer");
+    void* diff = out->diffuse_unblurred;
+    const size_t faceBytes = (size_t)diffuseRes * diffuseRes * 8;
+    if (!diff) { int rc = ensureScratch(ctx, 6 * faceBytes); if (rc) return rc; diff = ctx->scratch; }
+    int rc = vqhip_conv_diffuse(ctx, stream, equirect_mips, w0, h0, nMips, diffuseRes, diffuseStep, order, diff, VQHIP_FMT_RGBA16F);   // :181-277
+    if (rc) return rc;
+    VQ_BlurParams bp = { diffuseRes, diffuseRes };
+    for (int face = 0; face < 6; ++face) {                                   // :279-373
+        rc = vqhip_gaussian_blur_x(ctx, stream, (const char*)diff + face * faceBytes, out->blur_tmp, &bp, VQHIP_FMT_RGBA16F);
+        if (rc) return rc;
+        rc = vqhip_gaussian_blur_y(ctx, stream, out->blur_tmp, (char*)out->diffuse_blurred + face * faceBytes, nullptr, nullptr, 0, &bp, VQHIP_FMT_RGBA16F);
+        if (rc) return rc;
+    }
+    return vqhip_conv_specular(ctx, stream, equirect_mips, w0, h0, nMips, specRes0, order, out->specular, VQHIP_FMT_RGBA16F);             // :386-472
+}
+
+} // extern "C"

@@ -1,0 +1,289 @@
+// shade.hip — forward-PBR lighting kernel for gfx950: ForwardLighting.hlsl:PSMain :289-380 evaluated per
+// G-buffer pixel. One lane per pixel, 256-lane workgroups, float4 SoA plane
+// loads (16 B/lane, fully coalesced), light records read through the scalar cache (wave-uniform index),
+// all light-invariant terms of BRDF() hoisted out of the light loops without changing a single rounding.
+//
+// Arithmetic follows the contract in vq_devmath.h / DESIGN.md; expression order mirrors the HLSL:
+//   Shaders/BRDF.hlsl:65-79,82-97,118-121,132-136,152-161,163-207
+//   Shaders/Lighting.hlsl:29-32,57-73,110-174,177-272,308-395
+//   Shaders/ForwardLighting.hlsl:284-380
+#include "vq_internal.h"
+#include "vq_devmath.h"
+#include "vq_sampling.h"
+
+using namespace vqd;
+
+namespace {
+
+constexpr float PI_      = 3.14159265359f;    // ShadingMath.hlsl:25
+constexpr float EPSILON_ = 0.000000000001f;   // BRDF.hlsl:21
+
+// Per-pixel state: BRDF_Surface (BRDF.hlsl:50-58) + everything in BRDF() that does not depend on the light.
+struct Pixel {
+    f3 P, V, Wo, Nraw, Nn, albedo, F0, omF0;
+    float roughness, metalness, omm;      // omm = 1 - metalness
+    float NdotV4;                         // 4 * saturate(dot(N, Wo))
+    float G1V;                            // Geometry_Smiths_SchlickGGX(N, Wo, roughness)
+    float k, omk;                         // k = (roughness+1)^2/8, omk = 1-k
+    float a2, a2m1;                       // GGX alpha^2, alpha^2 - 1
+    float invPI;
+};
+
+VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
+
+VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
+    px.P = mk3(g0.x, g0.y, g0.z);
+    px.Nraw = mk3(g1.x, g1.y, g1.z);
+    px.roughness = g1.w;
+    px.albedo = mk3(g2.x, g2.y, g2.z);
+    px.metalness = g2.w;
+    px.V = normalize(sub(cam, px.P));                        // ForwardLighting.hlsl:285
+    px.Wo = normalize(px.V);                                 // BRDF.hlsl:166
+    px.Nn = normalize(px.Nraw);                              // :167
+    px.F0 = mk3(lerp(0.04f, px.albedo.x, px.metalness), lerp(0.04f, px.albedo.y, px.metalness), lerp(0.04f, px.albedo.z, px.metalness));   // :178
+    px.omF0 = mk3(1.0f - px.F0.x, 1.0f - px.F0.y, 1.0f - px.F0.z);
+    px.omm = 1.0f - px.metalness;
+    const float NdotV = saturate(dot(px.Nn, px.Wo));         // :171
+    px.NdotV4 = 4.0f * NdotV;
+    const float rp1 = px.roughness + 1.0f;                   // Geometry_Smiths_SchlickGGX :92-96
+    px.k = div_(rp1 * rp1, 8.0f);
+    px.omk = 1.0f - px.k;
+    const float NV = max_(0.0f, dot(px.Nn, px.Wo));
+    px.G1V = div_(NV, (NV * px.omk + px.k) + 0.0001f);
+    const float a = px.roughness * px.roughness;             // NormalDistributionGGX :74-75
+    px.a2 = a * a;
+    px.a2m1 = px.a2 - 1.0f;
+    px.invPI = rcp(PI_);
+}
+
+// BRDF(s, Wi, V), BRDF.hlsl:163-194, with the hoisted terms of `px`
+VQD f3 brdf(const Pixel& px, f3 Wi) {
+    const f3 H = normalize(add(px.Wo, Wi));
+    const float NdotH = saturate(dot(px.Nn, H));
+    const float dNL = dot(px.Nn, Wi);
+    const float NdotL = saturate(dNL);
+    // Fresnel_Schlick(H, V, F0) :132-136
+    const float p5 = pow_(1.0f - max_(0.0f, dot(H, px.V)), 5.0f);
+    const f3 F = mk3(px.F0.x + px.omF0.x * p5, px.F0.y + px.omF0.y * p5, px.F0.z + px.omF0.z * p5);
+    // Geometry_Smith :118-121
+    const float NL = max_(0.0f, dNL);
+    const float G = px.G1V * div_(NL, (NL * px.omk + px.k) + 0.0001f);
+    // NormalDistributionGGX :65-79
+    const float nh2 = NdotH * NdotH;
+    const float t = nh2 * px.a2m1 + 1.0f;
+    const float dd = PI_ * (t * t);
+    const float D = (dd < EPSILON_) ? 1.0f : div_(px.a2, dd);
+    const float rd = rcp(max_(px.NdotV4 * NdotL, 0.0001f));
+    const f3 spec = mk3(((D * F.x) * G) * rd, ((D * F.y) * G) * rd, ((D * F.z) * G) * rd);
+    const f3 kD = mk3((1.0f - F.x) * px.omm, (1.0f - F.y) * px.omm, (1.0f - F.z) * px.omm);
+    const f3 Id = mk3((kD.x * px.albedo.x) * px.invPI, (kD.y * px.albedo.y) * px.invPI, (kD.z * px.albedo.z) * px.invPI);
+    return add(Id, spec);
+}
+
+// CalculatePointLightIllumination, Lighting.hlsl:308-322
+VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {
+    const f3 d = sub(ld3(l.position), px.P);
+    const float D = sqrt_(dot(d, d));                        // length(Lw - P); normalize() shares the sqrt
+    const f3 Wi = mul(d, rcp(D));
+    f3 r = mk3(0.0f, 0.0f, 0.0f);
+    if (D < l.range) {
+        const float NdotL = saturate(dot(px.Nraw, Wi));
+        const float att = rcp(D * D);                        // AttenuationBRDF :29-32
+        const f3 radiance = mk3((att * l.color.x) * l.brightness, (att * l.color.y) * l.brightness, (att * l.color.z) * l.brightness);
+        const f3 b = brdf(px, Wi);
+        r = mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
+    }
+    return r;
+}
+
+// SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333
+VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l) {
+    const f3 d = sub(ld3(l.position), px.P);
+    const float D = sqrt_(dot(d, d));
+    const f3 Wi = mul(d, rcp(D));
+    const f3 pd = normalize(sub(px.P, ld3(l.position)));
+    const f3 sd = normalize(ld3(l.spotDir));
+    const float theta = acos_(dot(pd, sd));
+    float cone;
+    if (theta > l.outerConeAngle) cone = 0.0f;
+    else if (theta <= l.innerConeAngle) cone = 1.0f;
+    else cone = 1.0f - div_(theta - l.innerConeAngle, l.outerConeAngle - l.innerConeAngle);
+    const float att = rcp(D * D);
+    const f3 radiance = mk3(((cone * l.color.x) * l.brightness) * att, ((cone * l.color.y) * l.brightness) * att, ((cone * l.color.z) * l.brightness) * att);
+    const float NdotL = saturate(dot(px.Nraw, Wi));
+    const f3 b = brdf(px, Wi);
+    return mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
+}
+
+// CalculateDirectionalLightIllumination :334-345
+VQD f3 directional_light(const Pixel& px, const VQ_DirectionalLight& l) {
+    const f3 Wi = normalize(neg(ld3(l.lightDirection)));
+    const f3 radiance = mk3(l.color.x * l.brightness, l.color.y * l.brightness, l.color.z * l.brightness);
+    const float NdotL = saturate(dot(px.Nraw, Wi));
+    const f3 b = brdf(px, Wi);
+    return mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
+}
+
+VQD f3 mul_v_m3(f3 v, float c, float s) {     // mul(v, GetHDRIRotationMatrix) with m = {c,0,s; 0,1,0; -s,0,c}
+    return mk3(fma_(v.z, -s, fma_(v.y, 0.0f, v.x * c)),
+               fma_(v.z, 0.0f, fma_(v.y, 1.0f, v.x * 0.0f)),
+               fma_(v.z, c, fma_(v.y, 0.0f, v.x * s)));
+}
+
+// CalculateEnvironmentMapIllumination(+_DiffuseOnly), Lighting.hlsl:348-395 ; EnvironmentBRDF BRDF.hlsl:196-207
+VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
+    float sn, cs;
+    sincos_(-fc->perFrame.fHDRIOffsetInRadians, &sn, &cs);
+    const float NdotV = saturate(dot(px.Nraw, px.V));
+    const f3 N = mul_v_m3(px.Nraw, cs, sn);
+    const float4 irr = sample_cube_rgba16f(fc->env.diffuse_cube, fc->env.diffuse_res, N);
+    f3 spec = mk3(0, 0, 0); float2 sb = make_float2(0, 0);
+    if (!fc->perView.EnvironmentMapDiffuseOnlyIllumination) {
+        const f3 R = mul_v_m3(reflect(neg(px.V), px.Nraw), cs, sn);
+        const int maxLod = f2i_trunc(fc->perView.MaxEnvMapLODLevels);
+        int mip = f2i_trunc(px.roughness * (float)maxLod);
+        mip = min(max(mip, 0), fc->env.spec_mips - 1);
+        size_t off = 0;
+        for (int m = 0; m < mip; ++m) { size_t r = (size_t)(fc->env.spec_res0 >> m); off += 6 * r * r; }
+        const float4 sp = sample_cube_rgba16f((const h4*)fc->env.specular_cube + off, fc->env.spec_res0 >> mip, R);
+        spec = mk3(sp.x, sp.y, sp.z);
+        sb = sample_2d_rg16f_clamp(fc->env.brdf_lut, fc->env.lut_size, fc->env.lut_size, NdotV, px.roughness);
+    }
+    const float p5 = pow_(1.0f - NdotV, 5.0f);                                  // FresnelWithRoughness :152-156
+    const float omr = 1.0f - px.roughness;
+    const f3 Ks = mk3(px.F0.x + (max_(omr, px.F0.x) - px.F0.x) * p5, px.F0.y + (max_(omr, px.F0.y) - px.F0.y) * p5, px.F0.z + (max_(omr, px.F0.z) - px.F0.z) * p5);
+    const f3 Kd = mk3((1.0f - Ks.x) * px.omm, (1.0f - Ks.y) * px.omm, (1.0f - Ks.z) * px.omm);
+    const f3 diffuse = mk3(irr.x * px.albedo.x, irr.y * px.albedo.y, irr.z * px.albedo.z);
+    const f3 specular = mk3(spec.x * (Ks.x * sb.x + sb.y), spec.y * (Ks.y * sb.x + sb.y), spec.z * (Ks.z * sb.x + sb.y));
+    return mk3(Kd.x * diffuse.x + specular.x, Kd.y * diffuse.y + specular.y, Kd.z * diffuse.z + specular.z);
+}
+
+VQD float4 mul_M_v(const VQ_matrix& M, f3 P) {     // HLSL mul(M, float4(P,1)) == row vector * M_cpu
+    float o[4];
+    for (int j = 0; j < 4; ++j) o[j] = fma_(1.0f, M.m[3][j], fma_(P.z, M.m[2][j], fma_(P.y, M.m[1][j], P.x * M.m[0][j])));
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// SAMPLE_OFFSET_DIRS_NORMALIZED, Lighting.hlsl:123-131
+#define PA 0.5773502691896258f
+#define PB 0.7071067811865475f
+__device__ const float DX[20] = {  PA,  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PB,  PB, -PB, -PB,  PB, -PB,  PB, -PB,  0,  0,  0,  0 };
+__device__ const float DY[20] = {  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PA,  PB, -PB, -PB,  PB,  0,  0,  0,  0,  PB, -PB, -PB,  PB };
+__device__ const float DZ[20] = {  PA,  PA,  PA,  PA, -PA, -PA, -PA, -PA,  0,  0,  0,  0,  PB,  PB, -PB, -PB,  PB,  PB, -PB, -PB };
+#undef PA
+#undef PB
+// OmnidirectionalShadowTestPCF, Lighting.hlsl:110-174
+VQD float omni_pcf(const float* cubeArr, int dim, int index, f3 Lw, float farPlane, float depthBias, float viewDist) {
+    const float diskRadius = (1.0f + div_(viewDist, farPlane)) * 0.125f;
+    const float* cube = cubeArr + (size_t)index * 6 * dim * dim;
+    const float lenLw = length(Lw);
+    float shadow = 0.0f;
+    for (int i = 0; i < 20; ++i) {
+        const f3 sv = mk3(-(Lw.x + DX[i] * diskRadius), -(Lw.y + DY[i] * diskRadius), -(Lw.z + DZ[i] * diskRadius));
+        const float closest = fetch_cube_point(cube, dim, sv) * farPlane;
+        shadow += (lenLw > (closest + depthBias) + 0.001f) ? 1.0f : 0.0f;
+    }
+    return 1.0f - div_(shadow, 20.0f);
+}
+// ShadowTestPCF :177-218 (useTanBias) / ShadowTestPCF_Directional :222-272 (raw bias)
+VQD float pcf_2d(const float* slice, int dim, float2 smDims, float4 lsp, float bias) {
+    const float rw = rcp(lsp.w);
+    const f3 p = mk3(lsp.x * rw, lsp.y * rw, lsp.z * rw);
+    if (p.x < -1.0f || p.x > 1.0f || p.y < -1.0f || p.y > 1.0f || p.z < 0.0f || p.z > 1.0f) return 0.0f;
+    const float tx = rcp(smDims.x), ty = rcp(smDims.y);
+    const float u = 0.5f + p.x * 0.5f, v = 0.5f + p.y * -0.5f;
+    const float ref = p.z - bias;
+    float shadow = 0.0f;
+    for (int x = -2; x <= 2; ++x)
+        for (int y = -2; y <= 2; ++y) {
+            const float closest = fetch_point_wrap(slice, dim, u + (float)x * tx, v + (float)y * ty);
+            shadow += (ref > closest) ? 1.0f : 0.0f;
+        }
+    return 1.0f - div_(shadow, 25.0f);
+}
+
+template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT>
+__global__ __launch_bounds__(256) void k_forward_lighting(vqk::ShadeArgs a) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= a.width) return;
+    const size_t i = (size_t)y * a.pitch + x;
+    const float4 g0 = a.gb0[i], g1 = a.gb1[i], g2 = a.gb2[i], g3 = a.gb3[i];
+    const vqk::FrameConstants* fc = a.fc;
+
+    Pixel px;
+    const f3 cam = ld3(fc->perView.CameraPosition);
+    setup_pixel(px, g0, g1, g2, cam);
+    const float ao = g0.w;
+    // illumination accumulators, ForwardLighting.hlsl:290-293
+    f3 I = mk3(px.albedo.x * ao + g3.x * g3.w, px.albedo.y * ao + g3.y * g3.w, px.albedo.z * ao + g3.z * g3.w);
+
+    if (HAS_ENV) I = add(I, environment(px, fc));                                             // :299-306
+
+    const VQ_SceneLighting& L = fc->perFrame.Lights;
+    const int nP = L.numPointLights;
+    for (int p = 0; p < nP; ++p) I = add(I, point_light(px, L.point_lights[p]));              // :310-313
+    const int nE = fc->numExtraPoint;
+    const VQ_PointLight* extra = (const VQ_PointLight*)(fc + 1);
+    for (int p = 0; p < nE; ++p) I = add(I, point_light(px, extra[p]));                       // extension, vqhip.h
+    const int nS = L.numSpotLights;
+    for (int s = 0; s < nS; ++s) I = add(I, spot_light(px, L.spot_lights[s]));                // :314-317
+
+    if (HAS_CASTERS) {
+        const int nPC = L.numPointCasters;
+        for (int pc = 0; pc < nPC; ++pc) {                                                    // :321-339
+            const VQ_PointLight& l = L.point_casters[pc];
+            const f3 Lw = sub(ld3(l.position), px.P);
+            const float D = length(Lw);
+            if (D < l.range) {
+                const float viewDist = length(sub(px.P, cam));
+                const f3 c = point_light(px, l);
+                const float sh = omni_pcf(fc->sm.point, fc->sm.point_dim, pc, Lw, l.range, l.depthBias, viewDist);
+                I = mk3(I.x + c.x * sh, I.y + c.y * sh, I.z + c.z * sh);
+            }
+        }
+        const int nSC = L.numSpotCasters;
+        for (int sc = 0; sc < nSC; ++sc) {                                                    // :342-356
+            const VQ_SpotLight& l = L.spot_casters[sc];
+            const f3 Ln = normalize(sub(ld3(l.position), px.P));
+            const float NdotL = saturate(dot(px.Nraw, Ln));
+            const float4 lsp = mul_M_v(L.shadowViews[sc], px.P);
+            const f3 c = spot_light(px, l);
+            const float bias = l.depthBias * tan_(acos_(NdotL));
+            const float sh = pcf_2d(fc->sm.spot + (size_t)sc * fc->sm.spot_dim * fc->sm.spot_dim, fc->sm.spot_dim,
+                                    make_float2(fc->perFrame.f2SpotLightShadowMapDimensions.x, fc->perFrame.f2SpotLightShadowMapDimensions.y), lsp, bias);
+            I = mk3(I.x + c.x * sh, I.y + c.y * sh, I.z + c.z * sh);
+        }
+    }
+    {                                                                                         // :360-377
+        const VQ_DirectionalLight& l = L.directional;
+        if (l.enabled) {
+            float sh = 1.0f;
+            if (HAS_CASTERS && l.shadowing) {
+                const float4 lsp = mul_M_v(L.shadowViewDirectional, px.P);
+                sh = pcf_2d(fc->sm.directional, fc->sm.dir_dim,
+                            make_float2(fc->perFrame.f2DirectionalLightShadowMapDimensions.x, fc->perFrame.f2DirectionalLightShadowMapDimensions.y), lsp, l.depthBias);
+            }
+            const f3 c = directional_light(px, l);
+            I = mk3(I.x + c.x * sh, I.y + c.y * sh, I.z + c.z * sh);
+        }
+    }
+    store_px<OUTFMT>(a.out, (size_t)y * a.outPitch + x, make_float4(I.x, I.y, I.z, px.roughness));   // :380
+}
+
+template <bool E, bool C>
+hipError_t launch_fmt(hipStream_t s, const vqk::ShadeArgs& a, int outFmt, dim3 grid) {
+    if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_forward_lighting<E, C, 0>), grid, dim3(256), 0, s, a);
+    else                             hipLaunchKernelGGL((k_forward_lighting<E, C, 1>), grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+namespace vqk {
+hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt) {
+    dim3 grid((a.width + 255) / 256, a.height);
+    if (hasEnv) return hasCasters ? launch_fmt<true, true>(s, a, outFmt, grid) : launch_fmt<true, false>(s, a, outFmt, grid);
+    return hasCasters ? launch_fmt<false, true>(s, a, outFmt, grid) : launch_fmt<false, false>(s, a, outFmt, grid);
+}
+} // namespace vqk

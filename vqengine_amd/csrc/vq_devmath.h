@@ -1,0 +1,222 @@
+// vq_devmath.h — device-side float32 arithmetic of the vqhip kernels (gfx950).
+//
+// The kernels are bit-exact against the CPU oracle, which is only possible if every HLSL intrinsic is
+// lowered to operations that both a CPU and CDNA4 evaluate identically: IEEE add/sub/mul/fma,
+// correctly rounded 1/x and sqrt, and explicit polynomial kernels for the transcendentals (the
+// hardware v_exp/v_log/v_sin/v_rcp/v_rsq approximations are NOT used on value paths: their bits
+// are not reproducible off-chip). The lowering table is specified in DESIGN.md §"Arithmetic
+// contract"; this file is the product's own implementation of it (it does not include or link
+// anything from oracle/). Build flags that matter: -ffp-contract=off (no implicit FMA) and
+// -fhip-fp32-correctly-rounded-divide-sqrt (the hipcc default).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vqd {
+
+#define VQD __device__ __forceinline__
+
+VQD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+VQD float rcp(float b)   { return 1.0f / b; }               // correctly rounded reciprocal
+VQD float sqrt_(float x) { return __builtin_sqrtf(x); }     // correctly rounded
+VQD float rsqrt(float x) { return rcp(sqrt_(x)); }
+VQD float div_(float a, float b) { return a * rcp(b); }     // HLSL a / b
+VQD float max_(float a, float b) { return __builtin_fmaxf(a, b); }
+VQD float min_(float a, float b) { return __builtin_fminf(a, b); }
+VQD float saturate(float x) { return (x > 0.0f) ? ((x < 1.0f) ? x : 1.0f) : 0.0f; }   // NaN -> 0
+VQD float abs_(float x) { return __builtin_fabsf(x); }
+VQD float qnan() { return __uint_as_float(0x7fc00000u); }
+
+struct f3 { float x, y, z; };
+VQD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+VQD f3 add(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+VQD f3 sub(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+VQD f3 mul(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+VQD f3 mul(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+VQD f3 neg(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+VQD float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+VQD f3 normalize(f3 v) { return mul(v, rsqrt(dot(v, v))); }
+VQD float length(f3 v) { return sqrt_(dot(v, v)); }
+VQD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+VQD float lerp(float a, float b, float t) { return a + t * (b - a); }
+VQD f3 reflect(f3 i, f3 n) { float t = 2.0f * dot(n, i); return mk3(i.x - n.x * t, i.y - n.y * t, i.z - n.z * t); }
+
+// float -> int: truncation, NaN -> 0, saturating
+VQD int f2i_trunc(float x) {
+    if (!(x == x)) return 0;
+    if (x >=  2147483520.0f) return  2147483520;
+    if (x <= -2147483520.0f) return -2147483520;
+    return (int)x;
+}
+VQD int f2i_floor(float x) { return f2i_trunc(__builtin_floorf(x)); }
+
+// log2: mantissa in [sqrt(1/2), sqrt(2)), 9-term polynomial for ln(1+f), log2(e) split as 1 + 0.44269504
+VQD float log2_(float x) {
+    uint32_t u = __float_as_uint(x);
+    int e = 0;
+    float xs = x;
+    if (u < 0x00800000u) { xs = x * 8388608.0f; u = __float_as_uint(xs); e = -23; }   // +denormal (and +0, handled below)
+    e += (int)(u >> 23) - 126;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+    float f;
+    if (m < 0.70710678118654752440f) { e -= 1; f = (m + m) - 1.0f; } else { f = m - 1.0f; }
+    float z = f * f;
+    float p = 7.0376836292E-2f;
+    p = fma_(p, f, -1.1514610310E-1f);
+    p = fma_(p, f,  1.1676998740E-1f);
+    p = fma_(p, f, -1.2420140846E-1f);
+    p = fma_(p, f,  1.4249322787E-1f);
+    p = fma_(p, f, -1.6668057665E-1f);
+    p = fma_(p, f,  2.0000714765E-1f);
+    p = fma_(p, f, -2.4999993993E-1f);
+    p = fma_(p, f,  3.3333331174E-1f);
+    float y = (p * f) * z;
+    y = fma_(-0.5f, z, y);
+    const float L2EA = 0.44269504088896340736f;
+    float r = y * L2EA;
+    r = fma_(f, L2EA, r);
+    r = r + y;
+    r = r + f;
+    r = r + (float)e;
+    // special cases, same precedence as the reference restatement: NaN, negative, zero, +inf
+    if (x == __builtin_inff()) r = x;
+    if (x == 0.0f) r = -__builtin_inff();
+    if (x < 0.0f) r = qnan();
+    if (!(x == x)) r = x;
+    return r;
+}
+
+// exp2: n = nearest integer, 2^f ~ 1 + f*P(f) on [-0.5,0.5]; >= 128 -> inf, < -126 -> 0
+VQD float exp2_(float x) {
+    float n = __builtin_floorf(x);
+    float f = x - n;
+    if (f > 0.5f) { n += 1.0f; f -= 1.0f; }
+    float p = 1.535336188319500E-4f;
+    p = fma_(p, f, 1.339887440266574E-3f);
+    p = fma_(p, f, 9.618437357674640E-3f);
+    p = fma_(p, f, 5.550332471162809E-2f);
+    p = fma_(p, f, 2.402264791363012E-1f);
+    p = fma_(p, f, 6.931472028550421E-1f);
+    float r = fma_(p, f, 1.0f);
+    int ni = (int)max_(min_(n, 128.0f), -127.0f);       // n is an integer-valued float in [-126,128] for in-range x
+    if (ni > 127) { r = r * 2.0f; ni = 127; }
+    if (ni < -126) ni = -126;
+    float out = r * __uint_as_float((uint32_t)(ni + 127) << 23);
+    if (x >= 128.0f) out = __builtin_inff();
+    if (x < -126.0f) out = 0.0f;
+    if (!(x == x)) out = x;
+    return out;
+}
+VQD float pow_(float x, float y) { return exp2_(y * log2_(x)); }
+
+// sin/cos: octant reduction with a 3-part pi/4, Cephes kernels; |x| > 2^20 or non-finite -> NaN
+VQD void sincos_(float x, float* s, float* c) {
+    float ax = abs_(x);
+    bool bad = !(ax <= 1048576.0f);
+    float axc = bad ? 0.0f : ax;
+    int j = (int)(axc * 1.27323954473516f);
+    j = (j + 1) & ~1;
+    float y = (float)j;
+    float r = ((axc - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    float z = r * r;
+    float ps = -1.9515295891E-4f;
+    ps = fma_(ps, z, 8.3321608736E-3f);
+    ps = fma_(ps, z, -1.6666654611E-1f);
+    float sn = fma_(ps * z, r, r);
+    float pc = 2.443315711809948E-5f;
+    pc = fma_(pc, z, -1.388731625493765E-3f);
+    pc = fma_(pc, z, 4.166664568298827E-2f);
+    float cs = fma_(pc * z, z, fma_(-0.5f, z, 1.0f));
+    int q = (j >> 1) & 3;
+    float ss = (q & 1) ? cs : sn;
+    float cc = (q & 1) ? sn : cs;
+    if (q == 2 || q == 3) ss = -ss;
+    if (q == 1 || q == 2) cc = -cc;
+    if (x < 0.0f) ss = -ss;
+    *s = bad ? qnan() : ss;
+    *c = bad ? qnan() : cc;
+}
+VQD float tan_(float x) { float s, c; sincos_(x, &s, &c); return div_(s, c); }
+
+VQD float asin_poly(float x, float z) {
+    float p = 4.2163199048E-2f;
+    p = fma_(p, z, 2.4181311049E-2f);
+    p = fma_(p, z, 4.5470025998E-2f);
+    p = fma_(p, z, 7.4953002686E-2f);
+    p = fma_(p, z, 1.6666752422E-1f);
+    return fma_(p * z, x, x);
+}
+VQD float asin_(float x) {
+    float a = abs_(x);
+    float r;
+    if (a > 0.5f) {
+        float z = 0.5f * (1.0f - a);
+        float s = sqrt_(z);
+        float t = asin_poly(s, z);
+        r = 1.5707963267948966192f - (t + t);
+    } else {
+        r = asin_poly(a, a * a);
+    }
+    r = (x < 0.0f) ? -r : r;
+    return (a <= 1.0f) ? r : qnan();
+}
+VQD float acos_(float x) {
+    float r;
+    if (x < -0.5f)     { float z = 0.5f * (1.0f + x); float s = sqrt_(z); float t = asin_poly(s, z); r = 3.14159265358979323846f - (t + t); }
+    else if (x > 0.5f) { float z = 0.5f * (1.0f - x); float s = sqrt_(z); float t = asin_poly(s, z); r = t + t; }
+    else               { r = 1.5707963267948966192f - asin_poly(x, x * x); }
+    return (abs_(x) <= 1.0f) ? r : qnan();
+}
+VQD float atan_(float xx) {
+    float x = abs_(xx);
+    float y;
+    if (x > 2.414213562373095f)       { y = 1.5707963267948966192f; x = -rcp(x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483096f; x = div_(x - 1.0f, x + 1.0f); }
+    else                              { y = 0.0f; }
+    float z = x * x;
+    float p = 8.05374449538e-2f;
+    p = fma_(p, z, -1.38776856032E-1f);
+    p = fma_(p, z,  1.99777106478E-1f);
+    p = fma_(p, z, -3.33329491539E-1f);
+    y = y + fma_(p * z, x, x);
+    return (xx < 0.0f) ? -y : y;
+}
+VQD float atan2_(float y, float x) {
+    const float PI_F = 3.14159265358979323846f, PIO2_F = 1.5707963267948966192f;
+    if (!(x == x) || !(y == y)) return qnan();
+    if (x == 0.0f) { if (y > 0.0f) return PIO2_F; if (y < 0.0f) return -PIO2_F; return 0.0f; }
+    if (y == 0.0f) return (x < 0.0f) ? PI_F : 0.0f;
+    float w = 0.0f;
+    if (x < 0.0f) w = (y < 0.0f) ? -PI_F : PI_F;
+    return w + atan_(div_(y, x));
+}
+
+// ---- storage -----------------------------------------------------------------------------------
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+
+VQD float4 load_rgba16f(const void* base, size_t idx) {
+    h4 v = ((const h4*)base)[idx];
+    return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
+}
+VQD void store_rgba16f(void* base, size_t idx, float4 c) {      // v_cvt_f16_f32: round-to-nearest-even
+    h4 v; v.x = (_Float16)c.x; v.y = (_Float16)c.y; v.z = (_Float16)c.z; v.w = (_Float16)c.w;
+    ((h4*)base)[idx] = v;
+}
+VQD uint32_t unorm8(float f) { return (uint32_t)(int)(saturate(f) * 255.0f + 0.5f); }
+VQD void store_rgba8(void* base, size_t idx, float4 c) {
+    ((uint32_t*)base)[idx] = unorm8(c.x) | (unorm8(c.y) << 8) | (unorm8(c.z) << 16) | (unorm8(c.w) << 24);
+}
+template <int FMT> VQD float4 load_px(const void* base, size_t idx) {
+    if (FMT == 0) return ((const float4*)base)[idx];
+    return load_rgba16f(base, idx);
+}
+template <int FMT> VQD void store_px(void* base, size_t idx, float4 c) {
+    if (FMT == 0) ((float4*)base)[idx] = c;
+    else if (FMT == 1) store_rgba16f(base, idx, c);
+    else if (FMT == 2) store_rgba8(base, idx, c);
+    else if (FMT == 3) { h2 v; v.x = (_Float16)c.x; v.y = (_Float16)c.y; ((h2*)base)[idx] = v; }
+    else ((float2*)base)[idx] = make_float2(c.x, c.y);
+}
+
+} // namespace vqd

@@ -1,0 +1,45 @@
+// vq_internal.h — shared declarations between the C-ABI translation unit (capi.hip) and the kernel
+// translation units. Not part of the public boundary (that is include/vqhip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/vqhip.h"
+
+namespace vqk {
+
+// Device-resident per-call constant block == the cbuffers b0/b1 of ForwardLighting.hlsl:76-77 plus the
+// resource descriptors that replace its SRV tables. Uploaded once per vqhip_forward_lighting call into a
+// slot of the context's constant ring (the analogue of the reference's DynamicBufferHeap bump allocation,
+// SceneRendering.cpp:432-434,455-457). `extra` lights follow the struct in the same slot.
+struct alignas(16) FrameConstants {
+    VQ_PerFrameData        perFrame;       // 7120 B
+    VQ_PerViewLightingData perView;        // 320 B
+    vqhip_envmap           env;            // device pointers
+    vqhip_shadowmaps       sm;             // device pointers
+    int32_t                hasEnv;
+    int32_t                numExtraPoint;
+    int32_t                pad[2];
+    // VQ_PointLight extra[numExtraPoint] follows
+};
+static constexpr int    kMaxExtraPointLights = 1024;
+static constexpr size_t kConstSlotBytes = (sizeof(FrameConstants) + kMaxExtraPointLights * sizeof(VQ_PointLight) + 255) & ~(size_t)255;
+
+struct ShadeArgs {
+    const float4* gb0; const float4* gb1; const float4* gb2; const float4* gb3;
+    void* out;
+    const FrameConstants* fc;   // device
+    int width, height, pitch, outPitch;
+};
+
+// launchers (each returns the hipError_t of the launch)
+hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt);
+hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt);
+hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H, int fmt);
+hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt);
+hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt);
+hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw, int sh, int dw, int dh);
+hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
+                                      const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt);
+hipError_t launch_conv_specular(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res, int mip, int MIPS,
+                                int order, void* out, int fmt);
+
+} // namespace vqk

@@ -1,0 +1,175 @@
+"""Seeded synthetic inputs of the BASELINE.json configs. numpy only, CPU side;
+every generator is keyed so that any row range of a frame can be produced independently (row-tiled
+multi-GPU ranks generate just their tile and still agree with the single-GPU frame).
+
+Parameter sources in the reference: light defaults Source/Engine/Scene/Light.cpp:58-73, brightness range
+Data/Levels/Default.xml:202-308, fAmbientLightingFactor 0.055 Source/Engine/Scene/SceneViews.h:61,
+sun radiance cf. MaxCLL values in Data/EnvironmentMaps.ini."""
+import numpy as np
+
+from . import abi
+
+ROW_CHUNK = 32
+
+
+def _chunk_rng(seed, chunk):
+    return np.random.Generator(np.random.Philox(key=[int(seed), int(chunk)]))
+
+
+def gbuffer_rows(width, frame_height, row0, row1, seed=0xC0FFEE):
+    """Rows [row0,row1) of the 4 float4 G-buffer planes of a width x frame_height frame.
+    Returns 4 float32 arrays [row1-row0, width, 4]."""
+    planes = [np.empty((row1 - row0, width, 4), np.float32) for _ in range(4)]
+    c0, c1 = row0 // ROW_CHUNK, (row1 + ROW_CHUNK - 1) // ROW_CHUNK
+    for ch in range(c0, c1):
+        r = _chunk_rng(seed, ch)
+        n = ROW_CHUNK
+        rows = np.arange(ch * ROW_CHUNK, ch * ROW_CHUNK + n)
+        u = r.random((n, width, 16), dtype=np.float32)
+        g = [np.empty((n, width, 4), np.float32) for _ in range(4)]
+        # gb0 = (P, ao): P on a height field over [-50,50]^2, y in [-5,5]
+        cols = np.arange(width, dtype=np.float32)
+        g[0][..., 0] = (-50.0 + 100.0 * (cols + 0.5) / width)[None, :]
+        g[0][..., 1] = -5.0 + 10.0 * u[..., 0]
+        g[0][..., 2] = (-50.0 + 100.0 * (rows.astype(np.float32) + 0.5) / frame_height)[:, None]
+        g[0][..., 3] = 0.055 * (0.3 + 0.7 * u[..., 1])
+        # gb1 = (N, roughness): uniform upper hemisphere (+Y up), perturbed by +-1e-3 and NOT renormalised
+        z = u[..., 2]
+        phi = 2.0 * np.pi * u[..., 3]
+        rad = np.sqrt(np.maximum(0.0, 1.0 - z * z))
+        g[1][..., 0] = rad * np.cos(phi) + (u[..., 4] - 0.5) * 2e-3
+        g[1][..., 1] = z + (u[..., 5] - 0.5) * 2e-3
+        g[1][..., 2] = rad * np.sin(phi) + (u[..., 6] - 0.5) * 2e-3
+        g[1][..., 3] = 0.05 + 0.95 * u[..., 7]
+        # gb2 = (diffuse linear, metalness in {0,1} w.p. 1/2 else U[0,1])
+        g[2][..., 0:3] = u[..., 8:11]
+        m = u[..., 11]
+        g[2][..., 3] = np.where(m < 0.25, 0.0, np.where(m < 0.5, 1.0, (m - 0.5) * 2.0))
+        # gb3 = (emissive colour, intensity): zero for 95 % of the pixels
+        em = u[..., 12] > 0.95
+        g[3][..., 0:3] = np.where(em[..., None], u[..., 13:16], 0.0)
+        g[3][..., 3] = np.where(em, 5.0 * ((u[..., 12] - 0.95) * 20.0), 0.0)
+        lo, hi = max(row0, ch * ROW_CHUNK), min(row1, (ch + 1) * ROW_CHUNK)
+        for k in range(4):
+            planes[k][lo - row0:hi - row0] = g[k][lo - ch * ROW_CHUNK:hi - ch * ROW_CHUNK].astype(np.float32)
+    return planes
+
+
+def gbuffer(width, height, seed=0xC0FFEE):
+    return gbuffer_rows(width, height, 0, height, seed)
+
+
+def point_lights(n, seed=0x1600):
+    """n PointLight records: pos U([-50,50]x[0,20]x[-50,50]), colour U[0.2,1]^3, brightness U[100,1500], range U[20,200]."""
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0x11]))
+    arr = (abi.PointLight * n)()
+    for i in range(n):
+        u = r.random(8, dtype=np.float32)
+        l = arr[i]
+        l.position.set((-50 + 100 * u[0], 20 * u[1], -50 + 100 * u[2]))
+        l.range = float(np.float32(20 + 180 * u[3]))
+        l.color.set((0.2 + 0.8 * u[4], 0.2 + 0.8 * u[5], 0.2 + 0.8 * u[6]))
+        l.brightness = float(np.float32(100 + 1400 * u[7]))
+        l.attenuation.set((1.0, 0.0, 0.0))
+        l.depthBias = 0.0
+    return arr
+
+
+def spot_lights(n, seed=0x5907):
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0x22]))
+    arr = (abi.SpotLight * n)()
+    for i in range(n):
+        u = r.random(12, dtype=np.float32)
+        l = arr[i]
+        l.position.set((-40 + 80 * u[0], 10 + 20 * u[1], -40 + 80 * u[2]))
+        l.color.set((0.2 + 0.8 * u[3], 0.2 + 0.8 * u[4], 0.2 + 0.8 * u[5]))
+        l.brightness = float(np.float32(500 + 1500 * u[6]))
+        d = np.array([u[7] - 0.5, -1.0, u[8] - 0.5], np.float32)
+        l.spotDir.set(d * 3.0)                       # deliberately not unit length: the shader normalises (Lighting.hlsl:60)
+        outer = np.float32(np.deg2rad(20 + 25 * u[9]))
+        l.outerConeAngle = float(outer)
+        l.innerConeAngle = float(np.float32(outer * (0.6 + 0.3 * u[10])))
+        l.depthBias = 5e-5
+        l.range = 0.0                                # unset by the CPU side, Light.cpp:108-121
+    return arr
+
+
+def per_frame(points=None, spots=None, directional=None, ambient=0.055, hdri_offset=0.0):
+    """PerFrameData with up to 100 point lights in the cbuffer array; returns (PerFrameData, extra PointLight array or None)."""
+    pf = abi.PerFrameData()
+    n = len(points) if points is not None else 0
+    k = min(n, abi.NUM_LIGHTS__POINT)
+    pf.Lights.numPointLights = k
+    for i in range(k):
+        pf.Lights.point_lights[i] = points[i]
+    extra = None
+    if n > k:
+        extra = (abi.PointLight * (n - k))(*[points[i] for i in range(k, n)])
+    if spots is not None:
+        pf.Lights.numSpotLights = len(spots)
+        for i in range(len(spots)):
+            pf.Lights.spot_lights[i] = spots[i]
+    if directional is not None:
+        pf.Lights.directional = directional
+    pf.f2PointLightShadowMapDimensions = abi.float2(1024.0, 1024.0)          # SceneRendering.cpp:439-441
+    pf.f2SpotLightShadowMapDimensions = abi.float2(1024.0, 1024.0)
+    pf.f2DirectionalLightShadowMapDimensions = abi.float2(2048.0, 2048.0)
+    pf.fAmbientLightingFactor = ambient
+    pf.fHDRIOffsetInRadians = hdri_offset
+    return pf, extra
+
+
+def per_view(width, height, camera=(0.0, 10.0, -60.0), max_env_lod=0, diffuse_only=0):
+    pv = abi.PerViewLightingData()
+    for m in (pv.matView, pv.matViewToWorld, pv.matProjInverse):
+        for i in range(4):
+            m.m[i][i] = 1.0
+    pv.CameraPosition.set(camera)
+    pv.MaxEnvMapLODLevels = float(max_env_lod)
+    pv.ScreenDimensions = abi.float2(float(width), float(height))
+    pv.EnvironmentMapDiffuseOnlyIllumination = diffuse_only
+    return pv
+
+
+def directional_light(direction=(0.3, -1.0, 0.2), color=(1.0, 0.95, 0.9), brightness=0.9, shadowing=0, enabled=1, depth_bias=5e-5):
+    d = abi.DirectionalLight()
+    d.lightDirection.set(direction)
+    d.color.set(color)
+    d.brightness = brightness
+    d.depthBias = depth_bias
+    d.shadowing = shadowing
+    d.enabled = enabled
+    return d
+
+
+def equirect(width, height, seed=0xE9):
+    """RGBA32F equirect [H,W,4]: smooth sky gradient + 8 Gaussian 'suns' with peak radiance up to 2.6e4."""
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0x33]))
+    v = (np.arange(height, dtype=np.float32) + 0.5) / height
+    u = (np.arange(width, dtype=np.float32) + 0.5) / width
+    uu, vv = np.meshgrid(u, v)
+    sky = np.stack([0.25 + 0.35 * (1 - vv), 0.35 + 0.4 * (1 - vv), 0.55 + 0.45 * (1 - vv)], -1)
+    ground = np.stack([0.18 + 0.05 * np.sin(12 * uu), 0.15 + 0.05 * np.cos(9 * uu), 0.10 + 0.0 * uu], -1)
+    t = np.clip((vv - 0.5) * 8.0 + 0.5, 0, 1)[..., None]
+    img = sky * (1 - t) + ground * t
+    for _ in range(8):
+        cu, cv = r.random(), 0.05 + 0.4 * r.random()
+        sig = 0.004 + 0.02 * r.random()
+        peak = 10 ** (1.5 + 2.9 * r.random())          # 30 .. 2.5e4
+        col = 0.6 + 0.4 * r.random(3)
+        du = np.minimum(np.abs(uu - cu), 1 - np.abs(uu - cu))
+        img += (peak * np.exp(-(du * du + (vv - cv) ** 2) / (2 * sig * sig)))[..., None] * col
+    out = np.empty((height, width, 4), np.float32)
+    out[..., :3] = img.astype(np.float32)
+    out[..., 3] = 1.0
+    return out
+
+
+def hdr_image(width, height, seed=0x70E, scale=4.0):
+    """RGBA32F scene-colour-like image for blur/tonemap tests: log-uniform radiance with a few hot pixels."""
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0x44]))
+    img = np.exp(r.uniform(-6, np.log(scale), (height, width, 4))).astype(np.float32)
+    hot = r.random((height, width)) > 0.999
+    img[hot, :3] *= 500.0
+    img[..., 3] = r.random((height, width), dtype=np.float32)
+    return img

@@ -1,0 +1,67 @@
+"""Row-tiled multi-GPU mode: one process per GPU, the frame is cut into contiguous row tiles,
+light arrays / env cubemaps / LUT are replicated, and only two exchanges touch the data path:
+
+  1. blur halo  — the Y pass needs KERNEL_RANGE-1 = 10 rows of the X-blurred image above and below the tile
+                  (GaussianBlur.hlsl:54-55,176-180): point-to-point send/recv with ranks r-1 / r+1 (each GPU pair
+                  has its own xGMI link), or — as BASELINE.json words it — one small all-gather of boundary rows;
+  2. composite  — all-gather of the tonemapped tiles so every rank holds the whole frame.
+
+Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) with CUDA tensors on the GPU box, "gloo" with
+CPU tensors in the unit tests. There is no collective in the shade / X-blur / tonemap stages."""
+import torch
+import torch.distributed as dist
+
+HALO_ROWS = 10  # KERNEL_RANGE_MINUS1, Shaders/GaussianBlur.hlsl:54-55
+
+
+class RowTiling:
+    def __init__(self, width, frame_height, world_size, rank):
+        if frame_height % world_size:
+            raise ValueError(f"frame height {frame_height} is not divisible by world size {world_size}")
+        self.width, self.frame_height, self.world, self.rank = width, frame_height, world_size, rank
+        self.tile_rows = frame_height // world_size
+        if world_size > 1 and self.tile_rows < HALO_ROWS:
+            raise ValueError("tiles must be at least 10 rows tall (the halo comes from the direct neighbour only)")
+        self.row0 = rank * self.tile_rows
+        self.row1 = self.row0 + self.tile_rows
+
+
+def exchange_halos_p2p(x_tile, group=None):
+    """x_tile: [rows, W, C] X-blurred tile. Returns (halo_top, halo_bottom); None at the frame border."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    top = bottom = None
+    ops = []
+    if rank > 0:
+        top = torch.empty_like(x_tile[:HALO_ROWS])
+        ops.append(dist.P2POp(dist.isend, x_tile[:HALO_ROWS].contiguous(), dist.get_global_rank(group, rank - 1) if group else rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, top, dist.get_global_rank(group, rank - 1) if group else rank - 1, group))
+    if rank < world - 1:
+        bottom = torch.empty_like(x_tile[:HALO_ROWS])
+        ops.append(dist.P2POp(dist.isend, x_tile[-HALO_ROWS:].contiguous(), dist.get_global_rank(group, rank + 1) if group else rank + 1, group))
+        ops.append(dist.P2POp(dist.irecv, bottom, dist.get_global_rank(group, rank + 1) if group else rank + 1, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return top, bottom
+
+
+def exchange_halos_allgather(x_tile, group=None):
+    """Same result through ONE all-gather of each rank's 2x10 boundary rows (BASELINE.json's wording)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1:
+        return None, None
+    mine = torch.cat([x_tile[:HALO_ROWS], x_tile[-HALO_ROWS:]], 0).contiguous()
+    allb = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(allb, mine, group=group)
+    top = allb[rank - 1, HALO_ROWS:].contiguous() if rank > 0 else None
+    bottom = allb[rank + 1, :HALO_ROWS].contiguous() if rank < world - 1 else None
+    return top, bottom
+
+
+def composite(tile, out=None, group=None, async_op=False):
+    """All-gather the row tiles into the full frame [world*rows, W, C] on every rank. Returns (frame, work|None)."""
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty((world * tile.shape[0],) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
+    work = dist.all_gather_into_tensor(out, tile.contiguous(), group=group, async_op=async_op)
+    return out, work
