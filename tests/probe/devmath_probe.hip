@@ -1,0 +1,46 @@
+// devmath_probe.hip — TEST INFRASTRUCTURE: exposes the product's device math (vqengine_amd/csrc/vq_devmath.h,
+// vq_sampling.h) element-wise so tests can compare it bit-for-bit against the CPU oracle's lowering table.
+#include <hip/hip_runtime.h>
+#include "../../vqengine_amd/csrc/vq_devmath.h"
+#include "../../vqengine_amd/csrc/vq_sampling.h"
+using namespace vqd;
+
+__global__ void k_probe(int fn, const float* a, const float* b, float* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float x = a[i], y = b ? b[i] : 0.0f, r = 0.0f, s, c;
+    switch (fn) {
+        case 0: r = log2_(x); break;   case 1: r = exp2_(x); break;   case 2: r = pow_(x, y); break;
+        case 3: sincos_(x, &s, &c); r = s; break;                     case 4: sincos_(x, &s, &c); r = c; break;
+        case 5: r = tan_(x); break;    case 6: r = asin_(x); break;   case 7: r = acos_(x); break;
+        case 8: r = atan2_(x, y); break; case 9: r = rcp(x); break;   case 10: r = sqrt_(x); break; case 11: r = rsqrt(x); break;
+        case 12: r = (float)to_f16(x); break;                             // fp32 -> fp16 -> fp32 round trip
+        case 13: r = (float)unorm8(x); break;
+        case 14: r = max_(x, y); break; case 15: r = min_(x, y); break; case 16: r = saturate(x); break;
+        case 17: r = (float)f2i_floor(x); break; case 18: r = (float)f2i_trunc(x); break;
+    }
+    out[i] = r;
+}
+extern "C" __attribute__((visibility("default"))) int vqprobe_math(int fn, const float* a, const float* b, float* out, size_t n, void* stream) {
+    hipLaunchKernelGGL(k_probe, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, a, b, out, n);
+    return (int)hipGetLastError();
+}
+
+// ---- exhaustive checks (all 2^32 bit patterns) of the product's fast paths against the plain IEEE / general forms ----
+__global__ void k_exhaust_rcp(uint32_t base, unsigned long long* bad, uint32_t* first) {
+    uint32_t u = base + blockIdx.x * blockDim.x + threadIdx.x;
+    float x = __uint_as_float(u);
+    float ref = 1.0f / x, got = rcp(x);
+    if (__float_as_uint(ref) != __float_as_uint(got) && !(ref != ref && got != got)) { if (atomicAdd(bad, 1ull) == 0) *first = u; }
+}
+extern "C" __attribute__((visibility("default"))) long long vqprobe_rcp_exhaustive(uint32_t* first_bad) {
+    unsigned long long* d; uint32_t* f;
+    if (hipMalloc(&d, 8) != hipSuccess || hipMalloc(&f, 4) != hipSuccess) return -1;
+    (void)hipMemset(d, 0, 8); (void)hipMemset(f, 0, 4);
+    for (uint32_t hi = 0; hi < 256; ++hi) hipLaunchKernelGGL(k_exhaust_rcp, dim3((1u << 24) / 256), dim3(256), 0, 0, hi << 24, d, f);
+    unsigned long long h = 0;
+    if (hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    (void)hipMemcpy(first_bad, f, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d); (void)hipFree(f);
+    return (long long)h;
+}

@@ -216,7 +216,10 @@ def test_forward_edge_cases(ctx):
     ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F)
     got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F)
     assert_bits(got, ref, "forward edge cases")
-    assert np.isnan(ref[0, 0, :3]).all()
+    # zero normal: normalize() yields NaN but every use goes through saturate()/max(0,.) which map NaN -> 0 (HLSL semantics)
+    assert np.isfinite(ref[0, 0, :3]).all()
+    # D == 0: rcp(0) = inf and 0*inf = NaN propagate exactly as in the HLSL
+    assert np.isnan(ref[0, 1, :3]).all()
 
 
 def test_forward_full_size_properties(ctx):
@@ -246,8 +249,11 @@ def test_forward_full_size_properties(ctx):
     base = ctx.forward_lighting(gb_full, synth.per_frame()[0], pv, out_fmt=abi.FMT_RGBA32F)
     s = (a[..., :3].double() + b[..., :3].double() - base[..., :3].double())
     rel = ((s - out32[..., :3].double()).abs() / out32[..., :3].double().abs().clamp_min(1e-6))
-    assert torch.isfinite(out32).all()
-    assert rel.max().item() < 2e-5, rel.max().item()
+    # The HLSL itself yields NaN where dot(H,V) rounds above 1 (pow(negative, 5) == exp2(5*log2(x)), BRDF.hlsl:135):
+    # a handful of pixels per 531 M light-pixel pairs. They must be NaN in BOTH (crop check above) and stay rare.
+    finite = torch.isfinite(out32).all(dim=-1)
+    assert (~finite).sum().item() < 1e-4 * W * H, (~finite).sum().item()   # ~2e-5 observed on this scene
+    assert rel[finite].max().item() < 2e-5, rel[finite].max().item()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -31,6 +31,49 @@ struct Pixel {
 
 VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
 
+// pow_(x, 5.0f) == exp2_(5 * log2_(x)) for the Fresnel terms, where x = 1 - max(0, cos) is either 0, negative by a
+// rounding hair, or in [2^-24, 1]. On [2^-24, 1] none of log2_/exp2_'s special cases (zero, negative, denormal,
+// inf, NaN, overflow, underflow: 5*log2(x) >= -120) can fire, so the same arithmetic runs without their selects;
+// anything else (rare) goes through the general routine. Bit-identical to pow_(x, 5.0f) for every x.
+VQD float pow5(float x) {
+    if (__builtin_expect(!(x >= 5.9604644775390625e-8f && x <= 1.0f), 0)) return pow_(x, 5.0f);
+    const uint32_t u = __float_as_uint(x);
+    int e = (int)(u >> 23) - 126;
+    const float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
+    float f;
+    if (m < 0.70710678118654752440f) { e -= 1; f = (m + m) - 1.0f; } else { f = m - 1.0f; }
+    const float z = f * f;
+    float p = 7.0376836292E-2f;
+    p = fma_(p, f, -1.1514610310E-1f);
+    p = fma_(p, f,  1.1676998740E-1f);
+    p = fma_(p, f, -1.2420140846E-1f);
+    p = fma_(p, f,  1.4249322787E-1f);
+    p = fma_(p, f, -1.6668057665E-1f);
+    p = fma_(p, f,  2.0000714765E-1f);
+    p = fma_(p, f, -2.4999993993E-1f);
+    p = fma_(p, f,  3.3333331174E-1f);
+    float y = (p * f) * z;
+    y = fma_(-0.5f, z, y);
+    const float L2EA = 0.44269504088896340736f;
+    float r = y * L2EA;
+    r = fma_(f, L2EA, r);
+    r = r + y;
+    r = r + f;
+    r = r + (float)e;
+    const float t = 5.0f * r;                       // in [-120, 0]
+    float n = __builtin_floorf(t);
+    float g = t - n;
+    if (g > 0.5f) { n += 1.0f; g -= 1.0f; }
+    float q = 1.535336188319500E-4f;
+    q = fma_(q, g, 1.339887440266574E-3f);
+    q = fma_(q, g, 9.618437357674640E-3f);
+    q = fma_(q, g, 5.550332471162809E-2f);
+    q = fma_(q, g, 2.402264791363012E-1f);
+    q = fma_(q, g, 6.931472028550421E-1f);
+    const float s = fma_(q, g, 1.0f);
+    return s * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
+
 VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.P = mk3(g0.x, g0.y, g0.z);
     px.Nraw = mk3(g1.x, g1.y, g1.z);
@@ -56,42 +99,52 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.invPI = rcp(PI_);
 }
 
-// BRDF(s, Wi, V), BRDF.hlsl:163-194, with the hoisted terms of `px`
-VQD f3 brdf(const Pixel& px, f3 Wi) {
-    const f3 H = normalize(add(px.Wo, Wi));
+// BRDF(s, Wi, V), BRDF.hlsl:163-194, with the hoisted terms of `px`. `rc` is the reciprocal policy (vq_devmath.h).
+template <class R>
+VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
+    const f3 Hs = add(px.Wo, Wi);
+    const f3 H = mul(Hs, rc(sqrt_(dot(Hs, Hs))));            // normalize(Wo + Wi)
     const float NdotH = saturate(dot(px.Nn, H));
     const float dNL = dot(px.Nn, Wi);
     const float NdotL = saturate(dNL);
     // Fresnel_Schlick(H, V, F0) :132-136
-    const float p5 = pow_(1.0f - max_(0.0f, dot(H, px.V)), 5.0f);
+    const float p5 = pow5(1.0f - max_(0.0f, dot(H, px.V)));
     const f3 F = mk3(px.F0.x + px.omF0.x * p5, px.F0.y + px.omF0.y * p5, px.F0.z + px.omF0.z * p5);
     // Geometry_Smith :118-121
     const float NL = max_(0.0f, dNL);
-    const float G = px.G1V * div_(NL, (NL * px.omk + px.k) + 0.0001f);
+    const float G = px.G1V * (NL * rc((NL * px.omk + px.k) + 0.0001f));
     // NormalDistributionGGX :65-79
     const float nh2 = NdotH * NdotH;
     const float t = nh2 * px.a2m1 + 1.0f;
     const float dd = PI_ * (t * t);
-    const float D = (dd < EPSILON_) ? 1.0f : div_(px.a2, dd);
-    const float rd = rcp(max_(px.NdotV4 * NdotL, 0.0001f));
+    const float Dq = px.a2 * rc(max_(dd, EPSILON_));          // operand clamped only to keep the unused quotient finite
+    const float D = (dd < EPSILON_) ? 1.0f : Dq;
+    const float rd = rc(max_(px.NdotV4 * NdotL, 0.0001f));
     const f3 spec = mk3(((D * F.x) * G) * rd, ((D * F.y) * G) * rd, ((D * F.z) * G) * rd);
     const f3 kD = mk3((1.0f - F.x) * px.omm, (1.0f - F.y) * px.omm, (1.0f - F.z) * px.omm);
     const f3 Id = mk3((kD.x * px.albedo.x) * px.invPI, (kD.y * px.albedo.y) * px.invPI, (kD.z * px.albedo.z) * px.invPI);
     return add(Id, spec);
 }
+VQD f3 brdf(const Pixel& px, f3 Wi) { RcpIEEE rc; return brdf_t(px, Wi, rc); }
 
-// CalculatePointLightIllumination, Lighting.hlsl:308-322
+// CalculatePointLightIllumination, Lighting.hlsl:308-322, for a pixel already known to be in range (D < l.range)
+template <class R>
+VQD f3 point_light_t(const Pixel& px, const VQ_PointLight& l, f3 d, float D, R& rc) {
+    const f3 Wi = mul(d, rc(D));                             // normalize(Lw - P) shares length()'s sqrt
+    const float NdotL = saturate(dot(px.Nraw, Wi));
+    const float att = rc(D * D);                             // AttenuationBRDF :29-32
+    const f3 radiance = mk3((att * l.color.x) * l.brightness, (att * l.color.y) * l.brightness, (att * l.color.z) * l.brightness);
+    const f3 b = brdf_t(px, Wi, rc);
+    return mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
+}
 VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {
     const f3 d = sub(ld3(l.position), px.P);
-    const float D = sqrt_(dot(d, d));                        // length(Lw - P); normalize() shares the sqrt
-    const f3 Wi = mul(d, rcp(D));
+    const float D = sqrt_(dot(d, d));                        // length(Lw - P)
     f3 r = mk3(0.0f, 0.0f, 0.0f);
     if (D < l.range) {
-        const float NdotL = saturate(dot(px.Nraw, Wi));
-        const float att = rcp(D * D);                        // AttenuationBRDF :29-32
-        const f3 radiance = mk3((att * l.color.x) * l.brightness, (att * l.color.y) * l.brightness, (att * l.color.z) * l.brightness);
-        const f3 b = brdf(px, Wi);
-        r = mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
+        RcpFast fast;
+        r = point_light_t(px, l, d, D, fast);
+        if (__builtin_expect(!fast.ok, 0)) { RcpIEEE ieee; r = point_light_t(px, l, d, D, ieee); }
     }
     return r;
 }
@@ -149,7 +202,7 @@ VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
         spec = mk3(sp.x, sp.y, sp.z);
         sb = sample_2d_rg16f_clamp(fc->env.brdf_lut, fc->env.lut_size, fc->env.lut_size, NdotV, px.roughness);
     }
-    const float p5 = pow_(1.0f - NdotV, 5.0f);                                  // FresnelWithRoughness :152-156
+    const float p5 = pow5(1.0f - NdotV);                                         // FresnelWithRoughness :152-156
     const float omr = 1.0f - px.roughness;
     const f3 Ks = mk3(px.F0.x + (max_(omr, px.F0.x) - px.F0.x) * p5, px.F0.y + (max_(omr, px.F0.y) - px.F0.y) * p5, px.F0.z + (max_(omr, px.F0.z) - px.F0.z) * p5);
     const f3 Kd = mk3((1.0f - Ks.x) * px.omm, (1.0f - Ks.y) * px.omm, (1.0f - Ks.z) * px.omm);

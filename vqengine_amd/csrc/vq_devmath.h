@@ -17,7 +17,27 @@ namespace vqd {
 #define VQD __device__ __forceinline__
 
 VQD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
-VQD float rcp(float b)   { return 1.0f / b; }               // correctly rounded reciprocal
+// Correctly rounded reciprocal RN(1/b). Fast path: v_rcp_f32 (1 ulp) + one Newton step, i.e. Markstein's
+// r' = fma(fma(-b,r,1), r, r); checked EXHAUSTIVELY on gfx950 against IEEE 1.0f/b over all 2^32 inputs
+// (scripts/ubench/valu_ubench.hip, tests/test_gpu_devmath.py::test_rcp_exhaustive): whenever the result is a
+// normal number it is the correctly rounded quotient. Zero / denormal / inf / NaN results (denormal or huge
+// inputs, 0, inf, NaN) take the IEEE division expansion.
+VQD float rcp_newton(float b) {                              // == RN(1/b) whenever the RESULT is a normal number
+    const float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+VQD bool is_normal(float r) { return __builtin_amdgcn_classf(r, 0x108); }      // 0x108 = {-normal, +normal}
+VQD float rcp(float b) {
+    float r = rcp_newton(b);
+    if (__builtin_expect(!is_normal(r), 0)) r = 1.0f / b;
+    return r;
+}
+// Reciprocal policies for hot loops: RcpFast runs several reciprocals unchecked and accumulates ONE validity flag
+// (all results normal); when the flag drops (denormal/huge/zero/inf/NaN operand — rare) the caller redoes the whole
+// block with RcpIEEE. Results are bit-identical to rcp() either way.
+struct RcpFast { bool ok = true; VQD float operator()(float b) { const float r = rcp_newton(b); ok = ok & is_normal(r); return r; } };
+struct RcpIEEE { VQD float operator()(float b) const { return 1.0f / b; } };
 VQD float sqrt_(float x) { return __builtin_sqrtf(x); }     // correctly rounded
 VQD float rsqrt(float x) { return rcp(sqrt_(x)); }
 VQD float div_(float a, float b) { return a * rcp(b); }     // HLSL a / b
@@ -199,8 +219,12 @@ VQD float4 load_rgba16f(const void* base, size_t idx) {
     h4 v = ((const h4*)base)[idx];
     return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w);
 }
-VQD void store_rgba16f(void* base, size_t idx, float4 c) {      // v_cvt_f16_f32: round-to-nearest-even
-    h4 v; v.x = (_Float16)c.x; v.y = (_Float16)c.y; v.z = (_Float16)c.z; v.w = (_Float16)c.w;
+// fp32 -> fp16, round-to-nearest-even of the ALREADY ROUNDED fp32 value. The empty asm pins the fp32 value in a
+// VGPR: without it LLVM folds `(half)(a*b)` into v_fma_mixlo_f16, which rounds the exact product once to fp16 and
+// differs from RNE16(RNE32(a*b)) in rare double-rounding cases (seen: 1 texel of 32736 in the specular prefilter).
+VQD _Float16 to_f16(float f) { asm volatile("" : "+v"(f)); return (_Float16)f; }
+VQD void store_rgba16f(void* base, size_t idx, float4 c) {
+    h4 v; v.x = to_f16(c.x); v.y = to_f16(c.y); v.z = to_f16(c.z); v.w = to_f16(c.w);
     ((h4*)base)[idx] = v;
 }
 VQD uint32_t unorm8(float f) { return (uint32_t)(int)(saturate(f) * 255.0f + 0.5f); }
@@ -215,7 +239,7 @@ template <int FMT> VQD void store_px(void* base, size_t idx, float4 c) {
     if (FMT == 0) ((float4*)base)[idx] = c;
     else if (FMT == 1) store_rgba16f(base, idx, c);
     else if (FMT == 2) store_rgba8(base, idx, c);
-    else if (FMT == 3) { h2 v; v.x = (_Float16)c.x; v.y = (_Float16)c.y; ((h2*)base)[idx] = v; }
+    else if (FMT == 3) { h2 v; v.x = to_f16(c.x); v.y = to_f16(c.y); ((h2*)base)[idx] = v; }
     else ((float2*)base)[idx] = make_float2(c.x, c.y);
 }
 
