@@ -1,5 +1,6 @@
 // devmath_probe.hip — TEST INFRASTRUCTURE: exposes the product's device math (vqengine_amd/csrc/vq_devmath.h,
-// vq_sampling.h) element-wise so tests can compare it bit-for-bit against the CPU oracle's lowering table.
+// vq_sampling.h) element-wise so tests can compare it bit-for-bit against the CPU oracle's lowering table, and
+// runs exhaustive (all 2^32 bit patterns) checks of the product's fast paths against the plain IEEE forms.
 #include <hip/hip_runtime.h>
 #include "../../vqengine_amd/csrc/vq_devmath.h"
 #include "../../vqengine_amd/csrc/vq_sampling.h"
@@ -14,7 +15,7 @@ __global__ void k_probe(int fn, const float* a, const float* b, float* out, size
         case 3: sincos_(x, &s, &c); r = s; break;                     case 4: sincos_(x, &s, &c); r = c; break;
         case 5: r = tan_(x); break;    case 6: r = asin_(x); break;   case 7: r = acos_(x); break;
         case 8: r = atan2_(x, y); break; case 9: r = rcp(x); break;   case 10: r = sqrt_(x); break; case 11: r = rsqrt(x); break;
-        case 12: r = (float)to_f16(x); break;                             // fp32 -> fp16 -> fp32 round trip
+        case 12: r = (float)to_f16(x); break;                         // fp32 -> fp16 -> fp32 round trip
         case 13: r = (float)unorm8(x); break;
         case 14: r = max_(x, y); break; case 15: r = min_(x, y); break; case 16: r = saturate(x); break;
         case 17: r = (float)f2i_floor(x); break; case 18: r = (float)f2i_trunc(x); break;
@@ -26,18 +27,27 @@ extern "C" __attribute__((visibility("default"))) int vqprobe_math(int fn, const
     return (int)hipGetLastError();
 }
 
-// ---- exhaustive checks (all 2^32 bit patterns) of the product's fast paths against the plain IEEE / general forms ----
-__global__ void k_exhaust_rcp(uint32_t base, unsigned long long* bad, uint32_t* first) {
-    uint32_t u = base + blockIdx.x * blockDim.x + threadIdx.x;
-    float x = __uint_as_float(u);
-    float ref = 1.0f / x, got = rcp(x);
-    if (__float_as_uint(ref) != __float_as_uint(got) && !(ref != ref && got != got)) { if (atomicAdd(bad, 1ull) == 0) *first = u; }
+// which: 0 rcp() vs 1.0f/x | 1 sqrt_() vs IEEE sqrtf | 2 saturate() vs the select form | 3/4 the unchecked fast paths
+// inside their validated domains (rcp_newton: normal result; sqrt_newton: x in [2^-100, FLT_MAX])
+__global__ void k_exhaust(int which, uint32_t base, unsigned long long* bad, uint32_t* first) {
+    const uint32_t u = base + blockIdx.x * blockDim.x + threadIdx.x;
+    const float x = __uint_as_float(u);
+    float ref, got;
+    bool inDomain = true;
+    switch (which) {
+        case 0:  ref = 1.0f / x; got = rcp(x); break;
+        case 1:  ref = __builtin_sqrtf(x); got = sqrt_(x); break;
+        case 2:  ref = (x > 0.0f) ? ((x < 1.0f) ? x : 1.0f) : 0.0f; got = saturate(x); break;
+        case 3:  ref = 1.0f / x; got = rcp_newton(x); inDomain = is_normal(got); break;
+        default: ref = __builtin_sqrtf(x); got = sqrt_newton(x); inDomain = sqrt_fast_ok(x); break;
+    }
+    if (inDomain && __float_as_uint(ref) != __float_as_uint(got) && !(ref != ref && got != got)) { if (atomicAdd(bad, 1ull) == 0) *first = u; }
 }
-extern "C" __attribute__((visibility("default"))) long long vqprobe_rcp_exhaustive(uint32_t* first_bad) {
+extern "C" __attribute__((visibility("default"))) long long vqprobe_exhaustive(int which, uint32_t* first_bad) {
     unsigned long long* d; uint32_t* f;
     if (hipMalloc(&d, 8) != hipSuccess || hipMalloc(&f, 4) != hipSuccess) return -1;
     (void)hipMemset(d, 0, 8); (void)hipMemset(f, 0, 4);
-    for (uint32_t hi = 0; hi < 256; ++hi) hipLaunchKernelGGL(k_exhaust_rcp, dim3((1u << 24) / 256), dim3(256), 0, 0, hi << 24, d, f);
+    for (uint32_t hi = 0; hi < 256; ++hi) hipLaunchKernelGGL(k_exhaust, dim3((1u << 24) / 256), dim3(256), 0, 0, which, hi << 24, d, f);
     unsigned long long h = 0;
     if (hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     (void)hipMemcpy(first_bad, f, 4, hipMemcpyDeviceToHost);

@@ -92,10 +92,14 @@ def test_storage_conversions(probe):
     assert np.array_equal(probe(13, x), u8.astype(np.float32))
 
 
-def test_rcp_exhaustive(ctx):
-    """vqd::rcp (v_rcp_f32 + one Newton step + normal-class check) == IEEE 1.0f/x for ALL 2^32 float bit patterns."""
+@pytest.mark.parametrize("which,name", [(0, "rcp == 1.0f/x"), (1, "sqrt_ == IEEE sqrtf"), (2, "saturate == select form"),
+                                        (3, "rcp_newton correct whenever its result is normal"),
+                                        (4, "sqrt_newton correct on [2^-100, FLT_MAX]")])
+def test_fast_paths_exhaustive(ctx, which, name):
+    """The product's fast exact primitives against the plain IEEE forms for ALL 2^32 float bit patterns."""
     lib = C.CDLL(PROBE)
-    lib.vqprobe_rcp_exhaustive.restype = C.c_longlong
+    lib.vqprobe_exhaustive.restype = C.c_longlong
+    lib.vqprobe_exhaustive.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
     first = C.c_uint32(0)
-    n = lib.vqprobe_rcp_exhaustive(C.byref(first))
-    assert n == 0, f"{n} mismatching inputs, first 0x{first.value:08x}"
+    n = lib.vqprobe_exhaustive(which, C.byref(first))
+    assert n == 0, f"{name}: {n} mismatching inputs, first 0x{first.value:08x}"

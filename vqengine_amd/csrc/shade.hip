@@ -103,7 +103,7 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
 template <class R>
 VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const f3 Hs = add(px.Wo, Wi);
-    const f3 H = mul(Hs, rc(sqrt_(dot(Hs, Hs))));            // normalize(Wo + Wi)
+    const f3 H = mul(Hs, rc(rc.sqrt(dot(Hs, Hs))));          // normalize(Wo + Wi)
     const float NdotH = saturate(dot(px.Nn, H));
     const float dNL = dot(px.Nn, Wi);
     const float NdotL = saturate(dNL);
@@ -127,25 +127,26 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
 }
 VQD f3 brdf(const Pixel& px, f3 Wi) { RcpIEEE rc; return brdf_t(px, Wi, rc); }
 
-// CalculatePointLightIllumination, Lighting.hlsl:308-322, for a pixel already known to be in range (D < l.range)
+// CalculatePointLightIllumination, Lighting.hlsl:308-322
 template <class R>
-VQD f3 point_light_t(const Pixel& px, const VQ_PointLight& l, f3 d, float D, R& rc) {
-    const f3 Wi = mul(d, rc(D));                             // normalize(Lw - P) shares length()'s sqrt
-    const float NdotL = saturate(dot(px.Nraw, Wi));
-    const float att = rc(D * D);                             // AttenuationBRDF :29-32
-    const f3 radiance = mk3((att * l.color.x) * l.brightness, (att * l.color.y) * l.brightness, (att * l.color.z) * l.brightness);
-    const f3 b = brdf_t(px, Wi, rc);
-    return mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
-}
-VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {
+VQD f3 point_light_t(const Pixel& px, const VQ_PointLight& l, R& rc) {
     const f3 d = sub(ld3(l.position), px.P);
-    const float D = sqrt_(dot(d, d));                        // length(Lw - P)
+    const float D = rc.sqrt(dot(d, d));                      // length(Lw - P); normalize() shares the sqrt
     f3 r = mk3(0.0f, 0.0f, 0.0f);
     if (D < l.range) {
-        RcpFast fast;
-        r = point_light_t(px, l, d, D, fast);
-        if (__builtin_expect(!fast.ok, 0)) { RcpIEEE ieee; r = point_light_t(px, l, d, D, ieee); }
+        const f3 Wi = mul(d, rc(D));
+        const float NdotL = saturate(dot(px.Nraw, Wi));
+        const float att = rc(D * D);                         // AttenuationBRDF :29-32
+        const f3 radiance = mk3((att * l.color.x) * l.brightness, (att * l.color.y) * l.brightness, (att * l.color.z) * l.brightness);
+        const f3 b = brdf_t(px, Wi, rc);
+        r = mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
     }
+    return r;
+}
+VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {
+    RcpFast fast;
+    f3 r = point_light_t(px, l, fast);
+    if (__builtin_expect(!fast.ok, 0)) { RcpIEEE ieee; r = point_light_t(px, l, ieee); }
     return r;
 }
 

@@ -33,17 +33,40 @@ VQD float rcp(float b) {
     if (__builtin_expect(!is_normal(r), 0)) r = 1.0f / b;
     return r;
 }
-// Reciprocal policies for hot loops: RcpFast runs several reciprocals unchecked and accumulates ONE validity flag
-// (all results normal); when the flag drops (denormal/huge/zero/inf/NaN operand — rare) the caller redoes the whole
-// block with RcpIEEE. Results are bit-identical to rcp() either way.
-struct RcpFast { bool ok = true; VQD float operator()(float b) { const float r = rcp_newton(b); ok = ok & is_normal(r); return r; } };
-struct RcpIEEE { VQD float operator()(float b) const { return 1.0f / b; } };
-VQD float sqrt_(float x) { return __builtin_sqrtf(x); }     // correctly rounded
+// Correctly rounded square root. Fast path: v_rsq_f32 seed, s = x*y, one exact-residual correction
+// s' = fma(fma(-s,s,x), y/2, s); EXHAUSTIVELY equal to IEEE sqrtf for every x in [2^-100, FLT_MAX] on gfx950
+// (below 2^-100 the residual goes denormal). Everything else (0, tiny, inf, NaN, negative) takes the IEEE expansion.
+VQD float sqrt_newton(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x * y, h = 0.5f * y;
+    const float r = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(r, h, s);
+}
+VQD bool sqrt_fast_ok(float x) { return (x >= 0x1p-100f) & (x <= 3.4028234663852886e38f); }
+VQD float sqrt_(float x) {
+    float s = sqrt_newton(x);
+    if (__builtin_expect(!sqrt_fast_ok(x), 0)) s = __builtin_sqrtf(x);
+    return s;
+}
+// Arithmetic policies for hot loops: Fast runs reciprocals / square roots unchecked and accumulates ONE validity
+// flag; when it drops (operand outside the validated fast range — rare) the caller redoes the whole block with
+// IEEE. Results are bit-identical to rcp() / sqrt_() either way.
+struct RcpFast {
+    bool ok = true;
+    VQD float operator()(float b) { const float r = rcp_newton(b); ok = ok & is_normal(r); return r; }
+    VQD float sqrt(float x) { ok = ok & sqrt_fast_ok(x); return sqrt_newton(x); }
+};
+struct RcpIEEE {
+    VQD float operator()(float b) const { return 1.0f / b; }
+    VQD float sqrt(float x) const { return __builtin_sqrtf(x); }
+};
 VQD float rsqrt(float x) { return rcp(sqrt_(x)); }
 VQD float div_(float a, float b) { return a * rcp(b); }     // HLSL a / b
 VQD float max_(float a, float b) { return __builtin_fmaxf(a, b); }
 VQD float min_(float a, float b) { return __builtin_fminf(a, b); }
-VQD float saturate(float x) { return (x > 0.0f) ? ((x < 1.0f) ? x : 1.0f) : 0.0f; }   // NaN -> 0
+// saturate: clamp to [0,1], NaN -> 0, -0 -> +0. v_med3_f32(x,0,1) equals the select form (x>0 ? (x<1 ? x : 1) : 0) for ALL
+// 2^32 inputs on gfx950 (exhaustive: scripts/ubench/sqrt_ubench.hip, tests/test_gpu_devmath.py).
+VQD float saturate(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 VQD float abs_(float x) { return __builtin_fabsf(x); }
 VQD float qnan() { return __uint_as_float(0x7fc00000u); }
 
