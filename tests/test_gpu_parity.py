@@ -352,3 +352,33 @@ def test_abi_errors(ctx):
     rc = lib.vqhip_tonemap(ctx._h, None, None, out8.data_ptr(), 8, 2, C.byref(abi.TonemapperParams.default()), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
     assert rc == abi.VQHIP_ERR_INVALID_ARG
     assert lib.vqhip_forward_lighting(None, None, None, None, None, None, 0, None, None, None, 0, 0) == abi.VQHIP_ERR_INVALID_ARG
+
+
+# ---------------------------------------------------------------------------------------------------
+# committed golden fixtures (tests/golden/*.npz, produced by tests/golden/make_golden.py from the oracle)
+# ---------------------------------------------------------------------------------------------------
+def test_hip_path_reproduces_golden_fixtures(ctx):
+    import os
+    from tests.golden import make_golden as G
+    gdir = os.path.dirname(os.path.abspath(G.__file__))
+    eq = synth.equirect(64, 32)
+    chain, n = ctx.mip_chain(dev(eq))
+    pre = ctx.envmap_prefilter(chain, 64, 32, n, 8, 0.1, 16, abi.CONV_WAVE64)
+    lut = ctx.brdf_lut(32, 64, abi.FMT_RG16F)
+    fx = np.load(os.path.join(gdir, "ibl_small.npz"))
+    assert_bits(chain[64 * 32:], fx["mip_tail"], "golden mip_tail")
+    for k in ("diffuse_unblurred", "diffuse_blurred", "specular"):
+        assert_bits(pre[k], fx[k], f"golden {k}")
+    assert_bits(lut, fx["lut"], "golden lut")
+    assert_bits(ctx.conv_diffuse(chain, 64, 32, n, 4, 0.1, abi.CONV_SEQUENTIAL, abi.FMT_RGBA16F), fx["diffuse_sequential_4"], "golden sequential diffuse")
+    W, H, gb, pf, extra = G.shade_inputs()
+    fx = np.load(os.path.join(gdir, "shade_small.npz"))
+    g = [dev(x) for x in gb]
+    assert_bits(ctx.forward_lighting(g, pf, synth.per_view(W, H), out_fmt=abi.FMT_RGBA32F), fx["noenv_rgba32f"], "golden shade noenv")
+    env = capi.make_envmap(pre["diffuse_blurred"], pre["specular"], 16, pre["spec_mips"], lut)
+    assert_bits(ctx.forward_lighting(g, pf, synth.per_view(W, H, max_env_lod=pre["spec_mips"]), out_fmt=abi.FMT_RGBA16F, env=env), fx["env_rgba16f"], "golden shade env")
+    fx = np.load(os.path.join(gdir, "post_small.npz"))
+    bl = ctx.gaussian_blur(dev(G.post_inputs()), abi.FMT_RGBA16F)
+    assert_bits(bl, fx["blur_rgba16f"], "golden blur")
+    assert_bits(ctx.tonemap(bl, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM), fx["sdr_rgba8"], "golden sdr")
+    assert_bits(ctx.tonemap(bl, abi.FMT_RGBA16F, abi.FMT_RGBA16F, abi.TonemapperParams(0, abi.DISPLAY_CURVE_ST2084, 200.0, 1)), fx["pq_rgba16f"], "golden pq")

@@ -51,8 +51,9 @@ def exchange_halos_allgather(x_tile, group=None):
     if world == 1:
         return None, None
     mine = torch.cat([x_tile[:HALO_ROWS], x_tile[-HALO_ROWS:]], 0).contiguous()
-    allb = torch.empty((world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
-    dist.all_gather_into_tensor(allb, mine, group=group)
+    flat = torch.empty((world * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(flat, mine, group=group)          # concatenated along dim 0 (the form gloo and nccl share)
+    allb = flat.view((world,) + tuple(mine.shape))
     top = allb[rank - 1, HALO_ROWS:].contiguous() if rank > 0 else None
     bottom = allb[rank + 1, :HALO_ROWS].contiguous() if rank < world - 1 else None
     return top, bottom
