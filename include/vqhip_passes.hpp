@@ -1,0 +1,196 @@
+// vqhip_passes.hpp — host-side C++ mirror of the reference's render-pass interface for the hot path.
+//
+// VQEngine's passes derive IRenderPass / RenderPassBase (Source/Renderer/Rendering/RenderPass/RenderPass.h:44-89) and take
+// nested POD `FResourceCollection` / `FDrawParameters` structs (idiom: ApplyReflections.h:29-39, static_cast in
+// RecordCommands: ApplyReflections.cpp:45-50). The four functions on the hot path are NOT behind that interface in the
+// reference — they are VQRenderer members:
+//     RenderSceneColor          Source/Renderer/Rendering/SceneRendering.cpp:1619
+//     RenderPostProcess         SceneRendering.cpp:2507
+//     PreFilterEnvironmentMap   Source/Renderer/Rendering/EnvironmentMapRendering.cpp:139
+//     ComputeBRDFIntegrationLUT Source/Renderer/Renderer.cpp:871
+// These adaptors give them the IRenderPass shape so a maintainer can register them next to the other 8 passes
+// (Renderer.cpp:577-585) and call RecordCommands() where the D3D12 code recorded command lists. "Recording" here means
+// enqueueing HIP kernels on a stream through the C ABI (include/vqhip.h); nothing else is linked.
+// Header-only, C++17, needs the HIP runtime only for buffer allocation (hipMalloc/hipFree).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+#include <string>
+#include <vector>
+#include "vqhip.h"
+
+namespace vqhip {
+
+struct IRenderPassResourceCollection {};            // RenderPass.h:27
+struct IRenderPassDrawParameters {};                // RenderPass.h:29
+
+class IRenderPass {                                 // RenderPass.h:44-59 (CollectPSOCreationParameters has no analogue: kernels are AOT)
+public:
+    virtual ~IRenderPass() = default;
+    virtual bool Initialize() = 0;
+    virtual void Destroy() = 0;
+    virtual void OnCreateWindowSizeDependentResources(unsigned Width, unsigned Height, const IRenderPassResourceCollection* pRscParameters = nullptr) = 0;
+    virtual void OnDestroyWindowSizeDependentResources() = 0;
+    virtual void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) = 0;
+    int LastStatus() const { return mStatus; }      // the reference asserts/logs; here the last vqhip_status is kept
+protected:
+    int mStatus = VQHIP_OK;
+};
+
+class RenderPassBase : public IRenderPass {         // RenderPass.h:65-89: holds the renderer; here the vqhip context
+protected:
+    explicit RenderPassBase(vqhip_ctx* Ctx) : mCtx(Ctx) {}
+    vqhip_ctx* mCtx;
+    static void* Alloc(size_t bytes) { void* p = nullptr; return hipMalloc(&p, bytes) == hipSuccess ? p : nullptr; }
+    static void Free(void*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward lighting == VQRenderer::RenderSceneColor (SceneRendering.cpp:1619-1851, lit draws :1730-1784).
+// Owns the scene-colour target (Tex_SceneColor, RGBA16F: RenderResources.cpp:40,144-161).
+// ---------------------------------------------------------------------------------------------------------------
+class HipForwardLightingPass : public RenderPassBase {
+public:
+    struct FResourceCollection : public IRenderPassResourceCollection {};
+    struct FDrawParameters : public IRenderPassDrawParameters {
+        void* Stream = nullptr;                                  // replaces ID3D12GraphicsCommandList* pCmd
+        vqhip_gbuffer GBuffer = {};                              // replaces the rasterised PSInput + material textures
+        const VQ_PerFrameData* pPerFrame = nullptr;              // == cbPerFrame  (SceneRendering.cpp:429-450)
+        const VQ_PerViewLightingData* pPerView = nullptr;        // == cbPerView   (:452-467)
+        const VQ_PointLight* pExtraPointLights = nullptr;        // extension: lights beyond NUM_LIGHTS__POINT
+        int NumExtraPointLights = 0;
+        const vqhip_envmap* pEnvironmentMap = nullptr;           // nullptr == bDrawEnvironmentMap false (NullCubemapSRV, :1698-1709)
+        const vqhip_shadowmaps* pShadowMaps = nullptr;
+    };
+    explicit HipForwardLightingPass(vqhip_ctx* Ctx) : RenderPassBase(Ctx) {}
+    ~HipForwardLightingPass() override { OnDestroyWindowSizeDependentResources(); }
+    bool Initialize() override { return mCtx != nullptr; }
+    void Destroy() override { OnDestroyWindowSizeDependentResources(); }
+    void OnCreateWindowSizeDependentResources(unsigned Width, unsigned Height, const IRenderPassResourceCollection* = nullptr) override {
+        OnDestroyWindowSizeDependentResources();
+        mWidth = Width; mHeight = Height;
+        mSceneColor = Alloc((size_t)Width * Height * 8);
+    }
+    void OnDestroyWindowSizeDependentResources() override { Free(mSceneColor); mWidth = mHeight = 0; }
+    void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) override {
+        const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
+        if (!p || !mSceneColor) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
+        mStatus = vqhip_forward_lighting(mCtx, p->Stream, &p->GBuffer, p->pPerFrame, p->pPerView, p->pExtraPointLights, p->NumExtraPointLights,
+                                         p->pEnvironmentMap, p->pShadowMaps, mSceneColor, (int)mWidth, VQHIP_FMT_RGBA16F);
+    }
+    void* GetSceneColor() const { return mSceneColor; }          // RGBA16F, width*height
+    unsigned Width() const { return mWidth; }
+    unsigned Height() const { return mHeight; }
+private:
+    void* mSceneColor = nullptr;
+    unsigned mWidth = 0, mHeight = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Post-process == VQRenderer::RenderPostProcess (SceneRendering.cpp:2507-2788): [blur X,Y :2582-2638] -> tonemapper :2640-2656.
+// Owns BlurIntermediate / BlurOutput (RGBA16F, RenderResources.cpp:221-243) and TonemapperOut (RGBA8 SDR / RGBA16F HDR, :245-261).
+// Returns the buffer holding the final image like the reference returns ID3D12Resource*.
+// ---------------------------------------------------------------------------------------------------------------
+class HipPostProcessPass : public RenderPassBase {
+public:
+    struct FResourceCollection : public IRenderPassResourceCollection {};
+    struct FDrawParameters : public IRenderPassDrawParameters {
+        void* Stream = nullptr;
+        const void* pSceneColor = nullptr;                       // RGBA16F input (HipForwardLightingPass::GetSceneColor())
+        VQ_TonemapperParams TonemapperParams = { VQ_COLOR_SPACE_REC_709, VQ_DISPLAY_CURVE_SRGB, 200.0f, 1 };   // FTonemapper defaults, PostProcess.h:84-91
+        bool bEnableGaussianBlur = false;                        // FPostProcessParameters::bEnableGaussianBlur (PostProcess.h:166); compiled out in the reference (:2526)
+        bool bHDR = false;                                       // selects the RGBA16F tonemapper target
+    };
+    explicit HipPostProcessPass(vqhip_ctx* Ctx) : RenderPassBase(Ctx) {}
+    ~HipPostProcessPass() override { OnDestroyWindowSizeDependentResources(); }
+    bool Initialize() override { return mCtx != nullptr; }
+    void Destroy() override { OnDestroyWindowSizeDependentResources(); }
+    void OnCreateWindowSizeDependentResources(unsigned Width, unsigned Height, const IRenderPassResourceCollection* = nullptr) override {
+        OnDestroyWindowSizeDependentResources();
+        mWidth = Width; mHeight = Height;
+        const size_t px = (size_t)Width * Height;
+        mBlurIntermediate = Alloc(px * 8); mBlurOutput = Alloc(px * 8); mTonemapperOut = Alloc(px * 8);
+    }
+    void OnDestroyWindowSizeDependentResources() override { Free(mBlurIntermediate); Free(mBlurOutput); Free(mTonemapperOut); mWidth = mHeight = 0; }
+    void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) override {
+        const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
+        if (!p || !p->pSceneColor || !mTonemapperOut) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
+        const void* src = p->pSceneColor;
+        if (p->bEnableGaussianBlur) {
+            const VQ_BlurParams bp = { (int32_t)mWidth, (int32_t)mHeight };                                      // FBlurParams, PostProcess.h:92-96
+            mStatus = vqhip_gaussian_blur(mCtx, p->Stream, src, mBlurIntermediate, mBlurOutput, &bp, VQHIP_FMT_RGBA16F);
+            if (mStatus != VQHIP_OK) return;
+            src = mBlurOutput;
+        }
+        mOutFormat = p->bHDR ? VQHIP_FMT_RGBA16F : VQHIP_FMT_RGBA8_UNORM;
+        mStatus = vqhip_tonemap(mCtx, p->Stream, src, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
+    }
+    void* GetOutput() const { return mTonemapperOut; }
+    vqhip_format GetOutputFormat() const { return mOutFormat; }
+private:
+    void* mBlurIntermediate = nullptr; void* mBlurOutput = nullptr; void* mTonemapperOut = nullptr;
+    vqhip_format mOutFormat = VQHIP_FMT_RGBA8_UNORM;
+    unsigned mWidth = 0, mHeight = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Environment-map prefilter == FEnvironmentMapRenderingResources::CreateRenderingResources (EnvironmentMapRendering.cpp:20-106)
+// + VQRenderer::PreFilterEnvironmentMap (:139-486) + ComputeBRDFIntegrationLUT (Renderer.cpp:871-909).
+// "Window size" plays no role; resources depend on the HDRI and the two resolutions.
+// ---------------------------------------------------------------------------------------------------------------
+class HipEnvMapPrefilterPass : public RenderPassBase {
+public:
+    struct FResourceCollection : public IRenderPassResourceCollection {
+        int DiffuseIrradianceCubemapResolution = 64;             // EnvironmentMap.cpp:214
+        int SpecularMapMip0Resolution = 128;                     // gfx.EnvironmentMapResolution (Settings.h:48)
+        int HDRIWidth = 0, HDRIHeight = 0;
+    };
+    struct FDrawParameters : public IRenderPassDrawParameters {
+        void* Stream = nullptr;
+        const void* pEquirectRGBA32F = nullptr;                  // device, HDRIWidth x HDRIHeight float4 (level 0 only; mips are generated here)
+        float DiffuseIntegrationStep = 0.010f;                   // INTEGRATION_STEP_DIFFUSE_IRRADIANCE, PipelineStateObjects.cpp:1298-1306
+        vqhip_conv_order Order = VQHIP_CONV_WAVE64;
+        bool bComputeBRDFLUT = true;                             // LoadDefaultResources does this once (Renderer.cpp:934)
+    };
+    explicit HipEnvMapPrefilterPass(vqhip_ctx* Ctx) : RenderPassBase(Ctx) {}
+    ~HipEnvMapPrefilterPass() override { DestroyRenderingResources(); }
+    bool Initialize() override { return mCtx != nullptr; }
+    void Destroy() override { DestroyRenderingResources(); }
+    void OnCreateWindowSizeDependentResources(unsigned, unsigned, const IRenderPassResourceCollection* pRsc = nullptr) override {
+        const FResourceCollection* r = static_cast<const FResourceCollection*>(pRsc);
+        if (!r) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
+        DestroyRenderingResources();
+        mRsc = *r;
+        mNumMips = vqhip_mip_level_count(r->HDRIWidth, r->HDRIHeight);
+        mSpecMips = vqhip_specular_mip_count(r->SpecularMapMip0Resolution);
+        const size_t face = (size_t)r->DiffuseIrradianceCubemapResolution * r->DiffuseIrradianceCubemapResolution * 8;
+        mChain = Alloc(vqhip_mip_chain_bytes(r->HDRIWidth, r->HDRIHeight, mNumMips));
+        mDiff = Alloc(6 * face); mDiffBlurred = Alloc(6 * face); mBlurTemp = Alloc(face);
+        mSpec = Alloc(vqhip_cube_bytes(r->SpecularMapMip0Resolution, mSpecMips, VQHIP_FMT_RGBA16F));
+        mLUT = Alloc((size_t)1024 * 1024 * 4);                   // 1024^2 RG16F, Renderer.cpp:1026-1032
+    }
+    void OnDestroyWindowSizeDependentResources() override { DestroyRenderingResources(); }
+    void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) override {
+        const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
+        if (!p || !p->pEquirectRGBA32F || !mChain) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
+        const size_t l0 = (size_t)mRsc.HDRIWidth * mRsc.HDRIHeight * 16;
+        if (hipMemcpyAsync(mChain, p->pEquirectRGBA32F, l0, hipMemcpyDeviceToDevice, (hipStream_t)p->Stream) != hipSuccess) { mStatus = VQHIP_ERR_HIP; return; }
+        mStatus = vqhip_mip_chain_min_rgba32f(mCtx, p->Stream, mChain, mRsc.HDRIWidth, mRsc.HDRIHeight, mNumMips);   // TextureManager.cpp:590-592,643-738
+        if (mStatus != VQHIP_OK) return;
+        const vqhip_envmap_out out = { mDiff, mDiffBlurred, mBlurTemp, mSpec };
+        mStatus = vqhip_envmap_prefilter(mCtx, p->Stream, mChain, mRsc.HDRIWidth, mRsc.HDRIHeight, mNumMips, mRsc.DiffuseIrradianceCubemapResolution,
+                                         p->DiffuseIntegrationStep, mRsc.SpecularMapMip0Resolution, p->Order, &out);
+        if (mStatus != VQHIP_OK || !p->bComputeBRDFLUT) return;
+        mStatus = vqhip_brdf_lut(mCtx, p->Stream, mLUT, 1024, 2048, VQHIP_FMT_RG16F);                             // Renderer.cpp:895-900
+    }
+    // what RenderSceneColor binds at SceneRendering.cpp:1698-1709
+    vqhip_envmap GetEnvironmentMap() const { return vqhip_envmap{ mDiffBlurred, mRsc.DiffuseIrradianceCubemapResolution, mSpec, mRsc.SpecularMapMip0Resolution, mSpecMips, mLUT, 1024 }; }
+    int GetNumSpecularIrradianceCubemapLODLevels() const { return mSpecMips; }   // -> PerViewLightingData::MaxEnvMapLODLevels (SceneRendering.cpp:463)
+private:
+    void DestroyRenderingResources() { Free(mChain); Free(mDiff); Free(mDiffBlurred); Free(mBlurTemp); Free(mSpec); Free(mLUT); }   // :108
+    FResourceCollection mRsc;
+    int mNumMips = 0, mSpecMips = 0;
+    void* mChain = nullptr; void* mDiff = nullptr; void* mDiffBlurred = nullptr; void* mBlurTemp = nullptr; void* mSpec = nullptr; void* mLUT = nullptr;
+};
+
+} // namespace vqhip

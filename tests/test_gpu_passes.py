@@ -1,0 +1,45 @@
+"""The IRenderPass-shaped C++ adaptors (include/vqhip_passes.hpp) driven from a C++ program the way VQRenderer would
+drive them (tests/cpp/test_passes.cpp), checked bit-for-bit against the oracle."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from vqengine_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+EXE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "test_passes")
+
+
+def test_cpp_pass_adaptors(tmp_path, ctx):
+    W, H, EW, EH = 160, 24, 64, 32
+    gb = synth.gbuffer(W, H, seed=0xCAFE)
+    pf, _ = synth.per_frame(points=synth.point_lights(20, seed=0xCAFE), spots=synth.spot_lights(2, seed=0xCAFE),
+                            directional=synth.directional_light(), hdri_offset=0.3)
+    eq = synth.equirect(EW, EH)
+    chain, n = O.mip_chain(eq)
+    pre = O.envmap_prefilter(chain, EW, EH, n, 8, 0.1, 16, abi.CONV_WAVE64)
+    pv = synth.per_view(W, H, max_env_lod=pre["spec_mips"])
+    for k in range(4):
+        gb[k].tofile(tmp_path / f"gb{k}.bin")
+    eq.tofile(tmp_path / "equirect.bin")
+    (tmp_path / "perframe.bin").write_bytes(bytes(pf))
+    (tmp_path / "perview.bin").write_bytes(bytes(pv))
+    r = subprocess.run([EXE, str(tmp_path), str(W), str(H), str(EW), str(EH)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    diff = np.fromfile(tmp_path / "diffuse_blurred.bin", np.float16).reshape(6, 8, 8, 4)
+    n_bad, idx = O.bits_equal(diff, pre["diffuse_blurred"])
+    assert n_bad == 0, idx
+    # full-size LUT from the product (already checked row-wise against the oracle in test_gpu_parity) feeds the oracle shade
+    lut_g = ctx.brdf_lut(1024, 2048, abi.FMT_RG16F).cpu().numpy()
+    env = O.host_envmap(pre["diffuse_blurred"], pre["specular"], 16, pre["spec_mips"], lut_g)
+    scene = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F, env=env)
+    got = np.fromfile(tmp_path / "scene_rgba16f.bin", np.float16).reshape(H, W, 4)
+    n_bad, idx = O.bits_equal(got, scene)
+    assert n_bad == 0, (n_bad, idx)
+    sdr = O.tonemap(O.gaussian_blur(scene, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
+    got = np.fromfile(tmp_path / "sdr_rgba8.bin", np.uint8).reshape(H, W, 4)
+    assert np.array_equal(got, sdr)
