@@ -382,3 +382,34 @@ def test_hip_path_reproduces_golden_fixtures(ctx):
     assert_bits(bl, fx["blur_rgba16f"], "golden blur")
     assert_bits(ctx.tonemap(bl, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM), fx["sdr_rgba8"], "golden sdr")
     assert_bits(ctx.tonemap(bl, abi.FMT_RGBA16F, abi.FMT_RGBA16F, abi.TonemapperParams(0, abi.DISPLAY_CURVE_ST2084, 200.0, 1)), fx["pq_rgba16f"], "golden pq")
+
+
+def test_forward_fuzz_adversarial_inputs(ctx, env_small):
+    """Fuzz: G-buffer fields drawn from random BIT PATTERNS (all exponents, denormals, infs, NaNs) mixed with normal
+    values, lights at degenerate distances (0, 1e-25, 1e25). Exercises the slow (IEEE) fall-backs of the proven-range
+    fast reciprocals in add_point_light and every NaN/inf propagation path; must still match the oracle bit-for-bit."""
+    rng = np.random.default_rng(77)
+    W, H = 1024, 12
+    gb = synth.gbuffer(W, H, seed=0xF022)
+    for k in range(4):
+        bits = rng.integers(0, 2 ** 32, gb[k].shape, dtype=np.uint32).view(np.float32)
+        sel = rng.random(gb[k].shape) < 0.12
+        gb[k] = np.where(sel, bits, gb[k]).astype(np.float32)
+    gb[1][:, ::7, 3] = rng.choice(np.array([0.0, 1.0, 1.0000001, -1e-9, 2.0, 1e-20], np.float32), gb[1][:, ::7, 3].shape)   # roughness edge values
+    pts = synth.point_lights(10, seed=0xF022)
+    pts[1].position.set(gb[0][3, 100, :3]); pts[1].range = 1e9                     # D == 0 for one pixel
+    pts[2].position.set(gb[0][5, 200, :3] + np.float32(1e-25)); pts[2].range = 1e9 # D^2 below 2^-60
+    pts[3].position.set((1e25, 1e25, -1e25)); pts[3].range = 3.0e38                # D^2 overflows
+    pts[4].position.set((1e12, 0, 0)); pts[4].range = 3.0e38                       # D^2 = 1e24 > 2^60
+    pts[5].brightness = float("inf")
+    pts[6].color.set((float("nan"), 1.0, -1.0))
+    pts[7].range = float("nan")
+    pf, _ = synth.per_frame(points=pts, spots=synth.spot_lights(2, seed=3), directional=synth.directional_light(), hdri_offset=0.3)
+    env_o, env_g = _envs(env_small)
+    pv = synth.per_view(W, H, max_env_lod=env_small["pre_o"]["spec_mips"])
+    for env_pair in ((None, None), (env_o, env_g)):
+        with np.errstate(all="ignore"):
+            ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F, env=env_pair[0])
+        got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F, env=env_pair[1])
+        assert_bits(got, ref, "fuzz forward lighting")
+    assert np.isnan(ref).any() and np.isfinite(ref).any()

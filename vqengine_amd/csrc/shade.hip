@@ -27,6 +27,7 @@ struct Pixel {
     float k, omk;                         // k = (roughness+1)^2/8, omk = 1-k
     float a2, a2m1;                       // GGX alpha^2, alpha^2 - 1
     float invPI;
+    bool fastOK;                          // roughness in [0,1]: precondition of the unchecked fast reciprocals (add_point_light)
 };
 
 VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
@@ -97,18 +98,27 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.a2 = a * a;
     px.a2m1 = px.a2 - 1.0f;
     px.invPI = rcp(PI_);
+    px.fastOK = (px.roughness >= 0.0f) & (px.roughness <= 1.0f);
 }
 
 // BRDF(s, Wi, V), BRDF.hlsl:163-194, with the hoisted terms of `px`. `rc` is the reciprocal policy (vq_devmath.h).
 template <class R>
 VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const f3 Hs = add(px.Wo, Wi);
+#if VQ_ABLATE == 2
+    const f3 H = mul(Hs, 0.7f);                              // ablation: no H normalisation
+#else
     const f3 H = mul(Hs, rc(rc.sqrt(dot(Hs, Hs))));          // normalize(Wo + Wi)
+#endif
     const float NdotH = saturate(dot(px.Nn, H));
     const float dNL = dot(px.Nn, Wi);
     const float NdotL = saturate(dNL);
     // Fresnel_Schlick(H, V, F0) :132-136
+#if VQ_ABLATE == 1
+    const float p5 = 0.25f + 1e-9f * dot(H, px.V);           // ablation: no pow
+#else
     const float p5 = pow5(1.0f - max_(0.0f, dot(H, px.V)));
+#endif
     const f3 F = mk3(px.F0.x + px.omF0.x * p5, px.F0.y + px.omF0.y * p5, px.F0.z + px.omF0.z * p5);
     // Geometry_Smith :118-121
     const float NL = max_(0.0f, dNL);
@@ -143,11 +153,49 @@ VQD f3 point_light_t(const Pixel& px, const VQ_PointLight& l, R& rc) {
     }
     return r;
 }
-VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {
+VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // general form (shadow casters): per-op validity flag
     RcpFast fast;
     f3 r = point_light_t(px, l, fast);
     if (__builtin_expect(!fast.ok, 0)) { RcpIEEE ieee; r = point_light_t(px, l, ieee); }
     return r;
+}
+
+// Hot-loop form: I += CalculatePointLightIllumination(...). All reciprocals / square roots use the unchecked fast
+// sequences (RcpTrust); their validity is PROVEN from three range tests instead of being checked per operation:
+//   pixel  : roughness in [0,1]  (px.fastOK)  =>  k in [1/8,1/2], 1-k in [1/2,7/8], a2 in [0,1], hence
+//              G operand (NL(1-k)+k)+1e-4 in [0.125, 1.4]   (NL = max(0,.) <= 1+eps, NaN -> 0)
+//              GGX operand max(pi t^2, 1e-12) in [1e-12, pi] (t = nh2 (a2-1) + 1 in [a2,1], nh2 saturated)
+//              rd operand max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
+//   light  : dd = |Lw-P|^2 in [2^-60, 2^60] =>  D in [2^-30, 2^30], D*D in range, 1/D and 1/D^2 normal
+//   light  : hh = |Wo+Wi|^2 >= 2^-100 (and not NaN; it is <= ~4 for unit Wo, Wi) => sqrt and 1/sqrt normal
+// all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
+// degenerate geometry, roughness outside [0,1]) redoes that light with IEEE operations; results are identical bits.
+struct RcpTrust {
+    VQD float operator()(float b) const { return rcp_newton(b); }
+    VQD float sqrt(float x) const { return sqrt_newton(x); }
+};
+VQD void add_point_light(const Pixel& px, const VQ_PointLight& l, f3& I) {
+    const f3 Iprev = I;
+    const f3 d = sub(ld3(l.position), px.P);
+    const float dd = dot(d, d);
+    const float D = sqrt_newton(dd);
+    bool ok = px.fastOK & (dd >= 0x1p-60f) & (dd <= 0x1p60f);
+    if (D < l.range) {                                       // wave-coherent cull; a wrong D (ok == false) is redone below
+        RcpTrust rc;
+        const f3 Wi = mul(d, rc(D));
+        const f3 Hs = add(px.Wo, Wi);
+        ok = ok & (dot(Hs, Hs) >= 0x1p-100f);
+        const float NdotL = saturate(dot(px.Nraw, Wi));
+        const float att = rc(D * D);
+        const f3 radiance = mk3((att * l.color.x) * l.brightness, (att * l.color.y) * l.brightness, (att * l.color.z) * l.brightness);
+#if VQ_ABLATE == 3
+        const f3 b = mk3(Wi.x * px.k, Wi.y * px.a2, Wi.z * px.omk);   // ablation: no BRDF
+#else
+        const f3 b = brdf_t(px, Wi, rc);
+#endif
+        I = mk3(I.x + (b.x * radiance.x) * NdotL, I.y + (b.y * radiance.y) * NdotL, I.z + (b.z * radiance.z) * NdotL);
+    }
+    if (__builtin_expect(!ok, 0)) { RcpIEEE ieee; I = add(Iprev, point_light_t(px, l, ieee)); }
 }
 
 // SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333
@@ -256,8 +304,14 @@ VQD float pcf_2d(const float* slice, int dim, float2 smDims, float4 lsp, float b
     return 1.0f - div_(shadow, 25.0f);
 }
 
+#ifndef VQ_ABLATE
+#define VQ_ABLATE 0
+#endif
+#ifndef VQ_SHADE_WAVES
+#define VQ_SHADE_WAVES 1
+#endif
 template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT>
-__global__ __launch_bounds__(256) void k_forward_lighting(vqk::ShadeArgs a) {
+__global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::ShadeArgs a) {
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= a.width) return;
@@ -276,10 +330,10 @@ __global__ __launch_bounds__(256) void k_forward_lighting(vqk::ShadeArgs a) {
 
     const VQ_SceneLighting& L = fc->perFrame.Lights;
     const int nP = L.numPointLights;
-    for (int p = 0; p < nP; ++p) I = add(I, point_light(px, L.point_lights[p]));              // :310-313
+    for (int p = 0; p < nP; ++p) add_point_light(px, L.point_lights[p], I);                   // :310-313
     const int nE = fc->numExtraPoint;
     const VQ_PointLight* extra = (const VQ_PointLight*)(fc + 1);
-    for (int p = 0; p < nE; ++p) I = add(I, point_light(px, extra[p]));                       // extension, vqhip.h
+    for (int p = 0; p < nE; ++p) add_point_light(px, extra[p], I);                            // extension, vqhip.h
     const int nS = L.numSpotLights;
     for (int s = 0; s < nS; ++s) I = add(I, spot_light(px, L.spot_lights[s]));                // :314-317
 
