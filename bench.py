@@ -28,6 +28,10 @@ HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spe
 VALU_PEAK_TFLOPS = 157.3        # :40
 SHADE_BYTES_PER_PX = 64 + 8     # 4 float4 G-buffer planes in + RGBA16F out
 SHADE_FLOPS_PER_PX = 170 * N_LIGHTS + 160
+# HBM bytes per launch of the shade kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
+# FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950): profiles/r1b_pmc_hbm.md. Not measurable from inside
+# bench.py; the committed figure is for exactly this workload (3840x2160, 64 lights + IBL, RGBA16F out).
+SHADE_PMC_TRAFFIC_BYTES = (2 * 599481 + 64800) * 1024
 
 
 def build_ibl(ctx):
@@ -141,6 +145,8 @@ def main():
         ctx.gaussian_blur_y(xblur, F16, out=yblur, halo_top=top, halo_bottom=bottom)
         if ev:
             ev[2].record()
+        # (the fused vqhip_gaussian_blur_y_tonemap is bit-identical but measured slower than the two dispatches at 4K:
+        #  86 us vs 31 + 43 us — the 3 pow() per pixel want the tonemapper's own occupancy)
         ctx.tonemap(yblur, F16, R8, out=sdr[b])
         if ev:
             ev[3].record()
@@ -188,7 +194,8 @@ def main():
                                    "21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8" + ("" if world == 1 else f"; frame 3840x{frame_h} row-tiled, RCCL halo ({args.halo}) + all-gather composite"),
                        "width": W, "frame_height": frame_h, "lights": N_LIGHTS, "parallelism": f"rows{world}"},
             "roofline": {"bound": "hbm", "kernel": "k_forward_lighting<env,nocasters,RGBA16F>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": SHADE_PMC_TRAFFIC_BYTES, "traffic_unit": "bytes/launch",
+                         "traffic_source": "profiles/r1b_pmc_hbm.md (rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE); algorithmic = %d" % (SHADE_BYTES_PER_PX * px_tile),
                          "bytes_per_px": SHADE_BYTES_PER_PX, "ms": round(t_shade * 1e3, 4),
                          "note": "64-light shading is VALU-bound by construction (SURVEY.md 8d): see valu"},
             "valu": {"achieved_tflops_model": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12, 2), "peak": VALU_PEAK_TFLOPS,

@@ -282,6 +282,14 @@ VQHIP_API int vqhip_gaussian_blur_y(vqhip_ctx* ctx, void* stream, const void* in
         const void* halo_top, const void* halo_bottom, int halo_rows,
         const VQ_BlurParams* params, vqhip_format fmt);
 
+/* Fused form of the last two dispatches of the post chain when the blur is enabled: CSMain_Y (GaussianBlur.hlsl:155-187,
+ * SceneRendering.cpp:2613-2638) immediately followed by Tonemapper.hlsl:CSMain (:2640-2656). The blurred value is rounded
+ * to `blurFmt` exactly as if it had been stored to BlurOutput and re-read, then tonemapped in registers: identical bits to
+ * vqhip_gaussian_blur_y + vqhip_tonemap, one image round trip through HBM less. */
+VQHIP_API int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out,
+        const void* halo_top, const void* halo_bottom, int halo_rows,
+        const VQ_BlurParams* blurParams, const VQ_TonemapperParams* tonemapParams, vqhip_format blurFmt, vqhip_format outFmt);
+
 /* Replaces the Tonemapper.hlsl:CSMain dispatch (SceneRendering.cpp:2640-2656).
  * inFmt RGBA16F|RGBA32F; outFmt RGBA8_UNORM (SDR swapchain path) | RGBA16F (HDR path) | RGBA32F. */
 VQHIP_API int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,

@@ -115,15 +115,18 @@ public:
     void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) override {
         const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
         if (!p || !p->pSceneColor || !mTonemapperOut) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
-        const void* src = p->pSceneColor;
-        if (p->bEnableGaussianBlur) {
-            const VQ_BlurParams bp = { (int32_t)mWidth, (int32_t)mHeight };                                      // FBlurParams, PostProcess.h:92-96
-            mStatus = vqhip_gaussian_blur(mCtx, p->Stream, src, mBlurIntermediate, mBlurOutput, &bp, VQHIP_FMT_RGBA16F);
-            if (mStatus != VQHIP_OK) return;
-            src = mBlurOutput;
-        }
         mOutFormat = p->bHDR ? VQHIP_FMT_RGBA16F : VQHIP_FMT_RGBA8_UNORM;
-        mStatus = vqhip_tonemap(mCtx, p->Stream, src, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
+        if (p->bEnableGaussianBlur) {
+            // CSMain_X -> BlurIntermediate, then CSMain_Y + Tonemapper fused (identical bits to the separate dispatches
+            // through BlurOutput, one image round trip less; vqhip.h:vqhip_gaussian_blur_y_tonemap)
+            const VQ_BlurParams bp = { (int32_t)mWidth, (int32_t)mHeight };                                      // FBlurParams, PostProcess.h:92-96
+            mStatus = vqhip_gaussian_blur_x(mCtx, p->Stream, p->pSceneColor, mBlurIntermediate, &bp, VQHIP_FMT_RGBA16F);
+            if (mStatus != VQHIP_OK) return;
+            mStatus = vqhip_gaussian_blur_y_tonemap(mCtx, p->Stream, mBlurIntermediate, mTonemapperOut, nullptr, nullptr, 0, &bp, &p->TonemapperParams,
+                                                    VQHIP_FMT_RGBA16F, mOutFormat);
+            return;
+        }
+        mStatus = vqhip_tonemap(mCtx, p->Stream, p->pSceneColor, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
     }
     void* GetOutput() const { return mTonemapperOut; }
     vqhip_format GetOutputFormat() const { return mOutFormat; }

@@ -413,3 +413,19 @@ def test_forward_fuzz_adversarial_inputs(ctx, env_small):
         got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F, env=env_pair[1])
         assert_bits(got, ref, "fuzz forward lighting")
     assert np.isnan(ref).any() and np.isfinite(ref).any()
+
+
+@pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+@pytest.mark.parametrize("out_fmt", [abi.FMT_RGBA8_UNORM, abi.FMT_RGBA16F, abi.FMT_RGBA32F])
+def test_fused_blur_y_tonemap_equals_two_dispatches(ctx, fmt, out_fmt):
+    """vqhip_gaussian_blur_y_tonemap == vqhip_gaussian_blur_y then vqhip_tonemap == oracle, incl. row tiles with halos."""
+    h, w = 75, 203
+    x = O.blur_pass(synth.hdr_image(w, h, scale=30.0).astype(O._NP[fmt][0]), fmt, 0)
+    for p in (abi.TonemapperParams.default(), abi.TonemapperParams(abi.COLOR_SPACE_REC_709, abi.DISPLAY_CURVE_ST2084, 300.0, 1)):
+        ref = O.tonemap(O.blur_pass(x, fmt, 1), fmt, out_fmt, p)
+        xg = dev(x)
+        assert_bits(ctx.gaussian_blur_y_tonemap(xg, fmt, out_fmt, params=p), ref, "fused full image")
+        assert_bits(ctx.tonemap(ctx.gaussian_blur_y(xg, fmt), fmt, out_fmt, params=p), ref, "two dispatches")
+        t0, t1 = 25, 50
+        got = ctx.gaussian_blur_y_tonemap(xg[t0:t1].contiguous(), fmt, out_fmt, params=p, halo_top=xg[t0 - 10:t0].contiguous(), halo_bottom=xg[t1:t1 + 10].contiguous())
+        assert_bits(got, ref[t0:t1], "fused tile with halos")

@@ -45,6 +45,7 @@ def load_library():
         "vqhip_gaussian_blur_x": (i32, [vp, vp, vp, vp, C.POINTER(abi.BlurParams), i32]),
         "vqhip_gaussian_blur_y": (i32, [vp, vp, vp, vp, vp, vp, i32, C.POINTER(abi.BlurParams), i32]),
         "vqhip_tonemap": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.TonemapperParams), i32, i32]),
+        "vqhip_gaussian_blur_y_tonemap": (i32, [vp, vp, vp, vp, vp, vp, i32, C.POINTER(abi.BlurParams), C.POINTER(abi.TonemapperParams), i32, i32]),
         "vqhip_brdf_lut": (i32, [vp, vp, vp, i32, i32, i32]),
         "vqhip_mip_level_count": (i32, [i32, i32]),
         "vqhip_mip_chain_bytes": (sz, [i32, i32, i32]),
@@ -67,7 +68,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "vqhip_abi_version", "vqhip_create", "vqhip_destroy", "vqhip_last_error", "vqhip_forward_lighting",
-    "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_tonemap", "vqhip_brdf_lut",
+    "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_gaussian_blur_y_tonemap", "vqhip_tonemap", "vqhip_brdf_lut",
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
 ]
@@ -171,6 +172,23 @@ class Context:
                 rows = hh.shape[0]
         p = abi.BlurParams(src.shape[1], src.shape[0])
         self._ck(self.lib.vqhip_gaussian_blur_y(self._h, self._stream(stream), _ptr(src), _ptr(out), _ptr(halo_top), _ptr(halo_bottom), rows, C.byref(p), fmt))
+        return out
+
+    def gaussian_blur_y_tonemap(self, src, fmt, out_fmt=FMT_RGBA8_UNORM, params=None, out=None, halo_top=None, halo_bottom=None, stream=None):
+        """Fused CSMain_Y + Tonemapper (same bits as gaussian_blur_y followed by tonemap)."""
+        _check_img(src, fmt, "src")
+        h, w = src.shape[0], src.shape[1]
+        out = out if out is not None else empty_image(h, w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out")
+        rows = 0
+        for hh in (halo_top, halo_bottom):
+            if hh is not None:
+                _check_img(hh, fmt, "halo")
+                rows = hh.shape[0]
+        params = params if params is not None else abi.TonemapperParams.default()
+        p = abi.BlurParams(w, h)
+        self._ck(self.lib.vqhip_gaussian_blur_y_tonemap(self._h, self._stream(stream), _ptr(src), _ptr(out), _ptr(halo_top), _ptr(halo_bottom), rows,
+                                                         C.byref(p), C.byref(params), fmt, out_fmt))
         return out
 
     def tonemap(self, src, in_fmt, out_fmt=FMT_RGBA8_UNORM, params=None, out=None, stream=None):

@@ -190,6 +190,19 @@ int vqhip_gaussian_blur_y(vqhip_ctx* ctx, void* stream, const void* in, void* ou
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "blur_y launch");
 }
 
+int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, const void* halo_top, const void* halo_bottom, int halo_rows,
+                                  const VQ_BlurParams* p, const VQ_TonemapperParams* tm, vqhip_format blurFmt, vqhip_format outFmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: ctx is NULL");
+    if (!in || !out || !p || !tm || p->iImageSizeX <= 0 || p->iImageSizeY <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: bad argument");
+    if (!isImageFmt(blurFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_y_tonemap: blurFmt must be RGBA32F or RGBA16F");
+    if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_y_tonemap: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
+    if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: in-place is not supported");
+    if ((halo_top || halo_bottom) && halo_rows < 10) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: halo_rows must be >= 10");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_blur_y_tonemap((hipStream_t)stream, in, out, halo_top, halo_bottom, halo_rows, p->iImageSizeX, p->iImageSizeY, *tm, blurFmt, outFmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "blur_y_tonemap launch");
+}
+
 int vqhip_gaussian_blur(vqhip_ctx* ctx, void* stream, const void* in, void* tmp, void* out, const VQ_BlurParams* p, vqhip_format fmt) {
     if (!tmp) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur: tmp is NULL");
     int rc = vqhip_gaussian_blur_x(ctx, stream, in, tmp, p, fmt);

@@ -88,11 +88,7 @@ VQD float st2084(float c) {                                                   //
     return pow_(div_(c1 + c2 * cp, 1.0f + c3 * cp), m2);
 }
 
-template <int INFMT, int OUTFMT>
-__global__ __launch_bounds__(256) void k_tonemap(const void* __restrict__ in, void* __restrict__ out, size_t n, VQ_TonemapperParams p) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float4 c = load_px<INFMT>(in, i);
+VQD float4 tonemap_px(const float4 c, const VQ_TonemapperParams& p) {
     float ox, oy, oz;
     switch (p.OutputDisplayCurveEnum) {                                       // Tonemapper.hlsl:120-148
         case VQ_DISPLAY_CURVE_SRGB:
@@ -111,7 +107,65 @@ __global__ __launch_bounds__(256) void k_tonemap(const void* __restrict__ in, vo
         case VQ_DISPLAY_CURVE_LINEAR: ox = c.x; oy = c.y; oz = c.z; break;
         default: ox = 1.0f; oy = 1.0f; oz = 0.0f; break;
     }
-    store_px<OUTFMT>(out, i, make_float4(ox, oy, oz, c.w));                   // alpha passes through :150
+    return make_float4(ox, oy, oz, c.w);                                      // alpha passes through :150
+}
+
+template <int INFMT, int OUTFMT>
+__global__ __launch_bounds__(256) void k_tonemap(const void* __restrict__ in, void* __restrict__ out, size_t n, VQ_TonemapperParams p) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    store_px<OUTFMT>(out, i, tonemap_px(load_px<INFMT>(in, i), p));
+}
+
+// Fused Y blur + tonemapper: the blurred pixel is rounded to the blur format (as if stored to BlurOutput and
+// re-read) and tonemapped in registers — one image write + read less than the two dispatches. Same bits.
+// Tile: 64 columns x TR output rows per 256-lane workgroup; the TR+20 input rows are staged ONCE in LDS in the storage
+// format (8 B/px for RGBA16F), then lane (column c, row group g) produces TR/4 consecutive outputs from a register window
+// read out of LDS (wave = 64 adjacent columns of one row: conflict-free ds_read_b64/b128). Compared with the pure
+// register-window Y pass this has 4x more lanes and 4x shorter serial chains, which the 3 pow() per pixel need.
+template <int FMT, int OUTFMT, int TR>
+__global__ __launch_bounds__(256) void k_blur_y_tonemap(const void* __restrict__ in, void* __restrict__ out,
+                                                        const void* __restrict__ haloTop, const void* __restrict__ haloBottom, int haloRows,
+                                                        int W, int H, VQ_TonemapperParams p) {
+    constexpr int ROWS = TR / 4;                              // outputs per lane
+    constexpr int PXB = (FMT == 0) ? 16 : 8;
+    __shared__ __attribute__((aligned(16))) unsigned char tile[(TR + 2 * R) * 64 * PXB];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + c;
+    const int y0 = blockIdx.y * TR;
+    const int xc = min(x, W - 1);
+    for (int i = g; i < TR + 2 * R; i += 4) {                 // 4 waves stream the rows, 64 contiguous pixels each
+        int sy = y0 - R + i;
+        const void* src = in; size_t idx;
+        if (sy < 0 && haloTop)             { src = haloTop;    idx = (size_t)(haloRows + sy) * W + xc; }
+        else if (sy > H - 1 && haloBottom) { src = haloBottom; idx = (size_t)(sy - H) * W + xc; }
+        else                               { sy = min(max(sy, 0), H - 1); idx = (size_t)sy * W + xc; }            // clamp :178
+        if (FMT == 0) ((float4*)tile)[i * 64 + c] = ((const float4*)src)[idx];
+        else          ((h4*)tile)[i * 64 + c] = ((const h4*)src)[idx];
+    }
+    __syncthreads();
+    const int yBase = y0 + g * ROWS;
+    if (x >= W || yBase >= H) return;
+    float wx[ROWS + 2 * R], wy[ROWS + 2 * R], wz[ROWS + 2 * R];
+    #pragma unroll
+    for (int i = 0; i < ROWS + 2 * R; ++i) {
+        const float4 s = load_px<FMT>(tile, (size_t)(g * ROWS + i) * 64 + c);
+        wx[i] = s.x; wy[i] = s.y; wz[i] = s.z;
+    }
+    #pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        if (yBase + r >= H) break;
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        #pragma unroll
+        for (int it = 0; it < 21; ++it) {
+            const int off = it - R;
+            const float w = kW[off < 0 ? -off : off];
+            ax = ax + wx[r + it] * w; ay = ay + wy[r + it] * w; az = az + wz[r + it] * w;
+        }
+        float4 b = make_float4(ax, ay, az, 1.0f);
+        if (FMT == 1) b = make_float4((float)to_f16(ax), (float)to_f16(ay), (float)to_f16(az), 1.0f);      // BlurOutput is RGBA16F
+        store_px<OUTFMT>(out, (size_t)(yBase + r) * W + x, tonemap_px(b, p));
+    }
 }
 
 } // namespace
@@ -143,6 +197,23 @@ hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H
         if (outFmt == VQHIP_FMT_RGBA32F) TM(1, 0); else if (outFmt == VQHIP_FMT_RGBA16F) TM(1, 1); else TM(1, 2);
     }
 #undef TM
+    return hipGetLastError();
+}
+
+hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
+                                 const VQ_TonemapperParams& p, int fmt, int outFmt) {
+#ifndef VQ_FUSED_TR
+#define VQ_FUSED_TR 16
+#endif
+    constexpr int TR = VQ_FUSED_TR;                           // output rows per workgroup (TR/4 per lane); LDS (TR+20) rows x 64 px
+    dim3 grid((W + 63) / 64, (H + TR - 1) / TR);
+#define BT(F, O) hipLaunchKernelGGL((k_blur_y_tonemap<F, O, TR>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H, p)
+    if (fmt == VQHIP_FMT_RGBA32F) {
+        if (outFmt == VQHIP_FMT_RGBA32F) BT(0, 0); else if (outFmt == VQHIP_FMT_RGBA16F) BT(0, 1); else BT(0, 2);
+    } else {
+        if (outFmt == VQHIP_FMT_RGBA32F) BT(1, 0); else if (outFmt == VQHIP_FMT_RGBA16F) BT(1, 1); else BT(1, 2);
+    }
+#undef BT
     return hipGetLastError();
 }
 
