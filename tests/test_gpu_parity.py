@@ -429,3 +429,23 @@ def test_fused_blur_y_tonemap_equals_two_dispatches(ctx, fmt, out_fmt):
         t0, t1 = 25, 50
         got = ctx.gaussian_blur_y_tonemap(xg[t0:t1].contiguous(), fmt, out_fmt, params=p, halo_top=xg[t0 - 10:t0].contiguous(), halo_bottom=xg[t1:t1 + 10].contiguous())
         assert_bits(got, ref[t0:t1], "fused tile with halos")
+
+
+@pytest.mark.parametrize("out_fmt", [abi.FMT_RGBA8_UNORM, abi.FMT_RGBA16F])
+def test_tonemap_table_path(ctx, out_fmt):
+    """Images >= 65536 px in RGBA16F take the 65536-entry table kernel (k_tonemap_lut) whenever the curve does not mix
+    channels; it must equal the oracle for EVERY half bit pattern (all 65536 appear in the image) and every parameter set,
+    and the channel-mixing case (ST2084 on Rec.709 content) must still take the direct kernel."""
+    allh = np.arange(65536, dtype=np.uint16).view(np.float16)
+    img = np.empty((300, 256, 4), np.float16)
+    rng = np.random.default_rng(8)
+    for c in range(4):
+        img[..., c] = np.concatenate([rng.permutation(allh), rng.choice(allh, 300 * 256 - 65536)]).reshape(300, 256)
+    cases = [abi.TonemapperParams(0, abi.DISPLAY_CURVE_SRGB, 200.0, 1), abi.TonemapperParams(1, abi.DISPLAY_CURVE_SRGB, 200.0, 0),
+             abi.TonemapperParams(1, abi.DISPLAY_CURVE_ST2084, 450.0, 1), abi.TonemapperParams(0, abi.DISPLAY_CURVE_ST2084, 200.0, 1),
+             abi.TonemapperParams(0, abi.DISPLAY_CURVE_LINEAR, 200.0, 1), abi.TonemapperParams(0, 5, 200.0, 1)]
+    g = dev(img)
+    for p in cases:
+        with np.errstate(all="ignore"):
+            ref = O.tonemap(img, abi.FMT_RGBA16F, out_fmt, p)
+        assert_bits(ctx.tonemap(g, abi.FMT_RGBA16F, out_fmt, params=p), ref, f"table tonemap curve={p.OutputDisplayCurveEnum} cs={p.ContentColorSpaceEnum}")

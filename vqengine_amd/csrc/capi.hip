@@ -19,6 +19,7 @@ struct vqhip_ctx {
     bool slotBusy[kSlots] = {};
     int nextSlot = 0;
     void* scratch = nullptr; size_t scratchBytes = 0;
+    void* tonemapLut = nullptr;    // 128 KB: 65536-entry tonemap table (post.hip:k_tonemap_lut)
     std::string lastError;
 };
 
@@ -95,6 +96,7 @@ int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
         vqhip_destroy(ctx);
         return rc;
     }
+    if ((e = hipMalloc(&ctx->tonemapLut, 131072)) != hipSuccess) { int rc = failHip(nullptr, e, "vqhip_create: tonemap table"); vqhip_destroy(ctx); return rc; }
     for (int i = 0; i < vqhip_ctx::kSlots; ++i)
         if ((e = hipEventCreateWithFlags(&ctx->slotEvent[i], hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "hipEventCreate"); vqhip_destroy(ctx); return rc; }
     *out_ctx = ctx;
@@ -109,6 +111,7 @@ void vqhip_destroy(vqhip_ctx* ctx) {
     if (ctx->hostRing) (void)hipHostFree(ctx->hostRing);
     if (ctx->devRing) (void)hipFree(ctx->devRing);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->tonemapLut) (void)hipFree(ctx->tonemapLut);
     delete ctx;
 }
 
@@ -217,7 +220,7 @@ int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int w
     if (!isImageFmt(inFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "tonemap: inFmt must be RGBA32F or RGBA16F");
     if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "tonemap: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = launch_tonemap((hipStream_t)stream, in, out, width, height, *p, inFmt, outFmt);
+    hipError_t e = launch_tonemap((hipStream_t)stream, in, out, width, height, *p, inFmt, outFmt, ctx->tonemapLut);
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "tonemap launch");
 }
 

@@ -43,6 +43,47 @@ __global__ __launch_bounds__(256) void k_blur_x(const void* __restrict__ in, voi
     store_px<FMT>(out, row + x, make_float4(ax, ay, az, 1.0f));
 }
 
+// X pass, 4 consecutive pixels per lane: a 256-lane workgroup covers a 1024-pixel row segment whose 1044 input pixels
+// are staged once in LDS in the storage format; each lane reads a 24-pixel register window (6 LDS reads per output
+// instead of 21). One padding pixel after every 4 puts lane i's window element k at 5i + k + k/4: the stride-5-pixel
+// (10-dword) ds_read_b64 pattern is conflict-free within each 32-lane group.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, void* __restrict__ out, int W, int H) {
+    constexpr int PXB = (FMT == 0) ? 16 : 8;
+    constexpr int NPX = 1024 + 2 * R;
+    __shared__ __attribute__((aligned(16))) unsigned char tile[(NPX + NPX / 4 + 4) * PXB];
+    const int y = blockIdx.y, x0 = blockIdx.x * 1024, t = threadIdx.x;
+    const size_t row = (size_t)y * W;
+    for (int i = t; i < NPX; i += 256) {
+        const int sx = min(max(x0 - R + i, 0), W - 1);      // clamp(sampleCoord.x, 0, iImageSize.x - 1) :143
+        const int idx = i + (i >> 2);
+        if (FMT == 0) ((float4*)tile)[idx] = ((const float4*)in)[row + sx];
+        else          ((h4*)tile)[idx] = ((const h4*)in)[row + sx];
+    }
+    __syncthreads();
+    const int xb = x0 + 4 * t;
+    if (xb >= W) return;                                    // early out :129
+    float wx[24], wy[24], wz[24];
+    #pragma unroll
+    for (int k = 0; k < 24; ++k) {
+        const int p = 4 * t + k;
+        const float4 s = load_px<FMT>(tile, (size_t)(p + (p >> 2)));
+        wx[k] = s.x; wy[k] = s.y; wz[k] = s.z;
+    }
+    #pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (xb + j >= W) break;
+        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        #pragma unroll
+        for (int it = 0; it < 21; ++it) {
+            const int off = it - R;
+            const float w = kW[off < 0 ? -off : off];
+            ax = ax + wx[j + it] * w; ay = ay + wy[j + it] * w; az = az + wz[j + it] * w;
+        }
+        store_px<FMT>(out, row + xb + j, make_float4(ax, ay, az, 1.0f));
+    }
+}
+
 // Y pass: block = 64 columns x 4 row groups, each lane produces ROWS outputs of one column.
 template <int FMT, int ROWS>
 __global__ __launch_bounds__(256) void k_blur_y(const void* __restrict__ in, void* __restrict__ out,
@@ -123,7 +164,7 @@ __global__ __launch_bounds__(256) void k_tonemap(const void* __restrict__ in, vo
 // format (8 B/px for RGBA16F), then lane (column c, row group g) produces TR/4 consecutive outputs from a register window
 // read out of LDS (wave = 64 adjacent columns of one row: conflict-free ds_read_b64/b128). Compared with the pure
 // register-window Y pass this has 4x more lanes and 4x shorter serial chains, which the 3 pow() per pixel need.
-template <int FMT, int OUTFMT, int TR>
+template <int FMT, int OUTFMT, int TR, bool TM = true>
 __global__ __launch_bounds__(256) void k_blur_y_tonemap(const void* __restrict__ in, void* __restrict__ out,
                                                         const void* __restrict__ haloTop, const void* __restrict__ haloBottom, int haloRows,
                                                         int W, int H, VQ_TonemapperParams p) {
@@ -163,8 +204,53 @@ __global__ __launch_bounds__(256) void k_blur_y_tonemap(const void* __restrict__
             ax = ax + wx[r + it] * w; ay = ay + wy[r + it] * w; az = az + wz[r + it] * w;
         }
         float4 b = make_float4(ax, ay, az, 1.0f);
+        if (!TM) { store_px<OUTFMT>(out, (size_t)(yBase + r) * W + x, b); continue; }                     // plain CSMain_Y (OUTFMT == FMT)
         if (FMT == 1) b = make_float4((float)to_f16(ax), (float)to_f16(ay), (float)to_f16(az), 1.0f);      // BlurOutput is RGBA16F
         store_px<OUTFMT>(out, (size_t)(yBase + r) * W + x, tonemap_px(b, p));
+    }
+}
+
+// ---- tonemapper through a table: RGBA16F has only 65536 values per channel --------------------------------------
+// When the display curve does not mix channels (sRGB / LINEAR, or ST2084 on Rec.2020 content: no 3x3 matrix) the
+// tonemapped STORAGE value of a channel is a pure function of its 16 input bits. k_tonemap_lut_build evaluates the
+// contract arithmetic (reinhard_srgb / st2084 above, then the UNORM8 or fp16 store conversion) once for all 65536 half
+// bit patterns; k_tonemap_lut keeps the table in LDS (64 KB u8 / 128 KB u16) and turns the kernel into a pure
+// HBM stream (8 B in, 4-8 B out per pixel) instead of 3 x exp2(log2()) per pixel. Identical bits by construction.
+VQD float tonemap_channel(float c, const VQ_TonemapperParams& p) {
+    switch (p.OutputDisplayCurveEnum) {
+        case VQ_DISPLAY_CURVE_SRGB:   return reinhard_srgb(c, p.ToggleGammaCorrection);
+        case VQ_DISPLAY_CURVE_ST2084: return st2084(c * div_(p.DisplayReferenceBrightnessLevel, 10000.0f));   // Rec.2020 content only
+        default:                      return c;                                                                 // LINEAR
+    }
+}
+VQD float half_bits_to_float(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+VQD uint32_t float_to_half_bits(float f) { return (uint32_t)__builtin_bit_cast(uint16_t, to_f16(f)); }
+
+template <int OUTFMT>
+__global__ __launch_bounds__(256) void k_tonemap_lut_build(void* __restrict__ table, VQ_TonemapperParams p) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;        // 65536 lanes
+    const float r = tonemap_channel(half_bits_to_float(i), p);
+    if (OUTFMT == 2) ((uint8_t*)table)[i] = (uint8_t)unorm8(r);
+    else             ((uint16_t*)table)[i] = (uint16_t)float_to_half_bits(r);
+}
+
+template <int OUTFMT>
+__global__ __launch_bounds__(1024) void k_tonemap_lut(const uint2* __restrict__ in, void* __restrict__ out, size_t n, const void* __restrict__ table) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int TBYTES = (OUTFMT == 2) ? 65536 : 131072;
+    for (int i = threadIdx.x * 16; i < TBYTES; i += 1024 * 16) *(uint4*)(lds + i) = *(const uint4*)((const unsigned char*)table + i);
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += (size_t)gridDim.x * 1024) {
+        const uint2 v = in[i];                                // 4 halfs: x | y<<16, z | w<<16
+        const uint32_t hx = v.x & 0xffffu, hy = v.x >> 16, hz = v.y & 0xffffu, hw = v.y >> 16;
+        const float alpha = half_bits_to_float(hw);           // alpha passes through the same store conversion as k_tonemap
+        if (OUTFMT == 2) {
+            const uint8_t* t = lds;
+            ((uint32_t*)out)[i] = (uint32_t)t[hx] | ((uint32_t)t[hy] << 8) | ((uint32_t)t[hz] << 16) | (unorm8(alpha) << 24);
+        } else {
+            const uint16_t* t = (const uint16_t*)lds;
+            ((uint2*)out)[i] = make_uint2((uint32_t)t[hx] | ((uint32_t)t[hy] << 16), (uint32_t)t[hz] | (float_to_half_bits(alpha) << 16));
+        }
     }
 }
 
@@ -173,22 +259,60 @@ __global__ __launch_bounds__(256) void k_blur_y_tonemap(const void* __restrict__
 namespace vqk {
 
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt) {
+#ifndef VQ_BLUR_X4
+#define VQ_BLUR_X4 1
+#endif
+#if VQ_BLUR_X4
+    dim3 grid((W + 1023) / 1024, H);
+    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4<0>), grid, dim3(256), 0, s, in, out, W, H);
+    else                          hipLaunchKernelGGL((k_blur_x4<1>), grid, dim3(256), 0, s, in, out, W, H);
+#else
     dim3 grid((W + 255) / 256, H);
     if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x<0>), grid, dim3(256), 0, s, in, out, W, H);
     else                          hipLaunchKernelGGL((k_blur_x<1>), grid, dim3(256), 0, s, in, out, W, H);
+#endif
     return hipGetLastError();
 }
 
 hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H, int fmt) {
-    constexpr int ROWS = 16;
+#ifndef VQ_BLUR_Y_TR
+#define VQ_BLUR_Y_TR 0      // A/B at 4K RGBA16F (scripts/bench_variants.sh): register window 31 us, LDS tile TR=16/32/64: 41/36/49 us
+#endif
+#if VQ_BLUR_Y_TR
+    constexpr int TR = VQ_BLUR_Y_TR;                          // LDS-tiled: (TR+20) rows x 64 px staged once, TR/4 outputs per lane
+    dim3 grid((W + 63) / 64, (H + TR - 1) / TR);
+    const VQ_TonemapperParams none = {};
+    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_y_tonemap<0, 0, TR, false>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H, none);
+    else                          hipLaunchKernelGGL((k_blur_y_tonemap<1, 1, TR, false>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H, none);
+#else
+    constexpr int ROWS = 16;                                  // register-window variant
     dim3 grid((W + 63) / 64, (H + 4 * ROWS - 1) / (4 * ROWS));
     if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_y<0, ROWS>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H);
     else                          hipLaunchKernelGGL((k_blur_y<1, ROWS>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H);
+#endif
     return hipGetLastError();
 }
 
-hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt) {
+hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, void* lutScratch) {
     const size_t n = (size_t)W * H;
+    const bool perChannel = p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_SRGB || p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_LINEAR ||
+                            (p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_ST2084 && p.ContentColorSpaceEnum != VQ_COLOR_SPACE_REC_709);
+    if (lutScratch && perChannel && inFmt == VQHIP_FMT_RGBA16F && (outFmt == VQHIP_FMT_RGBA8_UNORM || outFmt == VQHIP_FMT_RGBA16F) && n >= (size_t)1 << 16) {
+        if (outFmt == VQHIP_FMT_RGBA8_UNORM) {
+            hipLaunchKernelGGL((k_tonemap_lut_build<2>), dim3(256), dim3(256), 0, s, lutScratch, p);
+            hipLaunchKernelGGL((k_tonemap_lut<2>), dim3(512), dim3(1024), 65536, s, (const uint2*)in, out, n, (const void*)lutScratch);
+        } else {
+            static bool attrSet = false;                      // > 64 KB of dynamic LDS needs the opt-in once per process
+            if (!attrSet) {
+                hipError_t e = hipFuncSetAttribute((const void*)k_tonemap_lut<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+                if (e != hipSuccess) return e;
+                attrSet = true;
+            }
+            hipLaunchKernelGGL((k_tonemap_lut_build<1>), dim3(256), dim3(256), 0, s, lutScratch, p);
+            hipLaunchKernelGGL((k_tonemap_lut<1>), dim3(256), dim3(1024), 131072, s, (const uint2*)in, out, n, (const void*)lutScratch);
+        }
+        return hipGetLastError();
+    }
     dim3 grid((unsigned)((n + 255) / 256));
 #define TM(I, O) hipLaunchKernelGGL((k_tonemap<I, O>), grid, dim3(256), 0, s, in, out, n, p)
     if (inFmt == VQHIP_FMT_RGBA32F) {

@@ -34,7 +34,7 @@ struct ShadeArgs {
 hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt);
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt);
 hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H, int fmt);
-hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt);
+hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, void* lutScratch);
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
                                  const VQ_TonemapperParams& p, int fmt, int outFmt);
 hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt);
