@@ -1,0 +1,204 @@
+"""Host-side mirror of the reference's CPU producers of the hot path's inputs:
+
+  Light            Source/Engine/Scene/Light.h:45-187, Light.cpp:58-121   -> abi.PointLight / SpotLight / DirectionalLight
+  gather_scene_light_data   Scene::GatherSceneLightData, Scene.cpp:978-1027 -> abi.SceneLighting
+  Material         Source/Engine/Scene/Material.h:44-133, Material.cpp:23-36 -> abi.MaterialData (+ textureConfig bits)
+  gbuffer_from_material     the texture-less branch of ForwardLighting.hlsl:PSMain :247-281 (HasXMap == 0)
+
+Same names, defaults and packing rules as the reference so tests read like the engine's own call sites. Pure Python /
+numpy; no compute kernels here."""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+
+DEG2RAD = math.pi / 180.0
+
+
+def _quat_rotate(q, v):
+    """Rotate v by the unit quaternion q = (w, x, y, z) (Transform::NormalMatrix of a rigid transform == its rotation)."""
+    w, x, y, z = q
+    u = np.array([x, y, z], np.float64)
+    v = np.asarray(v, np.float64)
+    return v + 2.0 * np.cross(u, np.cross(u, v) + w * v)
+
+
+@dataclass
+class Light:
+    """Light.h:45-187 with the constructor defaults of Light.cpp:58-73."""
+    POINT, SPOT, DIRECTIONAL = 0, 1, 2
+    STATIC, STATIONARY, DYNAMIC = 0, 1, 2
+
+    Type: int = 0
+    Mobility: int = 2
+    Position: tuple = (0.0, 0.0, 0.0)
+    Range: float = 1000.0
+    RotationQuaternion: tuple = (1.0, 0.0, 0.0, 0.0)       # (w, x, y, z), identity
+    bEnabled: bool = True
+    bCastingShadows: bool = False
+    Color: tuple = (1.0, 1.0, 1.0)
+    Brightness: float = 300.0
+    DepthBias: float = 0.00005                               # FShadowData(0.00005f, 0.01f, 1500.0f)
+    SpotInnerConeAngleDegrees: float = 25.0                  # MakeSpotLight, Light.cpp:47-55
+    SpotOuterConeAngleDegrees: float = 35.0
+    ViewProjection: object = None                            # GetViewProjectionMatrix() result when casting shadows (4x4 row-major)
+
+    def _common(self, dst):                                  # COPY_COMMON_LIGHT_DATA, Light.cpp:75-78
+        dst.brightness = self.Brightness
+        dst.color.set(self.Color)
+        dst.depthBias = self.DepthBias
+
+    def get_gpu_data(self):
+        """Light::GetGPUData overloads, Light.cpp:81-121."""
+        if self.Type == Light.DIRECTIONAL:
+            d = abi.DirectionalLight()
+            self._common(d)
+            d.enabled = int(self.bEnabled)
+            d.shadowing = int(self.bCastingShadows)
+            d.lightDirection.set(_quat_rotate(self.RotationQuaternion, (0.0, -1.0, 0.0)))   # default orientation looks down (:90)
+            return d
+        if self.Type == Light.POINT:
+            p = abi.PointLight()
+            self._common(p)
+            p.position.set(self.Position)
+            p.range = self.Range                             # attenuation is left untouched (:104)
+            return p
+        s = abi.SpotLight()
+        self._common(s)
+        s.spotDir.set(_quat_rotate(self.RotationQuaternion, (0.0, 0.0, 1.0)))               # default orientation looks forward (:112)
+        s.position.set(self.Position)
+        s.innerConeAngle = self.SpotInnerConeAngleDegrees * DEG2RAD
+        s.outerConeAngle = self.SpotOuterConeAngleDegrees * DEG2RAD
+        return s                                             # `range` is NOT set by the CPU side (:108-121)
+
+
+def _set_matrix(dst, m):
+    m = np.asarray(m, np.float32).reshape(4, 4)
+    for i in range(4):
+        for j in range(4):
+            dst.m[i][j] = float(m[i, j])
+
+
+def gather_scene_light_data(lights):
+    """Scene::GatherSceneLightData (Scene.cpp:978-1027): static, then stationary, then dynamic lights; disabled point/spot
+    lights are skipped, the directional light is copied even when disabled (its `enabled` flag tells the shader)."""
+    data = abi.SceneLighting()
+    i_spot = i_spot_sh = i_point = i_point_sh = 0
+    for mobility in (Light.STATIC, Light.STATIONARY, Light.DYNAMIC):
+        for l in lights:
+            if not l.bEnabled and l.Type != Light.DIRECTIONAL:
+                continue
+            if l.Mobility != mobility:
+                continue
+            if l.Type == Light.DIRECTIONAL:
+                data.directional = l.get_gpu_data()
+                if l.bCastingShadows and l.ViewProjection is not None:
+                    _set_matrix(data.shadowViewDirectional, l.ViewProjection)
+            elif l.Type == Light.SPOT:
+                if l.bCastingShadows:
+                    if i_spot_sh >= abi.NUM_SHADOWING_LIGHTS__SPOT:
+                        raise ValueError("more than NUM_SHADOWING_LIGHTS__SPOT spot casters")
+                    data.spot_casters[i_spot_sh] = l.get_gpu_data()
+                    if l.ViewProjection is not None:
+                        _set_matrix(data.shadowViews[i_spot_sh], l.ViewProjection)
+                    i_spot_sh += 1
+                else:
+                    if i_spot >= abi.NUM_LIGHTS__SPOT:
+                        raise ValueError("more than NUM_LIGHTS__SPOT spot lights")
+                    data.spot_lights[i_spot] = l.get_gpu_data()
+                    i_spot += 1
+            else:
+                if l.bCastingShadows:
+                    if i_point_sh >= abi.NUM_SHADOWING_LIGHTS__POINT:
+                        raise ValueError("more than NUM_SHADOWING_LIGHTS__POINT point casters")
+                    data.point_casters[i_point_sh] = l.get_gpu_data()
+                    i_point_sh += 1
+                else:
+                    if i_point >= abi.NUM_LIGHTS__POINT:
+                        raise ValueError("more than NUM_LIGHTS__POINT point lights (use the extraPoint extension of the C ABI)")
+                    data.point_lights[i_point] = l.get_gpu_data()
+                    i_point += 1
+    data.numPointCasters, data.numPointLights = i_point_sh, i_point
+    data.numSpotCasters, data.numSpotLights = i_spot_sh, i_spot
+    return data
+
+
+INVALID_ID = -1
+
+
+@dataclass
+class Material:
+    """Material.h:44-70 defaults; texture IDs are INVALID_ID (-1) when the map is absent."""
+    diffuse: tuple = (1.0, 1.0, 1.0)
+    alpha: float = 1.0
+    emissiveColor: tuple = (1.0, 1.0, 1.0)
+    emissiveIntensity: float = 0.0
+    specular: tuple = (1.0, 1.0, 1.0)
+    normalMapMipBias: float = 0.0
+    tiling: tuple = (1.0, 1.0)
+    uv_bias: tuple = (0.0, 0.0)
+    roughness: float = 0.8
+    metalness: float = 0.0
+    displacement: float = 0.0
+    TexDiffuseMap: int = INVALID_ID
+    TexNormalMap: int = INVALID_ID
+    TexEmissiveMap: int = INVALID_ID
+    TexAlphaMaskMap: int = INVALID_ID
+    TexMetallicMap: int = INVALID_ID
+    TexRoughnessMap: int = INVALID_ID
+    TexOcclusionRoughnessMetalnessMap: int = INVALID_ID
+    TexAmbientOcclusionMap: int = INVALID_ID
+    TexHeightMap: int = INVALID_ID
+
+    def get_texture_config(self):
+        """Material::GetTextureConfig, Material.cpp:23-36 (bit order must match HasXMap, LightingConstantBufferData.h:116-124)."""
+        cfg = 0
+        for bit, tex in enumerate((self.TexDiffuseMap, self.TexNormalMap, self.TexAmbientOcclusionMap, self.TexAlphaMaskMap,
+                                   self.TexRoughnessMap, self.TexMetallicMap, self.TexHeightMap, self.TexEmissiveMap,
+                                   self.TexOcclusionRoughnessMetalnessMap)):
+            if tex != INVALID_ID:
+                cfg |= 1 << bit
+        return cfg
+
+    def get_cbuffer_data(self):
+        """Material::GetCBufferData, Material.h:120-127: memcpy of the first 80 bytes + textureConfig as a FLOAT."""
+        d = abi.MaterialData()
+        d.diffuse.set(self.diffuse); d.alpha = self.alpha
+        d.emissiveColor.set(self.emissiveColor); d.emissiveIntensity = self.emissiveIntensity
+        d.specular.set(self.specular); d.normalMapMipBias = self.normalMapMipBias
+        d.uvScaleOffset = abi.float4(self.tiling[0], self.tiling[1], self.uv_bias[0], self.uv_bias[1])
+        d.roughness, d.metalness, d.displacement = self.roughness, self.metalness, self.displacement
+        d.textureConfig = float(self.get_texture_config())
+        return d
+
+
+def has_map(texture_config, bit):
+    """HasDiffuseMap .. HasOcclusionRoughnessMetalnessMap, LightingConstantBufferData.h:116-124."""
+    return 1 if (int(texture_config) & (1 << bit)) > 0 else 0
+
+
+def gbuffer_from_material(material_data, world_pos, world_normal, ambient_factor, ssao=None):
+    """G-buffer planes for pixels of ONE texture-less material == ForwardLighting.hlsl:PSMain :247-281 with every
+    HasXMap() == 0 and a zero normal-map sample (length(Normal) < 0.01 -> Surface.N = normalize(WorldSpaceNormal), :266-267):
+      gb0 = (P, ao) with ao = fAmbientLightingFactor * ssao (:247,280-281; SSAO target cleared to 1 when off, SceneRendering.cpp:1543-1553)
+      gb1 = (normalize(N), roughness)   gb2 = (diffuse, metalness)   gb3 = (emissiveColor, emissiveIntensity)
+    world_pos / world_normal: float arrays [..., 3]. Returns 4 float32 arrays [..., 4]."""
+    if int(material_data.textureConfig) != 0:
+        raise NotImplementedError("textured materials need the G-buffer producer kernel (SURVEY.md §8f item 1)")
+    P = np.asarray(world_pos, np.float32)
+    N = np.asarray(world_normal, np.float32)
+    shape = P.shape[:-1]
+    ssao = np.ones(shape, np.float32) if ssao is None else np.asarray(ssao, np.float32)
+    n = (N / np.sqrt((N.astype(np.float32) ** 2).sum(-1, keepdims=True))).astype(np.float32)
+    g = [np.empty(shape + (4,), np.float32) for _ in range(4)]
+    g[0][..., :3] = P
+    g[0][..., 3] = np.float32(ambient_factor) * ssao
+    g[1][..., :3] = n
+    g[1][..., 3] = np.float32(material_data.roughness)
+    g[2][..., :3] = np.array([material_data.diffuse.x, material_data.diffuse.y, material_data.diffuse.z], np.float32)
+    g[2][..., 3] = np.float32(material_data.metalness)
+    g[3][..., :3] = np.array([material_data.emissiveColor.x, material_data.emissiveColor.y, material_data.emissiveColor.z], np.float32)
+    g[3][..., 3] = np.float32(material_data.emissiveIntensity)
+    return g
