@@ -9,8 +9,10 @@
 // bits exactly.
 //
 // Lowering rules (each cites the HLSL construct it stands for):
-//   a + b, a - b, a * b      IEEE-754 binary32, round-to-nearest-even, NO contraction into FMA
-//                            (compile with -ffp-contract=off).
+//   a + b, a - b, a * b      IEEE-754 binary32, round-to-nearest-even, NO implicit contraction into FMA
+//                            (compile with -ffp-contract=off). Where an expression tree uses a fused multiply-add
+//                            ("mad", as D3D compilers/drivers emit for a*b+c) it is WRITTEN as fma_() — see the
+//                            lighting functions in vqo_oracle.cpp and DESIGN.md §3 "expression trees".
 //   a / b                    a * rcp(b), rcp(b) = correctly rounded 1/b.  (What D3D drivers emit for
 //                            HLSL '/'; within the D3D 1-ULP 'div' allowance per factor.)
 //   sqrt(x)                  correctly rounded.
@@ -20,7 +22,7 @@
 //                            and mul(matrix,vec) are dots of the same form.
 //   normalize(v)             v * rsqrt(dot(v,v))          (DXC lowers normalize this way)
 //   length(v)                sqrt(dot(v,v))
-//   lerp(a,b,t)              a + t*(b-a)
+//   lerp(a,b,t)              fma(t, b-a, a)               (a + t*(b-a) as one mad)
 //   reflect(i,n)             i - (2*dot(n,i))*n           written as i - n*(2*dot(n,i)) per component
 //   cross(a,b)               (ay*bz - az*by, az*bx - ax*bz, ax*by - ay*bx), no FMA
 //   saturate(x)              min(max(x,0),1) with NaN -> 0
@@ -68,7 +70,7 @@ static inline float dot4(f4 a, f4 b) { return fma_(a.w, b.w, fma_(a.z, b.z, fma_
 static inline f3 normalize(f3 v) { return mul(v, rsqrt(dot(v, v))); }
 static inline float length(f3 v) { return sqrt_(dot(v, v)); }
 static inline f3 cross(f3 a, f3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
-static inline float lerp(float a, float b, float t) { return a + t * (b - a); }
+static inline float lerp(float a, float b, float t) { return fma_(t, b - a, a); }
 static inline f3 reflect(f3 i, f3 n) { float t = 2.0f * dot(n, i); return { i.x - n.x * t, i.y - n.y * t, i.z - n.z * t }; }
 
 // float -> int, truncation toward zero, NaN -> 0, saturating (HLSL (int)x; also used for texel addressing)
@@ -81,9 +83,12 @@ static inline int f2i_trunc(float x) {
 static inline int f2i_floor(float x) { return f2i_trunc(__builtin_floorf(x)); }
 
 // ---------------------------------------------------------------------------------------------
-// log2(x): x = m * 2^e, m in [sqrt(1/2), sqrt(2)), f = m - 1,
-//   ln(1+f) ~ f - f^2/2 + f^3 * P(f)   (9-term minimax, Cephes logf),  log2 = e + ln(1+f)*log2(e)
-//   with log2(e) split as 1 + 0.4426950408889634.  x<0 -> NaN, x==0 -> -inf, denormals are scaled.
+// log2(x): x = m * 2^e with m in [sqrt(1/2), sqrt(2)) obtained by integer arithmetic on the bit pattern
+//   (u' = u - bits(sqrt(1/2)); e = u' >> 23 (arithmetic); m = bits(u - (u' & 0xff800000))), f = m - 1,
+//   log2(1+f) = f * Q(f), Q = degree-8 near-minimax fit of log2(1+f)/f on [sqrt(1/2)-1, sqrt(2)-1]
+//   (max error 3.8e-8; fitted by tests-independent least-squares/Lawson iteration, coefficients below are exact
+//   binary32 values), log2(x) = fma(f, Q(f), e).  <= 2.1 ULP vs float64 (tests/test_oracle_math.py); because the
+//   mantissa is centred on 1 there is no cancellation near x = 1.  x<0 -> NaN, x==0 -> -inf, denormals are scaled.
 // ---------------------------------------------------------------------------------------------
 static inline float log2_(float x) {
     if (!(x == x)) return x;
@@ -93,29 +98,20 @@ static inline float log2_(float x) {
     int e = 0;
     uint32_t u = f2u(x);
     if (u < 0x00800000u) { x = x * 8388608.0f; u = f2u(x); e = -23; }     // denormal
-    e += (int)(u >> 23) - 126;                                             // x = m * 2^e, m in [0.5,1)
-    float m = u2f((u & 0x007fffffu) | 0x3f000000u);
-    float f;
-    if (m < 0.70710678118654752440f) { e -= 1; f = (m + m) - 1.0f; } else { f = m - 1.0f; }
-    float z = f * f;
-    float p = 7.0376836292E-2f;
-    p = fma_(p, f, -1.1514610310E-1f);
-    p = fma_(p, f,  1.1676998740E-1f);
-    p = fma_(p, f, -1.2420140846E-1f);
-    p = fma_(p, f,  1.4249322787E-1f);
-    p = fma_(p, f, -1.6668057665E-1f);
-    p = fma_(p, f,  2.0000714765E-1f);
-    p = fma_(p, f, -2.4999993993E-1f);
-    p = fma_(p, f,  3.3333331174E-1f);
-    float y = (p * f) * z;
-    y = fma_(-0.5f, z, y);
-    const float L2EA = 0.44269504088896340736f;   // log2(e) - 1
-    float r = y * L2EA;
-    r = fma_(f, L2EA, r);
-    r = r + y;
-    r = r + f;
-    r = r + (float)e;
-    return r;
+    const uint32_t up = u - 0x3f3504f3u;                                   // bits(0.70710677f)
+    e += (int32_t)up >> 23;
+    const float m = u2f(u - (up & 0xff800000u));
+    const float f = m - 1.0f;
+    float q = 0x1.08baeap-3f;
+    q = fma_(q, f, -0x1.abe534p-3f);
+    q = fma_(q, f,  0x1.b8c15cp-3f);
+    q = fma_(q, f, -0x1.e8ced8p-3f);
+    q = fma_(q, f,  0x1.26d980p-2f);
+    q = fma_(q, f, -0x1.715f9ap-2f);
+    q = fma_(q, f,  0x1.ec73bep-2f);
+    q = fma_(q, f, -0x1.71546cp-1f);
+    q = fma_(q, f,  0x1.715476p+0f);
+    return fma_(f, q, (float)e);
 }
 
 // exp2(x): n = nearest integer, f = x - n in [-0.5, 0.5], 2^f ~ 1 + f*P(f) (Cephes exp2f), scale by 2^n.

@@ -40,7 +40,7 @@ inline float NormalDistributionGGX(float NdotH, float roughness) {
     const float a = roughness * roughness;
     const float a2 = a * a;
     const float nh2 = NdotH * NdotH;
-    const float t = nh2 * (a2 - 1.0f) + 1.0f;
+    const float t = fma_(nh2, a2 - 1.0f, 1.0f);                    // (nh2 * (a2 - 1) + 1) as one mad
     const float denom = PI_ * (t * t);
     if (denom < EPSILON_) return 1.0f;
     return div_(a2, denom);
@@ -50,14 +50,14 @@ inline float Geometry_Smiths_SchlickGGX(f3 N, f3 V, float roughness) {
     const float rp1 = roughness + 1.0f;
     const float k = div_(rp1 * rp1, 8.0f);
     const float NV = max_(0.0f, dot(N, V));
-    const float denom = (NV * (1.0f - k) + k) + 0.0001f;
+    const float denom = fma_(NV, 1.0f - k, k) + 0.0001f;              // (NV*(1-k) + k) as one mad
     return div_(NV, denom);
 }
 // Geometry_Smiths_SchlickGGX_EnvironmentMap, BRDF.hlsl:100-115
 inline float Geometry_Smiths_SchlickGGX_EnvironmentMap(f3 N, f3 V, float roughness) {
     const float k = div_(roughness * roughness, 2.0f);
     const float NV = max_(0.0f, dot(N, V));
-    const float denom = (NV * (1.0f - k) + k) + 0.0001f;
+    const float denom = fma_(NV, 1.0f - k, k) + 0.0001f;              // (NV*(1-k) + k) as one mad
     return div_(NV, denom);
 }
 // Geometry_Smith, BRDF.hlsl:118-121 (its 'k' argument is the roughness: BRDF() passes roughness, :184)
@@ -73,18 +73,22 @@ inline float GeometryEnvironmentMap(f3 N, f3 V, f3 L, float k) {
 // Fresnel_Schlick, BRDF.hlsl:132-136 — called as Fresnel_Schlick(H, V, F0) (:183): "N" is H, V is the caller's V
 inline f3 Fresnel_Schlick(f3 N, f3 V, f3 F0) {
     const float p = pow_(1.0f - max_(0.0f, dot(N, V)), 5.0f);
-    return { F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p };
+    return { fma_(1.0f - F0.x, p, F0.x), fma_(1.0f - F0.y, p, F0.y), fma_(1.0f - F0.z, p, F0.z) };      // F0 + (1-F0)*p, mad
 }
 // FresnelWithRoughness, BRDF.hlsl:152-156
 inline f3 FresnelWithRoughness(float cosTheta, f3 F0, float roughness) {
     const float p = pow_(1.0f - cosTheta, 5.0f);
     const float omr = 1.0f - roughness;
-    return { F0.x + (max_(omr, F0.x) - F0.x) * p, F0.y + (max_(omr, F0.y) - F0.y) * p, F0.z + (max_(omr, F0.z) - F0.z) * p };
+    return { fma_(max_(omr, F0.x) - F0.x, p, F0.x), fma_(max_(omr, F0.y) - F0.y, p, F0.y), fma_(max_(omr, F0.z) - F0.z, p, F0.z) };
 }
 // F_LambertDiffuse, BRDF.hlsl:158-161
 inline f3 F_LambertDiffuse(f3 kd) { return { div_(kd.x, PI_), div_(kd.y, PI_), div_(kd.z, PI_) }; }
 
-// BRDF, BRDF.hlsl:163-194
+// BRDF, BRDF.hlsl:163-194. Expression tree = the HLSL's value with the scalar factors of the two vector products
+// gathered (what an optimising D3D compiler emits; DXC runs without IEEE strictness, ShaderCompileUtils.cpp:56):
+//   specular = D*F*G/denom          ->  F * sG,  sG = (D*G) * rcp(denom)           (scalar)
+//   diffuse  = (1-F)*(1-metal)*albedo/PI -> (1-F) * kA,  kA = ((1-metal)*albedo) * rcp(PI)   (light independent)
+//   result   = Id + Is              ->  fma(F, sG, (1-F)*kA)
 inline f3 BRDF(const Surface& s, f3 Wi, f3 V) {
     const f3 Wo = normalize(V);
     const f3 N = normalize(s.N);
@@ -99,12 +103,10 @@ inline f3 BRDF(const Surface& s, f3 Wi, f3 V) {
     const float G = Geometry_Smith(N, Wo, Wi, roughness);
     const float D = NormalDistributionGGX(NdotH, roughness);
     const float denom = max_((4.0f * NdotV) * NdotL, 0.0001f);
-    const float rd = rcp(denom);
-    const f3 specular = { ((D * F.x) * G) * rd, ((D * F.y) * G) * rd, ((D * F.z) * G) * rd };   // D * F * G / denom
-    const float omm = 1.0f - metalness;
-    const f3 kD = { (1.0f - F.x) * omm, (1.0f - F.y) * omm, (1.0f - F.z) * omm };
-    const f3 Id = F_LambertDiffuse(mul(kD, albedo));
-    return add(Id, specular);
+    const float sG = (D * G) * rcp(denom);
+    const float omm = 1.0f - metalness, invPI = rcp(PI_);
+    const f3 kA = { (omm * albedo.x) * invPI, (omm * albedo.y) * invPI, (omm * albedo.z) * invPI };
+    return { fma_(F.x, sG, (1.0f - F.x) * kA.x), fma_(F.y, sG, (1.0f - F.y) * kA.y), fma_(F.z, sG, (1.0f - F.z) * kA.z) };
 }
 // EnvironmentBRDF, BRDF.hlsl:196-207
 inline f3 EnvironmentBRDF(float NdotV, float roughness, float metallic, f3 diffuseColor, f3 diffuseIrradiance, f3 preFilteredSpecular, f2 F0ScaleBias) {
@@ -113,10 +115,10 @@ inline f3 EnvironmentBRDF(float NdotV, float roughness, float metallic, f3 diffu
     const float omm = 1.0f - metallic;
     const f3 Kd = { (1.0f - Ks.x) * omm, (1.0f - Ks.y) * omm, (1.0f - Ks.z) * omm };
     const f3 diffuse = mul(diffuseIrradiance, diffuseColor);
-    const f3 specular = { preFilteredSpecular.x * (Ks.x * F0ScaleBias.x + F0ScaleBias.y),
-                          preFilteredSpecular.y * (Ks.y * F0ScaleBias.x + F0ScaleBias.y),
-                          preFilteredSpecular.z * (Ks.z * F0ScaleBias.x + F0ScaleBias.y) };
-    return { Kd.x * diffuse.x + specular.x, Kd.y * diffuse.y + specular.y, Kd.z * diffuse.z + specular.z };
+    const f3 specular = { preFilteredSpecular.x * fma_(Ks.x, F0ScaleBias.x, F0ScaleBias.y),
+                          preFilteredSpecular.y * fma_(Ks.y, F0ScaleBias.x, F0ScaleBias.y),
+                          preFilteredSpecular.z * fma_(Ks.z, F0ScaleBias.x, F0ScaleBias.y) };
+    return { fma_(Kd.x, diffuse.x, specular.x), fma_(Kd.y, diffuse.y, specular.y), fma_(Kd.z, diffuse.z, specular.z) };   // Kd*diffuse + specular, mad
 }
 
 // ---- Shaders/ShadingMath.hlsl -----------------------------------------------------------------
@@ -262,40 +264,39 @@ inline float ShadowTestPCF_Directional(const ShadowTestPCFData& d, const float* 
     return 1.0f - shadow;
 }
 
+// Light illumination functions, Lighting.hlsl:308-345. Each returns BRDF * radiance * NdotL with the scalar factors
+// gathered:  radiance * NdotL = (l.color * l.brightness) * w  with the per-light colour cb = color*brightness (a
+// loop-invariant a compiler hoists; the product's HOST side precomputes it with the same IEEE multiply) and the
+// scalar w = attenuation [* cone] * NdotL.  Result = acc + b * (cb * w) per channel (one mad).
+inline f3 light_cb(const VQ_float3& color, float brightness) { return { color.x * brightness, color.y * brightness, color.z * brightness }; }
+// acc + b * (cb * w): the caller's `I_total += ...` is fused into the final mad (acc = 0 gives the plain product)
+inline f3 lit(f3 acc, f3 b, f3 cb, float w) { return { fma_(b.x, cb.x * w, acc.x), fma_(b.y, cb.y * w, acc.y), fma_(b.z, cb.z * w, acc.z) }; }
+
 // CalculatePointLightIllumination, Lighting.hlsl:308-322
-inline f3 CalculatePointLightIllumination(const VQ_PointLight& l, const Surface& s, f3 P, f3 V) {
-    f3 IdIs = { 0, 0, 0 };
+inline f3 CalculatePointLightIllumination(const VQ_PointLight& l, const Surface& s, f3 P, f3 V, f3 acc = { 0, 0, 0 }) {
     const f3 Lw = to3(l.position);
     const f3 d = sub(Lw, P);
     const f3 Wi = normalize(d);
     const float D = length(d);
     const float NdotL = saturate(dot(s.N, Wi));
-    const float att = AttenuationBRDF(D);
-    const f3 radiance = { (att * l.color.x) * l.brightness, (att * l.color.y) * l.brightness, (att * l.color.z) * l.brightness };
-    if (D < l.range) {
-        const f3 b = BRDF(s, Wi, V);
-        IdIs = { (b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL };   // "0 +" folded
-    }
-    return IdIs;
+    const float w = AttenuationBRDF(D) * NdotL;
+    if (D < l.range) return lit(acc, BRDF(s, Wi, V), light_cb(l.color, l.brightness), w);
+    return acc;
 }
 // CalculateSpotLightIllumination, Lighting.hlsl:323-333 (no range cull)
-inline f3 CalculateSpotLightIllumination(const VQ_SpotLight& l, const Surface& s, f3 P, f3 V) {
+inline f3 CalculateSpotLightIllumination(const VQ_SpotLight& l, const Surface& s, f3 P, f3 V, f3 acc = { 0, 0, 0 }) {
     const f3 d = sub(to3(l.position), P);
     const f3 Wi = normalize(d);
     const float cone = SpotlightIntensity(l, P);
-    const float att = AttenuationBRDF(length(d));
-    const f3 radiance = { ((cone * l.color.x) * l.brightness) * att, ((cone * l.color.y) * l.brightness) * att, ((cone * l.color.z) * l.brightness) * att };
     const float NdotL = saturate(dot(s.N, Wi));
-    const f3 b = BRDF(s, Wi, V);
-    return { (b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL };   // IdIs = 0; IdIs += x  ==> x
+    const float w = (cone * AttenuationBRDF(length(d))) * NdotL;
+    return lit(acc, BRDF(s, Wi, V), light_cb(l.color, l.brightness), w);
 }
 // CalculateDirectionalLightIllumination, Lighting.hlsl:334-345
 inline f3 CalculateDirectionalLightIllumination(const VQ_DirectionalLight& l, const Surface& s, f3 V) {
     const f3 Wi = normalize(neg(to3(l.lightDirection)));
-    const f3 radiance = { l.color.x * l.brightness, l.color.y * l.brightness, l.color.z * l.brightness };
     const float NdotL = saturate(dot(s.N, Wi));
-    const f3 b = BRDF(s, Wi, V);
-    return { (b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL };
+    return lit({ 0, 0, 0 }, BRDF(s, Wi, V), light_cb(l.color, l.brightness), NdotL);
 }
 
 // GetHDRIRotationMatrix, Lighting.hlsl:348-358; mul(v, m) = row vector times matrix
@@ -351,18 +352,18 @@ inline f4 ShadePixel(f4 g0, f4 g1, f4 g2, f4 g3, const VQ_PerFrameData& F, const
     const f3 P = { g0.x, g0.y, g0.z };                                   // :284
     const f3 cam = to3(Vw.CameraPosition);
     const f3 V = normalize(sub(cam, P));                                  // :285
-    f3 I = { S.diffuseColor.x * ao + S.emissiveColor.x * S.emissiveIntensity,     // :290-293
-             S.diffuseColor.y * ao + S.emissiveColor.y * S.emissiveIntensity,
-             S.diffuseColor.z * ao + S.emissiveColor.z * S.emissiveIntensity };
+    f3 I = { fma_(S.emissiveColor.x, S.emissiveIntensity, S.diffuseColor.x * ao),     // :290-293, diffuse*ao + emissive*intensity (mad)
+             fma_(S.emissiveColor.y, S.emissiveIntensity, S.diffuseColor.y * ao),
+             fma_(S.emissiveColor.z, S.emissiveIntensity, S.diffuseColor.z * ao) };
     if (env) {                                                            // :299-306 (NULL == NullCubemap: adds 0)
         const f3 e = CalculateEnvironmentMapIllumination(S, V, f2i_trunc(Vw.MaxEnvMapLODLevels), *env, F.fHDRIOffsetInRadians,
                                                          Vw.EnvironmentMapDiffuseOnlyIllumination != 0);
         I = add(I, e);
     }
     const VQ_SceneLighting& L = F.Lights;
-    for (int p = 0; p < L.numPointLights; ++p) I = add(I, CalculatePointLightIllumination(L.point_lights[p], S, P, V));   // :310-313
-    for (int p = 0; p < nExtra; ++p)           I = add(I, CalculatePointLightIllumination(extra[p], S, P, V));             // extension (vqhip.h)
-    for (int s = 0; s < L.numSpotLights; ++s)  I = add(I, CalculateSpotLightIllumination(L.spot_lights[s], S, P, V));      // :314-317
+    for (int p = 0; p < L.numPointLights; ++p) I = CalculatePointLightIllumination(L.point_lights[p], S, P, V, I);         // :310-313 (I_total += ...)
+    for (int p = 0; p < nExtra; ++p)           I = CalculatePointLightIllumination(extra[p], S, P, V, I);                   // extension (vqhip.h)
+    for (int s = 0; s < L.numSpotLights; ++s)  I = CalculateSpotLightIllumination(L.spot_lights[s], S, P, V, I);            // :314-317
     for (int pc = 0; pc < L.numPointCasters; ++pc) {                      // :321-339
         const VQ_PointLight& l = L.point_casters[pc];
         const f3 Lw = sub(to3(l.position), P);
@@ -375,7 +376,7 @@ inline f4 ShadePixel(f4 g0, f4 g1, f4 g2, f4 g3, const VQ_PerFrameData& F, const
             d.viewDistanceOfPixel = length(sub(P, cam));
             const f3 c = CalculatePointLightIllumination(l, S, P, V);
             const float sh = OmnidirectionalShadowTestPCF(d, sm->point, sm->point_dim, pc, Lw, l.range);
-            I = { I.x + c.x * sh, I.y + c.y * sh, I.z + c.z * sh };
+            I = { fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z) };
         }
     }
     for (int sc = 0; sc < L.numSpotCasters; ++sc) {                       // :342-356
@@ -388,7 +389,7 @@ inline f4 ShadePixel(f4 g0, f4 g1, f4 g2, f4 g3, const VQ_PerFrameData& F, const
         d.viewDistanceOfPixel = length(sub(P, cam));
         const f3 c = CalculateSpotLightIllumination(l, S, P, V);
         const float sh = ShadowTestPCF(d, sm->spot, sm->spot_dim, { F.f2SpotLightShadowMapDimensions.x, F.f2SpotLightShadowMapDimensions.y }, sc);
-        I = { I.x + c.x * sh, I.y + c.y * sh, I.z + c.z * sh };
+        I = { fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z) };
     }
     {                                                                     // :360-377
         const VQ_DirectionalLight& l = L.directional;
@@ -404,7 +405,7 @@ inline f4 ShadePixel(f4 g0, f4 g1, f4 g2, f4 g3, const VQ_PerFrameData& F, const
                                       { F.f2DirectionalLightShadowMapDimensions.x, F.f2DirectionalLightShadowMapDimensions.y });
             }
             const f3 c = CalculateDirectionalLightIllumination(l, S, V);
-            I = { I.x + c.x * ShadowingFactor, I.y + c.y * ShadowingFactor, I.z + c.z * ShadowingFactor };
+            I = { fma_(c.x, ShadowingFactor, I.x), fma_(c.y, ShadowingFactor, I.y), fma_(c.z, ShadowingFactor, I.z) };
         }
     }
     return { I.x, I.y, I.z, S.roughness };                                // :380

@@ -73,8 +73,8 @@ def test_forward_lighting_structure():
     gb = synth.gbuffer(W, H, seed=5)
     pv = synth.per_view(W, H)
     base = O.forward_lighting(gb, synth.per_frame()[0], pv, abi.FMT_RGBA32F)
-    exp = gb[2][..., :3] * gb[0][..., 3:4] + gb[3][..., :3] * gb[3][..., 3:4]
-    assert np.array_equal(base[..., :3], exp.astype(np.float32))
+    exp = gb[2][..., :3].astype(np.float64) * gb[0][..., 3:4] + gb[3][..., :3].astype(np.float64) * gb[3][..., 3:4]
+    assert np.allclose(base[..., :3], exp, rtol=2e-7, atol=0)            # fma(emissive, intensity, diffuse*ao): two roundings
     pts = synth.point_lights(4, seed=6)
     for p in pts:
         p.range = 1e-3                                                    # D < range never true -> contributes nothing

@@ -28,9 +28,10 @@ def test_basic_ops_are_ieee(rng):
 
 def test_log2_exp2_pow(rng):
     x = np.exp(rng.uniform(-85, 85, N)).astype(np.float32)
-    assert ulp_err(O.math_array(0, x), np.log2(x.astype(np.float64))).max() < 1.6
-    x = rng.uniform(0.5, 2.0, N).astype(np.float32)                                      # near 1: absolute accuracy
+    assert ulp_err(O.math_array(0, x), np.log2(x.astype(np.float64))).max() < 2.2
+    x = rng.uniform(0.5, 2.0, N).astype(np.float32)                                      # near 1: no cancellation (mantissa centred on 1)
     assert np.abs(O.math_array(0, x).astype(np.float64) - np.log2(x.astype(np.float64))).max() < 1.2e-7
+    assert ulp_err(O.math_array(0, x), np.log2(x.astype(np.float64))).max() < 2.2
     x = rng.uniform(-126, 128, N).astype(np.float32)
     assert ulp_err(O.math_array(1, x), np.exp2(x.astype(np.float64))).max() < 1.6
     x = rng.uniform(0, 1, N).astype(np.float32)

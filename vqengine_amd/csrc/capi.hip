@@ -157,9 +157,17 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
     if (env) fc->env = *env;
     if (sm) fc->sm = *sm;
     fc->hasEnv = env ? 1 : 0;
-    fc->numExtraPoint = numExtraPoint;
-    if (numExtraPoint) std::memcpy(fc + 1, extraPoint, (size_t)numExtraPoint * sizeof(VQ_PointLight));
-    rc = commitSlot(ctx, slot, sizeof(FrameConstants) + (size_t)numExtraPoint * sizeof(VQ_PointLight), st);
+    // pack the non-shadowing point lights for the hot loop: cbuffer array first, then the extension array, in index order
+    DevPointLight* pts = (DevPointLight*)(fc + 1);
+    const int nPts = L.numPointLights + numExtraPoint;
+    for (int i = 0; i < nPts; ++i) {
+        const VQ_PointLight& l = i < L.numPointLights ? L.point_lights[i] : extraPoint[i - L.numPointLights];
+        pts[i].px = l.position.x; pts[i].py = l.position.y; pts[i].pz = l.position.z; pts[i].range = l.range;
+        pts[i].cbx = l.color.x * l.brightness; pts[i].cby = l.color.y * l.brightness; pts[i].cbz = l.color.z * l.brightness;   // l.color * l.brightness (Lighting.hlsl:317)
+        pts[i].pad = 0.0f;
+    }
+    fc->numPointAll = nPts;
+    rc = commitSlot(ctx, slot, sizeof(FrameConstants) + (size_t)nPts * sizeof(DevPointLight), st);
     if (rc) return rc;
     ShadeArgs a;
     a.gb0 = (const float4*)gb->gb0; a.gb1 = (const float4*)gb->gb1; a.gb2 = (const float4*)gb->gb2; a.gb3 = (const float4*)gb->gb3;

@@ -34,7 +34,7 @@ VQD float NormalDistributionGGX(float NdotH, float roughness) { // BRDF.hlsl:65-
     const float a = roughness * roughness;
     const float a2 = a * a;
     const float nh2 = NdotH * NdotH;
-    const float t = nh2 * (a2 - 1.0f) + 1.0f;
+    const float t = fma_(nh2, a2 - 1.0f, 1.0f);                 // one mad (contract v2 tree of BRDF.hlsl:76)
     const float denom = PI_ * (t * t);
     if (denom < EPSILON_) return 1.0f;
     return div_(a2, denom);
@@ -42,7 +42,7 @@ VQD float NormalDistributionGGX(float NdotH, float roughness) { // BRDF.hlsl:65-
 VQD float G1_env(f3 N, f3 V, float roughness) {                 // Geometry_Smiths_SchlickGGX_EnvironmentMap, BRDF.hlsl:100-115
     const float k = div_(roughness * roughness, 2.0f);
     const float NV = max_(0.0f, dot(N, V));
-    return div_(NV, (NV * (1.0f - k) + k) + 0.0001f);
+    return div_(NV, fma_(NV, 1.0f - k, k) + 0.0001f);           // (NV*(1-k) + k) as one mad
 }
 // ImportanceSampleGGX, BRDF.hlsl:217-238, with sin/cos(phi) supplied by the caller
 VQD f3 ImportanceSampleGGX(float Xiy, float sinPhi, float cosPhi, f3 N, float roughness) {

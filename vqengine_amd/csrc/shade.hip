@@ -1,9 +1,10 @@
 // shade.hip — forward-PBR lighting kernel for gfx950: ForwardLighting.hlsl:PSMain :289-380 evaluated per
 // G-buffer pixel. One lane per pixel, 256-lane workgroups, float4 SoA plane
 // loads (16 B/lane, fully coalesced), light records read through the scalar cache (wave-uniform index),
-// all light-invariant terms of BRDF() hoisted out of the light loops without changing a single rounding.
+// every light-invariant term hoisted to per-pixel setup.
 //
-// Arithmetic follows the contract in vq_devmath.h / DESIGN.md; expression order mirrors the HLSL:
+// Arithmetic follows the contract in DESIGN.md §3 (intrinsic lowering: vq_devmath.h; expression trees of the
+// lighting functions: "contract v2" — scalar factors of vector products gathered, a*b+c written as one mad):
 //   Shaders/BRDF.hlsl:65-79,82-97,118-121,132-136,152-161,163-207
 //   Shaders/Lighting.hlsl:29-32,57-73,110-174,177-272,308-395
 //   Shaders/ForwardLighting.hlsl:284-380
@@ -18,15 +19,21 @@ namespace {
 constexpr float PI_      = 3.14159265359f;    // ShadingMath.hlsl:25
 constexpr float EPSILON_ = 0.000000000001f;   // BRDF.hlsl:21
 
+#ifndef VQ_ABLATE
+#define VQ_ABLATE 0                           // timing-only ablations (scripts/bench_variants.sh); 0 = the product
+#endif
+#ifndef VQ_SHADE_WAVES
+#define VQ_SHADE_WAVES 1
+#endif
+
 // Per-pixel state: BRDF_Surface (BRDF.hlsl:50-58) + everything in BRDF() that does not depend on the light.
 struct Pixel {
-    f3 P, V, Wo, Nraw, Nn, albedo, F0, omF0;
+    f3 P, V, Wo, Nraw, Nn, albedo, F0, omF0, kA;
     float roughness, metalness, omm;      // omm = 1 - metalness
     float NdotV4;                         // 4 * saturate(dot(N, Wo))
     float G1V;                            // Geometry_Smiths_SchlickGGX(N, Wo, roughness)
     float k, omk;                         // k = (roughness+1)^2/8, omk = 1-k
     float a2, a2m1;                       // GGX alpha^2, alpha^2 - 1
-    float invPI;
     bool fastOK;                          // roughness in [0,1]: precondition of the unchecked fast reciprocals (add_point_light)
 };
 
@@ -38,30 +45,7 @@ VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
 // anything else (rare) goes through the general routine. Bit-identical to pow_(x, 5.0f) for every x.
 VQD float pow5(float x) {
     if (__builtin_expect(!(x >= 5.9604644775390625e-8f && x <= 1.0f), 0)) return pow_(x, 5.0f);
-    const uint32_t u = __float_as_uint(x);
-    int e = (int)(u >> 23) - 126;
-    const float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
-    float f;
-    if (m < 0.70710678118654752440f) { e -= 1; f = (m + m) - 1.0f; } else { f = m - 1.0f; }
-    const float z = f * f;
-    float p = 7.0376836292E-2f;
-    p = fma_(p, f, -1.1514610310E-1f);
-    p = fma_(p, f,  1.1676998740E-1f);
-    p = fma_(p, f, -1.2420140846E-1f);
-    p = fma_(p, f,  1.4249322787E-1f);
-    p = fma_(p, f, -1.6668057665E-1f);
-    p = fma_(p, f,  2.0000714765E-1f);
-    p = fma_(p, f, -2.4999993993E-1f);
-    p = fma_(p, f,  3.3333331174E-1f);
-    float y = (p * f) * z;
-    y = fma_(-0.5f, z, y);
-    const float L2EA = 0.44269504088896340736f;
-    float r = y * L2EA;
-    r = fma_(f, L2EA, r);
-    r = r + y;
-    r = r + f;
-    r = r + (float)e;
-    const float t = 5.0f * r;                       // in [-120, 0]
+    const float t = 5.0f * log2_normal_bits(__float_as_uint(x), 0);      // in [-120, 0]
     float n = __builtin_floorf(t);
     float g = t - n;
     if (g > 0.5f) { n += 1.0f; g -= 1.0f; }
@@ -87,29 +71,27 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.F0 = mk3(lerp(0.04f, px.albedo.x, px.metalness), lerp(0.04f, px.albedo.y, px.metalness), lerp(0.04f, px.albedo.z, px.metalness));   // :178
     px.omF0 = mk3(1.0f - px.F0.x, 1.0f - px.F0.y, 1.0f - px.F0.z);
     px.omm = 1.0f - px.metalness;
+    const float invPI = rcp(PI_);
+    px.kA = mk3((px.omm * px.albedo.x) * invPI, (px.omm * px.albedo.y) * invPI, (px.omm * px.albedo.z) * invPI);     // (1-metal)*albedo/PI
     const float NdotV = saturate(dot(px.Nn, px.Wo));         // :171
     px.NdotV4 = 4.0f * NdotV;
     const float rp1 = px.roughness + 1.0f;                   // Geometry_Smiths_SchlickGGX :92-96
     px.k = div_(rp1 * rp1, 8.0f);
     px.omk = 1.0f - px.k;
     const float NV = max_(0.0f, dot(px.Nn, px.Wo));
-    px.G1V = div_(NV, (NV * px.omk + px.k) + 0.0001f);
+    px.G1V = div_(NV, fma_(NV, px.omk, px.k) + 0.0001f);
     const float a = px.roughness * px.roughness;             // NormalDistributionGGX :74-75
     px.a2 = a * a;
     px.a2m1 = px.a2 - 1.0f;
-    px.invPI = rcp(PI_);
     px.fastOK = (px.roughness >= 0.0f) & (px.roughness <= 1.0f);
 }
 
-// BRDF(s, Wi, V), BRDF.hlsl:163-194, with the hoisted terms of `px`. `rc` is the reciprocal policy (vq_devmath.h).
+// BRDF(s, Wi, V), BRDF.hlsl:163-194 (contract v2 tree): fma(F, sG, (1-F)*kA) with sG = (D*G)*rcp(denom) and the
+// per-pixel kA = ((1-metal)*albedo)*rcp(PI). `rc` is the reciprocal / sqrt policy (vq_devmath.h).
 template <class R>
 VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const f3 Hs = add(px.Wo, Wi);
-#if VQ_ABLATE == 2
-    const f3 H = mul(Hs, 0.7f);                              // ablation: no H normalisation
-#else
     const f3 H = mul(Hs, rc(rc.sqrt(dot(Hs, Hs))));          // normalize(Wo + Wi)
-#endif
     const float NdotH = saturate(dot(px.Nn, H));
     const float dNL = dot(px.Nn, Wi);
     const float NdotL = saturate(dNL);
@@ -119,53 +101,51 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
 #else
     const float p5 = pow5(1.0f - max_(0.0f, dot(H, px.V)));
 #endif
-    const f3 F = mk3(px.F0.x + px.omF0.x * p5, px.F0.y + px.omF0.y * p5, px.F0.z + px.omF0.z * p5);
+    const f3 F = mk3(fma_(px.omF0.x, p5, px.F0.x), fma_(px.omF0.y, p5, px.F0.y), fma_(px.omF0.z, p5, px.F0.z));
     // Geometry_Smith :118-121
     const float NL = max_(0.0f, dNL);
-    const float G = px.G1V * (NL * rc((NL * px.omk + px.k) + 0.0001f));
+    const float G = px.G1V * (NL * rc(fma_(NL, px.omk, px.k) + 0.0001f));
     // NormalDistributionGGX :65-79
     const float nh2 = NdotH * NdotH;
-    const float t = nh2 * px.a2m1 + 1.0f;
+    const float t = fma_(nh2, px.a2m1, 1.0f);
     const float dd = PI_ * (t * t);
     const float Dq = px.a2 * rc(max_(dd, EPSILON_));          // operand clamped only to keep the unused quotient finite
     const float D = (dd < EPSILON_) ? 1.0f : Dq;
-    const float rd = rc(max_(px.NdotV4 * NdotL, 0.0001f));
-    const f3 spec = mk3(((D * F.x) * G) * rd, ((D * F.y) * G) * rd, ((D * F.z) * G) * rd);
-    const f3 kD = mk3((1.0f - F.x) * px.omm, (1.0f - F.y) * px.omm, (1.0f - F.z) * px.omm);
-    const f3 Id = mk3((kD.x * px.albedo.x) * px.invPI, (kD.y * px.albedo.y) * px.invPI, (kD.z * px.albedo.z) * px.invPI);
-    return add(Id, spec);
+    const float sG = (D * G) * rc(max_(px.NdotV4 * NdotL, 0.0001f));
+    return mk3(fma_(F.x, sG, (1.0f - F.x) * px.kA.x), fma_(F.y, sG, (1.0f - F.y) * px.kA.y), fma_(F.z, sG, (1.0f - F.z) * px.kA.z));
 }
-VQD f3 brdf(const Pixel& px, f3 Wi) { RcpIEEE rc; return brdf_t(px, Wi, rc); }
 
-// CalculatePointLightIllumination, Lighting.hlsl:308-322
+// acc + b * (cb * w): cb = l.color * l.brightness, w = attenuation [* cone] * NdotL (one mad per channel)
+VQD f3 lit(f3 acc, f3 b, f3 cb, float w) { return mk3(fma_(b.x, cb.x * w, acc.x), fma_(b.y, cb.y * w, acc.y), fma_(b.z, cb.z * w, acc.z)); }
+VQD f3 light_cb(const VQ_float3& color, float brightness) { return mk3(color.x * brightness, color.y * brightness, color.z * brightness); }
+
+// CalculatePointLightIllumination, Lighting.hlsl:308-322 (general form, shadow casters)
 template <class R>
-VQD f3 point_light_t(const Pixel& px, const VQ_PointLight& l, R& rc) {
-    const f3 d = sub(ld3(l.position), px.P);
+VQD f3 point_light_t(const Pixel& px, f3 lpos, float range, f3 cb, f3 acc, R& rc) {
+    const f3 d = sub(lpos, px.P);
     const float D = rc.sqrt(dot(d, d));                      // length(Lw - P); normalize() shares the sqrt
-    f3 r = mk3(0.0f, 0.0f, 0.0f);
-    if (D < l.range) {
+    if (D < range) {
         const f3 Wi = mul(d, rc(D));
         const float NdotL = saturate(dot(px.Nraw, Wi));
-        const float att = rc(D * D);                         // AttenuationBRDF :29-32
-        const f3 radiance = mk3((att * l.color.x) * l.brightness, (att * l.color.y) * l.brightness, (att * l.color.z) * l.brightness);
-        const f3 b = brdf_t(px, Wi, rc);
-        r = mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
+        const float w = rc(D * D) * NdotL;                   // AttenuationBRDF :29-32
+        return lit(acc, brdf_t(px, Wi, rc), cb, w);
     }
-    return r;
+    return acc;
 }
-VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // general form (shadow casters): per-op validity flag
+VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op validity flag; used for the <= 5 casters
+    const f3 zero = mk3(0.0f, 0.0f, 0.0f), cb = light_cb(l.color, l.brightness);
     RcpFast fast;
-    f3 r = point_light_t(px, l, fast);
-    if (__builtin_expect(!fast.ok, 0)) { RcpIEEE ieee; r = point_light_t(px, l, ieee); }
+    f3 r = point_light_t(px, ld3(l.position), l.range, cb, zero, fast);
+    if (__builtin_expect(!fast.ok, 0)) { RcpIEEE ieee; r = point_light_t(px, ld3(l.position), l.range, cb, zero, ieee); }
     return r;
 }
 
-// Hot-loop form: I += CalculatePointLightIllumination(...). All reciprocals / square roots use the unchecked fast
-// sequences (RcpTrust); their validity is PROVEN from three range tests instead of being checked per operation:
+// Hot-loop form: I = CalculatePointLightIllumination(..., acc = I). All reciprocals / square roots use the unchecked
+// fast sequences (RcpTrust); their validity is PROVEN from three range tests instead of being checked per operation:
 //   pixel  : roughness in [0,1]  (px.fastOK)  =>  k in [1/8,1/2], 1-k in [1/2,7/8], a2 in [0,1], hence
-//              G operand (NL(1-k)+k)+1e-4 in [0.125, 1.4]   (NL = max(0,.) <= 1+eps, NaN -> 0)
-//              GGX operand max(pi t^2, 1e-12) in [1e-12, pi] (t = nh2 (a2-1) + 1 in [a2,1], nh2 saturated)
-//              rd operand max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
+//              G operand fma(NL,1-k,k)+1e-4 in [0.125, 1.4]   (NL = max(0,.) <= 1+eps, NaN -> 0)
+//              GGX operand max(pi t^2, 1e-12) in [1e-12, pi] (t = fma(nh2, a2-1, 1) in [a2,1], nh2 saturated)
+//              sG operand max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
 //   light  : dd = |Lw-P|^2 in [2^-60, 2^60] =>  D in [2^-30, 2^30], D*D in range, 1/D and 1/D^2 normal
 //   light  : hh = |Wo+Wi|^2 >= 2^-100 (and not NaN; it is <= ~4 for unit Wo, Wi) => sqrt and 1/sqrt normal
 // all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
@@ -174,9 +154,10 @@ struct RcpTrust {
     VQD float operator()(float b) const { return rcp_newton(b); }
     VQD float sqrt(float x) const { return sqrt_newton(x); }
 };
-VQD void add_point_light(const Pixel& px, const VQ_PointLight& l, f3& I) {
+VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
     const f3 Iprev = I;
-    const f3 d = sub(ld3(l.position), px.P);
+    const f3 lpos = mk3(l.px, l.py, l.pz), cb = mk3(l.cbx, l.cby, l.cbz);
+    const f3 d = sub(lpos, px.P);
     const float dd = dot(d, d);
     const float D = sqrt_newton(dd);
     bool ok = px.fastOK & (dd >= 0x1p-60f) & (dd <= 0x1p60f);
@@ -186,20 +167,19 @@ VQD void add_point_light(const Pixel& px, const VQ_PointLight& l, f3& I) {
         const f3 Hs = add(px.Wo, Wi);
         ok = ok & (dot(Hs, Hs) >= 0x1p-100f);
         const float NdotL = saturate(dot(px.Nraw, Wi));
-        const float att = rc(D * D);
-        const f3 radiance = mk3((att * l.color.x) * l.brightness, (att * l.color.y) * l.brightness, (att * l.color.z) * l.brightness);
+        const float w = rc(D * D) * NdotL;
 #if VQ_ABLATE == 3
         const f3 b = mk3(Wi.x * px.k, Wi.y * px.a2, Wi.z * px.omk);   // ablation: no BRDF
 #else
         const f3 b = brdf_t(px, Wi, rc);
 #endif
-        I = mk3(I.x + (b.x * radiance.x) * NdotL, I.y + (b.y * radiance.y) * NdotL, I.z + (b.z * radiance.z) * NdotL);
+        I = lit(I, b, cb, w);
     }
-    if (__builtin_expect(!ok, 0)) { RcpIEEE ieee; I = add(Iprev, point_light_t(px, l, ieee)); }
+    if (__builtin_expect(!ok, 0)) { RcpIEEE ieee; I = point_light_t(px, lpos, l.range, cb, Iprev, ieee); }
 }
 
-// SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333
-VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l) {
+// SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333 (no range cull)
+VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, f3 acc) {
     const f3 d = sub(ld3(l.position), px.P);
     const float D = sqrt_(dot(d, d));
     const f3 Wi = mul(d, rcp(D));
@@ -210,20 +190,18 @@ VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l) {
     if (theta > l.outerConeAngle) cone = 0.0f;
     else if (theta <= l.innerConeAngle) cone = 1.0f;
     else cone = 1.0f - div_(theta - l.innerConeAngle, l.outerConeAngle - l.innerConeAngle);
-    const float att = rcp(D * D);
-    const f3 radiance = mk3(((cone * l.color.x) * l.brightness) * att, ((cone * l.color.y) * l.brightness) * att, ((cone * l.color.z) * l.brightness) * att);
     const float NdotL = saturate(dot(px.Nraw, Wi));
-    const f3 b = brdf(px, Wi);
-    return mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
+    const float w = (cone * rcp(D * D)) * NdotL;
+    RcpIEEE rc;
+    return lit(acc, brdf_t(px, Wi, rc), light_cb(l.color, l.brightness), w);
 }
 
 // CalculateDirectionalLightIllumination :334-345
 VQD f3 directional_light(const Pixel& px, const VQ_DirectionalLight& l) {
     const f3 Wi = normalize(neg(ld3(l.lightDirection)));
-    const f3 radiance = mk3(l.color.x * l.brightness, l.color.y * l.brightness, l.color.z * l.brightness);
     const float NdotL = saturate(dot(px.Nraw, Wi));
-    const f3 b = brdf(px, Wi);
-    return mk3((b.x * radiance.x) * NdotL, (b.y * radiance.y) * NdotL, (b.z * radiance.z) * NdotL);
+    RcpIEEE rc;
+    return lit(mk3(0.0f, 0.0f, 0.0f), brdf_t(px, Wi, rc), light_cb(l.color, l.brightness), NdotL);
 }
 
 VQD f3 mul_v_m3(f3 v, float c, float s) {     // mul(v, GetHDRIRotationMatrix) with m = {c,0,s; 0,1,0; -s,0,c}
@@ -253,11 +231,11 @@ VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
     }
     const float p5 = pow5(1.0f - NdotV);                                         // FresnelWithRoughness :152-156
     const float omr = 1.0f - px.roughness;
-    const f3 Ks = mk3(px.F0.x + (max_(omr, px.F0.x) - px.F0.x) * p5, px.F0.y + (max_(omr, px.F0.y) - px.F0.y) * p5, px.F0.z + (max_(omr, px.F0.z) - px.F0.z) * p5);
+    const f3 Ks = mk3(fma_(max_(omr, px.F0.x) - px.F0.x, p5, px.F0.x), fma_(max_(omr, px.F0.y) - px.F0.y, p5, px.F0.y), fma_(max_(omr, px.F0.z) - px.F0.z, p5, px.F0.z));
     const f3 Kd = mk3((1.0f - Ks.x) * px.omm, (1.0f - Ks.y) * px.omm, (1.0f - Ks.z) * px.omm);
     const f3 diffuse = mk3(irr.x * px.albedo.x, irr.y * px.albedo.y, irr.z * px.albedo.z);
-    const f3 specular = mk3(spec.x * (Ks.x * sb.x + sb.y), spec.y * (Ks.y * sb.x + sb.y), spec.z * (Ks.z * sb.x + sb.y));
-    return mk3(Kd.x * diffuse.x + specular.x, Kd.y * diffuse.y + specular.y, Kd.z * diffuse.z + specular.z);
+    const f3 specular = mk3(spec.x * fma_(Ks.x, sb.x, sb.y), spec.y * fma_(Ks.y, sb.x, sb.y), spec.z * fma_(Ks.z, sb.x, sb.y));
+    return mk3(fma_(Kd.x, diffuse.x, specular.x), fma_(Kd.y, diffuse.y, specular.y), fma_(Kd.z, diffuse.z, specular.z));
 }
 
 VQD float4 mul_M_v(const VQ_matrix& M, f3 P) {     // HLSL mul(M, float4(P,1)) == row vector * M_cpu
@@ -304,12 +282,6 @@ VQD float pcf_2d(const float* slice, int dim, float2 smDims, float4 lsp, float b
     return 1.0f - div_(shadow, 25.0f);
 }
 
-#ifndef VQ_ABLATE
-#define VQ_ABLATE 0
-#endif
-#ifndef VQ_SHADE_WAVES
-#define VQ_SHADE_WAVES 1
-#endif
 template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT>
 __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::ShadeArgs a) {
     const int x = blockIdx.x * 256 + threadIdx.x;
@@ -323,19 +295,19 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     const f3 cam = ld3(fc->perView.CameraPosition);
     setup_pixel(px, g0, g1, g2, cam);
     const float ao = g0.w;
-    // illumination accumulators, ForwardLighting.hlsl:290-293
-    f3 I = mk3(px.albedo.x * ao + g3.x * g3.w, px.albedo.y * ao + g3.y * g3.w, px.albedo.z * ao + g3.z * g3.w);
+    // illumination accumulators, ForwardLighting.hlsl:290-293: diffuse*ao + emissive*intensity (mad)
+    f3 I = mk3(fma_(g3.x, g3.w, px.albedo.x * ao), fma_(g3.y, g3.w, px.albedo.y * ao), fma_(g3.z, g3.w, px.albedo.z * ao));
 
     if (HAS_ENV) I = add(I, environment(px, fc));                                             // :299-306
 
+    // non-shadowing point lights :310-313 — point_lights[0..numPointLights) followed by the extension array, packed by
+    // the host into 32-byte records {position, range, color*brightness}
+    const vqk::DevPointLight* pts = (const vqk::DevPointLight*)(fc + 1);
+    const int nP = fc->numPointAll;
+    for (int p = 0; p < nP; ++p) add_point_light(px, pts[p], I);
     const VQ_SceneLighting& L = fc->perFrame.Lights;
-    const int nP = L.numPointLights;
-    for (int p = 0; p < nP; ++p) add_point_light(px, L.point_lights[p], I);                   // :310-313
-    const int nE = fc->numExtraPoint;
-    const VQ_PointLight* extra = (const VQ_PointLight*)(fc + 1);
-    for (int p = 0; p < nE; ++p) add_point_light(px, extra[p], I);                            // extension, vqhip.h
     const int nS = L.numSpotLights;
-    for (int s = 0; s < nS; ++s) I = add(I, spot_light(px, L.spot_lights[s]));                // :314-317
+    for (int s = 0; s < nS; ++s) I = spot_light(px, L.spot_lights[s], I);                     // :314-317
 
     if (HAS_CASTERS) {
         const int nPC = L.numPointCasters;
@@ -347,7 +319,7 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
                 const float viewDist = length(sub(px.P, cam));
                 const f3 c = point_light(px, l);
                 const float sh = omni_pcf(fc->sm.point, fc->sm.point_dim, pc, Lw, l.range, l.depthBias, viewDist);
-                I = mk3(I.x + c.x * sh, I.y + c.y * sh, I.z + c.z * sh);
+                I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
             }
         }
         const int nSC = L.numSpotCasters;
@@ -356,11 +328,11 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
             const f3 Ln = normalize(sub(ld3(l.position), px.P));
             const float NdotL = saturate(dot(px.Nraw, Ln));
             const float4 lsp = mul_M_v(L.shadowViews[sc], px.P);
-            const f3 c = spot_light(px, l);
+            const f3 c = spot_light(px, l, mk3(0.0f, 0.0f, 0.0f));
             const float bias = l.depthBias * tan_(acos_(NdotL));
             const float sh = pcf_2d(fc->sm.spot + (size_t)sc * fc->sm.spot_dim * fc->sm.spot_dim, fc->sm.spot_dim,
                                     make_float2(fc->perFrame.f2SpotLightShadowMapDimensions.x, fc->perFrame.f2SpotLightShadowMapDimensions.y), lsp, bias);
-            I = mk3(I.x + c.x * sh, I.y + c.y * sh, I.z + c.z * sh);
+            I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
         }
     }
     {                                                                                         // :360-377
@@ -373,7 +345,7 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
                             make_float2(fc->perFrame.f2DirectionalLightShadowMapDimensions.x, fc->perFrame.f2DirectionalLightShadowMapDimensions.y), lsp, l.depthBias);
             }
             const f3 c = directional_light(px, l);
-            I = mk3(I.x + c.x * sh, I.y + c.y * sh, I.z + c.z * sh);
+            I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
         }
     }
     store_px<OUTFMT>(a.out, (size_t)y * a.outPitch + x, make_float4(I.x, I.y, I.z, px.roughness));   // :380

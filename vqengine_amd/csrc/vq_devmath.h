@@ -81,7 +81,7 @@ VQD float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 VQD f3 normalize(f3 v) { return mul(v, rsqrt(dot(v, v))); }
 VQD float length(f3 v) { return sqrt_(dot(v, v)); }
 VQD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
-VQD float lerp(float a, float b, float t) { return a + t * (b - a); }
+VQD float lerp(float a, float b, float t) { return fma_(t, b - a, a); }       // a + t*(b-a) as one mad
 VQD f3 reflect(f3 i, f3 n) { float t = 2.0f * dot(n, i); return mk3(i.x - n.x * t, i.y - n.y * t, i.z - n.z * t); }
 
 // float -> int: truncation, NaN -> 0, saturating
@@ -93,34 +93,28 @@ VQD int f2i_trunc(float x) {
 }
 VQD int f2i_floor(float x) { return f2i_trunc(__builtin_floorf(x)); }
 
-// log2: mantissa in [sqrt(1/2), sqrt(2)), 9-term polynomial for ln(1+f), log2(e) split as 1 + 0.44269504
+// log2 of a positive NORMAL number given its bit pattern: mantissa centred on 1 by integer arithmetic
+// (m in [sqrt(1/2), sqrt(2))), log2(x) = fma(f, Q(f), e) with the degree-8 polynomial of the arithmetic contract.
+VQD float log2_normal_bits(uint32_t u, int ebias) {
+    const uint32_t up = u - 0x3f3504f3u;                        // bits(0.70710677f)
+    const int e = ebias + ((int32_t)up >> 23);
+    const float f = __uint_as_float(u - (up & 0xff800000u)) - 1.0f;
+    float q = 0x1.08baeap-3f;
+    q = fma_(q, f, -0x1.abe534p-3f);
+    q = fma_(q, f,  0x1.b8c15cp-3f);
+    q = fma_(q, f, -0x1.e8ced8p-3f);
+    q = fma_(q, f,  0x1.26d980p-2f);
+    q = fma_(q, f, -0x1.715f9ap-2f);
+    q = fma_(q, f,  0x1.ec73bep-2f);
+    q = fma_(q, f, -0x1.71546cp-1f);
+    q = fma_(q, f,  0x1.715476p+0f);
+    return fma_(f, q, (float)e);
+}
 VQD float log2_(float x) {
     uint32_t u = __float_as_uint(x);
     int e = 0;
-    float xs = x;
-    if (u < 0x00800000u) { xs = x * 8388608.0f; u = __float_as_uint(xs); e = -23; }   // +denormal (and +0, handled below)
-    e += (int)(u >> 23) - 126;
-    float m = __uint_as_float((u & 0x007fffffu) | 0x3f000000u);
-    float f;
-    if (m < 0.70710678118654752440f) { e -= 1; f = (m + m) - 1.0f; } else { f = m - 1.0f; }
-    float z = f * f;
-    float p = 7.0376836292E-2f;
-    p = fma_(p, f, -1.1514610310E-1f);
-    p = fma_(p, f,  1.1676998740E-1f);
-    p = fma_(p, f, -1.2420140846E-1f);
-    p = fma_(p, f,  1.4249322787E-1f);
-    p = fma_(p, f, -1.6668057665E-1f);
-    p = fma_(p, f,  2.0000714765E-1f);
-    p = fma_(p, f, -2.4999993993E-1f);
-    p = fma_(p, f,  3.3333331174E-1f);
-    float y = (p * f) * z;
-    y = fma_(-0.5f, z, y);
-    const float L2EA = 0.44269504088896340736f;
-    float r = y * L2EA;
-    r = fma_(f, L2EA, r);
-    r = r + y;
-    r = r + f;
-    r = r + (float)e;
+    if (u < 0x00800000u) { u = __float_as_uint(x * 8388608.0f); e = -23; }           // +denormal (and +0, handled below)
+    float r = log2_normal_bits(u, e);
     // special cases, same precedence as the reference restatement: NaN, negative, zero, +inf
     if (x == __builtin_inff()) r = x;
     if (x == 0.0f) r = -__builtin_inff();

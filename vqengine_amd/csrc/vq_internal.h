@@ -16,12 +16,16 @@ struct alignas(16) FrameConstants {
     vqhip_envmap           env;            // device pointers
     vqhip_shadowmaps       sm;             // device pointers
     int32_t                hasEnv;
-    int32_t                numExtraPoint;
+    int32_t                numPointAll;    // numPointLights + numExtraPoint
     int32_t                pad[2];
-    // VQ_PointLight extra[numExtraPoint] follows
+    // DevPointLight pts[numPointAll] follows
 };
+// Non-shadowing point lights as the hot loop reads them (one s_load_dwordx8 per light): point_lights[0..numPointLights)
+// followed by the extension array, with the loop-invariant product color*brightness formed once on the host (IEEE
+// multiply, identical to the in-shader product).
+struct alignas(16) DevPointLight { float px, py, pz, range; float cbx, cby, cbz, pad; };
 static constexpr int    kMaxExtraPointLights = 1024;
-static constexpr size_t kConstSlotBytes = (sizeof(FrameConstants) + kMaxExtraPointLights * sizeof(VQ_PointLight) + 255) & ~(size_t)255;
+static constexpr size_t kConstSlotBytes = (sizeof(FrameConstants) + (VQ_NUM_LIGHTS__POINT + kMaxExtraPointLights) * sizeof(DevPointLight) + 255) & ~(size_t)255;
 
 struct ShadeArgs {
     const float4* gb0; const float4* gb1; const float4* gb2; const float4* gb3;
