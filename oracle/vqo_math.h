@@ -114,15 +114,14 @@ static inline float log2_(float x) {
     return fma_(f, q, (float)e);
 }
 
-// exp2(x): n = nearest integer, f = x - n in [-0.5, 0.5], 2^f ~ 1 + f*P(f) (Cephes exp2f), scale by 2^n.
+// exp2(x): n = rint(x) (round half to even), f = x - n in [-0.5, 0.5], 2^f ~ 1 + f*P(f) (Cephes exp2f), scale by 2^n.
 // x >= 128 -> +inf; x < -126 -> 0 (denormal results flush to zero like D3D); NaN -> NaN.
 static inline float exp2_(float x) {
     if (!(x == x)) return x;
     if (x >= 128.0f) return INFINITY;
     if (x < -126.0f) return 0.0f;
-    float n = __builtin_floorf(x);
+    float n = __builtin_rintf(x);                 // round-half-even (v_rndne_f32): f = x - n in [-0.5, 0.5]
     float f = x - n;
-    if (f > 0.5f) { n += 1.0f; f -= 1.0f; }
     float p = 1.535336188319500E-4f;
     p = fma_(p, f, 1.339887440266574E-3f);
     p = fma_(p, f, 9.618437357674640E-3f);

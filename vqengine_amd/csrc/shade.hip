@@ -46,9 +46,8 @@ VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
 VQD float pow5(float x) {
     if (__builtin_expect(!(x >= 5.9604644775390625e-8f && x <= 1.0f), 0)) return pow_(x, 5.0f);
     const float t = 5.0f * log2_normal_bits(__float_as_uint(x), 0);      // in [-120, 0]
-    float n = __builtin_floorf(t);
-    float g = t - n;
-    if (g > 0.5f) { n += 1.0f; g -= 1.0f; }
+    const float n = __builtin_rintf(t);                                   // v_rndne_f32
+    const float g = t - n;
     float q = 1.535336188319500E-4f;
     q = fma_(q, g, 1.339887440266574E-3f);
     q = fma_(q, g, 9.618437357674640E-3f);

@@ -125,9 +125,8 @@ VQD float log2_(float x) {
 
 // exp2: n = nearest integer, 2^f ~ 1 + f*P(f) on [-0.5,0.5]; >= 128 -> inf, < -126 -> 0
 VQD float exp2_(float x) {
-    float n = __builtin_floorf(x);
+    float n = __builtin_rintf(x);                          // v_rndne_f32: round half to even
     float f = x - n;
-    if (f > 0.5f) { n += 1.0f; f -= 1.0f; }
     float p = 1.535336188319500E-4f;
     p = fma_(p, f, 1.339887440266574E-3f);
     p = fma_(p, f, 9.618437357674640E-3f);
