@@ -230,6 +230,54 @@ typedef struct vqhip_envmap_out {
     void* specular;             /* Tex_IrradianceSpec        mip-major RGBA16F                                */
 } vqhip_envmap_out;
 
+/* ---- the G-buffer producer's inputs -------------------------------------------- */
+
+/* One material texture = the reference's DXGI_FORMAT_R8G8B8A8_UNORM Texture2D with its full mip chain
+ * (TextureManager.cpp:590; mips by VQ_DXGI_UTILS::MipImage's 4-byte branch, DXGIUtils.cpp:264-285).
+ * texels : device pointer, level 0 first, levels densely packed, `mips` levels, level l is
+ *          max(1,width>>l) x max(1,height>>l). NULL == the null SRV bound for a missing map
+ *          (Renderer_Resources.cpp:385-387): every sample returns 0. */
+typedef struct vqhip_texture2d {
+    const void* texels;
+    int32_t width, height, mips, reserved;
+} vqhip_texture2d;
+
+/* cbPerObject.materialData + the descriptor table t0..t7 of ForwardLighting.hlsl:84-92 that
+ * AssetLoader.cpp:406-420 fills per material (t3 texAlphaMask and t8 texHeightmap are not read by
+ * the non-tessellated, non-alpha-masked PSMain and are omitted). */
+typedef struct vqhip_material {
+    VQ_MaterialData data;
+    vqhip_texture2d texDiffuse;         /* t0 */
+    vqhip_texture2d texNormals;         /* t1 */
+    vqhip_texture2d texEmissive;        /* t2 */
+    vqhip_texture2d texMetalness;       /* t4 */
+    vqhip_texture2d texRoughness;       /* t5 */
+    vqhip_texture2d texOcclRoughMetal;  /* t6 */
+    vqhip_texture2d texLocalAO;         /* t7 */
+} vqhip_material;
+
+VQHIP_STATIC_ASSERT(sizeof(vqhip_texture2d) == 24, "vqhip_texture2d");
+VQHIP_STATIC_ASSERT(sizeof(vqhip_material) == 256 && offsetof(vqhip_material, texDiffuse) == 80 &&
+                    offsetof(vqhip_material, texLocalAO) == 224, "vqhip_material");
+
+/* The rasteriser's output that PSMain consumes (struct PSInput, ForwardLighting.hlsl:42-53), one record
+ * per pixel in three SoA float4 planes (device pointers, row_pitch_px pixels per row):
+ *   ip0 = (WorldSpacePosition.xyz, uv.x)
+ *   ip1 = (WorldSpaceNormal.xyz,   uv.y)
+ *   ip2 = (WorldSpaceTangent.xyz,  asfloat(int32 materialIndex))   materialIndex < 0: no geometry
+ * SV_POSITION.xy is implied: (x + 0.5, y + 0.5). Producing these planes (VS + rasteriser, or a
+ * visibility-buffer resolve) stays with the caller. */
+typedef struct vqhip_interpolants {
+    const void* ip0; const void* ip1; const void* ip2;
+    int32_t width, height, row_pitch_px;
+} vqhip_interpolants;
+
+/* texScreenSpaceAO (t9): R8_UNORM [height][width] (RenderResources.cpp:358-371), or NULL when SSAO is
+ * off (the reference then clears the target to 1.0, SceneRendering.cpp:1543-1553). */
+typedef struct vqhip_ssao {
+    const void* texels; int32_t width, height;
+} vqhip_ssao;
+
 typedef struct vqhip_ctx vqhip_ctx;
 
 /* summation order of the convolution integrals (DESIGN.md "Convolution order"):
@@ -332,6 +380,31 @@ VQHIP_API int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equi
  * convolution -> per-face blur X,Y -> specular mips, all outputs RGBA16F like the reference. */
 VQHIP_API int vqhip_envmap_prefilter(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
         int diffuseRes, float diffuseStep, int specRes0, vqhip_conv_order order, const vqhip_envmap_out* out);
+
+/* ---- G-buffer producer ----------------------------------------------------------
+ * Replaces the surface-assembly half of ForwardLighting.hlsl:PSMain (:226-287): uv transform, the seven
+ * material-map fetches, SRGBToLinear (ShadingMath.hlsl:65), Has*Map() selection
+ * (LightingConstantBufferData.h:116-124), UnpackNormal (ShadingMath.hlsl:44-52), the ORM / AO / SSAO
+ * multiplies — for every pixel of the interpolant planes at once, each pixel using
+ * materials[materialIndex] (the reference binds one material per draw: SceneRendering.cpp:1744-1750).
+ * Writes the four planes of `out` (their pointers are written through despite the const in
+ * vqhip_gbuffer); pixels without geometry get all-zero records.
+ *   materials : HOST array (copied; numMaterials <= vqhip_max_materials())
+ *   fAmbientLightingFactor : cbPerFrame.fAmbientLightingFactor (:247)
+ *   ssao : NULL or a descriptor with texels == NULL => factor 1.0
+ * Sampler s2 is ANISOTROPIC_WRAP with MaxAnisotropy = 0 (RootSignatures.cpp:111,149), s0 TRILINEAR_WRAP:
+ * both are evaluated as isotropic trilinear WRAP with the LOD of the pixel quad's uv differences
+ * (DESIGN.md "G-buffer producer"). */
+VQHIP_API int vqhip_max_materials(void);
+VQHIP_API int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream,
+        const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
+        float fAmbientLightingFactor, const vqhip_ssao* ssao, const vqhip_gbuffer* out);
+
+/* Replaces VQ_DXGI_UTILS::MipImage's 4-byte branch (DXGIUtils.cpp:264-285) as driven by
+ * TextureManager::GenerateMips: each channel = (sum of the 2x2 block) / 4, integer division.
+ * Same buffer convention as vqhip_mip_chain_min_rgba32f with 4-byte texels; w0, h0 powers of two. */
+VQHIP_API size_t vqhip_mip_chain_bytes_rgba8(int w0, int h0, int nMips);
+VQHIP_API int    vqhip_mip_chain_box_rgba8(vqhip_ctx* ctx, void* stream, void* mips, int w0, int h0, int nMips);
 
 #ifdef __cplusplus
 }

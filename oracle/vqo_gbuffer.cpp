@@ -1,0 +1,219 @@
+// vqo_gbuffer.cpp — CPU restatement of the surface-assembly half of ForwardLighting.hlsl:PSMain (:226-287)
+// and of MipImage's 4-byte branch ("G-buffer producer").
+//
+// ORACLE / TEST INFRASTRUCTURE ONLY (see vqo_oracle.cpp). PARITY UNPINNED: the reference holds no golden
+// vectors for this path and its HLSL/D3D12 implementation cannot be run here.
+//
+// Contract additions of this file (DESIGN.md "G-buffer producer"):
+//   * UNORM8 texels are filtered as the integers 0..255 and the filtered value is scaled once by rcp(255)
+//     (the contract's a/b = a*rcp(b)). With 8-bit weights the bilinear blend of bytes is EXACT in binary32
+//     (weights are multiples of 2^-16, sums <= 255 need 24 bits), so only the trilinear lerp and the final
+//     scale round. (D3D11.3 §7.18.8 lets filtering run at fixed-point texel precision.)
+//   * Material textures are R8G8B8A8_UNORM mip chains (TextureManager.cpp:590). AnisoSampler is
+//     ANISOTROPIC_WRAP with MaxAnisotropy = 0 (RootSignatures.cpp:111,149) and LinearSampler TRILINEAR_WRAP:
+//     both are evaluated as isotropic trilinear WRAP filtering, 8-bit fractions as in vqo_sampling.h.
+//   * Implicit derivatives are the fine 2x2-quad differences of the *transformed* uv:
+//       ddx = uv(x|1, y) - uv(x&~1, y),  ddy = uv(x, y|1) - uv(x, y&~1);
+//     when the quad neighbour is outside the image or belongs to another material index the derivative
+//     is 0 (hardware would extrapolate the triangle's plane through helper lanes; the planes do not hold it).
+//   * LOD = 0.5*log2(max(|ddx*(W,H)|^2, |ddy*(W,H)|^2)) + bias, clamped to [0, mips-1] (D3D11.3 §7.18.11,
+//     isotropic); -inf / NaN -> 0.
+//   * Everything else keeps the HLSL's literal operation order (this is not one of the v2 lighting functions).
+#include <cstdlib>
+#include <cstring>
+#include <omp.h>
+
+#include "../include/vqhip.h"
+#include "vqo_math.h"
+#include "vqo_sampling.h"
+
+using namespace vqo;
+
+namespace {
+
+inline float unorm8_to_float(float c) { return c * rcp(255.0f); }
+
+inline size_t tex_level_offset_px(int w0, int h0, int level) {
+    size_t off = 0;
+    for (int l = 0; l < level; ++l) off += (size_t)mip_dim(w0, l) * mip_dim(h0, l);
+    return off;
+}
+
+// bilinear WRAP of one RGBA8 level, in byte units (exact)
+inline f4 sample_2d_rgba8_wrap(const uint8_t* tex, int W, int H, float u, float v) {
+    int ix, iy; float wx, wy;
+    fixed8(u * (float)W - 0.5f, &ix, &wx);
+    fixed8(v * (float)H - 0.5f, &iy, &wy);
+    auto wrap = [](int i, int n) { int m = i % n; return m < 0 ? m + n : m; };
+    const int x0 = wrap(ix, W), x1 = wrap(ix + 1, W), y0 = wrap(iy, H), y1 = wrap(iy + 1, H);
+    auto ld = [&](int x, int y) -> f4 {
+        const uint8_t* p = tex + ((size_t)y * W + x) * 4;
+        return { (float)p[0], (float)p[1], (float)p[2], (float)p[3] };
+    };
+    return blend4(ld(x0, y0), ld(x1, y0), ld(x0, y1), ld(x1, y1), wx, wy);
+}
+
+// Texture2D.Sample / SampleBias with the quad derivatives ddx, ddy (already in uv units)
+inline f4 sample_material_tex(const vqhip_texture2d& t, f2 uv, f2 ddx, f2 ddy, float bias) {
+    if (!t.texels) return { 0, 0, 0, 0 };                                   // null SRV
+    const float W = (float)t.width, H = (float)t.height;
+    const f2 dX = { ddx.x * W, ddx.y * H }, dY = { ddy.x * W, ddy.y * H };
+    const float rx = fma_(dX.y, dX.y, dX.x * dX.x), ry = fma_(dY.y, dY.y, dY.x * dY.x);
+    const float lod = 0.5f * log2_(max_(rx, ry)) + bias;
+    const float maxl = (float)(t.mips - 1);
+    const float l = (lod > 0.0f) ? ((lod < maxl) ? lod : maxl) : 0.0f;      // NaN, -inf -> 0
+    const int fl = f2i_floor(l * 256.0f + 0.5f);
+    int lo = fl >> 8;
+    float f = (float)(fl & 255) * 0.00390625f;
+    if (lo >= t.mips - 1) { lo = t.mips - 1; f = 0.0f; }
+    const uint8_t* base = (const uint8_t*)t.texels;
+    const f4 a = sample_2d_rgba8_wrap(base + tex_level_offset_px(t.width, t.height, lo) * 4, mip_dim(t.width, lo), mip_dim(t.height, lo), uv.x, uv.y);
+    f4 r = a;
+    if (f != 0.0f) {
+        const f4 b = sample_2d_rgba8_wrap(base + tex_level_offset_px(t.width, t.height, lo + 1) * 4, mip_dim(t.width, lo + 1), mip_dim(t.height, lo + 1), uv.x, uv.y);
+        const float g = 1.0f - f;
+        r = { fma_(f, b.x, g * a.x), fma_(f, b.y, g * a.y), fma_(f, b.z, g * a.z), fma_(f, b.w, g * a.w) };
+    }
+    return { unorm8_to_float(r.x), unorm8_to_float(r.y), unorm8_to_float(r.z), unorm8_to_float(r.w) };
+}
+
+// LightingConstantBufferData.h:116-124
+inline bool has_bit(int cfg, int bit) { return (cfg & (1 << bit)) > 0; }
+
+// ShadingMath.hlsl:44-52
+inline f3 UnpackNormal(f3 S, f3 worldNormal, f3 worldTangent) {
+    S = normalize(f3{ S.x * 2.0f - 1.0f, S.y * 2.0f - 1.0f, S.z * 2.0f - 1.0f });
+    const f3 T = normalize(sub(worldTangent, mul(worldNormal, dot(worldNormal, worldTangent))));
+    const f3 N = normalize(worldNormal);
+    const f3 B = normalize(cross(T, N));
+    // mul(SampledNormal, float3x3(T, B, N)): row vector times matrix with rows T, B, N
+    return { fma_(S.z, N.x, fma_(S.y, B.x, S.x * T.x)),
+             fma_(S.z, N.y, fma_(S.y, B.y, S.x * T.y)),
+             fma_(S.z, N.z, fma_(S.y, B.z, S.x * T.z)) };
+}
+
+inline f3 SRGBToLinear(f3 c) { return { pow_(c.x, 2.2f), pow_(c.y, 2.2f), pow_(c.z, 2.2f) }; }   // ShadingMath.hlsl:65
+
+struct Planes { const float* ip0; const float* ip1; const float* ip2; int W, H, pitch; };
+
+inline int mat_index(const Planes& p, int x, int y) {
+    int32_t i; std::memcpy(&i, p.ip2 + ((size_t)y * p.pitch + x) * 4 + 3, 4); return i;
+}
+inline f2 uv_transformed(const Planes& p, int x, int y, const VQ_MaterialData& m) {     // ForwardLighting.hlsl:226
+    const size_t o = ((size_t)y * p.pitch + x) * 4;
+    return { p.ip0[o + 3] * m.uvScaleOffset.x + m.uvScaleOffset.z, p.ip1[o + 3] * m.uvScaleOffset.y + m.uvScaleOffset.w };
+}
+
+void gbuffer_pixel(const Planes& in, int x, int y, const vqhip_material* mats, int nMats, float ambient,
+                   const vqhip_ssao* ssao, float* o0, float* o1, float* o2, float* o3) {
+    const int idx = mat_index(in, x, y);
+    if (idx < 0 || idx >= nMats) {
+        for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = o3[k] = 0.0f;
+        return;
+    }
+    const vqhip_material& mt = mats[idx];
+    const VQ_MaterialData& m = mt.data;
+    const size_t o = ((size_t)y * in.pitch + x) * 4;
+
+    const f2 uv = uv_transformed(in, x, y, m);
+    f2 ddx = { 0, 0 }, ddy = { 0, 0 };
+    {
+        const int xa = x & ~1, xb = x | 1, ya = y & ~1, yb = y | 1;
+        if (xb < in.W && mat_index(in, xa, y) == idx && mat_index(in, xb, y) == idx) {
+            const f2 a = uv_transformed(in, xa, y, m), b = uv_transformed(in, xb, y, m);
+            ddx = { b.x - a.x, b.y - a.y };
+        }
+        if (yb < in.H && mat_index(in, x, ya) == idx && mat_index(in, x, yb) == idx) {
+            const f2 a = uv_transformed(in, x, ya, m), b = uv_transformed(in, x, yb, m);
+            ddy = { b.x - a.x, b.y - a.y };
+        }
+    }
+    const int TEX_CFG = f2i_trunc(m.textureConfig);                                   // :227
+
+    f4 AlbedoAlpha   = sample_material_tex(mt.texDiffuse,        uv, ddx, ddy, 0.0f); // :229
+    const f4 Normal4 = sample_material_tex(mt.texNormals,        uv, ddx, ddy, m.normalMapMipBias);
+    const f4 Emis4   = sample_material_tex(mt.texEmissive,       uv, ddx, ddy, 0.0f);
+    const float Metalness = sample_material_tex(mt.texMetalness, uv, ddx, ddy, 0.0f).x;
+    const float Roughness = sample_material_tex(mt.texRoughness, uv, ddx, ddy, 0.0f).x;
+    const f4 ORM     = sample_material_tex(mt.texOcclRoughMetal, uv, ddx, ddy, 0.0f);
+    const float LocalAO   = sample_material_tex(mt.texLocalAO,   uv, ddx, ddy, 0.0f).x;
+
+    const f3 Albedo   = SRGBToLinear({ AlbedoAlpha.x, AlbedoAlpha.y, AlbedoAlpha.z });     // :243
+    const f3 Emissive = SRGBToLinear({ Emis4.x, Emis4.y, Emis4.z });                       // :244
+
+    float ao = ambient;                                                                // :247
+    const f3 mdiff = { m.diffuse.x, m.diffuse.y, m.diffuse.z }, memis = { m.emissiveColor.x, m.emissiveColor.y, m.emissiveColor.z };
+    const f3 diffuseColor  = has_bit(TEX_CFG, 0) ? mul(Albedo, mdiff) : mdiff;         // :249
+    const f3 emissiveColor = has_bit(TEX_CFG, 7) ? mul(Emissive, memis) : memis;       // :250
+    float roughness = m.roughness, metalness = m.metalness;                            // :252-253
+
+    const f3 N = normalize(f3{ in.ip1[o], in.ip1[o + 1], in.ip1[o + 2] });             // :265
+    const f3 T = normalize(f3{ in.ip2[o], in.ip2[o + 1], in.ip2[o + 2] });             // :266
+    const f3 Nrm = { Normal4.x, Normal4.y, Normal4.z };
+    const f3 SurfN = (length(Nrm) < 0.01f) ? N : UnpackNormal(Nrm, N, T);              // :267
+
+    if (has_bit(TEX_CFG, 2)) ao *= LocalAO;                                            // :269
+    if (has_bit(TEX_CFG, 4)) roughness *= Roughness;                                   // :270
+    if (has_bit(TEX_CFG, 5)) metalness *= Metalness;                                   // :271
+    if (has_bit(TEX_CFG, 8)) { roughness *= ORM.y; metalness *= ORM.z; }               // :272-277
+
+    // :280-281  ScreenSpaceUV = (In.position.xy + 0.5) / ScreenDimensions, PointSampler = POINT_WRAP
+    if (ssao && ssao->texels) {
+        const float su = div_(((float)x + 0.5f) + 0.5f, (float)in.W), sv = div_(((float)y + 0.5f) + 0.5f, (float)in.H);
+        auto wrap = [](int i, int n) { int q = i % n; return q < 0 ? q + n : q; };
+        // texel = floor of the coordinate snapped to 8 fractional bits (D3D11.3 §7.18.7): these coordinates sit exactly on
+        // texel borders ((x+1)/W), the snap makes the choice (texel x+1, wrapping at the right/bottom edge) rounding-proof
+        const int tx = wrap(f2i_floor((su * (float)ssao->width) * 256.0f + 0.5f) >> 8, ssao->width);
+        const int ty = wrap(f2i_floor((sv * (float)ssao->height) * 256.0f + 0.5f) >> 8, ssao->height);
+        ao *= unorm8_to_float((float)((const uint8_t*)ssao->texels)[(size_t)ty * ssao->width + tx]);
+    }
+
+    o0[0] = in.ip0[o]; o0[1] = in.ip0[o + 1]; o0[2] = in.ip0[o + 2]; o0[3] = ao;      // :284
+    o1[0] = SurfN.x; o1[1] = SurfN.y; o1[2] = SurfN.z; o1[3] = roughness;
+    o2[0] = diffuseColor.x; o2[1] = diffuseColor.y; o2[2] = diffuseColor.z; o2[3] = metalness;
+    o3[0] = emissiveColor.x; o3[1] = emissiveColor.y; o3[2] = emissiveColor.z; o3[3] = m.emissiveIntensity;   // :251
+}
+
+} // namespace
+
+extern "C" {
+
+// all pointers are HOST pointers here (the structs are shared with the product's ABI for convenience)
+int vqo_gbuffer_from_materials(const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
+                               float fAmbientLightingFactor, const vqhip_ssao* ssao, const vqhip_gbuffer* out, int nthreads) {
+    if (!in || !out || (numMaterials > 0 && !materials)) return -1;
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    const Planes p = { (const float*)in->ip0, (const float*)in->ip1, (const float*)in->ip2, in->width, in->height, in->row_pitch_px };
+    float* g0 = (float*)out->gb0; float* g1 = (float*)out->gb1; float* g2 = (float*)out->gb2; float* g3 = (float*)out->gb3;
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int y = 0; y < in->height; ++y)
+        for (int x = 0; x < in->width; ++x) {
+            const size_t q = ((size_t)y * out->row_pitch_px + x) * 4;
+            gbuffer_pixel(p, x, y, materials, numMaterials, fAmbientLightingFactor, ssao, g0 + q, g1 + q, g2 + q, g3 + q);
+        }
+    return 0;
+}
+
+// VQ_DXGI_UTILS::MipImage 4-byte branch, DXGIUtils.cpp:264-285: per channel (a+b+c+d)/4, integer division.
+size_t vqo_mip_chain_texels(int w0, int h0, int nMips) { return tex_level_offset_px(w0, h0, nMips); }
+int vqo_mip_chain_box_rgba8(uint8_t* chain, int w0, int h0, int nMips) {
+    for (int l = 1; l < nMips; ++l) {
+        const int sw = mip_dim(w0, l - 1), sh = mip_dim(h0, l - 1), dw = mip_dim(w0, l), dh = mip_dim(h0, l);
+        const uint8_t* src = chain + tex_level_offset_px(w0, h0, l - 1) * 4;
+        uint8_t* dst = chain + tex_level_offset_px(w0, h0, l) * 4;
+        for (int y = 0; y < dh; ++y)
+            for (int x = 0; x < dw; ++x) {
+                const int x0 = 2 * x, y0 = 2 * y, x1 = (2 * x + 1 < sw) ? 2 * x + 1 : sw - 1, y1 = (2 * y + 1 < sh) ? 2 * y + 1 : sh - 1;
+                for (int ch = 0; ch < 4; ++ch) {
+                    const unsigned s = src[((size_t)y0 * sw + x0) * 4 + ch] + src[((size_t)y0 * sw + x1) * 4 + ch] +
+                                       src[((size_t)y1 * sw + x0) * 4 + ch] + src[((size_t)y1 * sw + x1) * 4 + ch];
+                    dst[((size_t)y * dw + x) * 4 + ch] = (uint8_t)(s / 4);
+                }
+            }
+    }
+    return 0;
+}
+
+float vqo_unorm8_to_float(int c) { return unorm8_to_float((float)(uint8_t)c); }
+
+} // extern "C"

@@ -51,6 +51,13 @@ def load():
     lib.vqo_conv_diffuse.argtypes = [vp, i32, i32, i32, i32, f32, i32, vp, i32, lg, lg, i32]
     lib.vqo_conv_specular.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, i32]
     lib.vqo_envmap_prefilter.argtypes = [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32]
+    lib.vqo_gbuffer_from_materials.argtypes = [C.POINTER(abi.Interpolants), C.POINTER(abi.MaterialDesc), i32, f32,
+                                               C.POINTER(abi.SSAO), C.POINTER(abi.GBuffer), i32]
+    lib.vqo_mip_chain_box_rgba8.argtypes = [vp, i32, i32, i32]
+    lib.vqo_mip_chain_texels.restype = sz
+    lib.vqo_mip_chain_texels.argtypes = [i32, i32, i32]
+    lib.vqo_unorm8_to_float.restype = f32
+    lib.vqo_unorm8_to_float.argtypes = [i32]
     if not lib.vqo_has_fma():
         raise RuntimeError("oracle needs a host CPU with FMA (it is compiled -mfma)")
     _lib = lib
@@ -177,6 +184,48 @@ def envmap_prefilter(chain, w0, h0, n_mips, diffuse_res, diffuse_step, spec_res0
     rc = lib.vqo_envmap_prefilter(_p(chain), w0, h0, n_mips, diffuse_res, diffuse_step, spec_res0, order, _p(d0), _p(d1), _p(sp), nthreads)
     assert rc == 0, rc
     return {"diffuse_unblurred": d0, "diffuse_blurred": d1, "specular": sp, "spec_mips": mips}
+
+
+def mip_chain_rgba8(level0):
+    """uint8 [H,W,4] -> (flat uint8 chain [px,4], n_mips): MipImage 4-byte branch, box filter with integer division."""
+    lib = load()
+    h, w = level0.shape[:2]
+    n = abi.mip_level_count(w, h)
+    chain = np.empty((abi.mip_chain_px(w, h, n), 4), np.uint8)
+    assert lib.vqo_mip_chain_texels(w, h, n) == chain.shape[0]
+    chain[: w * h] = level0.reshape(-1, 4)
+    assert lib.vqo_mip_chain_box_rgba8(_p(chain), w, h, n) == 0
+    return chain, n
+
+
+def host_materials(datas, chains):
+    """ctypes array of abi.MaterialDesc over HOST uint8 chains. chains[i] = {slot: (chain, w, h, n_mips)}.
+    Keeps the arrays alive through the returned object's `_keep`."""
+    arr = (abi.MaterialDesc * len(datas))()
+    for i, (d, cs) in enumerate(zip(datas, chains)):
+        arr[i].data = d
+        for slot, (chain, w, h, n) in cs.items():
+            setattr(arr[i], slot, abi.Texture2D(chain.ctypes.data, w, h, n, 0))
+    arr._keep = chains
+    return arr
+
+
+def gbuffer_from_materials(ip, materials, ambient, ssao=None, nthreads=0):
+    lib = load()
+    ip = [np.ascontiguousarray(p, np.float32) for p in ip]
+    h, w = ip[0].shape[:2]
+    out = [np.empty((h, w, 4), np.float32) for _ in range(4)]
+    inter = abi.Interpolants(ip[0].ctypes.data, ip[1].ctypes.data, ip[2].ctypes.data, w, h, w)
+    gb = abi.GBuffer(out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, out[3].ctypes.data, w, h, w)
+    s = None
+    if ssao is not None:
+        ssao = np.ascontiguousarray(ssao, np.uint8)
+        s = abi.SSAO(ssao.ctypes.data, ssao.shape[1], ssao.shape[0])
+    n = len(materials) if materials is not None else 0
+    rc = lib.vqo_gbuffer_from_materials(C.byref(inter), materials if n else None, n, float(ambient),
+                                        C.byref(s) if s is not None else None, C.byref(gb), nthreads)
+    assert rc == 0, rc
+    return out
 
 
 def bits_equal(a, b):

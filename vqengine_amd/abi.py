@@ -116,6 +116,26 @@ class EnvMapOut(C.Structure):
                 ("specular", C.c_void_p)]
 
 
+class Texture2D(C.Structure):  # vqhip_texture2d: RGBA8_UNORM mip chain, texels NULL == null SRV
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("mips", C.c_int32), ("reserved", C.c_int32)]
+
+
+MATERIAL_TEXTURE_SLOTS = ("texDiffuse", "texNormals", "texEmissive", "texMetalness", "texRoughness", "texOcclRoughMetal", "texLocalAO")
+
+
+class MaterialDesc(C.Structure):  # vqhip_material
+    _fields_ = [("data", MaterialData)] + [(s, Texture2D) for s in MATERIAL_TEXTURE_SLOTS] + [("_tail_pad", C.c_int32 * 2)]  # alignas(16)
+
+
+class Interpolants(C.Structure):  # vqhip_interpolants
+    _fields_ = [("ip0", C.c_void_p), ("ip1", C.c_void_p), ("ip2", C.c_void_p),
+                ("width", C.c_int32), ("height", C.c_int32), ("row_pitch_px", C.c_int32)]
+
+
+class SSAO(C.Structure):  # vqhip_ssao
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
+
+
 def _chk(t, size, **offs):
     assert C.sizeof(t) == size, (t.__name__, C.sizeof(t), size)
     for k, v in offs.items():
@@ -131,6 +151,8 @@ _chk(PerFrameData, 7120, f2PointLightShadowMapDimensions=7088, fAmbientLightingF
 _chk(PerViewLightingData, 320, WorldFrustumPlanes=192, CameraPosition=288, MaxEnvMapLODLevels=300,
      ScreenDimensions=304, EnvironmentMapDiffuseOnlyIllumination=312)
 _chk(MaterialData, 80, uvScaleOffset=48, roughness=64, textureConfig=76)
+_chk(Texture2D, 24, width=8, mips=16)
+_chk(MaterialDesc, 256, texDiffuse=80, texLocalAO=224)
 _chk(TonemapperParams, 16)
 _chk(BlurParams, 8)
 

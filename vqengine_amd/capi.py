@@ -56,6 +56,11 @@ def load_library():
         "vqhip_conv_diffuse": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, vp, i32]),
         "vqhip_conv_specular": (i32, [vp, vp, vp, i32, i32, i32, i32, i32, vp, i32]),
         "vqhip_envmap_prefilter": (i32, [vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, C.POINTER(abi.EnvMapOut)]),
+        "vqhip_max_materials": (i32, []),
+        "vqhip_gbuffer_from_materials": (i32, [vp, vp, C.POINTER(abi.Interpolants), C.POINTER(abi.MaterialDesc), i32, f32,
+                                               C.POINTER(abi.SSAO), C.POINTER(abi.GBuffer)]),
+        "vqhip_mip_chain_bytes_rgba8": (sz, [i32, i32, i32]),
+        "vqhip_mip_chain_box_rgba8": (i32, [vp, vp, vp, i32, i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -71,6 +76,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_gaussian_blur_y_tonemap", "vqhip_tonemap", "vqhip_brdf_lut",
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
+    "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
 ]
 
 _TORCH_DTYPE = {FMT_RGBA32F: (torch.float32, 4), FMT_RGBA16F: (torch.float16, 4), FMT_RGBA8_UNORM: (torch.uint8, 4),
@@ -215,6 +221,39 @@ class Context:
         chain[: w * h].copy_(level0.reshape(-1, 4))
         self._ck(self.lib.vqhip_mip_chain_min_rgba32f(self._h, self._stream(stream), _ptr(chain), w, h, n))
         return chain, n
+
+    # ---- G-buffer producer (ForwardLighting.hlsl:PSMain :226-287) --------------------------
+    def mip_chain_rgba8(self, level0, stream=None):
+        """level0: uint8 cuda [H,W,4], power-of-two dims. Returns (flat uint8 chain [px,4], n_mips), box-filtered mips."""
+        _check_img(level0, FMT_RGBA8_UNORM, "level0")
+        h, w = level0.shape[0], level0.shape[1]
+        n = abi.mip_level_count(w, h)
+        chain = torch.empty((abi.mip_chain_px(w, h, n), 4), dtype=torch.uint8, device=self.device)
+        chain[: w * h].copy_(level0.reshape(-1, 4))
+        self._ck(self.lib.vqhip_mip_chain_box_rgba8(self._h, self._stream(stream), _ptr(chain), w, h, n))
+        return chain, n
+
+    def gbuffer_from_materials(self, ip, materials, ambient, ssao=None, out=None, stream=None):
+        """ip: 3 float32 cuda tensors [H,W,4] (vqhip_interpolants planes); materials: ctypes array of abi.MaterialDesc whose
+        texture pointers are device pointers; ssao: uint8 cuda [H,W] or None. Returns the 4 G-buffer planes."""
+        for i, t in enumerate(ip):
+            _check_img(t, FMT_RGBA32F, f"ip{i}")
+        h, w = ip[0].shape[0], ip[0].shape[1]
+        if out is None:
+            out = tuple(torch.empty((h, w, 4), dtype=torch.float32, device=self.device) for _ in range(4))
+        for i, t in enumerate(out):
+            _check_img(t, FMT_RGBA32F, f"gb{i}")
+        inter = abi.Interpolants(ip[0].data_ptr(), ip[1].data_ptr(), ip[2].data_ptr(), w, h, w)
+        gbuf = abi.GBuffer(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), w, h, w)
+        s = None
+        if ssao is not None:
+            if not (ssao.is_cuda and ssao.is_contiguous() and ssao.dtype == torch.uint8 and ssao.dim() == 2):
+                raise ValueError("ssao: expected contiguous cuda uint8 [H,W]")
+            s = abi.SSAO(ssao.data_ptr(), ssao.shape[1], ssao.shape[0])
+        n = len(materials) if materials is not None else 0
+        self._ck(self.lib.vqhip_gbuffer_from_materials(self._h, self._stream(stream), C.byref(inter), materials if n else None, n,
+                                                       float(ambient), C.byref(s) if s is not None else None, C.byref(gbuf)))
+        return out
 
     def conv_diffuse(self, chain, w0, h0, n_mips, res=64, step=0.010, order=CONV_WAVE64, fmt=FMT_RGBA16F, stream=None):
         dt, ch = _TORCH_DTYPE[fmt]

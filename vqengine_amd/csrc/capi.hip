@@ -262,6 +262,68 @@ int vqhip_mip_chain_min_rgba32f(vqhip_ctx* ctx, void* stream, void* mips, int w0
     return VQHIP_OK;
 }
 
+// ---- G-buffer producer --------------------------------------------------------------
+size_t vqhip_mip_chain_bytes_rgba8(int w0, int h0, int nMips) { return vqhip_mip_level_offset_bytes(w0, h0, nMips) / 4; }
+
+int vqhip_mip_chain_box_rgba8(vqhip_ctx* ctx, void* stream, void* mips, int w0, int h0, int nMips) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "mip_chain_box_rgba8: ctx is NULL");
+    if (!mips || w0 <= 0 || h0 <= 0 || nMips <= 0 || nMips > vqhip_mip_level_count(w0, h0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "mip_chain_box_rgba8: bad argument");
+    if ((w0 & (w0 - 1)) || (h0 & (h0 - 1))) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "mip_chain_box_rgba8: w0 and h0 must be powers of two");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int l = 1; l < nMips; ++l) {
+        const void* src = (const char*)mips + vqhip_mip_level_offset_bytes(w0, h0, l - 1) / 4;
+        void* dst = (char*)mips + vqhip_mip_level_offset_bytes(w0, h0, l) / 4;
+        hipError_t e = launch_mip_box_rgba8((hipStream_t)stream, src, dst, mipDim(w0, l - 1), mipDim(h0, l - 1), mipDim(w0, l), mipDim(h0, l));
+        if (e != hipSuccess) return failHip(ctx, e, "mip_box_rgba8 launch");
+    }
+    return VQHIP_OK;
+}
+
+int vqhip_max_materials(void) { return kMaxMaterials; }
+
+static bool badTexture(const vqhip_texture2d& t) {
+    return t.texels && (t.width <= 0 || t.height <= 0 || t.mips <= 0 || t.mips > vqhip_mip_level_count(t.width, t.height));
+}
+
+int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
+                                 float fAmbientLightingFactor, const vqhip_ssao* ssao, const vqhip_gbuffer* out) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: ctx is NULL");
+    if (!in || !out || !in->ip0 || !in->ip1 || !in->ip2 || !out->gb0 || !out->gb1 || !out->gb2 || !out->gb3)
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: NULL plane");
+    if (in->width <= 0 || in->height <= 0 || in->row_pitch_px < in->width || out->width != in->width || out->height != in->height || out->row_pitch_px < in->width)
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: bad dimensions / pitch");
+    if (numMaterials < 0 || numMaterials > kMaxMaterials || (numMaterials > 0 && !materials))
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: bad materials / numMaterials (see vqhip_max_materials)");
+    for (int i = 0; i < numMaterials; ++i) {
+        const vqhip_material& m = materials[i];
+        if (badTexture(m.texDiffuse) || badTexture(m.texNormals) || badTexture(m.texEmissive) || badTexture(m.texMetalness) ||
+            badTexture(m.texRoughness) || badTexture(m.texOcclRoughMetal) || badTexture(m.texLocalAO))
+            return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: material " + std::to_string(i) + " has a texture with bad dimensions / mip count");
+    }
+    if (ssao && ssao->texels && (ssao->width <= 0 || ssao->height <= 0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: bad ssao dimensions");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int slot;
+    int rc = acquireSlot(ctx, &slot);
+    if (rc) return rc;
+    GbufConstants* gc = (GbufConstants*)(ctx->hostRing + (size_t)slot * kConstSlotBytes);
+    std::memset(gc, 0, offsetof(GbufConstants, mats));
+    gc->ambient = fAmbientLightingFactor;
+    gc->numMaterials = numMaterials;
+    if (ssao && ssao->texels) gc->ssao = *ssao;
+    if (numMaterials > 0) std::memcpy(gc->mats, materials, (size_t)numMaterials * sizeof(vqhip_material));
+    rc = commitSlot(ctx, slot, offsetof(GbufConstants, mats) + (size_t)numMaterials * sizeof(vqhip_material), st);
+    if (rc) return rc;
+    GbufArgs a;
+    a.ip0 = (const float4*)in->ip0; a.ip1 = (const float4*)in->ip1; a.ip2 = (const float4*)in->ip2;
+    a.gb0 = (float4*)out->gb0; a.gb1 = (float4*)out->gb1; a.gb2 = (float4*)out->gb2; a.gb3 = (float4*)out->gb3;
+    a.gc = (const GbufConstants*)(ctx->devRing + (size_t)slot * kConstSlotBytes);
+    a.width = in->width; a.height = in->height; a.pitch = in->row_pitch_px; a.outPitch = out->row_pitch_px;
+    hipError_t e = launch_gbuffer_from_materials(st, a);
+    if (e != hipSuccess) return failHip(ctx, e, "gbuffer_from_materials launch");
+    return releaseSlot(ctx, slot, st);
+}
+
 int vqhip_specular_mip_count(int spec_res0) { return vqhip_mip_level_count(spec_res0, spec_res0) - 1; }
 size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt) {
     const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;

@@ -34,6 +34,25 @@ struct ShadeArgs {
     int width, height, pitch, outPitch;
 };
 
+// G-buffer producer (§8f.1): per-call constants in a ring slot — cbPerObject.materialData + descriptor tables of every
+// material referenced by the interpolant planes.
+struct alignas(16) GbufConstants {
+    float      ambient;          // cbPerFrame.fAmbientLightingFactor
+    int32_t    numMaterials;
+    vqhip_ssao ssao;             // device pointer or NULL
+    int32_t    pad[2];
+    vqhip_material mats[1];      // numMaterials entries
+};
+static constexpr int kMaxMaterials = (int)((kConstSlotBytes - offsetof(GbufConstants, mats)) / sizeof(vqhip_material));
+struct GbufArgs {
+    const float4* ip0; const float4* ip1; const float4* ip2;
+    float4* gb0; float4* gb1; float4* gb2; float4* gb3;
+    const GbufConstants* gc;     // device
+    int width, height, pitch, outPitch;
+};
+hipError_t launch_gbuffer_from_materials(hipStream_t s, const GbufArgs& a);
+hipError_t launch_mip_box_rgba8(hipStream_t s, const void* src, void* dst, int sw, int sh, int dw, int dh);
+
 // launchers (each returns the hipError_t of the launch)
 hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt);
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt);

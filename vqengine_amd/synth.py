@@ -173,3 +173,81 @@ def hdr_image(width, height, seed=0x70E, scale=4.0):
     img[hot, :3] *= 500.0
     img[..., 3] = r.random((height, width), dtype=np.float32)
     return img
+
+
+# ---- inputs of the G-buffer producer -------------------------------------------------------
+def interpolants(width, height, n_materials, seed=0x1A7E):
+    """PSInput planes (ForwardLighting.hlsl:42-53) of a synthetic view: a ground plane receding towards the top of the
+    image (so the uv footprint — hence the mip level — grows with the row), material indices in 97x61-pixel blocks
+    (odd sizes: pixel quads straddle material borders), a sky band of no-geometry pixels and a few stray / invalid indices.
+    Returns 3 float32 arrays [H,W,4]: (P, u), (N, v), (T, asfloat(int32 index))."""
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0x1F]))
+    ys, xs = np.meshgrid(np.arange(height, dtype=np.float32), np.arange(width, dtype=np.float32), indexing="ij")
+    t = (ys + 0.5) / height
+    s = (xs + 0.5) / width
+    z = (4.0 + 120.0 * (1.0 - t) ** 3).astype(np.float32)
+    px = ((s - 0.5) * z * 1.4).astype(np.float32)
+    py = (0.25 * np.sin(px * 0.7) * np.cos(z * 0.3)).astype(np.float32)
+    ip0 = np.empty((height, width, 4), np.float32)
+    ip1 = np.empty_like(ip0)
+    ip2 = np.empty_like(ip0)
+    ip0[..., 0], ip0[..., 1], ip0[..., 2] = px, py, z
+    ip0[..., 3] = px * 0.37 + 0.11                      # uv.x
+    ip1[..., 3] = z * 0.37 - 0.05                       # uv.y
+    # interpolated (unnormalised) normal / tangent, deliberately not orthogonal
+    ip1[..., 0] = 0.35 * np.sin(px * 1.3) + 0.02 * (r.random((height, width), dtype=np.float32) - 0.5)
+    ip1[..., 1] = 1.3
+    ip1[..., 2] = 0.35 * np.cos(z * 0.9) + 0.02 * (r.random((height, width), dtype=np.float32) - 0.5)
+    ip2[..., 0] = 0.9
+    ip2[..., 1] = 0.15 * np.sin(z * 0.5)
+    ip2[..., 2] = 0.2 * np.cos(px * 0.4)
+    bx, by = (xs.astype(np.int64) // 97), (ys.astype(np.int64) // 61)
+    idx = ((bx * 5 + by * 3) % max(n_materials, 1)).astype(np.int32)
+    idx[ys < height * 0.08] = -1                        # sky
+    stray = r.random((height, width)) > 0.9995
+    idx[stray] = np.where(r.random(int(stray.sum())) > 0.5, -7, n_materials + 3).astype(np.int32)
+    ip2[..., 3] = idx.view(np.float32)
+    return ip0, ip1, ip2
+
+
+def material_set(n, seed=0x3A7, max_dim=256):
+    """n materials: (list of abi.MaterialData, list of {slot: uint8 [H,W,4] level 0}) with power-of-two texture sizes
+    (non-square allowed), random scalar parameters and uv tiling. textureConfig normally mirrors the bound maps
+    (Material::GetTextureConfig, Material.cpp:23-36); materials 3k+1 carry a deliberately inconsistent config (bit set
+    without a map / map without its bit) to exercise the null-SRV and ignored-map branches."""
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0x77]))
+    bits = {"texDiffuse": 0, "texNormals": 1, "texLocalAO": 2, "texRoughness": 4, "texMetalness": 5, "texEmissive": 7, "texOcclRoughMetal": 8}
+    datas, texsets = [], []
+    for i in range(n):
+        d = abi.MaterialData()
+        d.diffuse.set(tuple(r.uniform(0.2, 1.0, 3))); d.alpha = 1.0
+        d.emissiveColor.set(tuple(r.uniform(0.0, 1.0, 3))); d.emissiveIntensity = float(r.uniform(0, 3)) if i % 3 == 0 else 0.0
+        d.specular.set((1.0, 1.0, 1.0)); d.normalMapMipBias = float(r.choice([0.0, -0.5, 0.75, 1.0]))
+        d.uvScaleOffset = abi.float4(float(r.uniform(0.3, 6.0)), float(r.uniform(0.3, 6.0)), float(r.uniform(-1, 1)), float(r.uniform(-1, 1)))
+        d.roughness, d.metalness, d.displacement = float(r.uniform(0.05, 1.0)), float(r.uniform(0, 1)), 0.0
+        texs, cfg = {}, 0
+        for slot in abi.MATERIAL_TEXTURE_SLOTS:
+            if i == 0 or r.random() < 0.6:              # material 0 binds every map
+                w = int(2 ** r.integers(3, int(np.log2(max_dim)) + 1)); h = int(2 ** r.integers(3, int(np.log2(max_dim)) + 1))
+                yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+                img = np.empty((h, w, 4), np.float32)
+                for c in range(4):
+                    fx, fy, ph = r.integers(1, 5), r.integers(1, 5), r.uniform(0, 6.28)
+                    img[..., c] = 0.5 + 0.35 * np.sin(2 * np.pi * (fx * xx / w + fy * yy / h) + ph) + 0.15 * (r.random((h, w)) - 0.5)
+                if slot == "texNormals":                # mostly +Z tangent-space normals
+                    img[..., 2] = 0.75 + 0.25 * img[..., 2]
+                    if i % 4 == 2:
+                        img[: h // 2] = 0.0            # a region of all-zero normals: the length(Normal) < 0.01 branch
+                texs[slot] = np.clip(np.rint(img * 255.0), 0, 255).astype(np.uint8)
+                cfg |= 1 << bits[slot]
+        if i % 3 == 1:
+            cfg ^= (1 << 0) | (1 << 4) | (1 << 8)
+        d.textureConfig = float(cfg)
+        datas.append(d)
+        texsets.append(texs)
+    return datas, texsets
+
+
+def ssao_image(width, height, seed=0x55A0):
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0x0A]))
+    return r.integers(96, 256, (height, width), dtype=np.uint8)
