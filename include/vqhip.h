@@ -406,6 +406,27 @@ VQHIP_API int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream,
 VQHIP_API size_t vqhip_mip_chain_bytes_rgba8(int w0, int h0, int nMips);
 VQHIP_API int    vqhip_mip_chain_box_rgba8(vqhip_ctx* ctx, void* stream, void* mips, int w0, int h0, int nMips);
 
+/* ---- skydome ----------------------------------------------------------------------
+ * Replaces the "Draw Environment Map" draw of VQRenderer::RenderSceneColor (SceneRendering.cpp:1822-1850) ==
+ * Skydome.hlsl:VSMain/PSMain (:39-56): every pixel no geometry covers gets
+ * float4(texEquirectEnvironmentMap.SampleLevel(TRILINEAR_WRAP, DirectionToEquirectUV(normalize(dir)), 0).rgb, 1).
+ * The cube mesh is centred on the sky camera (position 0, yaw = camera yaw + HDRIYawOffset, pitch = camera pitch,
+ * projection of the main camera: Scene.cpp:573-584) and CubemapLookDirection = normalize(position) is linear on
+ * every cube face, so its perspective-correct interpolant at a pixel is parallel to the pixel's view ray:
+ *   dir = forward + (ndc.x * tanHalfFovX) * right + (ndc.y * tanHalfFovY) * up,
+ *   ndc = (2(x+.5)/W - 1, 1 - 2(y+.5)/H)          (VQ_SkydomeParams holds the sky camera's world-space basis).
+ *   equirect_level0 : RGBA32F w0 x h0 (level 0 of the HDRI chain; SRV_HDREnvironment, EnvironmentMap.cpp:142-209)
+ *   coverage        : NULL => every pixel is sky; else only pixels whose ip2.w material index is < 0 are written
+ *   color           : scene colour target (RGBA16F reference format, or RGBA32F), written in place. */
+typedef struct VQ_SkydomeParams {
+    VQ_float3 right;   float tanHalfFovX;
+    VQ_float3 up;      float tanHalfFovY;
+    VQ_float3 forward; float pad;
+} VQ_SkydomeParams;
+VQHIP_API int vqhip_skydome(vqhip_ctx* ctx, void* stream, const void* equirect_level0, int w0, int h0,
+        const VQ_SkydomeParams* params, const vqhip_interpolants* coverage,
+        void* color, int width, int height, int row_pitch_px, vqhip_format fmt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,12 @@ public:
     struct FDrawParameters : public IRenderPassDrawParameters {
         void* Stream = nullptr;                                  // replaces ID3D12GraphicsCommandList* pCmd
         vqhip_gbuffer GBuffer = {};                              // replaces the rasterised PSInput + material textures
+        // Alternative input: rasteriser output + materials; when pInterpolants != nullptr the pass first runs
+        // vqhip_gbuffer_from_materials (PSMain :226-287) into its own G-buffer planes and GBuffer above is ignored.
+        const vqhip_interpolants* pInterpolants = nullptr;
+        const vqhip_material* pMaterials = nullptr;              // cbPerObject.materialData + SRV tables of every material on screen
+        int NumMaterials = 0;
+        const vqhip_ssao* pScreenSpaceAO = nullptr;              // Tex_AmbientOcclusion or nullptr (SSAO off)
         const VQ_PerFrameData* pPerFrame = nullptr;              // == cbPerFrame  (SceneRendering.cpp:429-450)
         const VQ_PerViewLightingData* pPerView = nullptr;        // == cbPerView   (:452-467)
         const VQ_PointLight* pExtraPointLights = nullptr;        // extension: lights beyond NUM_LIGHTS__POINT
@@ -71,11 +77,24 @@ public:
         mWidth = Width; mHeight = Height;
         mSceneColor = Alloc((size_t)Width * Height * 8);
     }
-    void OnDestroyWindowSizeDependentResources() override { Free(mSceneColor); mWidth = mHeight = 0; }
+    void OnDestroyWindowSizeDependentResources() override {
+        Free(mSceneColor);
+        for (void*& g : mGB) Free(g);
+        mWidth = mHeight = 0;
+    }
     void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) override {
         const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
         if (!p || !mSceneColor) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
-        mStatus = vqhip_forward_lighting(mCtx, p->Stream, &p->GBuffer, p->pPerFrame, p->pPerView, p->pExtraPointLights, p->NumExtraPointLights,
+        vqhip_gbuffer gb = p->GBuffer;
+        if (p->pInterpolants) {
+            if (!p->pPerFrame) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
+            for (void*& g : mGB) if (!g) g = Alloc((size_t)mWidth * mHeight * 16);     // planes allocated on first use
+            gb = { mGB[0], mGB[1], mGB[2], mGB[3], (int32_t)mWidth, (int32_t)mHeight, (int32_t)mWidth };
+            mStatus = vqhip_gbuffer_from_materials(mCtx, p->Stream, p->pInterpolants, p->pMaterials, p->NumMaterials,
+                                                   p->pPerFrame->fAmbientLightingFactor, p->pScreenSpaceAO, &gb);
+            if (mStatus != VQHIP_OK) return;
+        }
+        mStatus = vqhip_forward_lighting(mCtx, p->Stream, &gb, p->pPerFrame, p->pPerView, p->pExtraPointLights, p->NumExtraPointLights,
                                          p->pEnvironmentMap, p->pShadowMaps, mSceneColor, (int)mWidth, VQHIP_FMT_RGBA16F);
     }
     void* GetSceneColor() const { return mSceneColor; }          // RGBA16F, width*height
@@ -83,6 +102,7 @@ public:
     unsigned Height() const { return mHeight; }
 private:
     void* mSceneColor = nullptr;
+    void* mGB[4] = { nullptr, nullptr, nullptr, nullptr };       // G-buffer planes of the §8f.1 producer path
     unsigned mWidth = 0, mHeight = 0;
 };
 
@@ -117,13 +137,15 @@ public:
         if (!p || !p->pSceneColor || !mTonemapperOut) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
         mOutFormat = p->bHDR ? VQHIP_FMT_RGBA16F : VQHIP_FMT_RGBA8_UNORM;
         if (p->bEnableGaussianBlur) {
-            // CSMain_X -> BlurIntermediate, then CSMain_Y + Tonemapper fused (identical bits to the separate dispatches
-            // through BlurOutput, one image round trip less; vqhip.h:vqhip_gaussian_blur_y_tonemap)
+            // CSMain_X -> BlurIntermediate, CSMain_Y -> BlurOutput, Tonemapper -> TonemapperOut, like SceneRendering.cpp:2582-2656.
+            // (vqhip_gaussian_blur_y_tonemap fuses the last two with identical bits but measured slower on MI355X at 4K:
+            // 95 us vs 31 + 23 us, profiles/r1d_stages.jsonl — so the three dispatches are kept.)
             const VQ_BlurParams bp = { (int32_t)mWidth, (int32_t)mHeight };                                      // FBlurParams, PostProcess.h:92-96
             mStatus = vqhip_gaussian_blur_x(mCtx, p->Stream, p->pSceneColor, mBlurIntermediate, &bp, VQHIP_FMT_RGBA16F);
             if (mStatus != VQHIP_OK) return;
-            mStatus = vqhip_gaussian_blur_y_tonemap(mCtx, p->Stream, mBlurIntermediate, mTonemapperOut, nullptr, nullptr, 0, &bp, &p->TonemapperParams,
-                                                    VQHIP_FMT_RGBA16F, mOutFormat);
+            mStatus = vqhip_gaussian_blur_y(mCtx, p->Stream, mBlurIntermediate, mBlurOutput, nullptr, nullptr, 0, &bp, VQHIP_FMT_RGBA16F);
+            if (mStatus != VQHIP_OK) return;
+            mStatus = vqhip_tonemap(mCtx, p->Stream, mBlurOutput, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
             return;
         }
         mStatus = vqhip_tonemap(mCtx, p->Stream, p->pSceneColor, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);

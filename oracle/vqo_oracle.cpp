@@ -768,4 +768,30 @@ int vqo_envmap_prefilter(const float* chain, int w0, int h0, int nMips, int diff
     return vqo_conv_specular(chain, w0, h0, nMips, specRes0, order, specular, VQHIP_FMT_RGBA16F, nthreads);
 }
 
+// Skydome.hlsl:VSMain/PSMain :39-56 as drawn at SceneRendering.cpp:1822-1850. CubemapLookDirection =
+// normalize(position) is linear on each face of the camera-centred cube, so its interpolant is parallel to the pixel's view ray:
+// dir = forward + (ndc.x*tanHalfFovX)*right + (ndc.y*tanHalfFovY)*up (one mad per term), then PSMain:
+// uv = DirectionToEquirectUV(normalize(dir)); SampleLevel(TRILINEAR_WRAP, uv, 0) == bilinear WRAP of level 0; alpha 1.
+// coverage_ip2 (nullable): plane ip2 of vqhip_interpolants — only pixels with material index < 0 are written.
+int vqo_skydome(const float* equirect0, int w0, int h0, const VQ_SkydomeParams* sp, const float* coverage_ip2, int cov_pitch,
+                void* color, int W, int H, int pitch, int fmt, int nthreads) {
+    if (!equirect0 || !sp || !color) return -1;
+    if (fmt != VQHIP_FMT_RGBA32F && fmt != VQHIP_FMT_RGBA16F) return -3;
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (coverage_ip2) { int32_t idx; std::memcpy(&idx, coverage_ip2 + ((size_t)y * cov_pitch + x) * 4 + 3, 4); if (idx >= 0) continue; }
+            const float nx = div_(2.0f * ((float)x + 0.5f), (float)W) - 1.0f, ny = 1.0f - div_(2.0f * ((float)y + 0.5f), (float)H);
+            const float a = nx * sp->tanHalfFovX, b = ny * sp->tanHalfFovY;
+            const f3 d = { fma_(b, sp->up.x, fma_(a, sp->right.x, sp->forward.x)),
+                           fma_(b, sp->up.y, fma_(a, sp->right.y, sp->forward.y)),
+                           fma_(b, sp->up.z, fma_(a, sp->right.z, sp->forward.z)) };
+            const f2 uv = DirectionToEquirectUV(normalize(d));
+            const f4 c = sample_2d_rgba32f_wrap(equirect0, w0, h0, uv.x, uv.y);
+            store_px(color, (size_t)y * pitch + x, fmt, { c.x, c.y, c.z, 1.0f });
+        }
+    return 0;
+}
+
 } // extern "C"

@@ -70,6 +70,21 @@ int main(int argc, char** argv) {
     writeDev(dir + "/scene_rgba16f.bin", lighting.GetSceneColor(), (size_t)W * H * 8);
     writeDev(dir + "/sdr_rgba8.bin", post.GetOutput(), (size_t)W * H * 4);
     writeDev(dir + "/diffuse_blurred.bin", env.diffuse_cube, (size_t)6 * 8 * 8 * 8);
+    // --- §8f.1 path: rasteriser planes + a material table (texture pointers in materials.bin are NULL: texture-less
+    // materials) -> producer -> lighting inside the same pass
+    if (FILE* probe = fopen((dir + "/ip0.bin").c_str(), "rb")) {
+        fclose(probe);
+        std::vector<char> mats = readFile(dir + "/materials.bin");
+        if (mats.size() % sizeof(vqhip_material) != 0) { fprintf(stderr, "materials.bin size\n"); return 2; }
+        vqhip_interpolants ip = { upload(readFile(dir + "/ip0.bin")), upload(readFile(dir + "/ip1.bin")), upload(readFile(dir + "/ip2.bin")), W, H, W };
+        ld.pInterpolants = &ip;
+        ld.pMaterials = (const vqhip_material*)mats.data();
+        ld.NumMaterials = (int)(mats.size() / sizeof(vqhip_material));
+        lighting.RecordCommands(&ld);
+        CHECK(lighting);
+        if (hipStreamSynchronize(stream) != hipSuccess) return 3;
+        writeDev(dir + "/scene_ip_rgba16f.bin", lighting.GetSceneColor(), (size_t)W * H * 8);
+    }
     // error behaviour: RecordCommands without parameters reports, never crashes
     lighting.RecordCommands(nullptr);
     if (lighting.LastStatus() != VQHIP_ERR_INVALID_ARG) return 5;

@@ -62,8 +62,29 @@ def post_small():
             "pq_rgba16f": O.tonemap(bl, abi.FMT_RGBA16F, abi.FMT_RGBA16F, abi.TonemapperParams(0, abi.DISPLAY_CURVE_ST2084, 200.0, 1))}
 
 
+def gbuffer_inputs():
+    """Interpolant planes 96x48, 4 materials with <= 64^2 maps, SSAO. Returns (ip, datas, level-0 texture sets, ssao)."""
+    W, H, NM = 96, 48, 4
+    datas, texsets = synth.material_set(NM, seed=0x601D, max_dim=64)
+    return synth.interpolants(W, H, NM, seed=0x601D), datas, texsets, synth.ssao_image(W, H, seed=0x601D)
+
+
+def gbuffer_small():
+    ip, datas, texsets, ssao = gbuffer_inputs()
+    chains = []
+    for ts in texsets:
+        cs = {}
+        for slot, img in ts.items():
+            chain, nm = O.mip_chain_rgba8(img)
+            cs[slot] = (chain, img.shape[1], img.shape[0], nm)
+        chains.append(cs)
+    gb = O.gbuffer_from_materials(ip, O.host_materials(datas, chains), 0.055, ssao)
+    first = next(iter(chains[0].values()))
+    return {"gb0": gb[0], "gb1": gb[1], "gb2": gb[2], "gb3": gb[3], "mat0_first_chain_tail": first[0][first[1] * first[2]:]}
+
+
 if __name__ == "__main__":
-    for fn in (ibl_small, shade_small, post_small):
+    for fn in (ibl_small, shade_small, post_small, gbuffer_small):
         out = fn()
         path = os.path.join(HERE, fn.__name__ + ".npz")
         np.savez_compressed(path, **out)

@@ -56,6 +56,7 @@ def load():
     lib.vqo_mip_chain_box_rgba8.argtypes = [vp, i32, i32, i32]
     lib.vqo_mip_chain_texels.restype = sz
     lib.vqo_mip_chain_texels.argtypes = [i32, i32, i32]
+    lib.vqo_skydome.argtypes = [vp, i32, i32, C.POINTER(abi.SkydomeParams), vp, i32, vp, i32, i32, i32, i32, i32]
     lib.vqo_unorm8_to_float.restype = f32
     lib.vqo_unorm8_to_float.argtypes = [i32]
     if not lib.vqo_has_fma():
@@ -226,6 +227,18 @@ def gbuffer_from_materials(ip, materials, ambient, ssao=None, nthreads=0):
                                         C.byref(s) if s is not None else None, C.byref(gb), nthreads)
     assert rc == 0, rc
     return out
+
+
+def skydome(equirect0, params, color, fmt, coverage_ip2=None, nthreads=0):
+    """Writes sky pixels into `color` (numpy image of `fmt`, modified in place and returned)."""
+    lib = load()
+    eq = np.ascontiguousarray(equirect0, np.float32)
+    h, w = color.shape[:2]
+    cov = np.ascontiguousarray(coverage_ip2, np.float32) if coverage_ip2 is not None else None
+    rc = lib.vqo_skydome(_p(eq), eq.shape[1], eq.shape[0], C.byref(params), _p(cov) if cov is not None else None, w,
+                         _p(color), w, h, w, fmt, nthreads)
+    assert rc == 0, rc
+    return color
 
 
 def bits_equal(a, b):

@@ -76,6 +76,64 @@ def test_gbuffer_producer_feeds_forward_lighting(ctx):
     assert n == 0, (n, idx)
 
 
+def test_hip_path_reproduces_gbuffer_golden_fixture(ctx):
+    """tests/golden/gbuffer_small.npz (committed, made by tests/golden/make_golden.py) without touching the oracle."""
+    import os
+    from tests.golden import make_golden as G
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(G.__file__)), "gbuffer_small.npz"))
+    ip, datas, texsets, ssao = G.gbuffer_inputs()
+    dmats = (abi.MaterialDesc * len(datas))()
+    keep = []
+    for i, (d, ts) in enumerate(zip(datas, texsets)):
+        dmats[i].data = d
+        for slot, img in ts.items():
+            chain, nm = ctx.mip_chain_rgba8(dev(img))
+            keep.append(chain)
+            setattr(dmats[i], slot, abi.Texture2D(chain.data_ptr(), img.shape[1], img.shape[0], nm, 0))
+    first = next(iter(texsets[0].values()))
+    assert np.array_equal(keep[0].cpu().numpy()[first.shape[0] * first.shape[1]:], fx["mat0_first_chain_tail"])
+    got = ctx.gbuffer_from_materials([dev(p) for p in ip], dmats, 0.055, dev(ssao))
+    for k in range(4):
+        n, idx = O.bits_equal(got[k].cpu().numpy(), fx[f"gb{k}"])
+        assert n == 0, (k, n, idx)
+
+
+@pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+@pytest.mark.parametrize("shape", [(640, 360), (333, 61), (1, 1)])
+def test_skydome_matches_oracle(ctx, fmt, shape):
+    """vqhip_skydome against the oracle: full-screen sky and sky composited over a lit frame."""
+    import math
+    from vqengine_amd import scene
+    W, H = shape
+    eq = synth.equirect(256, 128)
+    sp = scene.skydome_params(0.9, -0.35, 0.5, 65.0 * math.pi / 180.0, W, H)
+    dt = np.float32 if fmt == abi.FMT_RGBA32F else np.float16
+    ref = O.skydome(eq, sp, np.zeros((H, W, 4), dt), fmt, None)
+    got = ctx.skydome(dev(eq), sp, torch.zeros((H, W, 4), dtype=torch.float32 if fmt == abi.FMT_RGBA32F else torch.float16, device="cuda"), fmt)
+    n, idx = O.bits_equal(got.cpu().numpy(), ref)
+    assert n == 0, (n, idx)
+    ip = synth.interpolants(W, H, 3)
+    base = synth.hdr_image(W, H).astype(dt)
+    ref = O.skydome(eq, sp, base.copy(), fmt, ip[2])
+    got = ctx.skydome(dev(eq), sp, dev(base), fmt, coverage_ip=[dev(p) for p in ip])
+    n, idx = O.bits_equal(got.cpu().numpy(), ref)
+    assert n == 0, (n, idx)
+
+
+def test_skydome_abi_errors(ctx):
+    lib = ctx.lib
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    eq = torch.zeros((8, 16, 4), dtype=torch.float32, device="cuda")
+    col = torch.zeros((4, 8, 4), dtype=torch.float16, device="cuda")
+    sp = abi.SkydomeParams()
+    p = C.c_void_p
+    assert lib.vqhip_skydome(ctx._h, st, p(eq.data_ptr()), 16, 8, C.byref(sp), None, p(col.data_ptr()), 8, 4, 8, abi.FMT_RGBA16F) == 0
+    assert lib.vqhip_skydome(ctx._h, st, None, 16, 8, C.byref(sp), None, p(col.data_ptr()), 8, 4, 8, abi.FMT_RGBA16F) == abi.VQHIP_ERR_INVALID_ARG
+    assert lib.vqhip_skydome(ctx._h, st, p(eq.data_ptr()), 16, 8, C.byref(sp), None, p(col.data_ptr()), 8, 4, 8, abi.FMT_RGBA8_UNORM) == abi.VQHIP_ERR_UNSUPPORTED
+    cov = abi.Interpolants(eq.data_ptr(), eq.data_ptr(), eq.data_ptr(), 9, 4, 9)
+    assert lib.vqhip_skydome(ctx._h, st, p(eq.data_ptr()), 16, 8, C.byref(sp), C.byref(cov), p(col.data_ptr()), 8, 4, 8, abi.FMT_RGBA16F) == abi.VQHIP_ERR_INVALID_ARG
+
+
 def test_gbuffer_producer_abi_errors(ctx):
     lib = ctx.lib
     W, H = 8, 4

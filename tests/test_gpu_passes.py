@@ -28,6 +28,16 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
     eq.tofile(tmp_path / "equirect.bin")
     (tmp_path / "perframe.bin").write_bytes(bytes(pf))
     (tmp_path / "perview.bin").write_bytes(bytes(pv))
+    # §8f.1 inputs: interpolant planes + 3 texture-less materials (descriptor pointers NULL, so the table is position independent)
+    ip = synth.interpolants(W, H, 3, seed=0xCAFE)
+    for k in range(3):
+        ip[k].tofile(tmp_path / f"ip{k}.bin")
+    datas, _ = synth.material_set(3, seed=0xCAFE, max_dim=16)
+    mats = (abi.MaterialDesc * 3)()
+    for i, d in enumerate(datas):
+        mats[i].data = d
+        mats[i].data.textureConfig = 0.0
+    (tmp_path / "materials.bin").write_bytes(bytes(mats))
     r = subprocess.run([EXE, str(tmp_path), str(W), str(H), str(EW), str(EH)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     diff = np.fromfile(tmp_path / "diffuse_blurred.bin", np.float16).reshape(6, 8, 8, 4)
@@ -39,6 +49,11 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
     scene = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F, env=env)
     got = np.fromfile(tmp_path / "scene_rgba16f.bin", np.float16).reshape(H, W, 4)
     n_bad, idx = O.bits_equal(got, scene)
+    assert n_bad == 0, (n_bad, idx)
+    gb_ip = O.gbuffer_from_materials(ip, mats, pf.fAmbientLightingFactor, None)
+    scene_ip = O.forward_lighting(gb_ip, pf, pv, abi.FMT_RGBA16F, env=env)
+    got = np.fromfile(tmp_path / "scene_ip_rgba16f.bin", np.float16).reshape(H, W, 4)
+    n_bad, idx = O.bits_equal(got, scene_ip)
     assert n_bad == 0, (n_bad, idx)
     sdr = O.tonemap(O.gaussian_blur(scene, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
     got = np.fromfile(tmp_path / "sdr_rgba8.bin", np.uint8).reshape(H, W, 4)

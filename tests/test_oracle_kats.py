@@ -274,7 +274,7 @@ def test_conv_orders_agree_within_storage_precision():
 
 
 # --------------------------------------------------------------------------------------------------- golden fixtures
-@pytest.mark.parametrize("name", ["shade_small", "post_small", "ibl_small"])
+@pytest.mark.parametrize("name", ["shade_small", "post_small", "ibl_small", "gbuffer_small"])
 def test_oracle_reproduces_golden_fixtures(name):
     """tests/golden/*.npz were produced by tests/golden/make_golden.py (committed); the oracle must reproduce them bit-exactly."""
     from tests.golden import make_golden

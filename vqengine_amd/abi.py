@@ -136,6 +136,11 @@ class SSAO(C.Structure):  # vqhip_ssao
     _fields_ = [("texels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
 
 
+class SkydomeParams(C.Structure):  # VQ_SkydomeParams
+    _fields_ = [("right", float3), ("tanHalfFovX", C.c_float), ("up", float3), ("tanHalfFovY", C.c_float),
+                ("forward", float3), ("pad", C.c_float)]
+
+
 def _chk(t, size, **offs):
     assert C.sizeof(t) == size, (t.__name__, C.sizeof(t), size)
     for k, v in offs.items():

@@ -61,6 +61,7 @@ def load_library():
                                                C.POINTER(abi.SSAO), C.POINTER(abi.GBuffer)]),
         "vqhip_mip_chain_bytes_rgba8": (sz, [i32, i32, i32]),
         "vqhip_mip_chain_box_rgba8": (i32, [vp, vp, vp, i32, i32, i32]),
+        "vqhip_skydome": (i32, [vp, vp, vp, i32, i32, C.POINTER(abi.SkydomeParams), C.POINTER(abi.Interpolants), vp, i32, i32, i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -77,6 +78,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
+    "vqhip_skydome",
 ]
 
 _TORCH_DTYPE = {FMT_RGBA32F: (torch.float32, 4), FMT_RGBA16F: (torch.float16, 4), FMT_RGBA8_UNORM: (torch.uint8, 4),
@@ -254,6 +256,22 @@ class Context:
         self._ck(self.lib.vqhip_gbuffer_from_materials(self._h, self._stream(stream), C.byref(inter), materials if n else None, n,
                                                        float(ambient), C.byref(s) if s is not None else None, C.byref(gbuf)))
         return out
+
+    # ---- skydome (Skydome.hlsl:39-56, SceneRendering.cpp:1822-1850) -------------------------
+    def skydome(self, equirect_level0, params, color, fmt, coverage_ip=None, stream=None):
+        """equirect_level0: float32 cuda [h0,w0,4]; params: abi.SkydomeParams; color: scene-colour tensor [H,W,4] written in place
+        where coverage_ip (the 3 interpolant planes, or None = everywhere) has material index < 0."""
+        _check_img(equirect_level0, FMT_RGBA32F, "equirect_level0")
+        _check_img(color, fmt, "color")
+        h, w = color.shape[0], color.shape[1]
+        cov = None
+        if coverage_ip is not None:
+            for i, t in enumerate(coverage_ip):
+                _check_img(t, FMT_RGBA32F, f"ip{i}")
+            cov = abi.Interpolants(coverage_ip[0].data_ptr(), coverage_ip[1].data_ptr(), coverage_ip[2].data_ptr(), w, h, w)
+        self._ck(self.lib.vqhip_skydome(self._h, self._stream(stream), _ptr(equirect_level0), equirect_level0.shape[1], equirect_level0.shape[0],
+                                        C.byref(params), C.byref(cov) if cov is not None else None, _ptr(color), w, h, w, fmt))
+        return color
 
     def conv_diffuse(self, chain, w0, h0, n_mips, res=64, step=0.010, order=CONV_WAVE64, fmt=FMT_RGBA16F, stream=None):
         dt, ch = _TORCH_DTYPE[fmt]

@@ -324,6 +324,22 @@ int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_inter
     return releaseSlot(ctx, slot, st);
 }
 
+// ---- skydome ------------------------------------------------------------------------
+int vqhip_skydome(vqhip_ctx* ctx, void* stream, const void* equirect_level0, int w0, int h0, const VQ_SkydomeParams* params,
+                  const vqhip_interpolants* coverage, void* color, int width, int height, int row_pitch_px, vqhip_format fmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "skydome: ctx is NULL");
+    if (!equirect_level0 || !params || !color || w0 <= 0 || h0 <= 0 || width <= 0 || height <= 0 || row_pitch_px < width)
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "skydome: bad argument");
+    if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "skydome: fmt must be RGBA32F or RGBA16F");
+    if (coverage && (!coverage->ip2 || coverage->width != width || coverage->height != height || coverage->row_pitch_px < width))
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "skydome: coverage planes do not match the colour target");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_skydome((hipStream_t)stream, (const float4*)equirect_level0, w0, h0, *params,
+                                  coverage ? (const float4*)coverage->ip2 : nullptr, coverage ? coverage->row_pitch_px : 0,
+                                  color, width, height, row_pitch_px, fmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "skydome launch");
+}
+
 int vqhip_specular_mip_count(int spec_res0) { return vqhip_mip_level_count(spec_res0, spec_res0) - 1; }
 size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt) {
     const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;

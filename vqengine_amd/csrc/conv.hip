@@ -200,6 +200,32 @@ __global__ __launch_bounds__(256) void k_conv_specular(const float4* __restrict_
 
 namespace vqk {
 
+// ---- Skydome.hlsl:39-56: sky colour for the pixels no geometry covers ---------------------------
+// One lane per pixel; HBM-bound in the worst case (all-sky frame: 8 B/pixel written, equirect taps cache-resident).
+template <int FMT>
+__global__ __launch_bounds__(256) void k_skydome(const float4* __restrict__ eq0, int w0, int h0, VQ_SkydomeParams sp,
+                                                 const float4* __restrict__ cov, int covPitch, void* __restrict__ color, int W, int H, int pitch) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    if (cov && __float_as_int(cov[(size_t)y * covPitch + x].w) >= 0) return;
+    const float nx = div_(2.0f * ((float)x + 0.5f), (float)W) - 1.0f, ny = 1.0f - div_(2.0f * ((float)y + 0.5f), (float)H);
+    const float a = nx * sp.tanHalfFovX, b = ny * sp.tanHalfFovY;
+    const f3 d = mk3(fma_(b, sp.up.x, fma_(a, sp.right.x, sp.forward.x)),
+                     fma_(b, sp.up.y, fma_(a, sp.right.y, sp.forward.y)),
+                     fma_(b, sp.up.z, fma_(a, sp.right.z, sp.forward.z)));
+    const float2 uv = DirectionToEquirectUV(normalize(d));
+    const float4 c = sample_2d_rgba32f_wrap(eq0, w0, h0, uv.x, uv.y);
+    store_px<FMT>(color, (size_t)y * pitch + x, make_float4(c.x, c.y, c.z, 1.0f));
+}
+
+hipError_t launch_skydome(hipStream_t s, const float4* eq0, int w0, int h0, const VQ_SkydomeParams& sp, const float4* cov, int covPitch,
+                          void* color, int W, int H, int pitch, int fmt) {
+    dim3 grid((W + 255) / 256, H);
+    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_skydome<0>), grid, dim3(256), 0, s, eq0, w0, h0, sp, cov, covPitch, color, W, H, pitch);
+    else                          hipLaunchKernelGGL((k_skydome<1>), grid, dim3(256), 0, s, eq0, w0, h0, sp, cov, covPitch, color, W, H, pitch);
+    return hipGetLastError();
+}
+
 hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt) {
     dim3 grid((size + 255) / 256, size);
     if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut<3>), grid, dim3(256), 0, s, out, size, samples);

@@ -202,3 +202,23 @@ def gbuffer_from_material(material_data, world_pos, world_normal, ambient_factor
     g[3][..., :3] = np.array([material_data.emissiveColor.x, material_data.emissiveColor.y, material_data.emissiveColor.z], np.float32)
     g[3][..., 3] = np.float32(material_data.emissiveIntensity)
     return g
+
+
+def skydome_params(camera_yaw, camera_pitch, hdri_yaw_offset, fov_y, viewport_width, viewport_height):
+    """abi.SkydomeParams of the sky camera built at Scene.cpp:573-584: position 0, yaw = MainViewCameraYaw + HDRIYawOffset,
+    pitch = MainViewCameraPitch, the main camera's perspective projection (vertical FoV `fov_y` in radians,
+    Camera::SetProjectionMatrix, Camera.cpp:84-91). Basis as Camera::UpdateViewMatrix (Camera.cpp:94-110): lookAt (0,0,1) and
+    up (0,1,0) rotated by XMMatrixRotationRollPitchYaw(pitch, yaw, 0), then XMMatrixLookAtLH: z = forward,
+    x = normalize(cross(up, z)), y = cross(z, x). Angles in radians; computed in float64 and rounded to float32."""
+    yaw, p = float(camera_yaw) + float(hdri_yaw_offset), float(camera_pitch)
+    sy, cy, sp, cp = math.sin(yaw), math.cos(yaw), math.sin(p), math.cos(p)
+    fwd = np.array([cp * sy, -sp, cp * cy])                 # (0,0,1) * Rx(pitch) * Ry(yaw), row-vector convention
+    up0 = np.array([sp * sy, cp, sp * cy])                  # (0,1,0) * Rx(pitch) * Ry(yaw)
+    right = np.cross(up0, fwd); right /= np.linalg.norm(right)
+    up = np.cross(fwd, right)
+    t = math.tan(0.5 * float(fov_y))
+    sp_ = abi.SkydomeParams()
+    sp_.right.set(tuple(right)); sp_.up.set(tuple(up)); sp_.forward.set(tuple(fwd))
+    sp_.tanHalfFovY = t
+    sp_.tanHalfFovX = t * float(viewport_width) / float(viewport_height)
+    return sp_
