@@ -292,6 +292,9 @@ int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_inter
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: NULL plane");
     if (in->width <= 0 || in->height <= 0 || in->row_pitch_px < in->width || out->width != in->width || out->height != in->height || out->row_pitch_px < in->width)
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: bad dimensions / pitch");
+    if ((uint64_t)in->row_pitch_px * in->height * 16u >= (1ull << 32) || (uint64_t)out->row_pitch_px * out->height * 16u >= (1ull << 32) ||
+        in->row_pitch_px >= (1 << 24) || out->row_pitch_px >= (1 << 24) || in->height >= (1 << 24))
+        return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gbuffer_from_materials: a plane must be smaller than 4 GiB (32-bit offsets in the kernel)");
     if (numMaterials < 0 || numMaterials > kMaxMaterials || (numMaterials > 0 && !materials))
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: bad materials / numMaterials (see vqhip_max_materials)");
     for (int i = 0; i < numMaterials; ++i) {

@@ -10,11 +10,18 @@
 // implicit derivatives of Texture2D.Sample are two DPP quad swaps (lane^1 = horizontal, lane^2 = vertical
 // neighbour) and every row of the strip is still one contiguous 512-byte read per plane. Materials are
 // wave-coherent in practice, so the wave "waterfalls" over the distinct material indices it holds
-// (readfirstlane): inside one iteration the material record and its seven texture descriptors are wave-uniform
-// (SGPRs), null maps are skipped by a scalar branch, and the loop runs once for almost every wave.
+// (readlane of the first pending lane): inside one iteration the material record and its seven texture
+// descriptors are wave-uniform (SGPRs), null maps are skipped by a scalar branch, and the loop runs once for
+// almost every wave.
 //
-// Roofline: 48 B in + 64 B out = 112 B/pixel of HBM traffic (textures are cache-resident); with all seven maps
-// bound ~600-900 VALU/pixel (6 pow for the two sRGB decodes), i.e. roughly balanced between HBM and VALU.
+// Sampling. The filter footprint (mip level + fraction, the four tap offsets and weights of both levels)
+// depends only on (texture size, mip count, bias, uv, derivatives): it is computed once per distinct size and
+// reused by every map of the material that shares it (a scalar compare of SGPR descriptors) — material sets are
+// normally authored at one resolution, so seven maps cost one or two footprints. Power-of-two textures wrap by
+// AND and find their mip offset in closed form; horizontally adjacent taps are fetched as one 8-byte load.
+//
+// Roofline: 48 B in + 64 B out = 112 B/pixel of HBM traffic (textures are cache-resident). Texture-less
+// materials stream at the HBM roof; with all seven maps bound the kernel is bound by VALU + L1 gathers.
 //
 // Arithmetic/sampling contract: DESIGN.md "G-buffer producer".
 #include "vq_internal.h"
@@ -23,50 +30,108 @@
 namespace vqk {
 using namespace vqd;
 
-struct Tex { const uint8_t* p; int w, h, mips; };
+struct __attribute__((packed, aligned(4))) TexelPair { uint32_t a, b; };
 
-VQD int wrap_fast(int i, int n, bool pot) { return pot ? (i & (n - 1)) : wrapi(i, n); }
+// One level of a footprint: texel offsets (from the chain base) of the two rows, the two columns, the 4 weights.
+struct LevelTaps { uint32_t row0, row1; int x0, x1; float w00, w10, w01, w11; };
+struct Footprint { LevelTaps l0, l1; float f; };
 
-// bilinear WRAP of one RGBA8 level in byte units (exact: 8-bit weights x 8-bit texels fit binary32)
-VQD float4 sample_2d_rgba8_wrap(const uint8_t* tex, int W, int H, float u, float v) {
-    int ix, iy; float wx, wy;
-    fixed8(u * (float)W - 0.5f, &ix, &wx);
-    fixed8(v * (float)H - 0.5f, &iy, &wy);
-    const bool potx = (W & (W - 1)) == 0, poty = (H & (H - 1)) == 0;
-    const int x0 = wrap_fast(ix, W, potx), x1 = wrap_fast(ix + 1, W, potx), y0 = wrap_fast(iy, H, poty), y1 = wrap_fast(iy + 1, H, poty);
-    const uint32_t* t = (const uint32_t*)tex;
-    const uint32_t a = t[(size_t)y0 * W + x0], b = t[(size_t)y0 * W + x1], c = t[(size_t)y1 * W + x0], d = t[(size_t)y1 * W + x1];
-    auto dec = [](uint32_t q) { return make_float4((float)(q & 255u), (float)((q >> 8) & 255u), (float)((q >> 16) & 255u), (float)(q >> 24)); };
-    return blend4(dec(a), dec(b), dec(c), dec(d), wx, wy);
-}
+VQD int ilog2(int v) { return 31 - __builtin_clz(v); }
 
-VQD size_t tex_level_offset_px(int w0, int h0, int level) {
-    size_t off = 0;
-    for (int l = 0; l < level; ++l) off += (size_t)mip_dim(w0, l) * mip_dim(h0, l);
+// offset (in texels) of level l of a dense chain whose level k is max(1,w>>k) x max(1,h>>k)
+template <bool POT> VQD uint32_t level_offset(int w, int h, int l) {
+    if (POT) {
+        // levels 0..m (m = log2 of the short side) shrink by 4, the tail (short side clamped to 1) by 2:
+        // sum_{k<l1} wh/4^k = (4wh - wh/4^(l1-1))/3 ; sum_{k=m+1}^{l-1} L>>k = (L>>m) - (L>>(l-1))
+        const int m = min(ilog2(w), ilog2(h)), L = max(w, h);
+        const int l1 = min(l, m + 1);
+        const uint32_t wh = (uint32_t)w * (uint32_t)h;
+        uint32_t off = l1 >= 1 ? (4u * wh - (wh >> (2 * l1 - 2))) * 0xAAAAAAABu : 0u;   // exact /3 (the numerator is a multiple of 3): inverse of 3 mod 2^32
+        if (l > m + 1) off += (uint32_t)((L >> m) - (L >> (l - 1)));
+        return off;
+    }
+    uint32_t off = 0;
+    for (int k = 0; k < l; ++k) off += (uint32_t)mip_dim(w, k) * (uint32_t)mip_dim(h, k);
     return off;
 }
 
+template <bool POT> VQD LevelTaps level_taps(int w0, int h0, int level, float u, float v) {
+    const int W = mip_dim(w0, level), H = mip_dim(h0, level);
+    int ix, iy; float wx, wy;
+    fixed8(u * (float)W - 0.5f, &ix, &wx);
+    fixed8(v * (float)H - 0.5f, &iy, &wy);
+    LevelTaps t;
+    int y0, y1;
+    if (POT) { t.x0 = ix & (W - 1); t.x1 = (ix + 1) & (W - 1); y0 = iy & (H - 1); y1 = (iy + 1) & (H - 1); }
+    else     { t.x0 = wrapi(ix, W); t.x1 = wrapi(ix + 1, W); y0 = wrapi(iy, H); y1 = wrapi(iy + 1, H); }
+    const uint32_t base = level_offset<POT>(w0, h0, level);
+    t.row0 = base + __umul24(y0, W);                              // dims < 2^24: full-rate v_mad_u32_u24
+    t.row1 = base + __umul24(y1, W);
+    t.w00 = (1.0f - wx) * (1.0f - wy); t.w10 = wx * (1.0f - wy); t.w01 = (1.0f - wx) * wy; t.w11 = wx * wy;   // == blend4's weights
+    return t;
+}
+
 // Texture2D.Sample / SampleBias: isotropic trilinear WRAP, LOD from the quad derivatives
-VQD float4 sample_material_tex(const vqhip_texture2d& t, float2 uv, float2 ddx, float2 ddy, float bias) {
-    const float W = (float)t.width, H = (float)t.height;
+template <bool POT> VQD Footprint make_footprint(int w, int h, int mips, float2 uv, float2 ddx, float2 ddy, float bias) {
+    const float W = (float)w, H = (float)h;
     const float dXx = ddx.x * W, dXy = ddx.y * H, dYx = ddy.x * W, dYy = ddy.y * H;
     const float rx = fma_(dXy, dXy, dXx * dXx), ry = fma_(dYy, dYy, dYx * dYx);
     const float lod = 0.5f * log2_(max_(rx, ry)) + bias;
-    const float maxl = (float)(t.mips - 1);
+    const float maxl = (float)(mips - 1);
     const float l = (lod > 0.0f) ? ((lod < maxl) ? lod : maxl) : 0.0f;
     const int fl = f2i_floor(l * 256.0f + 0.5f);
     int lo = fl >> 8;
-    float f = (float)(fl & 255) * 0.00390625f;
-    if (lo >= t.mips - 1) { lo = t.mips - 1; f = 0.0f; }
-    const uint8_t* base = (const uint8_t*)t.texels;
-    const float4 a = sample_2d_rgba8_wrap(base + tex_level_offset_px(t.width, t.height, lo) * 4, mip_dim(t.width, lo), mip_dim(t.height, lo), uv.x, uv.y);
-    float4 r = a;
-    if (f != 0.0f) {
-        const float4 b = sample_2d_rgba8_wrap(base + tex_level_offset_px(t.width, t.height, lo + 1) * 4, mip_dim(t.width, lo + 1), mip_dim(t.height, lo + 1), uv.x, uv.y);
-        const float g = 1.0f - f;
-        r = make_float4(fma_(f, b.x, g * a.x), fma_(f, b.y, g * a.y), fma_(f, b.z, g * a.z), fma_(f, b.w, g * a.w));
+    Footprint fp;
+    fp.f = (float)(fl & 255) * 0.00390625f;
+    if (lo >= mips - 1) { lo = mips - 1; fp.f = 0.0f; }
+    fp.l0 = level_taps<POT>(w, h, lo, uv.x, uv.y);
+    fp.l1 = level_taps<POT>(w, h, min(lo + 1, mips - 1), uv.x, uv.y);     // unused (weight 0) when f == 0
+    return fp;
+}
+
+VQD float4 dec8(uint32_t q) { return make_float4((float)(q & 255u), (float)((q >> 8) & 255u), (float)((q >> 16) & 255u), (float)(q >> 24)); }
+
+// bilinear blend of one level in byte units (exact: 8-bit weights x 8-bit texels fit binary32); same FMA chain as blend4
+struct Taps4 { uint32_t a, b, c, d; };
+template <bool PAIRS> VQD Taps4 load_taps(const uint32_t* __restrict__ t, const LevelTaps& k) {
+    Taps4 q;
+    // 32-bit byte offsets from the wave-uniform chain pointer (a chain is < 4 GB): global_load with SGPR base + VGPR offset
+    const char* b = (const char*)t;
+    if (PAIRS) {                                                     // x1 == x0 + 1 in every lane: two 8-byte loads
+        const TexelPair p0 = *(const TexelPair*)(b + ((k.row0 + (uint32_t)k.x0) << 2)), p1 = *(const TexelPair*)(b + ((k.row1 + (uint32_t)k.x0) << 2));
+        q.a = p0.a; q.b = p0.b; q.c = p1.a; q.d = p1.b;
+    } else {
+        q.a = *(const uint32_t*)(b + ((k.row0 + (uint32_t)k.x0) << 2)); q.b = *(const uint32_t*)(b + ((k.row0 + (uint32_t)k.x1) << 2));
+        q.c = *(const uint32_t*)(b + ((k.row1 + (uint32_t)k.x0) << 2)); q.d = *(const uint32_t*)(b + ((k.row1 + (uint32_t)k.x1) << 2));
     }
-    const float s = 0.0039215688593685627f;     // RN(1/255) = rcp(255.0f)
+    return q;
+}
+VQD float4 blend_taps(const Taps4& q, const LevelTaps& k) {
+    const float4 c00 = dec8(q.a), c10 = dec8(q.b), c01 = dec8(q.c), c11 = dec8(q.d);
+    float4 r;
+    r.x = fma_(k.w11, c11.x, fma_(k.w01, c01.x, fma_(k.w10, c10.x, k.w00 * c00.x)));
+    r.y = fma_(k.w11, c11.y, fma_(k.w01, c01.y, fma_(k.w10, c10.y, k.w00 * c00.y)));
+    r.z = fma_(k.w11, c11.z, fma_(k.w01, c01.z, fma_(k.w10, c10.z, k.w00 * c00.z)));
+    r.w = 0.0f;                                                      // alpha is read by no consumer in PSMain (ENABLE_ALPHA_MASK off): not filtered
+    return r;
+}
+
+VQD float4 fetch(const void* texels, const Footprint& fp) {
+    const uint32_t* t = (const uint32_t*)texels;
+    const bool two = __builtin_amdgcn_ballot_w64(fp.f != 0.0f) != 0;                              // some lane blends two levels
+    const bool wraps = (fp.l0.x1 != fp.l0.x0 + 1) | (two & (fp.l1.x1 != fp.l1.x0 + 1));
+    const bool pairs = __builtin_amdgcn_ballot_w64(wraps) == 0;                                   // no lane wraps in x
+    // all loads of both levels are issued before the first use (one memory round trip per map)
+    Taps4 q0, q1 = { 0, 0, 0, 0 };
+    if (pairs) { q0 = load_taps<true>(t, fp.l0);  if (two) q1 = load_taps<true>(t, fp.l1); }
+    else       { q0 = load_taps<false>(t, fp.l0); if (two) q1 = load_taps<false>(t, fp.l1); }
+    float4 r = blend_taps(q0, fp.l0);
+    if (two) {
+        const float4 b = blend_taps(q1, fp.l1);
+        const float f = fp.f, g = 1.0f - f;                          // f == 0: fma(0, b, 1*a) == a exactly
+        r = make_float4(fma_(f, b.x, g * r.x), fma_(f, b.y, g * r.y), fma_(f, b.z, g * r.z), fma_(f, b.w, g * r.w));
+    }
+    const float s = 0.0039215688593685627f;                          // RN(1/255) = rcp(255.0f)
     return make_float4(r.x * s, r.y * s, r.z * s, r.w * s);
 }
 
@@ -82,18 +147,35 @@ VQD f3 UnpackNormal(f3 S, f3 worldNormal, f3 worldTangent) {          // Shading
 
 VQD bool has_bit(int cfg, int bit) { return (cfg & (1 << bit)) > 0; }   // LightingConstantBufferData.h:116-124
 
+// Samples the maps of one (wave-uniform) material, reusing the footprint between maps of equal size / bias.
+struct MaterialSampler {
+    float2 uv, ddx, ddy;
+    Footprint fp;
+    int cw = -1, ch = -1, cm = -1; float cb = 0.0f;
+    VQD float4 sample(const vqhip_texture2d& t, float bias) {
+        if (!t.texels) return make_float4(0, 0, 0, 0);                // null SRV
+        if (t.width != cw || t.height != ch || t.mips != cm || bias != cb) {
+            const bool pot = ((t.width & (t.width - 1)) | (t.height & (t.height - 1))) == 0;
+            fp = pot ? make_footprint<true>(t.width, t.height, t.mips, uv, ddx, ddy, bias)
+                     : make_footprint<false>(t.width, t.height, t.mips, uv, ddx, ddy, bias);
+            cw = t.width; ch = t.height; cm = t.mips; cb = bias;
+        }
+        return fetch(t.texels, fp);
+    }
+};
+
 __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
     const GbufConstants* __restrict__ gc = a.gc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = (blockIdx.x * 4 + wave) * 32 + ((lane >> 2) << 1) + (lane & 1);
     const int y = blockIdx.y * 2 + ((lane >> 1) & 1);
     const bool inside = (x < a.width) & (y < a.height);
-    const size_t o = (size_t)y * a.pitch + x;
+    const uint32_t o = (__umul24(y, a.pitch) + (uint32_t)x) << 4;      // 32-bit byte offsets: planes are < 4 GB (checked by the C ABI)
 
     float4 i0 = make_float4(0, 0, 0, 0), i1 = i0, i2 = i0;
     int idx = -1;
     if (inside) {
-        i0 = a.ip0[o]; i1 = a.ip1[o]; i2 = a.ip2[o];
+        i0 = *(const float4*)((const char*)a.ip0 + o); i1 = *(const float4*)((const char*)a.ip1 + o); i2 = *(const float4*)((const char*)a.ip2 + o);
         idx = __float_as_int(i2.w);
         if (idx >= gc->numMaterials) idx = -1;
     }
@@ -101,7 +183,11 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
     const float hu = __shfl_xor(i0.w, 1), hv = __shfl_xor(i1.w, 1); const int hidx = __shfl_xor(idx, 1);
     const float vu = __shfl_xor(i0.w, 2), vv = __shfl_xor(i1.w, 2); const int vidx = __shfl_xor(idx, 2);
 
-    float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = o0, o3 = o0;
+    const uint32_t q = (__umul24(y, a.outPitch) + (uint32_t)x) << 4;
+    if (inside && idx < 0) {                                          // no geometry: all-zero record
+        const float4 z = make_float4(0, 0, 0, 0);
+        *(float4*)((char*)a.gb0 + q) = z; *(float4*)((char*)a.gb1 + q) = z; *(float4*)((char*)a.gb2 + q) = z; *(float4*)((char*)a.gb3 + q) = z;
+    }
 
     bool todo = idx >= 0;
     for (;;) {
@@ -113,39 +199,58 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
             const vqhip_material& mt = gc->mats[mi];
             const VQ_MaterialData& m = mt.data;
             const float sx = m.uvScaleOffset.x, sy = m.uvScaleOffset.y, ox = m.uvScaleOffset.z, oy = m.uvScaleOffset.w;
-            const float2 uv = make_float2(i0.w * sx + ox, i1.w * sy + oy);                  // ForwardLighting.hlsl:226
-            float2 ddx = make_float2(0, 0), ddy = make_float2(0, 0);
+            MaterialSampler ms;
+            ms.uv = make_float2(i0.w * sx + ox, i1.w * sy + oy);                            // ForwardLighting.hlsl:226
+            ms.ddx = make_float2(0, 0); ms.ddy = make_float2(0, 0);
             if (hidx == mi) {
                 const float nu = hu * sx + ox, nv = hv * sy + oy;
-                ddx = (lane & 1) ? make_float2(uv.x - nu, uv.y - nv) : make_float2(nu - uv.x, nv - uv.y);
+                ms.ddx = (lane & 1) ? make_float2(ms.uv.x - nu, ms.uv.y - nv) : make_float2(nu - ms.uv.x, nv - ms.uv.y);
             }
             if (vidx == mi) {
                 const float nu = vu * sx + ox, nv = vv * sy + oy;
-                ddy = (lane & 2) ? make_float2(uv.x - nu, uv.y - nv) : make_float2(nu - uv.x, nv - uv.y);
+                ms.ddy = (lane & 2) ? make_float2(ms.uv.x - nu, ms.uv.y - nv) : make_float2(nu - ms.uv.x, nv - ms.uv.y);
             }
             const int TEX_CFG = f2i_trunc(m.textureConfig);                                // :227
-            const float4 z4 = make_float4(0, 0, 0, 0);
-            const float4 AlbedoAlpha = mt.texDiffuse.texels        ? sample_material_tex(mt.texDiffuse,        uv, ddx, ddy, 0.0f) : z4;   // :229-235
-            const float4 Normal4     = mt.texNormals.texels        ? sample_material_tex(mt.texNormals,        uv, ddx, ddy, m.normalMapMipBias) : z4;
-            const float4 Emis4       = mt.texEmissive.texels       ? sample_material_tex(mt.texEmissive,       uv, ddx, ddy, 0.0f) : z4;
-            const float Metalness    = mt.texMetalness.texels      ? sample_material_tex(mt.texMetalness,      uv, ddx, ddy, 0.0f).x : 0.0f;
-            const float Roughness    = mt.texRoughness.texels      ? sample_material_tex(mt.texRoughness,      uv, ddx, ddy, 0.0f).x : 0.0f;
-            const float4 ORM         = mt.texOcclRoughMetal.texels ? sample_material_tex(mt.texOcclRoughMetal, uv, ddx, ddy, 0.0f) : z4;
-            const float LocalAO      = mt.texLocalAO.texels        ? sample_material_tex(mt.texLocalAO,        uv, ddx, ddy, 0.0f).x : 0.0f;
+            // :229-235. A map whose Has*Map() bit is clear is fetched by the HLSL but never used: skipped here.
+            // The normal map has no HasNormalMap() test (:267) and is always fetched. One rolled loop over the seven descriptors
+            // (wave-uniform trip, scalar switch) keeps a single copy of the sampling code in the instruction cache.
+            float4 AlbedoAlpha = make_float4(0, 0, 0, 0), Emis4 = AlbedoAlpha, ORM = AlbedoAlpha, Normal4 = AlbedoAlpha;
+            float Metalness = 0.0f, Roughness = 0.0f, LocalAO = 0.0f;
+            const vqhip_texture2d* slots = &mt.texDiffuse;             // t0,t1,t2,t4,t5,t6,t7 are consecutive in vqhip_material
+            #pragma unroll 1
+            for (int k = 0; k < 7; ++k) {
+                const int bit = (0x2845710 >> (4 * k)) & 15;           // Has*Map bit of slot k: 0,1,7,5,4,8,2
+                if (k != 1 && !has_bit(TEX_CFG, bit)) continue;
+                const float4 r = ms.sample(slots[k], k == 1 ? m.normalMapMipBias : 0.0f);
+                switch (k) {
+                    case 0: AlbedoAlpha = r; break;
+                    case 1: Normal4 = r; break;
+                    case 2: Emis4 = r; break;
+                    case 3: Metalness = r.x; break;
+                    case 4: Roughness = r.x; break;
+                    case 5: ORM = r; break;
+                    default: LocalAO = r.x; break;
+                }
+            }
 
             float ao = gc->ambient;                                                        // :247
             const f3 mdiff = mk3(m.diffuse.x, m.diffuse.y, m.diffuse.z), memis = mk3(m.emissiveColor.x, m.emissiveColor.y, m.emissiveColor.z);
             f3 diffuseColor = mdiff, emissiveColor = memis;
             if (has_bit(TEX_CFG, 0))                                                       // :243,249  SRGBToLinear = pow(c, 2.2)
-                diffuseColor = mul(mk3(pow_(AlbedoAlpha.x, 2.2f), pow_(AlbedoAlpha.y, 2.2f), pow_(AlbedoAlpha.z, 2.2f)), mdiff);
+                diffuseColor = mul(mk3(pow_unit(AlbedoAlpha.x, 2.2f), pow_unit(AlbedoAlpha.y, 2.2f), pow_unit(AlbedoAlpha.z, 2.2f)), mdiff);   // filtered UNORM8: [0,1], normal or 0
             if (has_bit(TEX_CFG, 7))                                                       // :244,250
-                emissiveColor = mul(mk3(pow_(Emis4.x, 2.2f), pow_(Emis4.y, 2.2f), pow_(Emis4.z, 2.2f)), memis);
+                emissiveColor = mul(mk3(pow_unit(Emis4.x, 2.2f), pow_unit(Emis4.y, 2.2f), pow_unit(Emis4.z, 2.2f)), memis);
             float roughness = m.roughness, metalness = m.metalness;                        // :252-253
 
             const f3 N = normalize(mk3(i1.x, i1.y, i1.z));                                 // :265
-            const f3 T = normalize(mk3(i2.x, i2.y, i2.z));                                 // :266
             const f3 Nrm = mk3(Normal4.x, Normal4.y, Normal4.z);
-            const f3 SurfN = (length(Nrm) < 0.01f) ? N : UnpackNormal(Nrm, N, T);          // :267
+            f3 SurfN = N;                                                                  // :267  length(Normal) < 0.01 ? N : UnpackNormal(...)
+            const bool unpack = !(length(Nrm) < 0.01f);
+            if (__builtin_amdgcn_ballot_w64(unpack) != 0) {                                // a real branch: most waves of a normal-map-less material skip it
+                const f3 T = normalize(mk3(i2.x, i2.y, i2.z));                             // :266
+                const f3 U = UnpackNormal(Nrm, N, T);
+                if (unpack) SurfN = U;
+            }
 
             if (has_bit(TEX_CFG, 2)) ao *= LocalAO;                                        // :269
             if (has_bit(TEX_CFG, 4)) roughness *= Roughness;                               // :270
@@ -155,20 +260,18 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
             if (gc->ssao.texels) {                                                         // :280-281, POINT_WRAP
                 const float su = div_(((float)x + 0.5f) + 0.5f, (float)a.width), sv = div_(((float)y + 0.5f) + 0.5f, (float)a.height);
                 // coordinate snapped to 8 fractional bits before the floor (these coordinates sit exactly on texel borders)
-                const int tx = wrapi(f2i_floor((su * (float)gc->ssao.width) * 256.0f + 0.5f) >> 8, gc->ssao.width);
-                const int ty = wrapi(f2i_floor((sv * (float)gc->ssao.height) * 256.0f + 0.5f) >> 8, gc->ssao.height);
-                ao *= (float)((const uint8_t*)gc->ssao.texels)[(size_t)ty * gc->ssao.width + tx] * 0.0039215688593685627f;
+                // su, sv are in (0, 1] so the texel index is in [0, dim]: WRAP is one conditional subtract (== the modulo)
+                int tx = f2i_floor((su * (float)gc->ssao.width) * 256.0f + 0.5f) >> 8, ty = f2i_floor((sv * (float)gc->ssao.height) * 256.0f + 0.5f) >> 8;
+                tx = tx >= gc->ssao.width ? tx - gc->ssao.width : tx;
+                ty = ty >= gc->ssao.height ? ty - gc->ssao.height : ty;
+                ao *= (float)((const uint8_t*)gc->ssao.texels)[(uint32_t)ty * (uint32_t)gc->ssao.width + (uint32_t)tx] * 0.0039215688593685627f;
             }
-            o0 = make_float4(i0.x, i0.y, i0.z, ao);                                        // :284
-            o1 = make_float4(SurfN.x, SurfN.y, SurfN.z, roughness);
-            o2 = make_float4(diffuseColor.x, diffuseColor.y, diffuseColor.z, metalness);
-            o3 = make_float4(emissiveColor.x, emissiveColor.y, emissiveColor.z, m.emissiveIntensity);   // :251
+            *(float4*)((char*)a.gb0 + q) = make_float4(i0.x, i0.y, i0.z, ao);                                  // :284
+            *(float4*)((char*)a.gb1 + q) = make_float4(SurfN.x, SurfN.y, SurfN.z, roughness);
+            *(float4*)((char*)a.gb2 + q) = make_float4(diffuseColor.x, diffuseColor.y, diffuseColor.z, metalness);
+            *(float4*)((char*)a.gb3 + q) = make_float4(emissiveColor.x, emissiveColor.y, emissiveColor.z, m.emissiveIntensity);   // :251
             todo = false;
         }
-    }
-    if (inside) {
-        const size_t q = (size_t)y * a.outPitch + x;
-        a.gb0[q] = o0; a.gb1[q] = o1; a.gb2[q] = o2; a.gb3[q] = o3;
     }
 }
 

@@ -144,6 +144,20 @@ VQD float exp2_(float x) {
     return out;
 }
 VQD float pow_(float x, float y) { return exp2_(y * log2_(x)); }
+// pow_(x, y) for x in [0,1] known to be +0 or a positive NORMAL number and y > 0 with y*log2(x) >= -126 (e.g. UNORM8 data,
+// y = 2.2): the same operations as pow_ with the special-case selects that cannot trigger removed — identical bits.
+VQD float pow_unit(float x, float y) {
+    const float t = y * log2_normal_bits(__float_as_uint(x), 0);
+    const float n = __builtin_rintf(t), f = t - n;
+    float p = 1.535336188319500E-4f;
+    p = fma_(p, f, 1.339887440266574E-3f);
+    p = fma_(p, f, 9.618437357674640E-3f);
+    p = fma_(p, f, 5.550332471162809E-2f);
+    p = fma_(p, f, 2.402264791363012E-1f);
+    p = fma_(p, f, 6.931472028550421E-1f);
+    const float r = fma_(p, f, 1.0f) * __uint_as_float((uint32_t)((int)n + 127) << 23);
+    return x == 0.0f ? 0.0f : r;
+}
 
 // sin/cos: octant reduction with a 3-part pi/4, Cephes kernels; |x| > 2^20 or non-finite -> NaN
 VQD void sincos_(float x, float* s, float* c) {

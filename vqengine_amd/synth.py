@@ -210,7 +210,7 @@ def interpolants(width, height, n_materials, seed=0x1A7E):
     return ip0, ip1, ip2
 
 
-def material_set(n, seed=0x3A7, max_dim=256):
+def material_set(n, seed=0x3A7, max_dim=256, same_size=False):
     """n materials: (list of abi.MaterialData, list of {slot: uint8 [H,W,4] level 0}) with power-of-two texture sizes
     (non-square allowed), random scalar parameters and uv tiling. textureConfig normally mirrors the bound maps
     (Material::GetTextureConfig, Material.cpp:23-36); materials 3k+1 carry a deliberately inconsistent config (bit set
@@ -226,9 +226,13 @@ def material_set(n, seed=0x3A7, max_dim=256):
         d.uvScaleOffset = abi.float4(float(r.uniform(0.3, 6.0)), float(r.uniform(0.3, 6.0)), float(r.uniform(-1, 1)), float(r.uniform(-1, 1)))
         d.roughness, d.metalness, d.displacement = float(r.uniform(0.05, 1.0)), float(r.uniform(0, 1)), 0.0
         texs, cfg = {}, 0
+        if same_size:                                   # one square size per material (how material sets are normally authored)
+            mw = mh = int(2 ** r.integers(max(3, int(np.log2(max_dim)) - 1), int(np.log2(max_dim)) + 1))
         for slot in abi.MATERIAL_TEXTURE_SLOTS:
             if i == 0 or r.random() < 0.6:              # material 0 binds every map
                 w = int(2 ** r.integers(3, int(np.log2(max_dim)) + 1)); h = int(2 ** r.integers(3, int(np.log2(max_dim)) + 1))
+                if same_size:
+                    w, h = mw, mh
                 yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
                 img = np.empty((h, w, 4), np.float32)
                 for c in range(4):
