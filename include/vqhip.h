@@ -427,6 +427,21 @@ VQHIP_API int vqhip_skydome(vqhip_ctx* ctx, void* stream, const void* equirect_l
         const VQ_SkydomeParams* params, const vqhip_interpolants* coverage,
         void* color, int width, int height, int row_pitch_px, vqhip_format fmt);
 
+/* ---- HDRI ingest -------------------------------------------------------------------
+ * Replaces Image::LoadFromFile -> stbi_loadf for Radiance .hdr files (call site TextureManager.cpp:566; the decoder
+ * itself lives in stb_image inside the un-vendored Libs/VQUtils submodule — its published algorithm, stb_image.h
+ * v2.2x stbi__hdr_load / stbi__hdr_convert, is what is restated): header "#?RADIANCE" | "#?RGBE", a
+ * "FORMAT=32-bit_rle_rgbe" line, blank line, "-Y <height> +X <width>", then per scanline either new-style RLE
+ * (02 02 hi lo + four run-length coded byte planes) or flat RGBE quadruples (width < 8, width >= 32768, or no
+ * 02 02 marker); pixel = (r,g,b) * 2^(e-136), (0,0,0) when e == 0, alpha := 1.
+ * The header parse and the byte-serial run expansion stay on the host; the RGBE -> RGBA32F conversion (4 B in,
+ * 16 B out per pixel) runs on the GPU straight into level 0 of the chain that vqhip_mip_chain_min_rgba32f completes.
+ *   file / bytes : HOST memory holding the whole .hdr file
+ * Truncated or corrupt run data returns VQHIP_ERR_INVALID_ARG (stb_image reads zeros past the end of the file). */
+VQHIP_API int vqhip_hdr_parse_header(const void* file, size_t bytes, int* width, int* height, size_t* data_offset);
+VQHIP_API int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, size_t bytes,
+        void* out_rgba32f, int width, int height);
+
 #ifdef __cplusplus
 }
 #endif

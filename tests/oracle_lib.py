@@ -57,6 +57,8 @@ def load():
     lib.vqo_mip_chain_texels.restype = sz
     lib.vqo_mip_chain_texels.argtypes = [i32, i32, i32]
     lib.vqo_skydome.argtypes = [vp, i32, i32, C.POINTER(abi.SkydomeParams), vp, i32, vp, i32, i32, i32, i32, i32]
+    lib.vqo_hdr_parse_header.argtypes = [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]
+    lib.vqo_hdr_decode_rgba32f.argtypes = [C.c_char_p, sz, vp, i32, i32]
     lib.vqo_unorm8_to_float.restype = f32
     lib.vqo_unorm8_to_float.argtypes = [i32]
     if not lib.vqo_has_fma():
@@ -239,6 +241,20 @@ def skydome(equirect0, params, color, fmt, coverage_ip2=None, nthreads=0):
                          _p(color), w, h, w, fmt, nthreads)
     assert rc == 0, rc
     return color
+
+
+def hdr_decode(data):
+    """bytes of a .hdr file -> float32 [H,W,4] or raises ValueError(code) when the oracle rejects the file."""
+    lib = load()
+    w, h, off = C.c_int(), C.c_int(), C.c_size_t()
+    rc = lib.vqo_hdr_parse_header(data, len(data), C.byref(w), C.byref(h), C.byref(off))
+    if rc != 0:
+        raise ValueError(rc)
+    out = np.empty((h.value, w.value, 4), np.float32)
+    rc = lib.vqo_hdr_decode_rgba32f(data, len(data), _p(out), w.value, h.value)
+    if rc != 0:
+        raise ValueError(rc)
+    return out
 
 
 def bits_equal(a, b):

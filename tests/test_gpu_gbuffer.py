@@ -120,6 +120,46 @@ def test_skydome_matches_oracle(ctx, fmt, shape):
     assert n == 0, (n, idx)
 
 
+@pytest.mark.parametrize("rle", [True, False])
+def test_hdr_ingest_matches_oracle(ctx, rle):
+    """vqhip_hdr_decode_rgba32f against the oracle: every exponent (denormal scale factors included), runs,
+    zero exponents; then the min-filter mip chain built on the decoded level 0."""
+    h, w = 64, 256
+    r = np.random.default_rng(11)
+    rgbe = synth.float_to_rgbe(synth.equirect(w, h)[..., :3])
+    rgbe[5] = r.integers(0, 256, (w, 4), dtype=np.uint8)
+    rgbe[6, :, 3] = np.arange(w, dtype=np.uint8)               # all 256 exponents
+    rgbe[7, :100] = (1, 2, 3, 200)
+    data = synth.hdr_file_bytes(rgbe, rle=rle)
+    ref = O.hdr_decode(data)
+    got = ctx.load_hdr(data)
+    n, idx = O.bits_equal(got.cpu().numpy(), ref)
+    assert n == 0, (n, idx)
+    chain_g, nm = ctx.mip_chain(got)
+    chain_o, nm_o = O.mip_chain(ref)
+    assert nm == nm_o
+    n, idx = O.bits_equal(chain_g.cpu().numpy(), chain_o)
+    assert n == 0, (n, idx)
+
+
+def test_hdr_ingest_errors(ctx):
+    rgbe = synth.float_to_rgbe(synth.equirect(32, 4)[..., :3])
+    good = synth.hdr_file_bytes(rgbe)
+    out = torch.empty((4, 32, 4), dtype=torch.float32, device="cuda")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = C.c_void_p(out.data_ptr())
+    lib = ctx.lib
+    assert lib.vqhip_hdr_decode_rgba32f(ctx._h, st, good, len(good), p, 32, 4) == 0
+    assert lib.vqhip_hdr_decode_rgba32f(ctx._h, st, good, len(good), p, 31, 4) == abi.VQHIP_ERR_INVALID_ARG
+    assert lib.vqhip_hdr_decode_rgba32f(ctx._h, st, good[:-3], len(good) - 3, p, 32, 4) == abi.VQHIP_ERR_INVALID_ARG
+    assert b"truncated" in lib.vqhip_last_error(ctx._h)
+    bad = good.replace(b"#?RADIANCE", b"#?RADIANCX", 1)
+    assert lib.vqhip_hdr_decode_rgba32f(ctx._h, st, bad, len(bad), p, 32, 4) == abi.VQHIP_ERR_INVALID_ARG
+    w, h, off = capi.hdr_parse_header(good)
+    corrupt = good[:off + 4] + bytes((128,)) + good[off + 5:]
+    assert lib.vqhip_hdr_decode_rgba32f(ctx._h, st, corrupt, len(corrupt), p, 32, 4) == abi.VQHIP_ERR_INVALID_ARG
+
+
 def test_skydome_abi_errors(ctx):
     lib = ctx.lib
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

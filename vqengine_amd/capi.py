@@ -62,6 +62,8 @@ def load_library():
         "vqhip_mip_chain_bytes_rgba8": (sz, [i32, i32, i32]),
         "vqhip_mip_chain_box_rgba8": (i32, [vp, vp, vp, i32, i32, i32]),
         "vqhip_skydome": (i32, [vp, vp, vp, i32, i32, C.POINTER(abi.SkydomeParams), C.POINTER(abi.Interpolants), vp, i32, i32, i32, i32]),
+        "vqhip_hdr_parse_header": (i32, [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]),
+        "vqhip_hdr_decode_rgba32f": (i32, [vp, vp, C.c_char_p, sz, vp, i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -78,8 +80,18 @@ EXPORTED_SYMBOLS = [
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
-    "vqhip_skydome",
+    "vqhip_skydome", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
 ]
+
+
+def hdr_parse_header(data):
+    """(width, height, data_offset) of a Radiance .hdr file held in `data` (bytes). Host-only; raises VQHipError when malformed."""
+    lib = load_library()
+    w, h, off = C.c_int(), C.c_int(), C.c_size_t()
+    rc = lib.vqhip_hdr_parse_header(data, len(data), C.byref(w), C.byref(h), C.byref(off))
+    if rc != 0:
+        raise VQHipError(rc, (lib.vqhip_last_error(None) or b"").decode())
+    return w.value, h.value, off.value
 
 _TORCH_DTYPE = {FMT_RGBA32F: (torch.float32, 4), FMT_RGBA16F: (torch.float16, 4), FMT_RGBA8_UNORM: (torch.uint8, 4),
                 FMT_RG16F: (torch.float16, 2), FMT_RG32F: (torch.float32, 2)}
@@ -255,6 +267,14 @@ class Context:
         n = len(materials) if materials is not None else 0
         self._ck(self.lib.vqhip_gbuffer_from_materials(self._h, self._stream(stream), C.byref(inter), materials if n else None, n,
                                                        float(ambient), C.byref(s) if s is not None else None, C.byref(gbuf)))
+        return out
+
+    # ---- HDRI ingest (Image::LoadFromFile -> stbi_loadf, TextureManager.cpp:566) ----------------
+    def load_hdr(self, data, stream=None):
+        """data: bytes of a Radiance .hdr file. Returns the decoded float32 cuda image [H,W,4] (alpha 1) == level 0 of the chain."""
+        w, h, _ = hdr_parse_header(data)
+        out = torch.empty((h, w, 4), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.vqhip_hdr_decode_rgba32f(self._h, self._stream(stream), data, len(data), _ptr(out), w, h))
         return out
 
     # ---- skydome (Skydome.hlsl:39-56, SceneRendering.cpp:1822-1850; SURVEY.md §8f.2) -------------------------

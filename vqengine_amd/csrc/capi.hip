@@ -343,6 +343,35 @@ int vqhip_skydome(vqhip_ctx* ctx, void* stream, const void* equirect_level0, int
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "skydome launch");
 }
 
+// ---- HDRI ingest --------------------------------------------------------------------
+int vqhip_hdr_parse_header(const void* file, size_t bytes, int* width, int* height, size_t* data_offset) {
+    if (!file || !width || !height) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "hdr_parse_header: NULL argument");
+    const char* err = nullptr; size_t off = 0;
+    if (hdr_parse_header((const uint8_t*)file, bytes, width, height, &off, &err)) return fail(nullptr, VQHIP_ERR_INVALID_ARG, err);
+    if (data_offset) *data_offset = off;
+    return VQHIP_OK;
+}
+
+int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, size_t bytes, void* out_rgba32f, int width, int height) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "hdr_decode: ctx is NULL");
+    if (!file || !out_rgba32f) return fail(ctx, VQHIP_ERR_INVALID_ARG, "hdr_decode: NULL argument");
+    const char* err = nullptr; int w = 0, h = 0; size_t off = 0;
+    if (hdr_parse_header((const uint8_t*)file, bytes, &w, &h, &off, &err)) return fail(ctx, VQHIP_ERR_INVALID_ARG, err);
+    if (w != width || h != height) return fail(ctx, VQHIP_ERR_INVALID_ARG, "hdr_decode: width/height do not match the file header");
+    const size_t px = (size_t)w * h;
+    std::vector<uint8_t> rgbe(px * 4);
+    if (hdr_expand_rgbe((const uint8_t*)file, bytes, off, w, h, rgbe.data(), &err)) return fail(ctx, VQHIP_ERR_INVALID_ARG, err);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int rc = ensureScratch(ctx, px * 4);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch, rgbe.data(), px * 4, hipMemcpyHostToDevice, st));
+    hipError_t e = launch_rgbe_to_rgba32f(st, ctx->scratch, out_rgba32f, px);
+    if (e != hipSuccess) return failHip(ctx, e, "rgbe_to_rgba32f launch");
+    HIP_TRY(ctx, hipStreamSynchronize(st));      // load-time call: the staging vector and the scratch buffer are free again on return
+    return VQHIP_OK;
+}
+
 int vqhip_specular_mip_count(int spec_res0) { return vqhip_mip_level_count(spec_res0, spec_res0) - 1; }
 size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt) {
     const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;

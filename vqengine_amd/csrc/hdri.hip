@@ -1,0 +1,134 @@
+// hdri.hip — SURVEY.md §8(f).3: Radiance .hdr (RGBE) ingest.
+//
+// Replaces Image::LoadFromFile -> stbi_loadf (call site Source/Renderer/Resources/TextureManager.cpp:566). The decoder
+// the reference uses is stb_image's (Libs/VQUtils submodule, not vendored): stbi__hdr_test / stbi__hdr_load /
+// stbi__hdr_convert of stb_image.h v2.2x, whose published behaviour is restated here:
+//   * first line "#?RADIANCE" or "#?RGBE"; header lines until an empty line, one of them "FORMAT=32-bit_rle_rgbe";
+//     then "-Y <height> +X <width>" (any other orientation is rejected, as stb does);
+//   * width < 8 or >= 32768: flat RGBE quadruples; otherwise each scanline starts 02 02 hi lo (hi<<8|lo == width, hi < 0x80)
+//     followed by four run-length coded byte planes (count > 128: run of count-128 copies; else count literals; a count of
+//     0 or one overrunning the scanline is corrupt); a first scanline without the 02 02 marker means the whole image is flat;
+//   * pixel = (r,g,b) * 2^(e - 136) (ldexp(1, e-(128+8))), (0,0,0) for e == 0, alpha = 1.
+// Split: header parse + byte-serial run expansion on the host (each scanline's length is only known by walking its runs),
+// RGBE -> RGBA32F on the GPU (k_rgbe_to_rgba32f: 4 B in + 16 B out per pixel, HBM-bound), straight into level 0 of the mip chain.
+#include <cstdlib>
+#include <cstring>
+#include "vq_internal.h"
+
+namespace vqk {
+
+namespace {
+struct Cursor {
+    const uint8_t* p; size_t n, i;
+    bool eof() const { return i >= n; }
+    int get() { return i < n ? p[i++] : -1; }
+};
+// stbi__hdr_gettoken: reads up to the next '\n' (not included), at most 1023 chars kept
+bool getToken(Cursor& c, char* buf, size_t cap) {
+    size_t len = 0;
+    if (c.eof()) return false;
+    for (;;) {
+        const int ch = c.get();
+        if (ch < 0 || ch == '\n') break;
+        if (len + 1 < cap) buf[len++] = (char)ch;
+    }
+    buf[len] = 0;
+    return true;
+}
+} // namespace
+
+int hdr_parse_header(const uint8_t* f, size_t n, int* w, int* h, size_t* off, const char** err) {
+    Cursor c = { f, n, 0 };
+    char tok[1024];
+    if (!getToken(c, tok, sizeof tok) || (std::strcmp(tok, "#?RADIANCE") != 0 && std::strcmp(tok, "#?RGBE") != 0)) { *err = "hdr: not a Radiance file (missing #?RADIANCE / #?RGBE)"; return -1; }
+    bool valid = false;
+    for (;;) {
+        if (!getToken(c, tok, sizeof tok)) { *err = "hdr: truncated header"; return -1; }
+        if (tok[0] == 0) break;
+        if (std::strcmp(tok, "FORMAT=32-bit_rle_rgbe") == 0) valid = true;
+    }
+    if (!valid) { *err = "hdr: unsupported format (FORMAT=32-bit_rle_rgbe expected)"; return -1; }
+    if (!getToken(c, tok, sizeof tok)) { *err = "hdr: missing resolution line"; return -1; }
+    if (std::strncmp(tok, "-Y ", 3) != 0) { *err = "hdr: unsupported data layout (-Y expected)"; return -1; }
+    char* p = tok + 3;
+    const long hh = std::strtol(p, &p, 10);
+    while (*p == ' ') ++p;
+    if (std::strncmp(p, "+X ", 3) != 0) { *err = "hdr: unsupported data layout (+X expected)"; return -1; }
+    p += 3;
+    const long ww = std::strtol(p, nullptr, 10);
+    if (ww <= 0 || hh <= 0 || ww > (1 << 24) || hh > (1 << 24)) { *err = "hdr: bad image dimensions"; return -1; }
+    *w = (int)ww; *h = (int)hh; *off = c.i;
+    return 0;
+}
+
+// Expands the pixel data into w*h RGBE quadruples (host).
+int hdr_expand_rgbe(const uint8_t* f, size_t n, size_t off, int w, int h, uint8_t* rgbe, const char** err) {
+    Cursor c = { f, n, off };
+    const size_t px = (size_t)w * h;
+    auto flat = [&](size_t firstPixel) -> int {
+        const size_t need = (px - firstPixel) * 4;
+        if (c.n - c.i < need) { *err = "hdr: truncated pixel data"; return -1; }
+        std::memcpy(rgbe + firstPixel * 4, c.p + c.i, need);
+        c.i += need;
+        return 0;
+    };
+    if (w < 8 || w >= 32768) return flat(0);
+    for (int j = 0; j < h; ++j) {
+        const int c1 = c.get(), c2 = c.get(), len = c.get();
+        if (len < 0) { *err = "hdr: truncated pixel data"; return -1; }
+        if (c1 != 2 || c2 != 2 || (len & 0x80)) {
+            // not run-length encoded: these three bytes + the next one are the first pixel of flat data. stb_image takes this
+            // path with (i,j) = (1,0), i.e. it is only meaningful on the first scanline; later scanlines are corrupt.
+            if (j != 0) { *err = "hdr: scanline without run-length marker after the first"; return -1; }
+            const int c4 = c.get();
+            if (c4 < 0) { *err = "hdr: truncated pixel data"; return -1; }
+            rgbe[0] = (uint8_t)c1; rgbe[1] = (uint8_t)c2; rgbe[2] = (uint8_t)len; rgbe[3] = (uint8_t)c4;
+            return flat(1);
+        }
+        const int lo = c.get();
+        if (lo < 0) { *err = "hdr: truncated pixel data"; return -1; }
+        if (((len << 8) | lo) != w) { *err = "hdr: invalid decoded scanline length"; return -1; }
+        uint8_t* row = rgbe + (size_t)j * w * 4;
+        for (int k = 0; k < 4; ++k) {
+            int i = 0, nleft;
+            while ((nleft = w - i) > 0) {
+                int count = c.get();
+                if (count < 0) { *err = "hdr: truncated pixel data"; return -1; }
+                if (count > 128) {
+                    const int value = c.get();
+                    if (value < 0) { *err = "hdr: truncated pixel data"; return -1; }
+                    count -= 128;
+                    if (count == 0 || count > nleft) { *err = "hdr: corrupt run"; return -1; }
+                    for (int z = 0; z < count; ++z) row[(size_t)(i++) * 4 + k] = (uint8_t)value;
+                } else {
+                    if (count == 0 || count > nleft) { *err = "hdr: corrupt run"; return -1; }
+                    if (c.n - c.i < (size_t)count) { *err = "hdr: truncated pixel data"; return -1; }
+                    for (int z = 0; z < count; ++z) row[(size_t)(i++) * 4 + k] = c.p[c.i++];
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// stbi__hdr_convert, req_comp == 4: rgb * ldexp(1, e - 136), zero when e == 0, alpha 1
+__global__ __launch_bounds__(256) void k_rgbe_to_rgba32f(const uint32_t* __restrict__ rgbe, float4* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t q = rgbe[i];
+        const int e = (int)(q >> 24);
+        float4 c = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        if (e != 0) {
+            const float f1 = __builtin_ldexpf(1.0f, e - 136);       // exact, denormal below e = 10
+            c.x = (float)(q & 255u) * f1; c.y = (float)((q >> 8) & 255u) * f1; c.z = (float)((q >> 16) & 255u) * f1;
+        }
+        out[i] = c;
+    }
+}
+
+hipError_t launch_rgbe_to_rgba32f(hipStream_t s, const void* rgbe, void* out, size_t n) {
+    const size_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(k_rgbe_to_rgba32f, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, (const uint32_t*)rgbe, (float4*)out, n);
+    return hipGetLastError();
+}
+
+} // namespace vqk

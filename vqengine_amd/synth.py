@@ -255,3 +255,57 @@ def material_set(n, seed=0x3A7, max_dim=256, same_size=False):
 def ssao_image(width, height, seed=0x55A0):
     r = np.random.Generator(np.random.Philox(key=[int(seed), 0x0A]))
     return r.integers(96, 256, (height, width), dtype=np.uint8)
+
+
+# ---- Radiance .hdr files (the reference's HDRI assets, Data/EnvironmentMaps.ini) ----------------
+def float_to_rgbe(rgb):
+    """float [...,3] -> uint8 [...,4] RGBE (Ward's float2rgbe: mantissas scaled by 256/2^e of the largest channel)."""
+    rgb = np.asarray(rgb, np.float64)
+    v = rgb.max(-1)
+    out = np.zeros(rgb.shape[:-1] + (4,), np.uint8)
+    ok = v >= 1e-32
+    m, e = np.frexp(np.where(ok, v, 1.0))
+    scale = np.where(ok, m * 256.0 / np.where(ok, v, 1.0), 0.0)[..., None]
+    out[..., :3] = np.clip(np.floor(rgb * scale), 0, 255).astype(np.uint8)
+    out[..., 3] = np.where(ok, e + 128, 0).astype(np.uint8)
+    out[~ok] = 0
+    return out
+
+
+def _rle_plane(row):
+    """New-style Radiance run-length coding of one byte plane of a scanline: runs of >= 4 equal bytes, else literals <= 128."""
+    out = bytearray()
+    n, i = len(row), 0
+    while i < n:
+        run = 1
+        while i + run < n and run < 127 and row[i + run] == row[i]:
+            run += 1
+        if run >= 4:
+            out += bytes((128 + run, int(row[i])))
+            i += run
+            continue
+        j = i
+        while j < n and j - i < 128:
+            r = 1
+            while j + r < n and r < 4 and row[j + r] == row[j]:
+                r += 1
+            if r >= 4:
+                break
+            j += 1
+        out += bytes((j - i,)) + bytes(int(b) for b in row[i:j])
+        i = j
+    return bytes(out)
+
+
+def hdr_file_bytes(rgbe, rle=True, magic=b"#?RADIANCE", extra_header=(b"# synthetic", b"EXPOSURE=1.0")):
+    """A complete .hdr file for the uint8 [H,W,4] RGBE image: header + run-length coded (or flat) scanlines."""
+    h, w = rgbe.shape[:2]
+    head = magic + b"\n" + b"".join(l + b"\n" for l in extra_header) + b"FORMAT=32-bit_rle_rgbe\n\n" + b"-Y %d +X %d\n" % (h, w)
+    if not rle or w < 8 or w >= 32768:
+        return head + np.ascontiguousarray(rgbe).tobytes()
+    body = bytearray()
+    for y in range(h):
+        body += bytes((2, 2, w >> 8, w & 255))
+        for k in range(4):
+            body += _rle_plane(rgbe[y, :, k])
+    return head + bytes(body)
