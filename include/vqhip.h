@@ -442,6 +442,23 @@ VQHIP_API int vqhip_hdr_parse_header(const void* file, size_t bytes, int* width,
 VQHIP_API int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, size_t bytes,
         void* out_rgba32f, int width, int height);
 
+/* ---- FidelityFX Super Resolution 1.0 (post chain tail) ------------------------------
+ * Replace the FSR-EASU and FSR-RCAS dispatches of VQRenderer::RenderPostProcess (SceneRendering.cpp:2695-2784):
+ * Shaders/AMDFidelityFX.hlsl:FSR_EASU_CSMain / FSR_RCAS_CSMain, compiled without FSR_FP16
+ * (PipelineStateObjects.cpp:1366-1374) == FsrEasuF / FsrRcasF of Shaders/AMDFidelityFX/FSR1.0/ffx_fsr1.h.
+ * The constant blocks are exactly the reference's cbuffers: FFSR1_EASU::EASUConstantBlock[16] and
+ * FFSR1_RCAS::RCASConstantBlock[4] (PostProcess.h:114-130), filled by vqhip_fsr_easu_con / vqhip_fsr_rcas_con ==
+ * FsrEasuCon / FsrRcasCon on the CPU (PostProcess.cpp:39-79; default RCASSharpnessStops 0.2).
+ *   EASU : in (inW x inH, the tonemapper output: RGBA8_UNORM SDR or RGBA16F HDR; RGBA32F also accepted) -> out (outW x outH)
+ *   RCAS : in/out of the same size. Alpha is undefined in the reference (RWTexture2D<float3>): 1 is written. */
+VQHIP_API void vqhip_fsr_easu_con(uint32_t con[16], float inputViewportW, float inputViewportH,
+        float inputSizeW, float inputSizeH, float outputW, float outputH);
+VQHIP_API void vqhip_fsr_rcas_con(uint32_t con[4], float sharpnessStops);
+VQHIP_API int vqhip_fsr_easu(vqhip_ctx* ctx, void* stream, const void* in, int inW, int inH, vqhip_format inFmt,
+        const uint32_t con[16], void* out, int outW, int outH, vqhip_format outFmt);
+VQHIP_API int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
+        const uint32_t con[4], vqhip_format inFmt, vqhip_format outFmt);
+
 #ifdef __cplusplus
 }
 #endif

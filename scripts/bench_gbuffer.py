@@ -85,5 +85,21 @@ def main():
                       "hbm_frac": round((px * 16 + nsky * 8) / ms_band / 1e6 / 8000.0, 4)}), flush=True)
 
 
+    # FSR 1.0: 2560x1440 RGBA8 (tonemapper output) -> EASU -> 3840x2160 -> RCAS
+    iw, ih = 2560, 1440
+    src = torch.randint(0, 256, (ih, iw, 4), dtype=torch.uint8, device="cuda")
+    up = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+    fin = torch.empty_like(up)
+    econ, rcon = capi.fsr_easu_con(iw, ih, W, H), capi.fsr_rcas_con(0.2)
+    ms_e = gpu_ms(lambda: ctx.fsr_easu(src, abi.FMT_RGBA8_UNORM, W, H, con=econ, out=up))
+    ms_r = gpu_ms(lambda: ctx.fsr_rcas(up, abi.FMT_RGBA8_UNORM, con=rcon, out=fin))
+    print(json.dumps({"stage": "F4 FSR1 EASU 2560x1440 -> 3840x2160 RGBA8", "units": px, "unit": "output pixel", "gpu_ms": round(ms_e, 4),
+                      "M_units_per_s": round(px / ms_e / 1e3, 1), "algorithmic_GBps": round((px * 4 + iw * ih * 4) / ms_e / 1e6, 1),
+                      "hbm_frac": round((px * 4 + iw * ih * 4) / ms_e / 1e6 / 8000.0, 4), "note": "VALU-bound: ~450 operations per output pixel"}), flush=True)
+    print(json.dumps({"stage": "F4 FSR1 RCAS 3840x2160 RGBA8", "units": px, "unit": "pixel", "gpu_ms": round(ms_r, 4),
+                      "M_units_per_s": round(px / ms_r / 1e3, 1), "algorithmic_GBps": round(px * 8 / ms_r / 1e6, 1),
+                      "hbm_frac": round(px * 8 / ms_r / 1e6 / 8000.0, 4)}), flush=True)
+
+
 if __name__ == "__main__":
     main()

@@ -59,6 +59,10 @@ def load():
     lib.vqo_skydome.argtypes = [vp, i32, i32, C.POINTER(abi.SkydomeParams), vp, i32, vp, i32, i32, i32, i32, i32]
     lib.vqo_hdr_parse_header.argtypes = [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]
     lib.vqo_hdr_decode_rgba32f.argtypes = [C.c_char_p, sz, vp, i32, i32]
+    lib.vqo_fsr_easu_con.argtypes = [vp, f32, f32, f32, f32, f32, f32]
+    lib.vqo_fsr_rcas_con.argtypes = [vp, f32]
+    lib.vqo_fsr_easu.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, i32, i32]
+    lib.vqo_fsr_rcas.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32]
     lib.vqo_unorm8_to_float.restype = f32
     lib.vqo_unorm8_to_float.argtypes = [i32]
     if not lib.vqo_has_fma():
@@ -254,6 +258,38 @@ def hdr_decode(data):
     rc = lib.vqo_hdr_decode_rgba32f(data, len(data), _p(out), w.value, h.value)
     if rc != 0:
         raise ValueError(rc)
+    return out
+
+
+def fsr_easu_con(in_w, in_h, out_w, out_h):
+    con = np.zeros(16, np.uint32)
+    load().vqo_fsr_easu_con(_p(con), in_w, in_h, in_w, in_h, out_w, out_h)
+    return con
+
+
+def fsr_rcas_con(stops=0.2):
+    con = np.zeros(4, np.uint32)
+    load().vqo_fsr_rcas_con(_p(con), stops)
+    return con
+
+
+def fsr_easu(img, in_fmt, out_w, out_h, out_fmt=None, con=None, nthreads=0):
+    out_fmt = in_fmt if out_fmt is None else out_fmt
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    con = fsr_easu_con(w, h, out_w, out_h) if con is None else np.ascontiguousarray(con, np.uint32)
+    out = np_image(out_h, out_w, out_fmt)
+    assert load().vqo_fsr_easu(_p(img), w, h, in_fmt, _p(con), _p(out), out_w, out_h, out_fmt, nthreads) == 0
+    return out
+
+
+def fsr_rcas(img, in_fmt, out_fmt=None, con=None, nthreads=0):
+    out_fmt = in_fmt if out_fmt is None else out_fmt
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    con = fsr_rcas_con() if con is None else np.ascontiguousarray(con, np.uint32)
+    out = np_image(h, w, out_fmt)
+    assert load().vqo_fsr_rcas(_p(img), _p(out), w, h, _p(con), in_fmt, out_fmt, nthreads) == 0
     return out
 
 

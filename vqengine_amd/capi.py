@@ -64,6 +64,10 @@ def load_library():
         "vqhip_skydome": (i32, [vp, vp, vp, i32, i32, C.POINTER(abi.SkydomeParams), C.POINTER(abi.Interpolants), vp, i32, i32, i32, i32]),
         "vqhip_hdr_parse_header": (i32, [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]),
         "vqhip_hdr_decode_rgba32f": (i32, [vp, vp, C.c_char_p, sz, vp, i32, i32]),
+        "vqhip_fsr_easu_con": (None, [C.POINTER(C.c_uint32), f32, f32, f32, f32, f32, f32]),
+        "vqhip_fsr_rcas_con": (None, [C.POINTER(C.c_uint32), f32]),
+        "vqhip_fsr_easu": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(C.c_uint32), vp, i32, i32, i32]),
+        "vqhip_fsr_rcas": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(C.c_uint32), i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -81,7 +85,22 @@ EXPORTED_SYMBOLS = [
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
     "vqhip_skydome", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
+    "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas",
 ]
+
+
+def fsr_easu_con(in_w, in_h, out_w, out_h, container_w=None, container_h=None):
+    """FFSR1_EASU::UpdateEASUConstantBlock (PostProcess.cpp:47-79): the 16-dword EASU cbuffer. Host-only."""
+    con = (C.c_uint32 * 16)()
+    load_library().vqhip_fsr_easu_con(con, in_w, in_h, container_w or in_w, container_h or in_h, out_w, out_h)
+    return con
+
+
+def fsr_rcas_con(sharpness_stops=0.2):
+    """FFSR1_RCAS::UpdateRCASConstantBlock (PostProcess.cpp:39-45; default RCASSharpnessStops 0.2, PostProcess.h:129)."""
+    con = (C.c_uint32 * 4)()
+    load_library().vqhip_fsr_rcas_con(con, sharpness_stops)
+    return con
 
 
 def hdr_parse_header(data):
@@ -267,6 +286,29 @@ class Context:
         n = len(materials) if materials is not None else 0
         self._ck(self.lib.vqhip_gbuffer_from_materials(self._h, self._stream(stream), C.byref(inter), materials if n else None, n,
                                                        float(ambient), C.byref(s) if s is not None else None, C.byref(gbuf)))
+        return out
+
+    # ---- FSR 1.0 (SceneRendering.cpp:2695-2784) -----------------------------------------------
+    def fsr_easu(self, src, in_fmt, out_w, out_h, out_fmt=None, con=None, out=None, stream=None):
+        _check_img(src, in_fmt, "src")
+        out_fmt = in_fmt if out_fmt is None else out_fmt
+        h, w = src.shape[0], src.shape[1]
+        con = fsr_easu_con(w, h, out_w, out_h) if con is None else con
+        if out is None:
+            out = empty_image(out_h, out_w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out")
+        self._ck(self.lib.vqhip_fsr_easu(self._h, self._stream(stream), _ptr(src), w, h, in_fmt, con, _ptr(out), out_w, out_h, out_fmt))
+        return out
+
+    def fsr_rcas(self, src, in_fmt, out_fmt=None, con=None, out=None, stream=None):
+        _check_img(src, in_fmt, "src")
+        out_fmt = in_fmt if out_fmt is None else out_fmt
+        h, w = src.shape[0], src.shape[1]
+        con = fsr_rcas_con() if con is None else con
+        if out is None:
+            out = empty_image(h, w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out")
+        self._ck(self.lib.vqhip_fsr_rcas(self._h, self._stream(stream), _ptr(src), _ptr(out), w, h, con, in_fmt, out_fmt))
         return out
 
     # ---- HDRI ingest (Image::LoadFromFile -> stbi_loadf, TextureManager.cpp:566) ----------------

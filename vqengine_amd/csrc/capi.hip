@@ -372,6 +372,54 @@ int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, siz
     return VQHIP_OK;
 }
 
+// ---- FSR 1.0 ------------------------------------------------------------------------
+static uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+
+// FsrEasuCon, ffx_fsr1.h:156-203, as called on the CPU by FFSR1_EASU::UpdateEASUConstantBlock (PostProcess.cpp:47-79)
+void vqhip_fsr_easu_con(uint32_t con[16], float inVpW, float inVpH, float inSzW, float inSzH, float outW, float outH) {
+    const float rOutW = 1.0f / outW, rOutH = 1.0f / outH, rInW = 1.0f / inSzW, rInH = 1.0f / inSzH;
+    con[0] = fbits(inVpW * rOutW);                 con[1] = fbits(inVpH * rOutH);
+    con[2] = fbits(0.5f * inVpW * rOutW - 0.5f);   con[3] = fbits(0.5f * inVpH * rOutH - 0.5f);
+    con[4] = fbits(rInW);                          con[5] = fbits(rInH);
+    con[6] = fbits(1.0f * rInW);                   con[7] = fbits(-1.0f * rInH);
+    con[8] = fbits(-1.0f * rInW);                  con[9] = fbits(2.0f * rInH);
+    con[10] = fbits(1.0f * rInW);                  con[11] = fbits(2.0f * rInH);
+    con[12] = fbits(0.0f * rInW);                  con[13] = fbits(4.0f * rInH);
+    con[14] = con[15] = 0;
+}
+// FsrRcasCon, ffx_fsr1.h:662-674 (FFSR1_RCAS::UpdateRCASConstantBlock, PostProcess.cpp:39-45)
+void vqhip_fsr_rcas_con(uint32_t con[4], float sharpnessStops) {
+    const float s = exp2f(-sharpnessStops);
+    const _Float16 hs = (_Float16)s;
+    uint16_t hb; std::memcpy(&hb, &hs, 2);
+    con[0] = fbits(s); con[1] = (uint32_t)hb | ((uint32_t)hb << 16); con[2] = 0; con[3] = 0;
+}
+
+static bool isColorFmt(int f) { return f == VQHIP_FMT_RGBA32F || f == VQHIP_FMT_RGBA16F || f == VQHIP_FMT_RGBA8_UNORM; }
+
+int vqhip_fsr_easu(vqhip_ctx* ctx, void* stream, const void* in, int inW, int inH, vqhip_format inFmt, const uint32_t con[16],
+                   void* out, int outW, int outH, vqhip_format outFmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "fsr_easu: ctx is NULL");
+    if (!in || !out || !con || inW <= 0 || inH <= 0 || outW <= 0 || outH <= 0 || inW >= (1 << 24) || outW >= (1 << 24))
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "fsr_easu: bad argument");
+    if (!isColorFmt(inFmt) || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "fsr_easu: formats must be RGBA8_UNORM, RGBA16F or RGBA32F");
+    if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "fsr_easu: in-place is not supported");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_fsr_easu((hipStream_t)stream, in, inW, inH, inFmt, con, out, outW, outH, outFmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "fsr_easu launch");
+}
+
+int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height, const uint32_t con[4],
+                   vqhip_format inFmt, vqhip_format outFmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "fsr_rcas: ctx is NULL");
+    if (!in || !out || !con || width <= 0 || height <= 0 || width >= (1 << 24)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "fsr_rcas: bad argument");
+    if (!isColorFmt(inFmt) || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "fsr_rcas: formats must be RGBA8_UNORM, RGBA16F or RGBA32F");
+    if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "fsr_rcas: in-place is not supported");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_fsr_rcas((hipStream_t)stream, in, out, width, height, con, inFmt, outFmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "fsr_rcas launch");
+}
+
 int vqhip_specular_mip_count(int spec_res0) { return vqhip_mip_level_count(spec_res0, spec_res0) - 1; }
 size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt) {
     const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;

@@ -60,6 +60,10 @@ int hdr_parse_header(const uint8_t* f, size_t n, int* w, int* h, size_t* off, co
 int hdr_expand_rgbe(const uint8_t* f, size_t n, size_t off, int w, int h, uint8_t* rgbe, const char** err);
 hipError_t launch_rgbe_to_rgba32f(hipStream_t s, const void* rgbe, void* out, size_t n);
 
+// FSR 1.0 (§8f.4, fsr.hip)
+hipError_t launch_fsr_easu(hipStream_t s, const void* in, int inW, int inH, int inFmt, const uint32_t* con16, void* out, int outW, int outH, int outFmt);
+hipError_t launch_fsr_rcas(hipStream_t s, const void* in, void* out, int W, int H, const uint32_t* con4, int inFmt, int outFmt);
+
 // launchers (each returns the hipError_t of the launch)
 hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt);
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt);
