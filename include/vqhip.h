@@ -459,6 +459,15 @@ VQHIP_API int vqhip_fsr_easu(vqhip_ctx* ctx, void* stream, const void* in, int i
 VQHIP_API int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
         const uint32_t con[4], vqhip_format inFmt, vqhip_format outFmt);
 
+/* Replaces the debug-visualisation dispatch of RenderPostProcess (SceneRendering.cpp:2541-2576) == Visualization.hlsl:CSMain
+ * :34-120. VQ_VizParams == FPostProcessParameters::FVizualizationParams (the cbuffer :26-31); iDrawMode uses the SHADER's
+ * numbering (:71-80): 1 DEPTH pow(r,500), 2 NORMALS, 3 ROUGHNESS / 4 METALLIC (alpha), 5 AO (red), 6 ALBEDO / 7 REFLECTIONS
+ * (rgb), 8 MOTION_VECTORS; anything else (including 0) writes magenta. Output alpha = input alpha. The caller binds the
+ * image the reference's switch selects (:2555-2565); single-channel sources are passed expanded to (r,0,0,1). */
+typedef struct VQ_VizParams { int32_t iDrawMode; int32_t iUnpackNormals; float fInputStrength; } VQ_VizParams;
+VQHIP_API int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
+        const VQ_VizParams* params, vqhip_format inFmt, vqhip_format outFmt);
+
 #ifdef __cplusplus
 }
 #endif

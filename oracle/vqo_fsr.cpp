@@ -202,6 +202,38 @@ int vqo_fsr_easu(const void* in, int inW, int inH, int inFmt, const uint32_t* co
         for (int x = 0; x < outW; ++x) store(out, (size_t)y * outW + x, outFmt, Easu(im, x, y, con));
     return 0;
 }
+// Visualization.hlsl:CSMain :34-120 (dispatched at SceneRendering.cpp:2541-2576). pow(x, 500) = exp2(500*log2(x)).
+int vqo_visualize(const void* in, void* out, int W, int H, const VQ_VizParams* p, int inFmt, int outFmt, int nthreads) {
+    if (!in || !out || !p) return -1;
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const size_t i = (size_t)y * W + x;
+            f4 t;
+            if (inFmt == VQHIP_FMT_RGBA32F) { const float* q = (const float*)in + i * 4; t = { q[0], q[1], q[2], q[3] }; }
+            else if (inFmt == VQHIP_FMT_RGBA16F) { const uint16_t* q = (const uint16_t*)in + i * 4; t = { f16_to_f32(q[0]), f16_to_f32(q[1]), f16_to_f32(q[2]), f16_to_f32(q[3]) }; }
+            else { const uint8_t* q = (const uint8_t*)in + i * 4; const float s = rcp(255.0f); t = { q[0] * s, q[1] * s, q[2] * s, q[3] * s }; }
+            f3 o;
+            switch (p->iDrawMode) {
+                case 1: { const float d = pow_(t.x, 500.0f); o = { d, d, d }; } break;
+                case 2: {
+                    const float u = (float)p->iUnpackNormals, k = (float)(1 - p->iUnpackNormals);
+                    o = { ((t.x - 0.5f) * 2.0f) * u + k * t.x, ((t.y - 0.5f) * 2.0f) * u + k * t.y, ((t.z - 0.5f) * 2.0f) * u + k * t.z };
+                } break;
+                case 3: case 4: o = { t.w, t.w, t.w }; break;
+                case 5: o = { t.x, t.x, t.x }; break;
+                case 6: case 7: o = { t.x, t.y, t.z }; break;
+                case 8: o = { (t.x * 0.5f) * p->fInputStrength + 0.5f, (t.y * -0.5f) * p->fInputStrength + 0.5f, 0.0f + 0.5f }; break;
+                default: o = { 1.0f, 0.0f, 1.0f }; break;
+            }
+            if (outFmt == VQHIP_FMT_RGBA32F) { float* q = (float*)out + i * 4; q[0] = o.x; q[1] = o.y; q[2] = o.z; q[3] = t.w; }
+            else if (outFmt == VQHIP_FMT_RGBA16F) { uint16_t* q = (uint16_t*)out + i * 4; q[0] = f32_to_f16(o.x); q[1] = f32_to_f16(o.y); q[2] = f32_to_f16(o.z); q[3] = f32_to_f16(t.w); }
+            else { uint8_t* q = (uint8_t*)out + i * 4; q[0] = f32_to_unorm8(o.x); q[1] = f32_to_unorm8(o.y); q[2] = f32_to_unorm8(o.z); q[3] = f32_to_unorm8(t.w); }
+        }
+    return 0;
+}
+
 int vqo_fsr_rcas(const void* in, void* out, int W, int H, const uint32_t* con, int inFmt, int outFmt, int nthreads) {
     if (!in || !out || !con) return -1;
     if (nthreads <= 0) nthreads = omp_get_max_threads();

@@ -261,6 +261,17 @@ def hdr_decode(data):
     return out
 
 
+def visualize(img, in_fmt, params, out_fmt=None, nthreads=0):
+    lib = load()
+    lib.vqo_visualize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(abi.VizParams), C.c_int, C.c_int, C.c_int]
+    out_fmt = in_fmt if out_fmt is None else out_fmt
+    img = np.ascontiguousarray(img)
+    h, w = img.shape[:2]
+    out = np_image(h, w, out_fmt)
+    assert lib.vqo_visualize(_p(img), _p(out), w, h, C.byref(params), in_fmt, out_fmt, nthreads) == 0
+    return out
+
+
 def fsr_easu_con(in_w, in_h, out_w, out_h):
     con = np.zeros(16, np.uint32)
     load().vqo_fsr_easu_con(_p(con), in_w, in_h, in_w, in_h, out_w, out_h)

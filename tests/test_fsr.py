@@ -195,6 +195,32 @@ def test_easu_properties():
     assert o16.dtype == np.float16 and np.all(o16[..., 3] == 1.0)
 
 
+def test_visualization_modes_closed_form():
+    """Visualization.hlsl:34-120 — every draw mode against its closed form (numpy float32, same operation order)."""
+    r = np.random.default_rng(8)
+    img = r.random((9, 13, 4), dtype=F)
+    img[0, 0] = (1.0, 0.0, 0.5, 0.25)
+    V = lambda m, u=0, s=1.0: O.visualize(img, abi.FMT_RGBA32F, abi.VizParams(m, u, s))
+    lib = O.load(); lib.vqo_pow.restype = O.C.c_float; lib.vqo_pow.argtypes = [O.C.c_float, O.C.c_float]
+    d = V(1)
+    exp = np.array([[lib.vqo_pow(float(v), 500.0) for v in row] for row in img[..., 0]], F)
+    assert np.array_equal(d[..., 0], exp) and np.array_equal(d[..., 1], exp) and np.array_equal(d[..., 3], img[..., 3])
+    np.testing.assert_allclose(d[1:, :, 0], img[1:, :, 0].astype(np.float64) ** 500, rtol=2e-3, atol=1e-37)     # 500*log2 amplifies the log error
+    assert d[0, 0, 0] == 1.0
+    assert np.array_equal(V(2, 0)[..., :3], (img[..., :3] - F(0.5)) * F(2) * F(0) + F(1) * img[..., :3])
+    assert np.array_equal(V(2, 1)[..., :3], (img[..., :3] - F(0.5)) * F(2) * F(1) + F(0) * img[..., :3])
+    for m in (3, 4):
+        assert np.array_equal(V(m)[..., :3], np.repeat(img[..., 3:4], 3, -1))
+    assert np.array_equal(V(5)[..., :3], np.repeat(img[..., 0:1], 3, -1))
+    for m in (6, 7):
+        assert np.array_equal(V(m)[..., :3], img[..., :3])
+    mv = V(8, 0, 3.5)
+    assert np.array_equal(mv[..., 0], (img[..., 0] * F(0.5)) * F(3.5) + F(0.5)) and np.array_equal(mv[..., 1], (img[..., 1] * F(-0.5)) * F(3.5) + F(0.5))
+    assert np.all(mv[..., 2] == 0.5)
+    for m in (0, 9, -1):
+        assert np.all(V(m)[..., :3] == np.array([1, 0, 1], F))
+
+
 def test_rcas_sharpens_an_edge_and_keeps_flat_regions():
     img = np.ones((16, 32, 4), F); img[..., :3] = 0.25; img[:, 16:, :3] = 0.75
     out = O.fsr_rcas(img, abi.FMT_RGBA32F, con=O.fsr_rcas_con(0.0))

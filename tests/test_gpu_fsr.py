@@ -76,6 +76,17 @@ def test_fsr_full_size_properties(ctx):
     assert np.array_equal(fin, O.fsr_rcas(ref, abi.FMT_RGBA8_UNORM))
 
 
+@pytest.mark.parametrize("in_fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM])
+@pytest.mark.parametrize("out_fmt", [abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM])
+def test_visualize_matches_oracle(ctx, in_fmt, out_fmt):
+    r = np.random.default_rng(4)
+    img = _as(r.random((37, 129, 4), dtype=np.float32), in_fmt)
+    for mode, unpack, strength in ((1, 0, 1.0), (2, 0, 1.0), (2, 1, 1.0), (3, 0, 1.0), (4, 0, 1.0), (5, 0, 1.0), (6, 0, 1.0), (7, 0, 1.0), (8, 0, 7.25), (0, 0, 1.0), (42, 0, 1.0)):
+        p = abi.VizParams(mode, unpack, strength)
+        n, idx = O.bits_equal(ctx.visualize(dev(img), in_fmt, p, out_fmt).cpu().numpy(), O.visualize(img, in_fmt, p, out_fmt))
+        assert n == 0, (mode, n, idx)
+
+
 def test_fsr_abi_errors(ctx):
     lib = ctx.lib
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -136,6 +136,10 @@ class SSAO(C.Structure):  # vqhip_ssao
     _fields_ = [("texels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
 
 
+class VizParams(C.Structure):  # VQ_VizParams == FPostProcessParameters::FVizualizationParams (Visualization.hlsl:26-31)
+    _fields_ = [("iDrawMode", C.c_int32), ("iUnpackNormals", C.c_int32), ("fInputStrength", C.c_float)]
+
+
 class SkydomeParams(C.Structure):  # VQ_SkydomeParams
     _fields_ = [("right", float3), ("tanHalfFovX", C.c_float), ("up", float3), ("tanHalfFovY", C.c_float),
                 ("forward", float3), ("pad", C.c_float)]

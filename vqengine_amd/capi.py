@@ -68,6 +68,7 @@ def load_library():
         "vqhip_fsr_rcas_con": (None, [C.POINTER(C.c_uint32), f32]),
         "vqhip_fsr_easu": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(C.c_uint32), vp, i32, i32, i32]),
         "vqhip_fsr_rcas": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(C.c_uint32), i32, i32]),
+        "vqhip_visualize": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.VizParams), i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -85,7 +86,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
     "vqhip_skydome", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
-    "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas",
+    "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize",
 ]
 
 
@@ -309,6 +310,17 @@ class Context:
             out = empty_image(h, w, out_fmt, self.device)
         _check_img(out, out_fmt, "out")
         self._ck(self.lib.vqhip_fsr_rcas(self._h, self._stream(stream), _ptr(src), _ptr(out), w, h, con, in_fmt, out_fmt))
+        return out
+
+    def visualize(self, src, in_fmt, params, out_fmt=None, out=None, stream=None):
+        """Visualization.hlsl:CSMain (debug draw modes). params: abi.VizParams."""
+        _check_img(src, in_fmt, "src")
+        out_fmt = in_fmt if out_fmt is None else out_fmt
+        h, w = src.shape[0], src.shape[1]
+        if out is None:
+            out = empty_image(h, w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out")
+        self._ck(self.lib.vqhip_visualize(self._h, self._stream(stream), _ptr(src), _ptr(out), w, h, C.byref(params), in_fmt, out_fmt))
         return out
 
     # ---- HDRI ingest (Image::LoadFromFile -> stbi_loadf, TextureManager.cpp:566; SURVEY.md §8f.3) ----------------

@@ -420,6 +420,16 @@ int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void* out, int 
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "fsr_rcas launch");
 }
 
+int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height, const VQ_VizParams* params,
+                    vqhip_format inFmt, vqhip_format outFmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "visualize: ctx is NULL");
+    if (!in || !out || !params || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "visualize: bad argument");
+    if (!isColorFmt(inFmt) || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "visualize: formats must be RGBA8_UNORM, RGBA16F or RGBA32F");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_visualize((hipStream_t)stream, in, out, width, height, *params, inFmt, outFmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "visualize launch");
+}
+
 int vqhip_specular_mip_count(int spec_res0) { return vqhip_mip_level_count(spec_res0, spec_res0) - 1; }
 size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt) {
     const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;

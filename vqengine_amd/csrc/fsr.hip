@@ -150,6 +150,52 @@ __global__ __launch_bounds__(256) void k_fsr_rcas(const void* __restrict__ in, v
     store_rgb1<OUTFMT>(out, __umul24(y, W) + (uint32_t)x, pix);
 }
 
+// ---- Visualization.hlsl:CSMain :34-120 (debug draw modes, SceneRendering.cpp:2541-2576): a per-pixel switch, HBM-bound ----
+template <int INFMT, int OUTFMT>
+__global__ __launch_bounds__(256) void k_visualize(const void* __restrict__ in, void* __restrict__ out, uint32_t n, VQ_VizParams p) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 t;
+    if (INFMT == VQHIP_FMT_RGBA32F) t = ((const float4*)in)[i];
+    else if (INFMT == VQHIP_FMT_RGBA16F) t = load_rgba16f(in, i);
+    else { const uint32_t q = ((const uint32_t*)in)[i]; const float s = 0.0039215688593685627f;
+           t = make_float4((float)(q & 255u) * s, (float)((q >> 8) & 255u) * s, (float)((q >> 16) & 255u) * s, (float)(q >> 24) * s); }
+    f3 o;
+    switch (p.iDrawMode) {
+        case 1: { const float d = pow_(t.x, 500.0f); o = mk3(d, d, d); } break;
+        case 2: {
+            const float u = (float)p.iUnpackNormals, k = (float)(1 - p.iUnpackNormals);
+            o = mk3(((t.x - 0.5f) * 2.0f) * u + k * t.x, ((t.y - 0.5f) * 2.0f) * u + k * t.y, ((t.z - 0.5f) * 2.0f) * u + k * t.z);
+        } break;
+        case 3: case 4: o = mk3(t.w, t.w, t.w); break;
+        case 5: o = mk3(t.x, t.x, t.x); break;
+        case 6: case 7: o = mk3(t.x, t.y, t.z); break;
+        case 8: o = mk3((t.x * 0.5f) * p.fInputStrength + 0.5f, (t.y * -0.5f) * p.fInputStrength + 0.5f, 0.0f + 0.5f); break;
+        default: o = mk3(1.0f, 0.0f, 1.0f); break;
+    }
+    const float4 r = make_float4(o.x, o.y, o.z, t.w);
+    if (OUTFMT == VQHIP_FMT_RGBA32F) ((float4*)out)[i] = r;
+    else if (OUTFMT == VQHIP_FMT_RGBA16F) store_rgba16f(out, i, r);
+    else store_rgba8(out, i, r);
+}
+template <int INFMT> static hipError_t viz_out(hipStream_t s, const void* in, void* out, uint32_t n, const VQ_VizParams& p, int outFmt) {
+    dim3 grid((n + 255) / 256);
+    switch (outFmt) {
+        case VQHIP_FMT_RGBA32F: hipLaunchKernelGGL((k_visualize<INFMT, VQHIP_FMT_RGBA32F>), grid, dim3(256), 0, s, in, out, n, p); break;
+        case VQHIP_FMT_RGBA16F: hipLaunchKernelGGL((k_visualize<INFMT, VQHIP_FMT_RGBA16F>), grid, dim3(256), 0, s, in, out, n, p); break;
+        default:                hipLaunchKernelGGL((k_visualize<INFMT, VQHIP_FMT_RGBA8_UNORM>), grid, dim3(256), 0, s, in, out, n, p); break;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_visualize(hipStream_t s, const void* in, void* out, int W, int H, const VQ_VizParams& p, int inFmt, int outFmt) {
+    const uint32_t n = (uint32_t)W * (uint32_t)H;
+    switch (inFmt) {
+        case VQHIP_FMT_RGBA32F: return viz_out<VQHIP_FMT_RGBA32F>(s, in, out, n, p, outFmt);
+        case VQHIP_FMT_RGBA16F: return viz_out<VQHIP_FMT_RGBA16F>(s, in, out, n, p, outFmt);
+        default:                return viz_out<VQHIP_FMT_RGBA8_UNORM>(s, in, out, n, p, outFmt);
+    }
+}
+
 template <int INFMT> static hipError_t easu_out(hipStream_t s, const void* in, int inW, int inH, const EasuCon& con, void* out, int outW, int outH, int outFmt) {
     dim3 grid((outW + 255) / 256, outH);
     switch (outFmt) {
