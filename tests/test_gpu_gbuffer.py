@@ -64,6 +64,33 @@ def test_gbuffer_producer_many_materials_per_wave(ctx):
     assert len(np.unique(idx)) >= 17
 
 
+def test_gbuffer_producer_fuzz_adversarial_inputs(ctx):
+    """Interpolants made of random bit patterns, NaN / inf / denormals, zero and huge uv, zero normals and tangents: the HIP
+    kernel and the oracle must still agree bit for bit (NaN == NaN)."""
+    W, H, NM = 192, 64, 6
+    r = np.random.default_rng(99)
+    ip = [p.copy() for p in synth.interpolants(W, H, NM)]
+    idx = ip[2][..., 3].copy()
+    specials = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-45, -1e-40, 1e30, -1e30, 3.4e38, 1e-30, 0.5, 1.0, 255.0, 65536.0], np.float32)
+    for k in range(3):
+        flat = ip[k].reshape(-1)
+        sel = r.random(flat.size) < 0.15
+        flat[sel] = r.integers(0, 2 ** 32, int(sel.sum()), dtype=np.uint32).view(np.float32)        # arbitrary bit patterns
+        sel = r.random(flat.size) < 0.10
+        flat[sel] = specials[r.integers(0, len(specials), int(sel.sum()))]
+    ip[1][10:14, :, :3] = 0.0                                                                         # zero normals
+    ip[2][20:24, :, :3] = 0.0                                                                         # zero tangents
+    ip[2][..., 3] = idx                                                                               # keep material indices valid
+    datas, host_chains, hmats, dmats, keep = build_materials(ctx, NM, max_dim=64)
+    ref = O.gbuffer_from_materials(ip, hmats, 0.055, None)
+    got = ctx.gbuffer_from_materials([dev(p) for p in ip], dmats, 0.055, None)
+    for k in range(4):
+        g = got[k].cpu().numpy()
+        n, where = O.bits_equal(g, ref[k])
+        assert n == 0, f"gb{k}: {n} mismatches; first {where.tolist()} gpu={[g[tuple(i)] for i in where]} ref={[ref[k][tuple(i)] for i in where]}"
+    assert np.isnan(ref[1]).any()                      # the fuzz really reached the NaN paths
+
+
 def test_gbuffer_producer_feeds_forward_lighting(ctx):
     """Producer -> shade chain on the GPU equals the oracle's chain (planes handed over without leaving HBM)."""
     W, H = 320, 200
