@@ -527,7 +527,7 @@ int vqo_gaussian_blur_pass(const void* in, void* out, int W, int H, int fmt, int
                     else { sy = sy < 0 ? 0 : (sy > H - 1 ? H - 1 : sy); s = load_px(in, (size_t)sy * W + x, fmt); }
                 }
                 const float w = KERNEL_WEIGHTS[ki];
-                acc = { acc.x + s.x * w, acc.y + s.y * w, acc.z + s.z * w };      // OutRGB += rgb * KERNEL_WEIGHTS[i]
+                acc = { fma_(s.x, w, acc.x), fma_(s.y, w, acc.y), fma_(s.z, w, acc.z) };   // OutRGB += rgb * KERNEL_WEIGHTS[i], one mad (contract v2)
             }
             store_px(out, (size_t)y * W + x, fmt, { acc.x, acc.y, acc.z, 1.0f });
         }

@@ -5,7 +5,8 @@
 // "naive" blur re-reads 21 texels per output from the texture cache (PipelineStateObjects.cpp:1321);
 // here the X pass stages a row segment + halo in LDS once, and the Y pass keeps a 36-row register
 // window per column (16 outputs per lane) so each input row is fetched 36/16 times from L2, once from HBM.
-// Accumulation order is the HLSL's: kernelIt = 0..20 i.e. offset -10..+10, acc = acc + rgb*w (no FMA).
+// Accumulation order is the HLSL's: kernelIt = 0..20 i.e. offset -10..+10; each `OutRGB += rgb * w` is one mad,
+// acc = fma(rgb, w, acc) (arithmetic contract v2: halves the VALU work of the two HBM-bound passes).
 #include "vq_internal.h"
 #include "vq_devmath.h"
 
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void k_blur_x(const void* __restrict__ in, voi
         const int off = it - R;
         const float w = kW[off < 0 ? -off : off];
         const float4 s = tile[t + it];
-        ax = ax + s.x * w; ay = ay + s.y * w; az = az + s.z * w;
+        ax = fma_(s.x, w, ax); ay = fma_(s.y, w, ay); az = fma_(s.z, w, az);
     }
     store_px<FMT>(out, row + x, make_float4(ax, ay, az, 1.0f));
 }
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, vo
         for (int it = 0; it < 21; ++it) {
             const int off = it - R;
             const float w = kW[off < 0 ? -off : off];
-            ax = ax + wx[j + it] * w; ay = ay + wy[j + it] * w; az = az + wz[j + it] * w;
+            ax = fma_(wx[j + it], w, ax); ay = fma_(wy[j + it], w, ay); az = fma_(wz[j + it], w, az);
         }
         store_px<FMT>(out, row + xb + j, make_float4(ax, ay, az, 1.0f));
     }
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_blur_y(const void* __restrict__ in, voi
         for (int it = 0; it < 21; ++it) {
             const int off = it - R;
             const float w = kW[off < 0 ? -off : off];
-            ax = ax + wx[r + it] * w; ay = ay + wy[r + it] * w; az = az + wz[r + it] * w;
+            ax = fma_(wx[r + it], w, ax); ay = fma_(wy[r + it], w, ay); az = fma_(wz[r + it], w, az);
         }
         store_px<FMT>(out, (size_t)(yBase + r) * W + x, make_float4(ax, ay, az, 1.0f));
     }
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(256) void k_blur_y_tonemap(const void* __restrict__
         for (int it = 0; it < 21; ++it) {
             const int off = it - R;
             const float w = kW[off < 0 ? -off : off];
-            ax = ax + wx[r + it] * w; ay = ay + wy[r + it] * w; az = az + wz[r + it] * w;
+            ax = fma_(wx[r + it], w, ax); ay = fma_(wy[r + it], w, ay); az = fma_(wz[r + it], w, az);
         }
         float4 b = make_float4(ax, ay, az, 1.0f);
         if (!TM) { store_px<OUTFMT>(out, (size_t)(yBase + r) * W + x, b); continue; }                     // plain CSMain_Y (OUTFMT == FMT)
