@@ -7,6 +7,7 @@
 // window per column (16 outputs per lane) so each input row is fetched 36/16 times from L2, once from HBM.
 // Accumulation order is the HLSL's: kernelIt = 0..20 i.e. offset -10..+10; each `OutRGB += rgb * w` is one mad,
 // acc = fma(rgb, w, acc) (arithmetic contract v2: halves the VALU work of the two HBM-bound passes).
+#include <type_traits>
 #include "vq_internal.h"
 #include "vq_devmath.h"
 
@@ -82,6 +83,64 @@ __global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, vo
             ax = fma_(wx[j + it], w, ax); ay = fma_(wy[j + it], w, ay); az = fma_(wz[j + it], w, az);
         }
         store_px<FMT>(out, row + xb + j, make_float4(ax, ay, az, 1.0f));
+    }
+}
+
+// Same arithmetic as k_blur_x4, software-pipelined: a persistent workgroup walks over 1024-pixel row segments and issues the
+// global loads of segment n+1 (5 pixels per lane, kept in registers) before it filters segment n out of LDS, so the HBM
+// latency of the next tile hides behind the 252 mads of the current one instead of adding to them.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_blur_x4p(const void* __restrict__ in, void* __restrict__ out, int W, int H, int segsPerRow, int nSeg) {
+    constexpr int PXB = (FMT == 0) ? 16 : 8;
+    constexpr int NPX = 1024 + 2 * R;
+    using px_t = typename std::conditional<FMT == 0, float4, h4>::type;
+    __shared__ __attribute__((aligned(16))) unsigned char tile[(NPX + NPX / 4 + 4) * PXB];
+    const int t = threadIdx.x;
+    px_t pre[5];
+    auto fetch = [&](int seg) {
+        const int y = seg / segsPerRow, x0 = (seg - y * segsPerRow) * 1024;
+        const size_t row = (size_t)y * W;
+        #pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = t + 256 * j;
+            if (i < NPX) pre[j] = ((const px_t*)in)[row + min(max(x0 - R + i, 0), W - 1)];      // clamp(sampleCoord.x, 0, iImageSize.x - 1) :143
+        }
+    };
+    int seg = blockIdx.x;
+    if (seg < nSeg) fetch(seg);
+    for (; seg < nSeg; seg += gridDim.x) {
+        #pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int i = t + 256 * j;
+            if (i < NPX) ((px_t*)tile)[i + (i >> 2)] = pre[j];
+        }
+        __syncthreads();
+        if (seg + (int)gridDim.x < nSeg) fetch(seg + gridDim.x);
+        const int y = seg / segsPerRow, x0 = (seg - y * segsPerRow) * 1024;
+        const size_t row = (size_t)y * W;
+        const int xb = x0 + 4 * t;
+        if (xb < W) {                                       // early out :129
+            float wx[24], wy[24], wz[24];
+            #pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                const int p = 4 * t + k;
+                const float4 s = load_px<FMT>(tile, (size_t)(p + (p >> 2)));
+                wx[k] = s.x; wy[k] = s.y; wz[k] = s.z;
+            }
+            #pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (xb + j >= W) break;
+                float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                #pragma unroll
+                for (int it = 0; it < 21; ++it) {
+                    const int off = it - R;
+                    const float w = kW[off < 0 ? -off : off];
+                    ax = fma_(wx[j + it], w, ax); ay = fma_(wy[j + it], w, ay); az = fma_(wz[j + it], w, az);
+                }
+                store_px<FMT>(out, row + xb + j, make_float4(ax, ay, az, 1.0f));
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -263,7 +322,18 @@ hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H,
 #ifndef VQ_BLUR_X4
 #define VQ_BLUR_X4 1
 #endif
-#if VQ_BLUR_X4
+#ifndef VQ_BLUR_XP
+#define VQ_BLUR_XP 1
+#endif
+#ifndef VQ_BLUR_XP_WGS
+#define VQ_BLUR_XP_WGS 2048      // persistent workgroups (A/B at 4K, blur X+Y in the chain: non-persistent 65.1 us, 512: 64.1, 1024: 62.3, 2048: 61.2)
+#endif
+#if VQ_BLUR_XP
+    const int segsPerRow = (W + 1023) / 1024, nSeg = segsPerRow * H;
+    const int wgs = nSeg < VQ_BLUR_XP_WGS ? nSeg : VQ_BLUR_XP_WGS;
+    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4p<0>), dim3(wgs), dim3(256), 0, s, in, out, W, H, segsPerRow, nSeg);
+    else                          hipLaunchKernelGGL((k_blur_x4p<1>), dim3(wgs), dim3(256), 0, s, in, out, W, H, segsPerRow, nSeg);
+#elif VQ_BLUR_X4
     dim3 grid((W + 1023) / 1024, H);
     if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4<0>), grid, dim3(256), 0, s, in, out, W, H);
     else                          hipLaunchKernelGGL((k_blur_x4<1>), grid, dim3(256), 0, s, in, out, W, H);
