@@ -7,6 +7,7 @@
 #include <string>
 #include <vector>
 #include "vq_internal.h"
+#include "vq_devmath.h"      // vqd::sincos_ is __host__ __device__: frame-uniform trigonometry is evaluated here, once
 
 using namespace vqk;
 
@@ -157,6 +158,7 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
     if (env) fc->env = *env;
     if (sm) fc->sm = *sm;
     fc->hasEnv = env ? 1 : 0;
+    vqd::sincos_(-perFrame->fHDRIOffsetInRadians, &fc->hdriSin, &fc->hdriCos);      // GetHDRIRotationMatrix, Lighting.hlsl:348-358
     // pack the non-shadowing point lights for the hot loop: cbuffer array first, then the extension array, in index order
     DevPointLight* pts = (DevPointLight*)(fc + 1);
     const int nPts = L.numPointLights + numExtraPoint;

@@ -211,8 +211,7 @@ VQD f3 mul_v_m3(f3 v, float c, float s) {     // mul(v, GetHDRIRotationMatrix) w
 
 // CalculateEnvironmentMapIllumination(+_DiffuseOnly), Lighting.hlsl:348-395 ; EnvironmentBRDF BRDF.hlsl:196-207
 VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
-    float sn, cs;
-    sincos_(-fc->perFrame.fHDRIOffsetInRadians, &sn, &cs);
+    const float sn = fc->hdriSin, cs = fc->hdriCos;          // sincos_(-fHDRIOffsetInRadians), hoisted to the host (capi.hip)
     const float NdotV = saturate(dot(px.Nraw, px.V));
     const f3 N = mul_v_m3(px.Nraw, cs, sn);
     const float4 irr = sample_cube_rgba16f(fc->env.diffuse_cube, fc->env.diffuse_res, N);
@@ -222,9 +221,13 @@ VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
         const int maxLod = f2i_trunc(fc->perView.MaxEnvMapLODLevels);
         int mip = f2i_trunc(px.roughness * (float)maxLod);
         mip = min(max(mip, 0), fc->env.spec_mips - 1);
-        size_t off = 0;
-        for (int m = 0; m < mip; ++m) { size_t r = (size_t)(fc->env.spec_res0 >> m); off += 6 * r * r; }
-        const float4 sp = sample_cube_rgba16f((const h4*)fc->env.specular_cube + off, fc->env.spec_res0 >> mip, R);
+        // texel offset of level `mip` in the mip-major cube: sum_{m<mip} 6*(res0>>m)^2; for a power-of-two res0 (every mip
+        // exact) that is 8*(res0^2 - (res0>>mip)^2)
+        const int res0 = fc->env.spec_res0, rm = res0 >> mip;
+        uint32_t off;
+        if ((res0 & (res0 - 1)) == 0) off = 8u * (uint32_t)(res0 * res0 - rm * rm);
+        else { off = 0; for (int m = 0; m < mip; ++m) { const uint32_t r = (uint32_t)(res0 >> m); off += 6u * r * r; } }
+        const float4 sp = sample_cube_rgba16f((const h4*)fc->env.specular_cube + off, rm, R);
         spec = mk3(sp.x, sp.y, sp.z);
         sb = sample_2d_rg16f_clamp(fc->env.brdf_lut, fc->env.lut_size, fc->env.lut_size, NdotV, px.roughness);
     }

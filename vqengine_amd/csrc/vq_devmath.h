@@ -15,8 +15,9 @@
 namespace vqd {
 
 #define VQD __device__ __forceinline__
+#define VQHD __host__ __device__ __forceinline__     // also callable from the C-ABI translation unit (same IEEE operations on the host)
 
-VQD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+VQHD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // Correctly rounded reciprocal RN(1/b). Fast path: v_rcp_f32 (1 ulp) + one Newton step, i.e. Markstein's
 // r' = fma(fma(-b,r,1), r, r); checked EXHAUSTIVELY on gfx950 against IEEE 1.0f/b over all 2^32 inputs
 // (scripts/ubench/valu_ubench.hip, tests/test_gpu_devmath.py::test_rcp_exhaustive): whenever the result is a
@@ -67,8 +68,8 @@ VQD float min_(float a, float b) { return __builtin_fminf(a, b); }
 // saturate: clamp to [0,1], NaN -> 0, -0 -> +0. v_med3_f32(x,0,1) equals the select form (x>0 ? (x<1 ? x : 1) : 0) for ALL
 // 2^32 inputs on gfx950 (exhaustive: scripts/ubench/sqrt_ubench.hip, tests/test_gpu_devmath.py).
 VQD float saturate(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
-VQD float abs_(float x) { return __builtin_fabsf(x); }
-VQD float qnan() { return __uint_as_float(0x7fc00000u); }
+VQHD float abs_(float x) { return __builtin_fabsf(x); }
+VQHD float qnan() { return __builtin_bit_cast(float, 0x7fc00000u); }
 
 struct f3 { float x, y, z; };
 VQD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
@@ -160,7 +161,7 @@ VQD float pow_unit(float x, float y) {
 }
 
 // sin/cos: octant reduction with a 3-part pi/4, Cephes kernels; |x| > 2^20 or non-finite -> NaN
-VQD void sincos_(float x, float* s, float* c) {
+VQHD void sincos_(float x, float* s, float* c) {
     float ax = abs_(x);
     bool bad = !(ax <= 1048576.0f);
     float axc = bad ? 0.0f : ax;

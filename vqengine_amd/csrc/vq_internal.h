@@ -17,7 +17,8 @@ struct alignas(16) FrameConstants {
     vqhip_shadowmaps       sm;             // device pointers
     int32_t                hasEnv;
     int32_t                numPointAll;    // numPointLights + numExtraPoint
-    int32_t                pad[2];
+    float                  hdriSin, hdriCos;   // vqd::sincos_(-fHDRIOffsetInRadians): frame-uniform, evaluated once on the host by the
+                                               // very same routine (IEEE ops only, so host and device agree bit for bit)
     // DevPointLight pts[numPointAll] follows
 };
 // Non-shadowing point lights as the hot loop reads them (one s_load_dwordx8 per light): point_lights[0..numPointLights)

@@ -79,6 +79,64 @@ VQD void cube_edge_neighbor(int f, int i, int j, int N, int* nf, int* ni, int* n
     *nj = (b2 >= N) ? 0 : (b2 <= -N) ? N - 1 : (N - 1 - b2) / 2;
 }
 
+// The same adjacency as a 24-entry table, derived at COMPILE TIME from the face bases by probing the lattice construction
+// above with two taps per (face, exit edge): along an edge the neighbour's texel runs linearly with slope +-1 while its other
+// coordinate sits on the neighbour's border row/column. Entry bits: [2:0] neighbour face, [3] ni is the fixed coordinate
+// (nj runs), [4] fixed coordinate = N-1 (else 0), [5] running coordinate is flipped (N-1-r). Exit edges: 0 i<0, 1 i>=N, 2 j<0, 3 j>=N.
+namespace edge_tab {
+constexpr int8_t kB[6][9] = {
+    {  1, 0, 0,   0, 1, 0,   0, 0,-1 }, { -1, 0, 0,   0, 1, 0,   0, 0, 1 }, {  0, 1, 0,   0, 0,-1,   1, 0, 0 },
+    {  0,-1, 0,   0, 0, 1,   1, 0, 0 }, {  0, 0, 1,   0, 1, 0,   1, 0, 0 }, {  0, 0,-1,   0, 1, 0,  -1, 0, 0 } };
+struct NB { int f, i, j; };
+constexpr NB neighbor(int f, int i, int j, int N) {
+    int a = 2 * i + 1 - N, b = N - (2 * j + 1);
+    int ax[3] = { 0, 0, 0 };
+    if (i < 0)       { a = -N; for (int k = 0; k < 3; ++k) ax[k] = -kB[f][6 + k]; }
+    else if (i >= N) { a =  N; for (int k = 0; k < 3; ++k) ax[k] =  kB[f][6 + k]; }
+    else if (j < 0)  { b =  N; for (int k = 0; k < 3; ++k) ax[k] =  kB[f][3 + k]; }
+    else             { b = -N; for (int k = 0; k < 3; ++k) ax[k] = -kB[f][3 + k]; }
+    int q[3] = { 0, 0, 0 };
+    for (int k = 0; k < 3; ++k) q[k] = N * kB[f][k] + a * kB[f][6 + k] + b * kB[f][3 + k];
+    const int g = ax[0] ? (ax[0] > 0 ? 0 : 1) : ax[1] ? (ax[1] > 0 ? 2 : 3) : (ax[2] > 0 ? 4 : 5);
+    const int a2 = q[0] * kB[g][6] + q[1] * kB[g][7] + q[2] * kB[g][8];
+    const int b2 = q[0] * kB[g][3] + q[1] * kB[g][4] + q[2] * kB[g][5];
+    NB r = { g, (a2 >= N) ? N - 1 : (a2 <= -N) ? 0 : (a2 + N - 1) / 2, (b2 >= N) ? 0 : (b2 <= -N) ? N - 1 : (N - 1 - b2) / 2 };
+    return r;
+}
+constexpr uint32_t entry(int f, int e) {
+    const int N = 4;
+    const int i0 = e == 0 ? -1 : e == 1 ? N : 0, j0 = e == 2 ? -1 : e == 3 ? N : 0;
+    const int i1 = e < 2 ? i0 : 1, j1 = e < 2 ? 1 : j0;
+    const NB p = neighbor(f, i0, j0, N), q = neighbor(f, i1, j1, N);
+    const bool fixedIsI = (p.i == q.i);
+    const int fixedV = fixedIsI ? p.i : p.j, run0 = fixedIsI ? p.j : p.i;
+    return (uint32_t)p.f | ((uint32_t)fixedIsI << 3) | ((uint32_t)(fixedV != 0) << 4) | ((uint32_t)(run0 != 0) << 5);
+}
+// 24 six-bit entries packed into three 64-bit words (8 entries each), indexed by f*4 + e
+constexpr uint64_t word(int w) {
+    uint64_t r = 0;
+    for (int k = 0; k < 8; ++k) { const int idx = w * 8 + k; r |= (uint64_t)entry(idx >> 2, idx & 3) << (8 * k); }
+    return r;
+}
+constexpr uint64_t kW0 = word(0), kW1 = word(1), kW2 = word(2);
+} // namespace edge_tab
+
+// tap (i,j) of face f that left the face through exactly ONE edge -> texel (nf, ni, nj) of the adjacent face (table form of
+// cube_edge_neighbor; ~12 integer operations)
+VQD void cube_edge_lookup(int f, int i, int j, int N, int* nf, int* ni, int* nj) {
+    const bool ox = (i < 0) | (i >= N);
+    const int e = ox ? (i < 0 ? 0 : 1) : (j < 0 ? 2 : 3);
+    const int idx = f * 4 + e;
+    const uint64_t w = idx < 8 ? edge_tab::kW0 : (idx < 16 ? edge_tab::kW1 : edge_tab::kW2);
+    const uint32_t en = (uint32_t)(w >> (8 * (idx & 7))) & 63u;
+    const int r = ox ? j : i;
+    const int run = (en & 32u) ? N - 1 - r : r;
+    const int fix = (en & 16u) ? N - 1 : 0;
+    *nf = (int)(en & 7u);
+    *ni = (en & 8u) ? fix : run;
+    *nj = (en & 8u) ? run : fix;
+}
+
 VQD void fixed8(float x, int* ix, float* w) {
     int fx = f2i_floor(x * 256.0f + 0.5f);
     *ix = fx >> 8;
@@ -102,31 +160,36 @@ VQD float4 sample_cube_rgba16f(const void* cube, int N, f3 dir) {
     int ix, iy; float wx, wy;
     fixed8(su * (float)N - 0.5f, &ix, &wx);
     fixed8(sv * (float)N - 0.5f, &iy, &wy);
+    // One branch-free tap path for interior and edge footprints alike: on the 64^2 / <=128^2 cubes of the reference nearly
+    // every wave holds a lane whose footprint crosses a face edge, so a separate interior fast path only ever ran IN ADDITION
+    // to the general one. A tap outside through ONE edge comes from the adjacent face (table lookup, selected by predicate);
+    // a tap outside through a corner is "missing" (rare: handled in the only divergent branch).
     float4 c[4];
-    if (ix >= 0 && iy >= 0 && ix + 1 < N && iy + 1 < N) {            // interior footprint: the common case
-        size_t base = ((size_t)f * N + iy) * N + ix;
-        c[0] = load_rgba16f(cube, base);     c[1] = load_rgba16f(cube, base + 1);
-        c[2] = load_rgba16f(cube, base + N); c[3] = load_rgba16f(cube, base + N + 1);
-    } else {
-        int missing = -1;
-        for (int t = 0; t < 4; ++t) {
-            int i = ix + (t & 1), j = iy + (t >> 1);
-            bool ox = (i < 0 || i >= N), oy = (j < 0 || j >= N);
-            if (!ox && !oy)      c[t] = load_rgba16f(cube, ((size_t)f * N + j) * N + i);
-            else if (ox && oy) { c[t] = make_float4(0, 0, 0, 0); missing = t; }
-            else { int nf, ni, nj; cube_edge_neighbor(f, i, j, N, &nf, &ni, &nj); c[t] = load_rgba16f(cube, ((size_t)nf * N + nj) * N + ni); }
-        }
-        if (missing >= 0) {                                           // corner: mean of the other three, in tap order
-            float4 s = make_float4(0, 0, 0, 0); bool first = true;
-            for (int k = 0; k < 4; ++k) {
-                if (k == missing) continue;
-                if (first) { s = c[k]; first = false; }
-                else { s.x += c[k].x; s.y += c[k].y; s.z += c[k].z; s.w += c[k].w; }
-            }
-            const float third = 0.333333343267440796f;
-            float4 m = make_float4(s.x * third, s.y * third, s.z * third, s.w * third);
-            if (missing == 0) c[0] = m; else if (missing == 1) c[1] = m; else if (missing == 2) c[2] = m; else c[3] = m;
-        }
+#if VQ_CUBE_TWO_PATH                                                  // A/B switch (scripts/bench_variants.sh): interior fast path in front
+    if (ix >= 0 && iy >= 0 && ix + 1 < N && iy + 1 < N) {
+        const size_t base = ((size_t)f * N + iy) * N + ix;
+        return blend4(load_rgba16f(cube, base), load_rgba16f(cube, base + 1), load_rgba16f(cube, base + N), load_rgba16f(cube, base + N + 1), wx, wy);
+    }
+#endif
+    int missing = -1;
+    #pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = ix + (t & 1), j = iy + (t >> 1);
+        const bool ox = (i < 0) | (i >= N), oy = (j < 0) | (j >= N);
+        int nf, ni, nj;
+        cube_edge_lookup(f, i, j, N, &nf, &ni, &nj);                  // meaningful only when exactly one of ox, oy holds
+        const bool one = ox != oy;
+        nf = one ? nf : f;
+        ni = one ? ni : min(max(i, 0), N - 1);                        // identity inside the face; any valid address for a corner
+        nj = one ? nj : min(max(j, 0), N - 1);
+        if (ox & oy) missing = t;
+        c[t] = load_rgba16f(cube, (size_t)((nf * N + nj) * N + ni));
+    }
+    if (missing >= 0) {                                               // corner: mean of the other three, in tap order
+        const float4 a = missing == 0 ? c[1] : c[0], b = missing <= 1 ? c[2] : c[1], d = missing <= 2 ? c[3] : c[2];
+        const float third = 0.333333343267440796f;
+        const float4 m = make_float4(((a.x + b.x) + d.x) * third, ((a.y + b.y) + d.y) * third, ((a.z + b.z) + d.z) * third, ((a.w + b.w) + d.w) * third);
+        if (missing == 0) c[0] = m; else if (missing == 1) c[1] = m; else if (missing == 2) c[2] = m; else c[3] = m;
     }
     return blend4(c[0], c[1], c[2], c[3], wx, wy);
 }
