@@ -17,6 +17,8 @@ struct vqhip_ctx {
     char* hostRing = nullptr;      // pinned
     char* devRing = nullptr;
     hipEvent_t slotEvent[kSlots] = {};
+    hipStream_t copyStream = nullptr;          // constants are uploaded on their own stream: the DMA of call n+1 overlaps the kernels of call n
+    hipEvent_t copyEvent[kSlots] = {};
     bool slotBusy[kSlots] = {};
     int nextSlot = 0;
     void* scratch = nullptr; size_t scratchBytes = 0;
@@ -49,7 +51,11 @@ int acquireSlot(vqhip_ctx* ctx, int* slot) {
     return VQHIP_OK;
 }
 int commitSlot(vqhip_ctx* ctx, int slot, size_t bytes, hipStream_t st) {
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->devRing + (size_t)slot * kConstSlotBytes, ctx->hostRing + (size_t)slot * kConstSlotBytes, bytes, hipMemcpyHostToDevice, st));
+    // The slot is free (acquireSlot waited for its last reader), so the copy need not queue behind the caller's stream: it
+    // runs on the context's copy stream right away and the caller's stream only waits for its completion event.
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->devRing + (size_t)slot * kConstSlotBytes, ctx->hostRing + (size_t)slot * kConstSlotBytes, bytes, hipMemcpyHostToDevice, ctx->copyStream));
+    HIP_TRY(ctx, hipEventRecord(ctx->copyEvent[slot], ctx->copyStream));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->copyEvent[slot], 0));
     return VQHIP_OK;
 }
 int releaseSlot(vqhip_ctx* ctx, int slot, hipStream_t st) {
@@ -99,7 +105,9 @@ int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
     }
     if ((e = hipMalloc(&ctx->tonemapLut, 131072)) != hipSuccess) { int rc = failHip(nullptr, e, "vqhip_create: tonemap table"); vqhip_destroy(ctx); return rc; }
     for (int i = 0; i < vqhip_ctx::kSlots; ++i)
-        if ((e = hipEventCreateWithFlags(&ctx->slotEvent[i], hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "hipEventCreate"); vqhip_destroy(ctx); return rc; }
+        if ((e = hipEventCreateWithFlags(&ctx->slotEvent[i], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->copyEvent[i], hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "hipEventCreate"); vqhip_destroy(ctx); return rc; }
+    if ((e = hipStreamCreateWithFlags(&ctx->copyStream, hipStreamNonBlocking)) != hipSuccess) { int rc = failHip(nullptr, e, "hipStreamCreate"); vqhip_destroy(ctx); return rc; }
     *out_ctx = ctx;
     return VQHIP_OK;
 }
@@ -108,7 +116,8 @@ void vqhip_destroy(vqhip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    for (int i = 0; i < vqhip_ctx::kSlots; ++i) if (ctx->slotEvent[i]) (void)hipEventDestroy(ctx->slotEvent[i]);
+    for (int i = 0; i < vqhip_ctx::kSlots; ++i) { if (ctx->slotEvent[i]) (void)hipEventDestroy(ctx->slotEvent[i]); if (ctx->copyEvent[i]) (void)hipEventDestroy(ctx->copyEvent[i]); }
+    if (ctx->copyStream) (void)hipStreamDestroy(ctx->copyStream);
     if (ctx->hostRing) (void)hipHostFree(ctx->hostRing);
     if (ctx->devRing) (void)hipFree(ctx->devRing);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
