@@ -148,25 +148,27 @@ def main():
         ctx.forward_lighting(gb, pf, pv, out=scene[b], out_fmt=F16, extra_point=extra, env=env)
         if ev:
             ev[1].record(s_shade)
-        e_scene[b].record(s_shade)
+        if args.overlap:
+            e_scene[b].record(s_shade)
         with torch.cuda.stream(s_post):
-            s_post.wait_event(e_scene[b])
+            if args.overlap:
+                s_post.wait_event(e_scene[b])
             if world > 1 and pending[b] is not None:  # composite of step i-2 must have drained before sdr[b]/frame[b] are reused
                 pending[b].wait()
                 pending[b] = None
-            if ev:
+            if ev and len(ev) == 5:
                 ev[4].record(s_post)
             ctx.gaussian_blur_x(scene[b], F16, out=xblur)
             top = bottom = None
             if world > 1:
                 top, bottom = halo_fn(xblur)
             ctx.gaussian_blur_y(xblur, F16, out=yblur, halo_top=top, halo_bottom=bottom)
-            if ev:
+            if ev and len(ev) == 5:
                 ev[2].record(s_post)
             # (the fused vqhip_gaussian_blur_y_tonemap is bit-identical but measured slower than the two dispatches at 4K:
             #  86 us vs 31 + 23 us)
             ctx.tonemap(yblur, F16, R8, out=sdr[b])
-            if ev:
+            if ev and len(ev) == 5:
                 ev[3].record(s_post)
             if world > 1:                              # all-gather on RCCL's own stream, drained two steps later
                 _, pending[b] = tiling.composite(sdr[b], out=frame[b], async_op=True)
@@ -190,7 +192,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+    # timed region: only the dominant kernel is bracketed by HIP events (2 records per step); the per-stage timings of the
+    # HBM-bound post kernels are taken in a separate, untimed pass afterwards so their instrumentation does not sit in `value`
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -203,11 +207,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    n_detail = min(args.steps, 10)
+    evd = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n_detail)]
+    for i in range(n_detail):
+        step(args.steps + i + (args.steps & 1), evd[i])
+    drain()
+    barrier()
+
     if rank == 0:
         px_tile, px_frame = W * TILE_H, W * frame_h
         t_shade = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) * 1e-3
-        t_blur = float(np.mean([e[4].elapsed_time(e[2]) for e in evs])) * 1e-3
-        t_tm = float(np.mean([e[2].elapsed_time(e[3]) for e in evs])) * 1e-3
+        t_blur = float(np.mean([e[4].elapsed_time(e[2]) for e in evd])) * 1e-3
+        t_tm = float(np.mean([e[2].elapsed_time(e[3]) for e in evd])) * 1e-3
         ach = SHADE_BYTES_PER_PX * px_tile / t_shade / 1e9
         out = {
             "metric": "Mpixels/s forward-PBR @4K,64 lights", "value": round(px_frame * args.steps / dt / 1e6, 2), "unit": "Mpix/s",
