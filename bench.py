@@ -32,6 +32,10 @@ SHADE_FLOPS_PER_PX = 170 * N_LIGHTS + 160
 # FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950): profiles/r1b_pmc_hbm.md. Not measurable from inside
 # bench.py; the committed figure is for exactly this workload (3840x2160, 64 lights + IBL, RGBA16F out).
 SHADE_PMC_TRAFFIC_BYTES = (2 * 599481 + 64800) * 1024
+# VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_ab.sh, committed
+# summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
+SHADE_PMC_VALU_PER_WAVE = 7367
+VALU_ISSUE_CEILING_TLIS = 52.7  # T lane-instructions/s = 105 TFLOP/s of v_fma_f32, scripts/ubench/valu_ubench.hip
 
 
 def build_ibl(ctx):
@@ -235,6 +239,10 @@ def main():
                          "note": "64-light shading is VALU-bound by construction (SURVEY.md 8d): see valu"},
             "valu": {"achieved_tflops_model": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
                      "frac": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12 / VALU_PEAK_TFLOPS, 4), "flops_per_px_model": SHADE_FLOPS_PER_PX},
+            "valu_issue": {"achieved_T_lane_instr_s": round(SHADE_PMC_VALU_PER_WAVE * (px_tile / 64) * 64 / t_shade / 1e12, 2),
+                           "ceiling": VALU_ISSUE_CEILING_TLIS, "frac": round(SHADE_PMC_VALU_PER_WAVE * px_tile / t_shade / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
+                           "valu_instr_per_wave": SHADE_PMC_VALU_PER_WAVE,
+                           "note": "the binding roof: instructions issued per second vs the measured v_fma_f32 issue ceiling (PMC count x live kernel time)"},
             "stages": {"shade_Mpix_s": round(px_tile / t_shade / 1e6, 1), "shade_ms": round(t_shade * 1e3, 4),
                        "blur_xy_ms": round(t_blur * 1e3, 4), "blur_xy_GBps": round(px_tile * 32 / t_blur / 1e9, 1),
                        "tonemap_ms": round(t_tm * 1e3, 4), "tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1)},
