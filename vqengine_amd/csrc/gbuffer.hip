@@ -36,24 +36,6 @@ struct __attribute__((packed, aligned(4))) TexelPair { uint32_t a, b; };
 struct LevelTaps { uint32_t row0, row1; int x0, x1; float w00, w10, w01, w11; };
 struct Footprint { LevelTaps l0, l1; float f; };
 
-VQD int ilog2(int v) { return 31 - __builtin_clz(v); }
-
-// offset (in texels) of level l of a dense chain whose level k is max(1,w>>k) x max(1,h>>k)
-template <bool POT> VQD uint32_t level_offset(int w, int h, int l) {
-    if (POT) {
-        // levels 0..m (m = log2 of the short side) shrink by 4, the tail (short side clamped to 1) by 2:
-        // sum_{k<l1} wh/4^k = (4wh - wh/4^(l1-1))/3 ; sum_{k=m+1}^{l-1} L>>k = (L>>m) - (L>>(l-1))
-        const int m = min(ilog2(w), ilog2(h)), L = max(w, h);
-        const int l1 = min(l, m + 1);
-        const uint32_t wh = (uint32_t)w * (uint32_t)h;
-        uint32_t off = l1 >= 1 ? (4u * wh - (wh >> (2 * l1 - 2))) * 0xAAAAAAABu : 0u;   // exact /3 (the numerator is a multiple of 3): inverse of 3 mod 2^32
-        if (l > m + 1) off += (uint32_t)((L >> m) - (L >> (l - 1)));
-        return off;
-    }
-    uint32_t off = 0;
-    for (int k = 0; k < l; ++k) off += (uint32_t)mip_dim(w, k) * (uint32_t)mip_dim(h, k);
-    return off;
-}
 
 template <bool POT> VQD LevelTaps level_taps(int w0, int h0, int level, float u, float v) {
     const int W = mip_dim(w0, level), H = mip_dim(h0, level);
@@ -64,7 +46,7 @@ template <bool POT> VQD LevelTaps level_taps(int w0, int h0, int level, float u,
     int y0, y1;
     if (POT) { t.x0 = ix & (W - 1); t.x1 = (ix + 1) & (W - 1); y0 = iy & (H - 1); y1 = (iy + 1) & (H - 1); }
     else     { t.x0 = wrapi(ix, W); t.x1 = wrapi(ix + 1, W); y0 = wrapi(iy, H); y1 = wrapi(iy + 1, H); }
-    const uint32_t base = level_offset<POT>(w0, h0, level);
+    const uint32_t base = chain_level_offset<POT>(w0, h0, level);    // vq_sampling.h: closed form for power-of-two chains
     t.row0 = base + __umul24(y0, W);                              // dims < 2^24: full-rate v_mad_u32_u24
     t.row1 = base + __umul24(y1, W);
     t.w00 = (1.0f - wx) * (1.0f - wy); t.w10 = wx * (1.0f - wy); t.w01 = (1.0f - wx) * wy; t.w11 = wx * wy;   // == blend4's weights

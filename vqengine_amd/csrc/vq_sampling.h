@@ -217,27 +217,55 @@ VQD size_t mip_offset_px(int w0, int h0, int level) {
 }
 VQD int wrapi(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
 
-VQD float4 sample_2d_rgba32f_wrap(const float4* tex, int W, int H, float u, float v) {
+// POT = both dimensions are powers of two (every level then is, too): WRAP is an AND instead of an integer modulo (~20 VALU each)
+template <bool POT> VQD float4 sample_2d_rgba32f_wrap_t(const float4* tex, int W, int H, float u, float v) {
     int ix, iy; float wx, wy;
     fixed8(u * (float)W - 0.5f, &ix, &wx);
     fixed8(v * (float)H - 0.5f, &iy, &wy);
-    int x0 = wrapi(ix, W), x1 = wrapi(ix + 1, W), y0 = wrapi(iy, H), y1 = wrapi(iy + 1, H);
-    return blend4(tex[(size_t)y0 * W + x0], tex[(size_t)y0 * W + x1], tex[(size_t)y1 * W + x0], tex[(size_t)y1 * W + x1], wx, wy);
+    int x0, x1, y0, y1;
+    if (POT) { x0 = ix & (W - 1); x1 = (ix + 1) & (W - 1); y0 = iy & (H - 1); y1 = (iy + 1) & (H - 1); }
+    else     { x0 = wrapi(ix, W); x1 = wrapi(ix + 1, W); y0 = wrapi(iy, H); y1 = wrapi(iy + 1, H); }
+    const uint32_t r0 = __umul24(y0, W), r1 = __umul24(y1, W);       // level dimensions are < 2^24
+    return blend4(tex[r0 + (uint32_t)x0], tex[r0 + (uint32_t)x1], tex[r1 + (uint32_t)x0], tex[r1 + (uint32_t)x1], wx, wy);
+}
+VQD bool is_pot2(int w, int h) { return ((w & (w - 1)) | (h & (h - 1))) == 0; }
+VQD float4 sample_2d_rgba32f_wrap(const float4* tex, int W, int H, float u, float v) {
+    return is_pot2(W, H) ? sample_2d_rgba32f_wrap_t<true>(tex, W, H, u, v) : sample_2d_rgba32f_wrap_t<false>(tex, W, H, u, v);
+}
+
+// offset (in texels) of level l of a dense chain whose level k is max(1,w>>k) x max(1,h>>k). Power-of-two sizes in closed form:
+// levels 0..m (m = log2 of the short side) shrink by 4, the tail (short side clamped to 1) by 2:
+//   sum_{k<l1} wh/4^k = (4wh - wh/4^(l1-1))/3 (exact; /3 by the inverse of 3 mod 2^32), sum_{k=m+1}^{l-1} L>>k = (L>>m) - (L>>(l-1))
+template <bool POT> VQD uint32_t chain_level_offset(int w, int h, int l) {
+    if (POT) {
+        const int m = min(31 - __builtin_clz(w), 31 - __builtin_clz(h)), L = max(w, h);
+        const int l1 = min(l, m + 1);
+        const uint32_t wh = (uint32_t)w * (uint32_t)h;
+        uint32_t off = l1 >= 1 ? (4u * wh - (wh >> (2 * l1 - 2))) * 0xAAAAAAABu : 0u;
+        if (l > m + 1) off += (uint32_t)((L >> m) - (L >> (l - 1)));
+        return off;
+    }
+    uint32_t off = 0;
+    for (int k = 0; k < l; ++k) off += (uint32_t)mip_dim(w, k) * (uint32_t)mip_dim(h, k);
+    return off;
 }
 
 // SampleLevel(uv, lod) with TRILINEAR_WRAP on a dense chain (level 0 first)
-VQD float4 sample_equirect_lod(const float4* chain, int w0, int h0, int nMips, float u, float v, float lod) {
+template <bool POT> VQD float4 sample_equirect_lod_t(const float4* chain, int w0, int h0, int nMips, float u, float v, float lod) {
     float maxl = (float)(nMips - 1);
     float l = (lod > 0.0f) ? ((lod < maxl) ? lod : maxl) : 0.0f;
     int fl = f2i_floor(l * 256.0f + 0.5f);
     int lo = fl >> 8;
     float f = (float)(fl & 255) * 0.00390625f;
     if (lo >= nMips - 1) { lo = nMips - 1; f = 0.0f; }
-    float4 a = sample_2d_rgba32f_wrap(chain + mip_offset_px(w0, h0, lo), mip_dim(w0, lo), mip_dim(h0, lo), u, v);
+    float4 a = sample_2d_rgba32f_wrap_t<POT>(chain + chain_level_offset<POT>(w0, h0, lo), mip_dim(w0, lo), mip_dim(h0, lo), u, v);
     if (f == 0.0f) return a;
-    float4 b = sample_2d_rgba32f_wrap(chain + mip_offset_px(w0, h0, lo + 1), mip_dim(w0, lo + 1), mip_dim(h0, lo + 1), u, v);
+    float4 b = sample_2d_rgba32f_wrap_t<POT>(chain + chain_level_offset<POT>(w0, h0, lo + 1), mip_dim(w0, lo + 1), mip_dim(h0, lo + 1), u, v);
     float g = 1.0f - f;
     return make_float4(fma_(f, b.x, g * a.x), fma_(f, b.y, g * a.y), fma_(f, b.z, g * a.z), fma_(f, b.w, g * a.w));
+}
+VQD float4 sample_equirect_lod(const float4* chain, int w0, int h0, int nMips, float u, float v, float lod) {
+    return is_pot2(w0, h0) ? sample_equirect_lod_t<true>(chain, w0, h0, nMips, u, v, lod) : sample_equirect_lod_t<false>(chain, w0, h0, nMips, u, v, lod);
 }
 
 // ---- point sampling (shadow maps) ----------------------------------------------------------------
