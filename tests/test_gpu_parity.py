@@ -61,6 +61,28 @@ def test_brdf_lut_reference_size_rows(ctx):
     assert np.isfinite(f).all() and (f >= 0).all() and (f[..., 0] + f[..., 1] <= 1.001).all()
 
 
+def test_ibl_reference_sizes_cfg4(ctx):
+    """BASELINE config 4 at full size: 2048^2 equirect -> 12-level min-filter chain, diffuse 6x64^2 at step 0.010 (99 382 taps per
+    texel), 7-mip specular 128^2. The GPU computes everything; the oracle checks the whole mip chain, 96 diffuse texels spread
+    over the six faces (each a full 99 382-tap integral) and the complete specular cube."""
+    eq = synth.equirect(2048, 2048)
+    chain_g, n = ctx.mip_chain(dev(eq))
+    chain_o, n_o = O.mip_chain(eq)
+    assert n == n_o == 12
+    assert_bits(chain_g, chain_o, "2048^2 mip chain")
+    diff_g = ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, 0.010, abi.CONV_WAVE64, abi.FMT_RGBA16F).cpu().numpy().reshape(-1, 4)
+    for t0 in (0, 4095, 4096 + 1234, 3 * 4096 + 4000, 5 * 4096 + 64 * 63, 6 * 4096 - 16):
+        ref = O.conv_diffuse(chain_o, 2048, 2048, n, 64, 0.010, abi.CONV_WAVE64, abi.FMT_RGBA16F, t0=t0, t1=t0 + 16).reshape(-1, 4)
+        n_bad, idx = O.bits_equal(diff_g[t0:t0 + 16], ref[t0:t0 + 16])
+        assert n_bad == 0, (t0, n_bad, idx)
+    spec_g, mips = ctx.conv_specular(chain_g, 2048, 2048, n, 128, abi.CONV_WAVE64, abi.FMT_RGBA16F)
+    spec_o, mips_o = O.conv_specular(chain_o, 2048, 2048, n, 128, abi.CONV_WAVE64, abi.FMT_RGBA16F)
+    assert mips == mips_o == 7
+    assert_bits(spec_g, spec_o, "specular 128^2 x 7 mips from the 2048^2 equirect")
+    f = diff_g.astype(np.float32)
+    assert np.isfinite(f).all() and (f[:, :3] >= 0).all() and np.all(f[:, 3] == 1.0)
+
+
 def test_envmap_prefilter(env_small):
     for k in ("diffuse_unblurred", "diffuse_blurred", "specular"):
         assert_bits(env_small["pre_g"][k], env_small["pre_o"][k], f"prefilter {k}")
