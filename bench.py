@@ -6,7 +6,8 @@ A "step" is one pass of BASELINE config 3 over one synthetic frame tile that is 
     21-tap Gaussian blur X, Y                        -> RGBA16F                 [vqhip_gaussian_blur_x/_y]
     tonemap (Reinhard + sRGB OETF)                   -> RGBA8_UNORM             [vqhip_tonemap]
 N = 1: one 3840x2160 frame. N > 1 (weak scaling): the frame is 3840 x (2160*N), row-tiled one tile per GPU, with
-the RCCL halo exchange before the Y blur and the all-gather composite of the RGBA8 tiles inside the timed region.
+the RCCL halo exchange before the Y blur and the composite of the RGBA8 tiles (gather on rank 0, or --composite allgather)
+inside the timed region.
 `value` = pixels of the whole frame / max-over-ranks wall time. Prints ONE JSON line on rank 0."""
 import argparse
 import json
@@ -100,6 +101,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halo", choices=["p2p", "allgather"], default="p2p")
+    ap.add_argument("--composite", choices=["gather", "allgather"], default="gather",
+                    help="final composite of the RGBA8 tiles: gather on rank 0 (the presenting GPU; 1/N of the traffic, rank 0 receives over its "
+                         "N-1 direct xGMI links) or all-gather on every rank")
     ap.add_argument("--overlap", action="store_true",
                     help="post chain of frame n on a second (high-priority) HIP stream overlapping the shading of frame n+1. Measured "
                          "+1 %% only (the 32 400-workgroup shade dispatch starves the second queue), so the default is ONE stream, "
@@ -132,7 +136,8 @@ def main():
     xblur = capi.empty_image(TILE_H, W, F16, ctx.device)
     yblur = capi.empty_image(TILE_H, W, F16, ctx.device)
     sdr = [capi.empty_image(TILE_H, W, R8, ctx.device) for _ in range(2)]
-    frame = [torch.empty((frame_h, W, 4), dtype=torch.uint8, device=ctx.device) for _ in range(2)] if world > 1 else None
+    need_frame = world > 1 and (args.composite == "allgather" or rank == 0)
+    frame = [torch.empty((frame_h, W, 4), dtype=torch.uint8, device=ctx.device) for _ in range(2)] if need_frame else [None, None]
     pending = [None, None]
     halo_fn = tiling.exchange_halos_p2p if args.halo == "p2p" else tiling.exchange_halos_allgather
     # Two HIP streams, like the reference's GFX + async-compute queues (SceneRendering.cpp:605-606,629): the VALU-bound
@@ -175,7 +180,10 @@ def main():
             if ev and len(ev) == 5:
                 ev[3].record(s_post)
             if world > 1:                              # all-gather on RCCL's own stream, drained two steps later
-                _, pending[b] = tiling.composite(sdr[b], out=frame[b], async_op=True)
+                if args.composite == "gather":
+                    _, pending[b] = tiling.composite_to_root(sdr[b], out=frame[b], dst=0, async_op=True)
+                else:
+                    _, pending[b] = tiling.composite(sdr[b], out=frame[b], async_op=True)
             if args.overlap:
                 e_post[b] = torch.cuda.Event()
                 e_post[b].record(s_post)
@@ -229,7 +237,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE cfg3: 3840x2160 float4 G-buffer tile per GPU, 64 point lights + IBL sample -> RGBA16F, "
-                                   "21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8" + ("" if world == 1 else f"; frame 3840x{frame_h} row-tiled, RCCL halo ({args.halo}) + all-gather composite"),
+                                   "21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8" + ("" if world == 1 else f"; frame 3840x{frame_h} row-tiled, RCCL halo ({args.halo}) + composite ({args.composite}{' on rank 0' if args.composite == 'gather' else ''})"),
                        "width": W, "frame_height": frame_h, "lights": N_LIGHTS, "parallelism": f"rows{world}",
                        "streams": "2: post chain of frame n overlaps shading of frame n+1" if args.overlap else "1"},
             "roofline": {"bound": "hbm", "kernel": "k_forward_lighting<env,nocasters,RGBA16F>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,

@@ -35,7 +35,7 @@ def _full_frame(world):
     return O.tonemap(y, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
 
 
-def _worker(rank, world, port, halo_mode, q):
+def _worker(rank, world, port, halo_mode, q, comp="allgather"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,9 +55,15 @@ def _worker(rank, world, port, halo_mode, q):
         y = O.blur_pass(x, abi.FMT_RGBA16F, 1, halo_top=top.numpy() if top is not None else None,
                         halo_bottom=bottom.numpy() if bottom is not None else None)
         sdr = torch.from_numpy(O.tonemap(y, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM))
-        frame, work = tiling.composite(sdr, async_op=True)                     # exchange 2: all-gather composite
-        work.wait()
-        q.put((rank, frame.numpy().copy()))
+        if comp == "gather":                                                   # exchange 2: composite on rank 0 only
+            frame, work = tiling.composite_to_root(sdr, dst=0, async_op=True)
+            work.wait()
+            assert (frame is None) == (rank != 0)
+            q.put((rank, frame.numpy().copy() if frame is not None else None))
+        else:                                                                  # exchange 2: all-gather composite
+            frame, work = tiling.composite(sdr, async_op=True)
+            work.wait()
+            q.put((rank, frame.numpy().copy()))
         dist.barrier()
     except Exception as e:                                                     # surface failures immediately instead of a queue timeout
         q.put((rank, repr(e)))
@@ -66,12 +72,13 @@ def _worker(rank, world, port, halo_mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,halo_mode", [(2, "p2p"), (2, "allgather"), (3, "p2p")])
-def test_row_tiled_chain_equals_full_frame(world, halo_mode):
+@pytest.mark.parametrize("world,halo_mode,comp", [(2, "p2p", "allgather"), (2, "allgather", "allgather"), (3, "p2p", "allgather"),
+                                                  (2, "p2p", "gather"), (3, "allgather", "gather")])
+def test_row_tiled_chain_equals_full_frame(world, halo_mode, comp):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, halo_mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, halo_mode, q, comp)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -84,6 +91,9 @@ def test_row_tiled_chain_equals_full_frame(world, halo_mode):
         assert p.exitcode == 0
     ref = _full_frame(world)
     for r in range(world):
+        if comp == "gather" and r != 0:
+            assert got[r] is None
+            continue
         assert got[r].shape == ref.shape and np.array_equal(got[r], ref), f"rank {r}: composited frame differs from the full-frame result"
 
 

@@ -59,6 +59,23 @@ def exchange_halos_allgather(x_tile, group=None):
     return top, bottom
 
 
+def composite_to_root(tile, out=None, dst=0, group=None, async_op=False):
+    """Gather the row tiles into the full frame [world*rows, W, C] on rank `dst` only (the GPU that presents the frame, like
+    the reference's single swap chain). 1/world of the all-gather's traffic: `dst` receives world-1 tiles over its world-1
+    direct xGMI links, every other rank sends one. Returns (frame on dst | None elsewhere, work|None)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    root = dist.get_global_rank(group, dst) if group else dst
+    parts = None
+    if rank == dst:
+        if out is None:
+            out = torch.empty((world * tile.shape[0],) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
+        parts = list(out.chunk(world, 0))                               # contiguous row-tile views of the frame
+    else:
+        out = None
+    work = dist.gather(tile.contiguous(), parts, dst=root, group=group, async_op=async_op)
+    return out, work
+
+
 def composite(tile, out=None, group=None, async_op=False):
     """All-gather the row tiles into the full frame [world*rows, W, C] on every rank. Returns (frame, work|None)."""
     world = dist.get_world_size(group)
