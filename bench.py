@@ -35,6 +35,7 @@ SHADE_FLOPS_PER_PX = 170 * N_LIGHTS + 160
 SHADE_PMC_TRAFFIC_BYTES = (2 * 599481 + 64800) * 1024
 # VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_ab.sh, committed
 # summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
+SPINUP_STEPS = 200              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
 SHADE_PMC_VALU_PER_WAVE = 7367
 VALU_ISSUE_CEILING_TLIS = 52.7  # T lane-instructions/s = 105 TFLOP/s of v_fma_f32, scripts/ubench/valu_ubench.hip
 
@@ -97,8 +98,8 @@ def cpu_baseline(pre, lut, pf, pv, frame_h, target_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # a step is ~1.4 ms: 50 + 10 keep the clocks ramped, the run stays setup-dominated
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halo", choices=["p2p", "allgather"], default="p2p")
     ap.add_argument("--composite", choices=["gather", "allgather"], default="gather",
@@ -201,6 +202,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Untimed spin-up: the chip needs ~0.2-0.3 s of sustained load to reach its steady-state clocks (measured: the same
+    # kernel runs 1.33 ms right after the idle set-up phase and 1.25 ms once ramped), so a fixed number of extra untimed steps
+    # precedes the W warm-up steps whatever W is. The timed region is still exactly K steps.
+    for i in range(SPINUP_STEPS):
+        step(i)
+    drain()
     for i in range(args.warmup):
         step(i)
     drain()
@@ -239,7 +246,8 @@ def main():
             "config": {"workload": "BASELINE cfg3: 3840x2160 float4 G-buffer tile per GPU, 64 point lights + IBL sample -> RGBA16F, "
                                    "21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8" + ("" if world == 1 else f"; frame 3840x{frame_h} row-tiled, RCCL halo ({args.halo}) + composite ({args.composite}{' on rank 0' if args.composite == 'gather' else ''})"),
                        "width": W, "frame_height": frame_h, "lights": N_LIGHTS, "parallelism": f"rows{world}",
-                       "streams": "2: post chain of frame n overlaps shading of frame n+1" if args.overlap else "1"},
+                       "streams": "2: post chain of frame n overlaps shading of frame n+1" if args.overlap else "1",
+                       "untimed_spinup_steps": SPINUP_STEPS},
             "roofline": {"bound": "hbm", "kernel": "k_forward_lighting<env,nocasters,RGBA16F>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": SHADE_PMC_TRAFFIC_BYTES, "traffic_unit": "bytes/launch",
                          "traffic_source": "profiles/r1b_pmc_hbm.md (rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE); algorithmic = %d" % (SHADE_BYTES_PER_PX * px_tile),
