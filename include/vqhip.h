@@ -464,6 +464,12 @@ VQHIP_API int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void*
  * numbering (:71-80): 1 DEPTH pow(r,500), 2 NORMALS, 3 ROUGHNESS / 4 METALLIC (alpha), 5 AO (red), 6 ALBEDO / 7 REFLECTIONS
  * (rgb), 8 MOTION_VECTORS; anything else (including 0) writes magenta. Output alpha = input alpha. The caller binds the
  * image the reference's switch selects (:2555-2565); single-channel sources are passed expanded to (r,0,0,1). */
+/* Replaces ApplyReflectionsPass::RecordCommands (ApplyReflections.cpp:45-80) == ApplyReflections.hlsl:CSMain :30-50 without
+ * COMPOSITE_BOUNDING_VOLUMES: sceneColor.rgb += reflectionRadiance.rgb, alpha (roughness) kept; in place on the scene colour.
+ * (The producer of the reflection radiance, FidelityFX SSSR + denoiser, is out of scope.) fmt: RGBA16F | RGBA32F for both. */
+VQHIP_API int vqhip_apply_reflections(vqhip_ctx* ctx, void* stream, const void* reflectionRadiance, void* sceneColor,
+        int width, int height, vqhip_format fmt);
+
 typedef struct VQ_VizParams { int32_t iDrawMode; int32_t iUnpackNormals; float fInputStrength; } VQ_VizParams;
 VQHIP_API int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
         const VQ_VizParams* params, vqhip_format inFmt, vqhip_format outFmt);

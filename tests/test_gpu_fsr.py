@@ -87,6 +87,21 @@ def test_visualize_matches_oracle(ctx, in_fmt, out_fmt):
         assert n == 0, (mode, n, idx)
 
 
+@pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+def test_apply_reflections(ctx, fmt):
+    """ApplyReflections.hlsl:30-50: one IEEE add per colour channel in fp32, result rounded to the target format, alpha kept."""
+    dt = _NP[fmt]
+    scene = synth.hdr_image(157, 43, seed=3).astype(dt)
+    refl = synth.hdr_image(157, 43, seed=4, scale=0.5).astype(dt)
+    refl[5, 7] = (np.inf, -1.0, np.nan, 9.0)
+    exp = scene.copy()
+    with np.errstate(invalid="ignore", over="ignore"):
+        exp[..., :3] = (scene[..., :3].astype(np.float32) + refl[..., :3].astype(np.float32)).astype(dt)
+    got = ctx.apply_reflections(dev(refl), dev(scene), fmt).cpu().numpy()
+    n, idx = O.bits_equal(got, exp)
+    assert n == 0, (n, idx)
+
+
 def test_fsr_abi_errors(ctx):
     lib = ctx.lib
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -69,6 +69,7 @@ def load_library():
         "vqhip_fsr_easu": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(C.c_uint32), vp, i32, i32, i32]),
         "vqhip_fsr_rcas": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(C.c_uint32), i32, i32]),
         "vqhip_visualize": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.VizParams), i32, i32]),
+        "vqhip_apply_reflections": (i32, [vp, vp, vp, vp, i32, i32, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -86,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
     "vqhip_skydome", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
-    "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize",
+    "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections",
 ]
 
 
@@ -311,6 +312,14 @@ class Context:
         _check_img(out, out_fmt, "out")
         self._ck(self.lib.vqhip_fsr_rcas(self._h, self._stream(stream), _ptr(src), _ptr(out), w, h, con, in_fmt, out_fmt))
         return out
+
+    def apply_reflections(self, reflection, scene_color, fmt, stream=None):
+        """ApplyReflections.hlsl:CSMain: scene_color.rgb += reflection.rgb in place (alpha kept)."""
+        _check_img(reflection, fmt, "reflection")
+        _check_img(scene_color, fmt, "scene_color")
+        h, w = scene_color.shape[0], scene_color.shape[1]
+        self._ck(self.lib.vqhip_apply_reflections(self._h, self._stream(stream), _ptr(reflection), _ptr(scene_color), w, h, fmt))
+        return scene_color
 
     def visualize(self, src, in_fmt, params, out_fmt=None, out=None, stream=None):
         """Visualization.hlsl:CSMain (debug draw modes). params: abi.VizParams."""

@@ -441,6 +441,15 @@ int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "visualize launch");
 }
 
+int vqhip_apply_reflections(vqhip_ctx* ctx, void* stream, const void* reflectionRadiance, void* sceneColor, int width, int height, vqhip_format fmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "apply_reflections: ctx is NULL");
+    if (!reflectionRadiance || !sceneColor || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "apply_reflections: bad argument");
+    if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "apply_reflections: fmt must be RGBA32F or RGBA16F");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipError_t e = launch_apply_reflections((hipStream_t)stream, reflectionRadiance, sceneColor, width, height, fmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "apply_reflections launch");
+}
+
 int vqhip_specular_mip_count(int spec_res0) { return vqhip_mip_level_count(spec_res0, spec_res0) - 1; }
 size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt) {
     const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;

@@ -178,6 +178,21 @@ __global__ __launch_bounds__(256) void k_visualize(const void* __restrict__ in, 
     else if (OUTFMT == VQHIP_FMT_RGBA16F) store_rgba16f(out, i, r);
     else store_rgba8(out, i, r);
 }
+// ---- ApplyReflections.hlsl:CSMain :30-50: scene.rgb += reflection.rgb, alpha kept; in place, HBM-bound (24 B/pixel RGBA16F) ----
+template <int FMT>
+__global__ __launch_bounds__(256) void k_apply_reflections(const void* __restrict__ refl, void* scene, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 r = load_px<FMT>(refl, i), s = load_px<FMT>(scene, i);
+    store_px<FMT>(scene, i, make_float4(s.x + r.x, s.y + r.y, s.z + r.z, s.w));
+}
+hipError_t launch_apply_reflections(hipStream_t s, const void* refl, void* scene, int W, int H, int fmt) {
+    const uint32_t n = (uint32_t)W * (uint32_t)H;
+    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_apply_reflections<0>), dim3((n + 255) / 256), dim3(256), 0, s, refl, scene, n);
+    else                          hipLaunchKernelGGL((k_apply_reflections<1>), dim3((n + 255) / 256), dim3(256), 0, s, refl, scene, n);
+    return hipGetLastError();
+}
+
 template <int INFMT> static hipError_t viz_out(hipStream_t s, const void* in, void* out, uint32_t n, const VQ_VizParams& p, int outFmt) {
     dim3 grid((n + 255) / 256);
     switch (outFmt) {

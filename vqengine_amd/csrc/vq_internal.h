@@ -65,6 +65,7 @@ hipError_t launch_rgbe_to_rgba32f(hipStream_t s, const void* rgbe, void* out, si
 hipError_t launch_fsr_easu(hipStream_t s, const void* in, int inW, int inH, int inFmt, const uint32_t* con16, void* out, int outW, int outH, int outFmt);
 hipError_t launch_fsr_rcas(hipStream_t s, const void* in, void* out, int W, int H, const uint32_t* con4, int inFmt, int outFmt);
 hipError_t launch_visualize(hipStream_t s, const void* in, void* out, int W, int H, const VQ_VizParams& p, int inFmt, int outFmt);
+hipError_t launch_apply_reflections(hipStream_t s, const void* refl, void* scene, int W, int H, int fmt);
 
 // launchers (each returns the hipError_t of the launch)
 hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt);
