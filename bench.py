@@ -33,10 +33,10 @@ SHADE_FLOPS_PER_PX = 170 * N_LIGHTS + 160
 # FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950): profiles/r1b_pmc_hbm.md. Not measurable from inside
 # bench.py; the committed figure is for exactly this workload (3840x2160, 64 lights + IBL, RGBA16F out).
 SHADE_PMC_TRAFFIC_BYTES = (2 * 599481 + 64800) * 1024
-# VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_ab.sh, committed
+# VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_shade.sh, committed
 # summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
 SPINUP_STEPS = 200              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
-SHADE_PMC_VALU_PER_WAVE = 7367
+SHADE_PMC_VALU_PER_WAVE = 7166
 VALU_ISSUE_CEILING_TLIS = 52.7  # T lane-instructions/s = 105 TFLOP/s of v_fma_f32, scripts/ubench/valu_ubench.hip
 
 

@@ -82,7 +82,7 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     const float a = px.roughness * px.roughness;             // NormalDistributionGGX :74-75
     px.a2 = a * a;
     px.a2m1 = px.a2 - 1.0f;
-    px.fastOK = (px.roughness >= 0.0f) & (px.roughness <= 1.0f);
+    px.fastOK = (px.roughness >= 0.04f) & (px.roughness <= 1.0f);     // below 0.04 the GGX EPSILON early-out may fire: IEEE path
 }
 
 // BRDF(s, Wi, V), BRDF.hlsl:163-194 (contract v2 tree): fma(F, sG, (1-F)*kA) with sG = (D*G)*rcp(denom) and the
@@ -108,8 +108,13 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const float nh2 = NdotH * NdotH;
     const float t = fma_(nh2, px.a2m1, 1.0f);
     const float dd = PI_ * (t * t);
-    const float Dq = px.a2 * rc(max_(dd, EPSILON_));          // operand clamped only to keep the unused quotient finite
-    const float D = (dd < EPSILON_) ? 1.0f : Dq;
+    float D;
+    if constexpr (R::kGgxDenomAboveEps) {
+        D = px.a2 * rc(dd);                                  // `if (denom < EPSILON) return 1` (:76) cannot trigger: proven below (RcpTrust)
+    } else {
+        const float Dq = px.a2 * rc(max_(dd, EPSILON_));      // operand clamped only to keep the unused quotient finite
+        D = (dd < EPSILON_) ? 1.0f : Dq;
+    }
     const float sG = (D * G) * rc(max_(px.NdotV4 * NdotL, 0.0001f));
     return mk3(fma_(F.x, sG, (1.0f - F.x) * px.kA.x), fma_(F.y, sG, (1.0f - F.y) * px.kA.y), fma_(F.z, sG, (1.0f - F.z) * px.kA.z));
 }
@@ -141,7 +146,7 @@ VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op va
 
 // Hot-loop form: I = CalculatePointLightIllumination(..., acc = I). All reciprocals / square roots use the unchecked
 // fast sequences (RcpTrust); their validity is PROVEN from three range tests instead of being checked per operation:
-//   pixel  : roughness in [0,1]  (px.fastOK)  =>  k in [1/8,1/2], 1-k in [1/2,7/8], a2 in [0,1], hence
+//   pixel  : roughness in [0.04,1]  (px.fastOK)  =>  k in [1/8,1/2], 1-k in [1/2,7/8], a2 in [2.5e-6,1], hence
 //              G operand fma(NL,1-k,k)+1e-4 in [0.125, 1.4]   (NL = max(0,.) <= 1+eps, NaN -> 0)
 //              GGX operand max(pi t^2, 1e-12) in [1e-12, pi] (t = fma(nh2, a2-1, 1) in [a2,1], nh2 saturated)
 //              sG operand max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
@@ -150,6 +155,9 @@ VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op va
 // all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
 // degenerate geometry, roughness outside [0,1]) redoes that light with IEEE operations; results are identical bits.
 struct RcpTrust {
+    // roughness >= 0.04 (px.fastOK) => a2 >= 2.5e-6, t = fma(nh2, a2-1, 1) >= a2 - 2^-25 >= 2.5e-6 for nh2 in [0,1]
+    // => pi t^2 >= 1.9e-11 > EPSILON (1e-12): the GGX early-out never fires on this path
+    static constexpr bool kGgxDenomAboveEps = true;
     VQD float operator()(float b) const { return rcp_newton(b); }
     VQD float sqrt(float x) const { return sqrt_newton(x); }
 };

@@ -53,11 +53,13 @@ VQD float sqrt_(float x) {
 // flag; when it drops (operand outside the validated fast range — rare) the caller redoes the whole block with
 // IEEE. Results are bit-identical to rcp() / sqrt_() either way.
 struct RcpFast {
+    static constexpr bool kGgxDenomAboveEps = false;         // policies that make no claim about the GGX denominator keep its EPSILON test
     bool ok = true;
     VQD float operator()(float b) { const float r = rcp_newton(b); ok = ok & is_normal(r); return r; }
     VQD float sqrt(float x) { ok = ok & sqrt_fast_ok(x); return sqrt_newton(x); }
 };
 struct RcpIEEE {
+    static constexpr bool kGgxDenomAboveEps = false;
     VQD float operator()(float b) const { return 1.0f / b; }
     VQD float sqrt(float x) const { return __builtin_sqrtf(x); }
 };
