@@ -100,10 +100,20 @@ inline f3 BRDF(const Surface& s, f3 Wi, f3 V) {
     const float roughness = s.roughness, metalness = s.metalness;
     const f3 F0 = { lerp(0.04f, albedo.x, metalness), lerp(0.04f, albedo.y, metalness), lerp(0.04f, albedo.z, metalness) };
     const f3 F = Fresnel_Schlick(H, V, F0);
-    const float G = Geometry_Smith(N, Wo, Wi, roughness);
-    const float D = NormalDistributionGGX(NdotH, roughness);
+    // D*G/denom with its three divisions merged into one (contract v3; fast-math arcp + reassoc):
+    //   D  = a2 / (PI t^2)                      NormalDistributionGGX :65-79 (returns 1 when PI t^2 < EPSILON)
+    //   G  = G1(N,V) * NL / (NL(1-k) + k + 1e-4) Geometry_Smith :118-121, Geometry_Smiths_SchlickGGX :82-97
+    //   sG = ((a2*G1V) * NL) * rcp((PI t^2 * gL) * denom)          [ (G1V*NL) * rcp(gL*denom) on the EPSILON branch ]
+    const float rp1 = roughness + 1.0f;
+    const float k = div_(rp1 * rp1, 8.0f);
+    const float G1V = Geometry_Smiths_SchlickGGX(N, Wo, roughness);          // per pixel: keeps its own division
+    const float NL = max_(0.0f, dot(N, Wi));
+    const float gL = fma_(NL, 1.0f - k, k) + 0.0001f;
+    const float a = roughness * roughness, a2 = a * a;
+    const float t = fma_(NdotH * NdotH, a2 - 1.0f, 1.0f);
+    const float dd = PI_ * (t * t);
     const float denom = max_((4.0f * NdotV) * NdotL, 0.0001f);
-    const float sG = (D * G) * rcp(denom);
+    const float sG = (dd < EPSILON_) ? (G1V * NL) * rcp(gL * denom) : ((a2 * G1V) * NL) * rcp((dd * gL) * denom);
     const float omm = 1.0f - metalness, invPI = rcp(PI_);
     const f3 kA = { (omm * albedo.x) * invPI, (omm * albedo.y) * invPI, (omm * albedo.z) * invPI };
     return { fma_(F.x, sG, (1.0f - F.x) * kA.x), fma_(F.y, sG, (1.0f - F.y) * kA.y), fma_(F.z, sG, (1.0f - F.z) * kA.z) };
@@ -276,20 +286,22 @@ inline f3 lit(f3 acc, f3 b, f3 cb, float w) { return { fma_(b.x, cb.x * w, acc.x
 inline f3 CalculatePointLightIllumination(const VQ_PointLight& l, const Surface& s, f3 P, f3 V, f3 acc = { 0, 0, 0 }) {
     const f3 Lw = to3(l.position);
     const f3 d = sub(Lw, P);
-    const f3 Wi = normalize(d);
     const float D = length(d);
+    const float rD = rcp(D);                                 // normalize(d) = d * rsqrt(dot(d,d)) = d * rcp(D): one reciprocal ...
+    const f3 Wi = mul(d, rD);
     const float NdotL = saturate(dot(s.N, Wi));
-    const float w = AttenuationBRDF(D) * NdotL;
+    const float w = (rD * rD) * NdotL;                       // ... shared with AttenuationBRDF: 1/(D*D) as (1/D)*(1/D) (contract v3)
     if (D < l.range) return lit(acc, BRDF(s, Wi, V), light_cb(l.color, l.brightness), w);
     return acc;
 }
 // CalculateSpotLightIllumination, Lighting.hlsl:323-333 (no range cull)
 inline f3 CalculateSpotLightIllumination(const VQ_SpotLight& l, const Surface& s, f3 P, f3 V, f3 acc = { 0, 0, 0 }) {
     const f3 d = sub(to3(l.position), P);
-    const f3 Wi = normalize(d);
+    const float rD = rcp(length(d));
+    const f3 Wi = mul(d, rD);
     const float cone = SpotlightIntensity(l, P);
     const float NdotL = saturate(dot(s.N, Wi));
-    const float w = (cone * AttenuationBRDF(length(d))) * NdotL;
+    const float w = (cone * (rD * rD)) * NdotL;
     return lit(acc, BRDF(s, Wi, V), light_cb(l.color, l.brightness), w);
 }
 // CalculateDirectionalLightIllumination, Lighting.hlsl:334-345

@@ -34,6 +34,7 @@ struct Pixel {
     float G1V;                            // Geometry_Smiths_SchlickGGX(N, Wo, roughness)
     float k, omk;                         // k = (roughness+1)^2/8, omk = 1-k
     float a2, a2m1;                       // GGX alpha^2, alpha^2 - 1
+    float a2G1V;                          // a2 * G1V: the light-independent part of the merged D*G numerator
     bool fastOK;                          // roughness in [0,1]: precondition of the unchecked fast reciprocals (add_point_light)
 };
 
@@ -82,6 +83,7 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     const float a = px.roughness * px.roughness;             // NormalDistributionGGX :74-75
     px.a2 = a * a;
     px.a2m1 = px.a2 - 1.0f;
+    px.a2G1V = px.a2 * px.G1V;
     px.fastOK = (px.roughness >= 0.04f) & (px.roughness <= 1.0f);     // below 0.04 the GGX EPSILON early-out may fire: IEEE path
 }
 
@@ -101,21 +103,24 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const float p5 = pow5(1.0f - max_(0.0f, dot(H, px.V)));
 #endif
     const f3 F = mk3(fma_(px.omF0.x, p5, px.F0.x), fma_(px.omF0.y, p5, px.F0.y), fma_(px.omF0.z, p5, px.F0.z));
-    // Geometry_Smith :118-121
+    // D*G/denom with the three divisions merged into one (contract v3):
+    //   D = a2/(PI t^2) (NormalDistributionGGX :65-79; 1 when PI t^2 < EPSILON), G = G1V * NL/(NL(1-k)+k+1e-4) (Geometry_Smith :118-121)
+    //   sG = ((a2*G1V) * NL) * rcp((PI t^2 * gL) * denom)      [ (G1V*NL) * rcp(gL*denom) on the EPSILON branch ]
     const float NL = max_(0.0f, dNL);
-    const float G = px.G1V * (NL * rc(fma_(NL, px.omk, px.k) + 0.0001f));
-    // NormalDistributionGGX :65-79
+    const float gL = fma_(NL, px.omk, px.k) + 0.0001f;
     const float nh2 = NdotH * NdotH;
     const float t = fma_(nh2, px.a2m1, 1.0f);
     const float dd = PI_ * (t * t);
-    float D;
+    const float den = max_(px.NdotV4 * NdotL, 0.0001f);
+    float sG;
     if constexpr (R::kGgxDenomAboveEps) {
-        D = px.a2 * rc(dd);                                  // `if (denom < EPSILON) return 1` (:76) cannot trigger: proven below (RcpTrust)
+        sG = (px.a2G1V * NL) * rc((dd * gL) * den);          // `if (denom < EPSILON) return 1` (:76) cannot trigger: proven below (RcpTrust)
     } else {
-        const float Dq = px.a2 * rc(max_(dd, EPSILON_));      // operand clamped only to keep the unused quotient finite
-        D = (dd < EPSILON_) ? 1.0f : Dq;
+        const bool eps = dd < EPSILON_;
+        const float num = (eps ? px.G1V : px.a2G1V) * NL;
+        const float d3 = eps ? gL * den : (dd * gL) * den;
+        sG = num * rc(d3);
     }
-    const float sG = (D * G) * rc(max_(px.NdotV4 * NdotL, 0.0001f));
     return mk3(fma_(F.x, sG, (1.0f - F.x) * px.kA.x), fma_(F.y, sG, (1.0f - F.y) * px.kA.y), fma_(F.z, sG, (1.0f - F.z) * px.kA.z));
 }
 
@@ -129,9 +134,10 @@ VQD f3 point_light_t(const Pixel& px, f3 lpos, float range, f3 cb, f3 acc, R& rc
     const f3 d = sub(lpos, px.P);
     const float D = rc.sqrt(dot(d, d));                      // length(Lw - P); normalize() shares the sqrt
     if (D < range) {
-        const f3 Wi = mul(d, rc(D));
+        const float rD = rc(D);                              // one reciprocal for normalize(Lw - P) and for AttenuationBRDF :29-32,
+        const f3 Wi = mul(d, rD);
         const float NdotL = saturate(dot(px.Nraw, Wi));
-        const float w = rc(D * D) * NdotL;                   // AttenuationBRDF :29-32
+        const float w = (rD * rD) * NdotL;                   // 1/(D*D) as (1/D)*(1/D) (contract v3)
         return lit(acc, brdf_t(px, Wi, rc), cb, w);
     }
     return acc;
@@ -147,10 +153,11 @@ VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op va
 // Hot-loop form: I = CalculatePointLightIllumination(..., acc = I). All reciprocals / square roots use the unchecked
 // fast sequences (RcpTrust); their validity is PROVEN from three range tests instead of being checked per operation:
 //   pixel  : roughness in [0.04,1]  (px.fastOK)  =>  k in [1/8,1/2], 1-k in [1/2,7/8], a2 in [2.5e-6,1], hence
-//              G operand fma(NL,1-k,k)+1e-4 in [0.125, 1.4]   (NL = max(0,.) <= 1+eps, NaN -> 0)
-//              GGX operand max(pi t^2, 1e-12) in [1e-12, pi] (t = fma(nh2, a2-1, 1) in [a2,1], nh2 saturated)
-//              sG operand max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
-//   light  : dd = |Lw-P|^2 in [2^-60, 2^60] =>  D in [2^-30, 2^30], D*D in range, 1/D and 1/D^2 normal
+//              gL = fma(NL,1-k,k)+1e-4 in [0.125, 1.4]   (NL = max(0,.) <= 1+eps, NaN -> 0)
+//              pi t^2 in [1.9e-11, pi] (t = fma(nh2, a2-1, 1) in [a2 - 2^-25, 1], nh2 saturated)
+//              denom = max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
+//              => the merged reciprocal's operand (pi t^2 * gL) * denom in [2.4e-16, 17.6]: operand and result normal
+//   light  : dd = |Lw-P|^2 in [2^-60, 2^60] =>  D in [2^-30, 2^30], 1/D normal (and (1/D)^2 is a plain product)
 //   light  : hh = |Wo+Wi|^2 >= 2^-100 (and not NaN; it is <= ~4 for unit Wo, Wi) => sqrt and 1/sqrt normal
 // all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
 // degenerate geometry, roughness outside [0,1]) redoes that light with IEEE operations; results are identical bits.
@@ -170,11 +177,12 @@ VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
     bool ok = px.fastOK & (dd >= 0x1p-60f) & (dd <= 0x1p60f);
     if (D < l.range) {                                       // wave-coherent cull; a wrong D (ok == false) is redone below
         RcpTrust rc;
-        const f3 Wi = mul(d, rc(D));
+        const float rD = rc(D);
+        const f3 Wi = mul(d, rD);
         const f3 Hs = add(px.Wo, Wi);
         ok = ok & (dot(Hs, Hs) >= 0x1p-100f);
         const float NdotL = saturate(dot(px.Nraw, Wi));
-        const float w = rc(D * D) * NdotL;
+        const float w = (rD * rD) * NdotL;
 #if VQ_ABLATE == 3
         const f3 b = mk3(Wi.x * px.k, Wi.y * px.a2, Wi.z * px.omk);   // ablation: no BRDF
 #else
@@ -189,7 +197,8 @@ VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
 VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, f3 acc) {
     const f3 d = sub(ld3(l.position), px.P);
     const float D = sqrt_(dot(d, d));
-    const f3 Wi = mul(d, rcp(D));
+    const float rD = rcp(D);
+    const f3 Wi = mul(d, rD);
     const f3 pd = normalize(sub(px.P, ld3(l.position)));
     const f3 sd = normalize(ld3(l.spotDir));
     const float theta = acos_(dot(pd, sd));
@@ -198,7 +207,7 @@ VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, f3 acc) {
     else if (theta <= l.innerConeAngle) cone = 1.0f;
     else cone = 1.0f - div_(theta - l.innerConeAngle, l.outerConeAngle - l.innerConeAngle);
     const float NdotL = saturate(dot(px.Nraw, Wi));
-    const float w = (cone * rcp(D * D)) * NdotL;
+    const float w = (cone * (rD * rD)) * NdotL;
     RcpIEEE rc;
     return lit(acc, brdf_t(px, Wi, rc), light_cb(l.color, l.brightness), w);
 }
