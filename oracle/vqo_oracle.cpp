@@ -116,7 +116,8 @@ inline f3 BRDF(const Surface& s, f3 Wi, f3 V) {
     const float sG = (dd < EPSILON_) ? (G1V * NL) * rcp(gL * denom) : ((a2 * G1V) * NL) * rcp((dd * gL) * denom);
     const float omm = 1.0f - metalness, invPI = rcp(PI_);
     const f3 kA = { (omm * albedo.x) * invPI, (omm * albedo.y) * invPI, (omm * albedo.z) * invPI };
-    return { fma_(F.x, sG, (1.0f - F.x) * kA.x), fma_(F.y, sG, (1.0f - F.y) * kA.y), fma_(F.z, sG, (1.0f - F.z) * kA.z) };
+    // Id + Is = (1-F)*kA + F*sG regrouped as kA + F*(sG - kA): one subtraction and one mad per channel (contract v3)
+    return { fma_(F.x, sG - kA.x, kA.x), fma_(F.y, sG - kA.y, kA.y), fma_(F.z, sG - kA.z, kA.z) };
 }
 // EnvironmentBRDF, BRDF.hlsl:196-207
 inline f3 EnvironmentBRDF(float NdotV, float roughness, float metallic, f3 diffuseColor, f3 diffuseIrradiance, f3 preFilteredSpecular, f2 F0ScaleBias) {

@@ -121,7 +121,8 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
         const float d3 = eps ? gL * den : (dd * gL) * den;
         sG = num * rc(d3);
     }
-    return mk3(fma_(F.x, sG, (1.0f - F.x) * px.kA.x), fma_(F.y, sG, (1.0f - F.y) * px.kA.y), fma_(F.z, sG, (1.0f - F.z) * px.kA.z));
+    // Id + Is = (1-F)*kA + F*sG regrouped as kA + F*(sG - kA) (contract v3)
+    return mk3(fma_(F.x, sG - px.kA.x, px.kA.x), fma_(F.y, sG - px.kA.y, px.kA.y), fma_(F.z, sG - px.kA.z, px.kA.z));
 }
 
 // acc + b * (cb * w): cb = l.color * l.brightness, w = attenuation [* cone] * NdotL (one mad per channel)
