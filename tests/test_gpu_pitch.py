@@ -39,6 +39,30 @@ def test_forward_lighting_pitched_planes(ctx):
     assert ctx.lib.vqhip_forward_lighting(ctx._h, st, C.byref(g), C.byref(pf), C.byref(pv), None, 0, None, None, C.c_void_p(out.data_ptr()), OP, abi.FMT_RGBA16F) == abi.VQHIP_ERR_INVALID_ARG
 
 
+def test_constant_ring_back_to_back_calls_see_their_own_constants(ctx):
+    """600 forward-lighting calls enqueued without any host synchronisation, each with different cbuffer contents (the light's
+    brightness and position change per call), wrap the 32-slot constant ring many times while uploads run on the context's copy
+    stream. Every result must equal the one obtained with a device synchronisation after every call."""
+    W, H, N = 96, 16, 600
+    gb = [dev(g) for g in synth.gbuffer(W, H, seed=0xA11)]
+    pts = synth.point_lights(3, seed=0xA11)
+    pv = synth.per_view(W, H)
+    frames = []
+    for i in range(N):
+        pts[0].brightness = 100.0 + i
+        pts[1].position.x = -40.0 + 0.1 * i
+        pf, _ = synth.per_frame(points=pts)
+        frames.append(pf)
+    outs = [ctx.forward_lighting(gb, frames[i], pv, out_fmt=abi.FMT_RGBA32F) for i in range(N)]      # no sync in between
+    torch.cuda.synchronize()
+    got = torch.stack(outs).cpu().numpy()
+    for i in list(range(0, N, 37)) + [N - 1]:
+        ref = ctx.forward_lighting(gb, frames[i], pv, out_fmt=abi.FMT_RGBA32F)
+        torch.cuda.synchronize()
+        assert np.array_equal(got[i].view(np.uint32), ref.cpu().numpy().view(np.uint32)), i
+    assert not np.array_equal(got[0], got[1])                     # the constants really differed
+
+
 def test_gbuffer_producer_and_skydome_pitched(ctx):
     import math
     from vqengine_amd import scene
