@@ -36,7 +36,7 @@ SHADE_PMC_TRAFFIC_BYTES = (2 * 599481 + 64800) * 1024
 # VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_shade.sh, committed
 # summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
 SPINUP_STEPS = 200              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
-SHADE_PMC_VALU_PER_WAVE = 6617
+SHADE_PMC_VALU_PER_WAVE = 6550
 VALU_ISSUE_CEILING_TLIS = 52.7  # T lane-instructions/s = 105 TFLOP/s of v_fma_f32, scripts/ubench/valu_ubench.hip
 
 

@@ -4,7 +4,8 @@
 // every light-invariant term hoisted to per-pixel setup.
 //
 // Arithmetic follows the contract in DESIGN.md §3 (intrinsic lowering: vq_devmath.h; expression trees of the
-// lighting functions: "contract v2" — scalar factors of vector products gathered, a*b+c written as one mad):
+// lighting functions: "contract v2/v3" — scalar factors of vector products gathered, a*b+c written as one mad, the three
+// divisions of D*G/denom merged into one reciprocal, 1/(D*D) formed from the reciprocal that normalises Lw - P):
 //   Shaders/BRDF.hlsl:65-79,82-97,118-121,132-136,152-161,163-207
 //   Shaders/Lighting.hlsl:29-32,57-73,110-174,177-272,308-395
 //   Shaders/ForwardLighting.hlsl:284-380

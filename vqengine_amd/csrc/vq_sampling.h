@@ -44,11 +44,22 @@ VQD f3 cube_texel_dir(int face, int x, int y, int res) {
 
 // direction -> face and [0,1] face coordinates (sv grows down the rows); ties: z over y over x
 VQD int cube_face_uv(f3 d, float* su, float* sv) {
-    float ax = abs_(d.x), ay = abs_(d.y), az = abs_(d.z);
-    int face; float sc, tc, ma;
-    if (az >= ax && az >= ay) { ma = az; if (d.z < 0.0f) { face = 5; sc = -d.x; tc = -d.y; } else { face = 4; sc =  d.x; tc = -d.y; } }
-    else if (ay >= ax)        { ma = ay; if (d.y < 0.0f) { face = 3; sc =  d.x; tc = -d.z; } else { face = 2; sc =  d.x; tc =  d.z; } }
-    else                      { ma = ax; if (d.x < 0.0f) { face = 1; sc =  d.z; tc = -d.y; } else { face = 0; sc = -d.z; tc = -d.y; } }
+    // Branch-free form of the 6-way table (only selects and sign flips, so the values are those of the if/else ladder):
+    //   face  +X(0)  -X(1)  +Y(2)  -Y(3)  +Z(4)  -Z(5)
+    //   sc     -z     +z     +x     +x     +x     -x
+    //   tc     -y     -y     +z     -z     -y     -y
+    const float ax = abs_(d.x), ay = abs_(d.y), az = abs_(d.z);
+    const bool isZ = (az >= ax) & (az >= ay);
+    const bool isY = !isZ & (ay >= ax);
+    const bool isX = !(isZ | isY);
+    const float major = isZ ? d.z : (isY ? d.y : d.x);
+    const float ma = isZ ? az : (isY ? ay : ax);
+    const bool neg = major < 0.0f;
+    const float sc0 = isX ? -d.z : d.x;
+    const float tc0 = isY ? d.z : -d.y;
+    const float sc = (neg & !isY) ? -sc0 : sc0;
+    const float tc = (neg & isY) ? -tc0 : tc0;
+    const int face = (isZ ? 4 : (isY ? 2 : 0)) + (neg ? 1 : 0);
     float r = rcp(ma);
     *su = (sc * r) * 0.5f + 0.5f;
     *sv = (tc * r) * 0.5f + 0.5f;
@@ -123,18 +134,22 @@ constexpr uint64_t kW0 = word(0), kW1 = word(1), kW2 = word(2);
 
 // tap (i,j) of face f that left the face through exactly ONE edge -> texel (nf, ni, nj) of the adjacent face (table form of
 // cube_edge_neighbor; ~12 integer operations)
-VQD void cube_edge_lookup(int f, int i, int j, int N, int* nf, int* ni, int* nj) {
-    const bool ox = (i < 0) | (i >= N);
-    const int e = ox ? (i < 0 ? 0 : 1) : (j < 0 ? 2 : 3);
+VQD uint32_t cube_edge_entry(int f, int e) {
     const int idx = f * 4 + e;
     const uint64_t w = idx < 8 ? edge_tab::kW0 : (idx < 16 ? edge_tab::kW1 : edge_tab::kW2);
-    const uint32_t en = (uint32_t)(w >> (8 * (idx & 7))) & 63u;
-    const int r = ox ? j : i;
+    return (uint32_t)(w >> (8 * (idx & 7))) & 63u;
+}
+// r = the tap's coordinate ALONG the edge it left through (j for an x edge, i for a y edge)
+VQD void cube_edge_apply(uint32_t en, int r, int N, int* nf, int* ni, int* nj) {
     const int run = (en & 32u) ? N - 1 - r : r;
     const int fix = (en & 16u) ? N - 1 : 0;
     *nf = (int)(en & 7u);
     *ni = (en & 8u) ? fix : run;
     *nj = (en & 8u) ? run : fix;
+}
+VQD void cube_edge_lookup(int f, int i, int j, int N, int* nf, int* ni, int* nj) {
+    const bool ox = (i < 0) | (i >= N);
+    cube_edge_apply(cube_edge_entry(f, ox ? (i < 0 ? 0 : 1) : (j < 0 ? 2 : 3)), ox ? j : i, N, nf, ni, nj);
 }
 
 VQD void fixed8(float x, int* ix, float* w) {
@@ -172,12 +187,15 @@ VQD float4 sample_cube_rgba16f(const void* cube, int N, f3 dir) {
     }
 #endif
     int missing = -1;
+    // the two columns of a footprint can only leave the face on the same side (ix < 0: left, else right), likewise the rows:
+    // two table entries per sample serve all four taps
+    const uint32_t enx = cube_edge_entry(f, ix < 0 ? 0 : 1), eny = cube_edge_entry(f, iy < 0 ? 2 : 3);
     #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int i = ix + (t & 1), j = iy + (t >> 1);
         const bool ox = (i < 0) | (i >= N), oy = (j < 0) | (j >= N);
         int nf, ni, nj;
-        cube_edge_lookup(f, i, j, N, &nf, &ni, &nj);                  // meaningful only when exactly one of ox, oy holds
+        cube_edge_apply(ox ? enx : eny, ox ? j : i, N, &nf, &ni, &nj); // meaningful only when exactly one of ox, oy holds
         const bool one = ox != oy;
         nf = one ? nf : f;
         ni = one ? ni : min(max(i, 0), N - 1);                        // identity inside the face; any valid address for a corner
