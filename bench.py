@@ -37,7 +37,9 @@ SHADE_PMC_TRAFFIC_BYTES = (2 * 599481 + 64800) * 1024
 # summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
 SPINUP_STEPS = 200              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
 SHADE_PMC_VALU_PER_WAVE = 6550
-VALU_ISSUE_CEILING_TLIS = 52.7  # T lane-instructions/s = 105 TFLOP/s of v_fma_f32, scripts/ubench/valu_ubench.hip
+SHADE_TRANS_PER_WAVE = 285      # quarter-rate v_rcp_f32 / v_rsq_f32 per wave: 5 per executed light (81.7 % of 64) + 1 per culled one + ~12 in set-up / IBL
+VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip;
+                                # the single-shot figure of round 1a-1e, 52.7, was taken on cold clocks)
 
 
 def build_ibl(ctx):
@@ -263,10 +265,12 @@ def main():
                          "note": "64-light shading is VALU-bound by construction (SURVEY.md 8d): see valu"},
             "valu": {"achieved_tflops_model": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
                      "frac": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12 / VALU_PEAK_TFLOPS, 4), "flops_per_px_model": SHADE_FLOPS_PER_PX},
-            "valu_issue": {"achieved_T_lane_instr_s": round(SHADE_PMC_VALU_PER_WAVE * (px_tile / 64) * 64 / t_shade / 1e12, 2),
+            "valu_issue": {"achieved_T_lane_instr_s": round(SHADE_PMC_VALU_PER_WAVE * px_tile / t_shade / 1e12, 2),
                            "ceiling": VALU_ISSUE_CEILING_TLIS, "frac": round(SHADE_PMC_VALU_PER_WAVE * px_tile / t_shade / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
-                           "valu_instr_per_wave": SHADE_PMC_VALU_PER_WAVE,
-                           "note": "the binding roof: instructions issued per second vs the measured v_fma_f32 issue ceiling (PMC count x live kernel time)"},
+                           "frac_slot_weighted": round((SHADE_PMC_VALU_PER_WAVE + 3 * SHADE_TRANS_PER_WAVE) * px_tile / t_shade / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
+                           "valu_instr_per_wave": SHADE_PMC_VALU_PER_WAVE, "quarter_rate_instr_per_wave": SHADE_TRANS_PER_WAVE,
+                           "note": "the binding roof: VALU instructions issued per second (PMC count x live kernel time) vs the steady-state v_fma_f32 "
+                                   "issue rate of the chip (scripts/ubench/valu_ceiling.hip); slot-weighted counts each quarter-rate v_rcp/v_rsq as 4 slots"},
             "stages": {"shade_Mpix_s": round(px_tile / t_shade / 1e6, 1), "shade_ms": round(t_shade * 1e3, 4),
                        **({"blur_xy_ms": round(t_blur * 1e3, 4), "blur_xy_GBps": round(px_tile * 32 / t_blur / 1e9, 1),
                            "tonemap_ms": round(t_tm * 1e3, 4), "tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1)} if args.post == "split" else
