@@ -325,7 +325,23 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     // the host into 32-byte records {position, range, color*brightness}
     const vqk::DevPointLight* pts = (const vqk::DevPointLight*)(fc + 1);
     const int nP = fc->numPointAll;
+#ifndef VQ_LIGHT_PREFETCH
+#define VQ_LIGHT_PREFETCH 0      // A/B (same box, scripts/bench_variants.sh): prefetching the next record 1.034 ms vs 1.022 ms without: off
+#endif
+#if VQ_LIGHT_PREFETCH
+    // software-pipelined scalar loads: the record of light p+1 is requested before light p is evaluated (6 waves per SIMD
+    // already hide the scalar-cache latency, so this only adds SGPR moves)
+    if (nP > 0) {
+        vqk::DevPointLight cur = pts[0];
+        for (int p = 0; p < nP; ++p) {
+            const vqk::DevPointLight nxt = pts[p + 1 < nP ? p + 1 : p];
+            add_point_light(px, cur, I);
+            cur = nxt;
+        }
+    }
+#else
     for (int p = 0; p < nP; ++p) add_point_light(px, pts[p], I);
+#endif
     const VQ_SceneLighting& L = fc->perFrame.Lights;
     const int nS = L.numSpotLights;
     for (int s = 0; s < nS; ++s) I = spot_light(px, L.spot_lights[s], I);                     // :314-317
