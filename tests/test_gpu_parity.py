@@ -203,6 +203,39 @@ def _shadow_setup(W, H):
     return pf, dmap, smap, pmap
 
 
+def test_forward_range_cull_boundary(ctx):
+    """`if (D < range)` (Lighting.hlsl:318) is evaluated in the kernel as dd < rangeSq with a host-made exact threshold: pixels placed
+    within a few ulps of the range sphere of every light must be lit / culled exactly like the oracle's sqrt-and-compare."""
+    r = np.random.default_rng(1234)
+    ranges = np.concatenate([r.uniform(0.5, 200.0, 12), [1.0, 2.0, 1e-3, 3e4]]).astype(np.float32)
+    K = 48
+    W, H = 2 * K + 1, len(ranges)
+    gb = [g.copy() for g in synth.gbuffer(W, H, seed=0xB0B)]
+    pts = synth.point_lights(len(ranges), seed=0xB0B)
+    for y, rg in enumerate(ranges):
+        pts[y].position.x, pts[y].position.y, pts[y].position.z = 0.0, 0.0, 0.0
+        pts[y].range = float(rg)
+        x = np.float32(rg)
+        xs = [x]
+        for _ in range(K):
+            xs.append(np.nextafter(xs[-1], np.float32(np.inf), dtype=np.float32))
+        lo = [x]
+        for _ in range(K):
+            lo.append(np.nextafter(lo[-1], np.float32(0), dtype=np.float32))
+        row = np.array(lo[:0:-1] + xs, np.float32)                      # K below, range itself, K above
+        gb[0][y, :, 0] = row; gb[0][y, :, 1] = 0.0; gb[0][y, :, 2] = 0.0
+        gb[1][y, :, :3] = (-1.0, 0.0, 0.0)                               # facing the light at the origin
+    pf, extra = synth.per_frame(points=pts)
+    pv = synth.per_view(W, H)
+    ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F)
+    got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F)
+    assert_bits(got, ref, "range-cull boundary")
+    # the rows really straddle the boundary: the own light's contribution switches off somewhere along each row
+    for y in range(H):
+        lit_first, lit_last = ref[y, 0, :3].sum(), ref[y, -1, :3].sum()
+        assert lit_first != lit_last
+
+
 def test_forward_shadow_casters_pcf(ctx):
     W, H = 200, 40
     gb = synth.gbuffer(W, H, seed=0x5AD0)

@@ -2,6 +2,8 @@
 // analogue of the reference's DynamicBufferHeap upload heap) and kernel dispatch. There is no CPU
 // fallback anywhere in this library: without a gfx950 device vqhip_create() fails and every other
 // entry point needs a context.
+#include <cfloat>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -73,6 +75,19 @@ int ensureScratch(vqhip_ctx* ctx, size_t bytes) {
 }
 
 int mipDim(int d0, int l) { int d = d0 >> l; return d < 1 ? 1 : d; }
+
+// Smallest float t >= 0 with sqrtf(t) >= range: `length(Lw - P) < range` (Lighting.hlsl:318) <=> `dot(d,d) < t` exactly, because the
+// correctly rounded sqrt is monotonic. NaN range -> NaN (never lit); range <= 0 -> 0 (never lit); +inf -> +inf (every finite distance).
+float rangeCullThreshold(float range) {
+    if (!(range == range)) return range;
+    if (range <= 0.0f) return 0.0f;
+    if (range == INFINITY) return INFINITY;
+    const double r2 = (double)range * (double)range;
+    float t = r2 >= (double)FLT_MAX ? FLT_MAX : (float)r2;
+    while (t > 0.0f && sqrtf(t) >= range) t = nextafterf(t, 0.0f);           // now sqrtf(t) < range (or t == 0)
+    while (sqrtf(t) < range) { if (t == FLT_MAX) return INFINITY; t = nextafterf(t, INFINITY); }
+    return t;
+}
 
 } // namespace
 
@@ -175,7 +190,7 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
         const VQ_PointLight& l = i < L.numPointLights ? L.point_lights[i] : extraPoint[i - L.numPointLights];
         pts[i].px = l.position.x; pts[i].py = l.position.y; pts[i].pz = l.position.z; pts[i].range = l.range;
         pts[i].cbx = l.color.x * l.brightness; pts[i].cby = l.color.y * l.brightness; pts[i].cbz = l.color.z * l.brightness;   // l.color * l.brightness (Lighting.hlsl:317)
-        pts[i].pad = 0.0f;
+        pts[i].rangeSq = rangeCullThreshold(l.range);
     }
     fc->numPointAll = nPts;
     rc = commitSlot(ctx, slot, sizeof(FrameConstants) + (size_t)nPts * sizeof(DevPointLight), st);

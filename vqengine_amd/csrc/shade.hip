@@ -175,10 +175,10 @@ VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
     const f3 lpos = mk3(l.px, l.py, l.pz), cb = mk3(l.cbx, l.cby, l.cbz);
     const f3 d = sub(lpos, px.P);
     const float dd = dot(d, d);
-    const float D = sqrt_newton(dd);
     bool ok = px.fastOK & (dd >= 0x1p-60f) & (dd <= 0x1p60f);
-    if (D < l.range) {                                       // wave-coherent cull; a wrong D (ok == false) is redone below
-        RcpTrust rc;
+    if (dd < l.rangeSq) {                                    // == (length(Lw - P) < l.range), exactly (host-made threshold): culled lights
+        RcpTrust rc;                                         // need no square root; wave-coherent (execz skip)
+        const float D = sqrt_newton(dd);
         const float rD = rc(D);
         const f3 Wi = mul(d, rD);
         const f3 Hs = add(px.Wo, Wi);

@@ -24,7 +24,9 @@ struct alignas(16) FrameConstants {
 // Non-shadowing point lights as the hot loop reads them (one s_load_dwordx8 per light): point_lights[0..numPointLights)
 // followed by the extension array, with the loop-invariant product color*brightness formed once on the host (IEEE
 // multiply, identical to the in-shader product).
-struct alignas(16) DevPointLight { float px, py, pz, range; float cbx, cby, cbz, pad; };
+// `rangeSq` is the exact threshold of the range cull in squared distance: the smallest float t with sqrtf(t) >= range, so that
+// (sqrt(dd) < range) == (dd < rangeSq) for every dd (sqrt is correctly rounded, hence monotonic) and culled lights need no sqrt.
+struct alignas(16) DevPointLight { float px, py, pz, range; float cbx, cby, cbz, rangeSq; };
 static constexpr int    kMaxExtraPointLights = 1024;
 static constexpr size_t kConstSlotBytes = (sizeof(FrameConstants) + (VQ_NUM_LIGHTS__POINT + kMaxExtraPointLights) * sizeof(DevPointLight) + 255) & ~(size_t)255;
 
