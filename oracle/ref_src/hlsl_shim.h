@@ -1,0 +1,285 @@
+// hlsl_shim.h — the subset of HLSL's types and intrinsics that the reference's shaders on this path use, as C++17,
+// so that oracle/ref_src/hlsl2cpp.py's output (the reference's OWN shader sources, read where they lie under
+// /root/reference/Shaders and rewritten only syntactically) compiles with g++ into oracle/_ref/libvqref_shaders.so.
+//
+// TEST INFRASTRUCTURE (oracle side). Arithmetic model of the shim = "HLSL as written, IEEE binary32, no fast-math":
+//   * every operator is one correctly rounded binary32 operation, evaluated in source order (-ffp-contract=off);
+//   * dot(a,b) = a.x*b.x + a.y*b.y + ... left to right; length = sqrt(dot); normalize(v) = v / length(v) per component;
+//   * pow(x,y) = exp2(y*log2(x)) (how DXC lowers it; negative bases give NaN like on a GPU), exp2/log2/sin/... = libm;
+//   * saturate/min/max drop NaN like the DXIL ops (fmin/fmax); lerp(a,b,t) = a + t*(b-a); reflect(i,n) = i - 2*dot(n,i)*n.
+// What a GPU compiler does on top of that (fast-math regrouping, approximate transcendentals) is exactly what the
+// oracle's arithmetic contract pins down by choice; the comparison of the two is therefore made with a tolerance
+// (tests/test_ref_pinning.py), and what it pins is the ALGORITHM: constants, branches, operand order, loop bounds.
+// Texture sampling has no source in the reference (fixed-function hardware): the Texture* objects below forward to hooks
+// that the harness (ref_shaders.cpp) implements with the oracle's sampling contract.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+namespace hlsl {
+
+typedef unsigned int uint;
+typedef float half;
+
+struct float2; struct float3; struct float4;
+
+// ---- swizzle proxies (live inside the vector's union; N = components of the owning vector) ----------------------------
+template <int N, int A, int B> struct sw2 {
+    float d[N];
+    operator float2() const;
+    sw2& operator=(const float2& v);
+    sw2& operator=(const sw2& o);
+};
+template <int N, int A, int B, int C> struct sw3 {
+    float d[N];
+    operator float3() const;
+    sw3& operator=(const float3& v);
+    sw3& operator=(const sw3& o);
+    sw3& operator+=(const float3& v);
+};
+template <int N, int A, int B, int C, int D> struct sw4 {
+    float d[N];
+    operator float4() const;
+};
+
+struct float2 {
+    union {
+        struct { float x, y; };
+        struct { float r, g; };
+        float d[2];
+        sw2<2, 0, 1> xy; sw2<2, 1, 0> yx; sw2<2, 0, 0> xx; sw2<2, 1, 1> yy; sw2<2, 0, 1> rg;
+        sw3<2, 0, 0, 0> xxx;
+    };
+    float2() : d{ 0, 0 } {}
+    float2(float a, float b) : d{ a, b } {}
+    explicit float2(float s) : d{ s, s } {}
+    float2(const float2& o) : d{ o.d[0], o.d[1] } {}
+    float2& operator=(const float2& o) { d[0] = o.d[0]; d[1] = o.d[1]; return *this; }
+    float& operator[](int i) { return d[i]; }
+    const float& operator[](int i) const { return d[i]; }
+};
+struct float3 {
+    union {
+        struct { float x, y, z; };
+        struct { float r, g, b; };
+        float d[3];
+        sw2<3, 0, 1> xy; sw2<3, 0, 2> xz; sw2<3, 1, 2> yz; sw2<3, 0, 1> rg;
+        sw3<3, 0, 1, 2> xyz; sw3<3, 0, 1, 2> rgb; sw3<3, 0, 0, 0> xxx; sw3<3, 0, 0, 0> rrr; sw3<3, 2, 1, 0> zyx;
+    };
+    float3() : d{ 0, 0, 0 } {}
+    float3(float a, float b, float c) : d{ a, b, c } {}
+    explicit float3(float s) : d{ s, s, s } {}
+    float3(const float2& v, float c) : d{ v.d[0], v.d[1], c } {}
+    float3(const float3& o) : d{ o.d[0], o.d[1], o.d[2] } {}
+    float3& operator=(const float3& o) { d[0] = o.d[0]; d[1] = o.d[1]; d[2] = o.d[2]; return *this; }
+    float& operator[](int i) { return d[i]; }
+    const float& operator[](int i) const { return d[i]; }
+};
+struct float4 {
+    union {
+        struct { float x, y, z, w; };
+        struct { float r, g, b, a; };
+        float d[4];
+        sw2<4, 0, 1> xy; sw2<4, 2, 3> zw; sw2<4, 0, 1> rg; sw2<4, 0, 2> xz;
+        sw3<4, 0, 1, 2> xyz; sw3<4, 0, 1, 2> rgb; sw3<4, 0, 0, 0> xxx; sw3<4, 0, 0, 0> rrr; sw3<4, 3, 3, 3> aaa; sw3<4, 3, 3, 3> www;
+        sw4<4, 0, 1, 2, 3> xyzw; sw4<4, 0, 1, 2, 3> rgba; sw4<4, 0, 1, 3, 3> xyww;
+    };
+    float4() : d{ 0, 0, 0, 0 } {}
+    float4(float a, float b, float c, float e) : d{ a, b, c, e } {}
+    explicit float4(float s) : d{ s, s, s, s } {}
+    float4(const float3& v, float e) : d{ v.d[0], v.d[1], v.d[2], e } {}
+    float4(const float2& v, float c, float e) : d{ v.d[0], v.d[1], c, e } {}
+    float4(const float2& a, const float2& b) : d{ a.d[0], a.d[1], b.d[0], b.d[1] } {}
+    float4(const float4& o) : d{ o.d[0], o.d[1], o.d[2], o.d[3] } {}
+    float4& operator=(const float4& o) { for (int i = 0; i < 4; ++i) d[i] = o.d[i]; return *this; }
+    float& operator[](int i) { return d[i]; }
+    const float& operator[](int i) const { return d[i]; }
+};
+typedef float2 half2; typedef float3 half3; typedef float4 half4;
+
+template <int N, int A, int B> sw2<N, A, B>::operator float2() const { return float2(d[A], d[B]); }
+template <int N, int A, int B> sw2<N, A, B>& sw2<N, A, B>::operator=(const float2& v) { d[A] = v.x; d[B] = v.y; return *this; }
+template <int N, int A, int B> sw2<N, A, B>& sw2<N, A, B>::operator=(const sw2& o) { const float2 v = o; return *this = v; }
+template <int N, int A, int B, int C> sw3<N, A, B, C>::operator float3() const { return float3(d[A], d[B], d[C]); }
+template <int N, int A, int B, int C> sw3<N, A, B, C>& sw3<N, A, B, C>::operator=(const float3& v) { d[A] = v.x; d[B] = v.y; d[C] = v.z; return *this; }
+template <int N, int A, int B, int C> sw3<N, A, B, C>& sw3<N, A, B, C>::operator=(const sw3& o) { const float3 v = o; return *this = v; }
+template <int N, int A, int B, int C> sw3<N, A, B, C>& sw3<N, A, B, C>::operator+=(const float3& v) { d[A] += v.x; d[B] += v.y; d[C] += v.z; return *this; }
+template <int N, int A, int B, int C, int D> sw4<N, A, B, C, D>::operator float4() const { return float4(d[A], d[B], d[C], d[D]); }
+
+// ---- integer vectors (plain; only the members the shaders touch) ------------------------------------------------------
+struct int2 { int x, y; int2() : x(0), y(0) {} int2(int a, int b) : x(a), y(b) {} };
+struct int3 { int x, y, z; int3() : x(0), y(0), z(0) {} int3(int a, int b, int c) : x(a), y(b), z(c) {} };
+struct int4 { int x, y, z, w; int4() : x(0), y(0), z(0), w(0) {} int4(int a, int b, int c, int e) : x(a), y(b), z(c), w(e) {} };
+struct uint2 { uint x, y; uint2() : x(0), y(0) {} uint2(uint a, uint b) : x(a), y(b) {} };
+struct usw_xy { uint d[3]; operator uint2() const { return uint2(d[0], d[1]); } operator int2() const { return int2((int)d[0], (int)d[1]); } };
+struct uint3 {
+    union { struct { uint x, y, z; }; usw_xy xy; };
+    uint3() : x(0), y(0), z(0) {}
+    uint3(uint a, uint b, uint c) : x(a), y(b), z(c) {}
+};
+inline int2 operator+(int2 a, int2 b) { return int2(a.x + b.x, a.y + b.y); }
+inline int2 operator-(int2 a, int2 b) { return int2(a.x - b.x, a.y - b.y); }
+
+// ---- component-wise arithmetic ------------------------------------------------------------------------------------------
+#define VQ_HLSL_OPS(V, N)                                                                                           \
+    inline V operator+(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; } \
+    inline V operator-(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; } \
+    inline V operator*(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.d[i]; return r; } \
+    inline V operator/(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] / b.d[i]; return r; } \
+    inline V operator+(const V& a, float b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b; return r; }         \
+    inline V operator-(const V& a, float b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b; return r; }         \
+    inline V operator*(const V& a, float b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r; }         \
+    inline V operator/(const V& a, float b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] / b; return r; }         \
+    inline V operator+(float a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a + b.d[i]; return r; }         \
+    inline V operator-(float a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a - b.d[i]; return r; }         \
+    inline V operator*(float a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a * b.d[i]; return r; }         \
+    inline V operator/(float a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a / b.d[i]; return r; }         \
+    inline V operator-(const V& a) { V r; for (int i = 0; i < N; ++i) r.d[i] = -a.d[i]; return r; }                     \
+    inline V& operator+=(V& a, const V& b) { for (int i = 0; i < N; ++i) a.d[i] += b.d[i]; return a; }                  \
+    inline V& operator-=(V& a, const V& b) { for (int i = 0; i < N; ++i) a.d[i] -= b.d[i]; return a; }                  \
+    inline V& operator*=(V& a, const V& b) { for (int i = 0; i < N; ++i) a.d[i] *= b.d[i]; return a; }                  \
+    inline V& operator/=(V& a, const V& b) { for (int i = 0; i < N; ++i) a.d[i] /= b.d[i]; return a; }                  \
+    inline V& operator*=(V& a, float b) { for (int i = 0; i < N; ++i) a.d[i] *= b; return a; }                          \
+    inline V& operator/=(V& a, float b) { for (int i = 0; i < N; ++i) a.d[i] /= b; return a; }                          \
+    inline V& operator+=(V& a, float b) { for (int i = 0; i < N; ++i) a.d[i] += b; return a; }
+VQ_HLSL_OPS(float2, 2)
+VQ_HLSL_OPS(float3, 3)
+VQ_HLSL_OPS(float4, 4)
+#undef VQ_HLSL_OPS
+
+// ---- scalar intrinsics --------------------------------------------------------------------------------------------------
+inline float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+inline float max(float a, float b) { return fmaxf(a, b); }
+inline float min(float a, float b) { return fminf(a, b); }
+inline float clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+inline float abs(float x) { return fabsf(x); }
+inline float sqrt(float x) { return sqrtf(x); }
+inline float rsqrt(float x) { return 1.0f / sqrtf(x); }
+inline float rcp(float x) { return 1.0f / x; }
+inline float sin(float x) { return sinf(x); }
+inline float cos(float x) { return cosf(x); }
+inline float tan(float x) { return tanf(x); }
+inline float acos(float x) { return acosf(x); }
+inline float asin(float x) { return asinf(x); }
+inline float atan2(float y, float x) { return atan2f(y, x); }
+inline float exp2(float x) { return exp2f(x); }
+inline float log2(float x) { return log2f(x); }
+inline float exp(float x) { return expf(x); }
+inline float log(float x) { return logf(x); }
+inline float floor(float x) { return floorf(x); }
+inline float frac(float x) { return x - floorf(x); }
+inline float pow(float x, float y) { return exp2f(y * log2f(x)); }          // DXC: pow -> exp2(y * log2(x))
+inline float lerp(float a, float b, float t) { return a + t * (b - a); }
+inline float step(float e, float x) { return x >= e ? 1.0f : 0.0f; }
+inline float sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+inline float asfloat(uint u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline uint asuint(float f) { uint u; std::memcpy(&u, &f, 4); return u; }
+
+#define VQ_HLSL_MAP1(V, N, FN) inline V FN(const V& a) { V r; for (int i = 0; i < N; ++i) r.d[i] = FN(a.d[i]); return r; }
+#define VQ_HLSL_MAP2(V, N, FN) inline V FN(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = FN(a.d[i], b.d[i]); return r; }
+#define VQ_HLSL_VEC(V, N)                                                                                            \
+    VQ_HLSL_MAP1(V, N, saturate) VQ_HLSL_MAP1(V, N, abs) VQ_HLSL_MAP1(V, N, sqrt) VQ_HLSL_MAP1(V, N, floor)              \
+    VQ_HLSL_MAP1(V, N, frac) VQ_HLSL_MAP1(V, N, exp2) VQ_HLSL_MAP1(V, N, log2) VQ_HLSL_MAP1(V, N, sin) VQ_HLSL_MAP1(V, N, cos) \
+    VQ_HLSL_MAP2(V, N, max) VQ_HLSL_MAP2(V, N, min) VQ_HLSL_MAP2(V, N, pow)                                               \
+    inline V pow(const V& a, float b) { V r; for (int i = 0; i < N; ++i) r.d[i] = pow(a.d[i], b); return r; }             \
+    inline V max(const V& a, float b) { V r; for (int i = 0; i < N; ++i) r.d[i] = max(a.d[i], b); return r; }             \
+    inline V max(float a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = max(a, b.d[i]); return r; }             \
+    inline V min(const V& a, float b) { V r; for (int i = 0; i < N; ++i) r.d[i] = min(a.d[i], b); return r; }             \
+    inline V clamp(const V& a, float lo, float hi) { V r; for (int i = 0; i < N; ++i) r.d[i] = clamp(a.d[i], lo, hi); return r; } \
+    inline V clamp(const V& a, const V& lo, const V& hi) { V r; for (int i = 0; i < N; ++i) r.d[i] = clamp(a.d[i], lo.d[i], hi.d[i]); return r; } \
+    inline V lerp(const V& a, const V& b, float t) { V r; for (int i = 0; i < N; ++i) r.d[i] = lerp(a.d[i], b.d[i], t); return r; } \
+    inline V lerp(const V& a, const V& b, const V& t) { V r; for (int i = 0; i < N; ++i) r.d[i] = lerp(a.d[i], b.d[i], t.d[i]); return r; } \
+    inline float dot(const V& a, const V& b) { float s = a.d[0] * b.d[0]; for (int i = 1; i < N; ++i) s = s + a.d[i] * b.d[i]; return s; } \
+    inline float length(const V& a) { return sqrtf(dot(a, a)); }                                                           \
+    inline V normalize(const V& a) { return a / length(a); }                                                               \
+    inline V reflect(const V& i, const V& n) { return i - 2.0f * dot(n, i) * n; }
+VQ_HLSL_VEC(float2, 2)
+VQ_HLSL_VEC(float3, 3)
+VQ_HLSL_VEC(float4, 4)
+#undef VQ_HLSL_VEC
+#undef VQ_HLSL_MAP1
+#undef VQ_HLSL_MAP2
+inline float3 cross(const float3& a, const float3& b) { return float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+// ---- matrices (m[row][col], HLSL element order) -------------------------------------------------------------------------
+struct float3x3 {
+    float m[3][3];
+    float3x3() : m{} {}
+    float3x3(const float3& r0, const float3& r1, const float3& r2) : m{ { r0.x, r0.y, r0.z }, { r1.x, r1.y, r1.z }, { r2.x, r2.y, r2.z } } {}
+    float3x3(float a, float b, float c, float d, float e, float f, float g, float h, float i) : m{ { a, b, c }, { d, e, f }, { g, h, i } } {}
+    float* operator[](int r) { return m[r]; }
+    const float* operator[](int r) const { return m[r]; }
+};
+typedef float3x3 half3x3;
+struct float4x4 {
+    float m[4][4];
+    float4x4() : m{} {}
+    float* operator[](int r) { return m[r]; }
+    const float* operator[](int r) const { return m[r]; }
+};
+typedef float4x4 matrix;
+// mul(vector, matrix): row vector times matrix;  mul(matrix, vector): matrix times column vector
+inline float3 mul(const float3& v, const float3x3& M) {
+    float3 r;
+    for (int c = 0; c < 3; ++c) r.d[c] = v.x * M.m[0][c] + v.y * M.m[1][c] + v.z * M.m[2][c];
+    return r;
+}
+inline float3 mul(const float3x3& M, const float3& v) {
+    float3 r;
+    for (int i = 0; i < 3; ++i) r.d[i] = M.m[i][0] * v.x + M.m[i][1] * v.y + M.m[i][2] * v.z;
+    return r;
+}
+inline float4 mul(const float4x4& M, const float4& v) {
+    float4 r;
+    for (int i = 0; i < 4; ++i) r.d[i] = M.m[i][0] * v.x + M.m[i][1] * v.y + M.m[i][2] * v.z + M.m[i][3] * v.w;
+    return r;
+}
+inline float4 mul(const float4& v, const float4x4& M) {
+    float4 r;
+    for (int c = 0; c < 4; ++c) r.d[c] = v.x * M.m[0][c] + v.y * M.m[1][c] + v.z * M.m[2][c] + v.w * M.m[3][c];
+    return r;
+}
+
+// ---- resources: fixed-function sampling is delegated to the harness -----------------------------------------------------
+struct SamplerState { int id = 0; };
+enum { kSampleImplicit = 0, kSampleBias = 1, kSampleLevel = 2 };
+struct Texture2D;  struct TextureCube;  struct Texture2DArray;  struct TextureCubeArray;
+float4 vqref_sample_2d(const Texture2D& t, const SamplerState& s, float2 uv, int mode, float arg);
+float4 vqref_sample_cube(const TextureCube& t, const SamplerState& s, float3 dir, int mode, float arg);
+float4 vqref_sample_2d_array(const Texture2DArray& t, const SamplerState& s, float3 uvw);
+float4 vqref_sample_cube_array(const TextureCubeArray& t, const SamplerState& s, float4 dirw);
+float4 vqref_load_2d(const Texture2D& t, int x, int y, int mip);
+void   vqref_dims_2d(const Texture2D& t, uint* w, uint* h);
+struct Texture2D {
+    const void* res = nullptr; int kind = 0;
+    float4 Sample(const SamplerState& s, float2 uv) const { return vqref_sample_2d(*this, s, uv, kSampleImplicit, 0.0f); }
+    float4 SampleBias(const SamplerState& s, float2 uv, float bias) const { return vqref_sample_2d(*this, s, uv, kSampleBias, bias); }
+    float4 SampleLevel(const SamplerState& s, float2 uv, float lod) const { return vqref_sample_2d(*this, s, uv, kSampleLevel, lod); }
+    float4 Load(int3 p) const { return vqref_load_2d(*this, p.x, p.y, p.z); }
+    float4 operator[](uint2 p) const { return vqref_load_2d(*this, (int)p.x, (int)p.y, 0); }
+    float4 operator[](int2 p) const { return vqref_load_2d(*this, p.x, p.y, 0); }
+    void GetDimensions(uint& w, uint& h) const { vqref_dims_2d(*this, &w, &h); }
+};
+struct TextureCube {
+    const void* res = nullptr; int kind = 0;
+    float4 Sample(const SamplerState& s, float3 d) const { return vqref_sample_cube(*this, s, d, kSampleImplicit, 0.0f); }
+    float4 SampleLevel(const SamplerState& s, float3 d, float lod) const { return vqref_sample_cube(*this, s, d, kSampleLevel, lod); }
+};
+struct Texture2DArray {
+    const void* res = nullptr; int kind = 0;
+    float4 Sample(const SamplerState& s, float3 uvw) const { return vqref_sample_2d_array(*this, s, uvw); }
+};
+struct TextureCubeArray {
+    const void* res = nullptr; int kind = 0;
+    float4 Sample(const SamplerState& s, float4 dirw) const { return vqref_sample_cube_array(*this, s, dirw); }
+};
+// RWTexture2D<T>: a plain row-major image the harness owns
+template <class T> struct RWTexture2D {
+    T* data = nullptr; int width = 0, height = 0;
+    T& operator[](uint2 p) { return data[(size_t)p.y * width + p.x]; }
+    T& operator[](int2 p) { return data[(size_t)p.y * width + p.x]; }
+    void GetDimensions(uint& w, uint& h) const { w = (uint)width; h = (uint)height; }
+};
+
+} // namespace hlsl

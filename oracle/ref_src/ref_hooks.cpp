@@ -1,0 +1,85 @@
+// ref_hooks.cpp — texture fetch hooks of the CPU-run reference shaders (see ref_hooks.h). TEST INFRASTRUCTURE.
+#include "ref_hooks.h"
+
+namespace vqref { Ctx g_ctx; }
+
+namespace hlsl {
+using namespace vqref;
+
+float4 vqref_sample_2d(const Texture2D& t, const SamplerState&, float2 uv, int mode, float arg) {
+    switch (t.kind) {
+    case kTexMaterial: {
+        const vqhip_texture2d* tx = (const vqhip_texture2d*)t.res;
+        if (mode == kSampleLevel) {      // explicit LOD = the level as the bias of a unit (one texel per pixel) footprint
+            const float w = (float)tx->width, h = (float)tx->height;
+            const vqo::f4 r = vqo::sample_material_tex(*tx, { uv.x, uv.y }, { 1.0f / w, 0 }, { 0, 1.0f / h }, arg);
+            return float4(r.x, r.y, r.z, r.w);
+        }
+        const vqo::f4 r = vqo::sample_material_tex(*tx, { uv.x, uv.y }, g_ctx.ddx, g_ctx.ddy, mode == kSampleBias ? arg : 0.0f);
+        return float4(r.x, r.y, r.z, r.w);
+    }
+    case kTexSSAO: {
+        const vqhip_ssao* s = (const vqhip_ssao*)t.res;
+        const float a = vqo::fetch_r8_point_wrap((const uint8_t*)s->texels, s->width, s->height, uv.x, uv.y);
+        return float4(a, a, a, a);
+    }
+    case kTexOne: return float4(1, 1, 1, 1);
+    case kTexLUT: {
+        const vqhip_envmap* e = g_ctx.env;
+        const vqo::f2 r = vqo::sample_2d_rg16f_clamp((const uint16_t*)e->brdf_lut, e->lut_size, e->lut_size, uv.x, uv.y);
+        return float4(r.x, r.y, 0, 0);
+    }
+    case kTexShadowDir: {
+        const float d = vqo::fetch_point_wrap(g_ctx.sm->directional, g_ctx.sm->dir_dim, uv.x, uv.y);
+        return float4(d, d, d, d);
+    }
+    case kTexEquirect: {
+        const EquirectChain* c = (const EquirectChain*)t.res;
+        const vqo::f4 r = vqo::sample_equirect_lod(c->chain, c->w0, c->h0, c->nMips, uv.x, uv.y, mode == kSampleLevel ? arg : 0.0f);
+        return float4(r.x, r.y, r.z, r.w);
+    }
+    default: return float4(0, 0, 0, 0);                                  // null SRV
+    }
+}
+float4 vqref_sample_cube(const TextureCube& t, const SamplerState&, float3 d, int mode, float arg) {
+    const vqhip_envmap* e = g_ctx.env;
+    if (t.kind == kCubeDiffuse) {                                         // single-mip cube: every LOD is level 0
+        const vqo::f4 r = vqo::sample_cube_rgba16f((const uint16_t*)e->diffuse_cube, e->diffuse_res, { d.x, d.y, d.z });
+        return float4(r.x, r.y, r.z, r.w);
+    }
+    if (t.kind == kCubeSpecular) {                                        // SampleLevel with an integral level, clamped by the sampler
+        int mip = mode == kSampleLevel ? (int)arg : 0;
+        if (mip < 0) mip = 0;
+        if (mip > e->spec_mips - 1) mip = e->spec_mips - 1;
+        size_t off = 0;
+        for (int m = 0; m < mip; ++m) { const size_t r = (size_t)(e->spec_res0 >> m); off += 6 * r * r * 4; }
+        const vqo::f4 r = vqo::sample_cube_rgba16f((const uint16_t*)e->specular_cube + off, e->spec_res0 >> mip, { d.x, d.y, d.z });
+        return float4(r.x, r.y, r.z, r.w);
+    }
+    return float4(0, 0, 0, 0);
+}
+float4 vqref_sample_2d_array(const Texture2DArray& t, const SamplerState&, float3 uvw) {
+    if (t.kind != kArrSpot) return float4(0, 0, 0, 0);
+    const int dim = g_ctx.sm->spot_dim;
+    const float d = vqo::fetch_point_wrap(g_ctx.sm->spot + (size_t)(int)uvw.z * dim * dim, dim, uvw.x, uvw.y);
+    return float4(d, d, d, d);
+}
+float4 vqref_sample_cube_array(const TextureCubeArray& t, const SamplerState&, float4 dw) {
+    if (t.kind != kArrPoint) return float4(0, 0, 0, 0);
+    const int dim = g_ctx.sm->point_dim;
+    const float d = vqo::fetch_cube_point(g_ctx.sm->point + (size_t)(int)dw.w * 6 * dim * dim, dim, { dw.x, dw.y, dw.z });
+    return float4(d, d, d, d);
+}
+float4 vqref_load_2d(const Texture2D& t, int x, int y, int) {
+    if (t.kind != kTexImage) return float4(0, 0, 0, 0);
+    const Image* im = (const Image*)t.res;
+    if (x < 0 || y < 0 || x >= im->width || y >= im->height) return float4(0, 0, 0, 0);      // out-of-bounds loads return 0
+    const float* p = im->rgba + ((size_t)y * im->width + x) * 4;
+    return float4(p[0], p[1], p[2], p[3]);
+}
+void vqref_dims_2d(const Texture2D& t, uint* w, uint* h) {
+    if (t.kind == kTexImage) { const Image* im = (const Image*)t.res; *w = (uint)im->width; *h = (uint)im->height; }
+    else { *w = 0; *h = 0; }
+}
+
+} // namespace hlsl

@@ -186,10 +186,22 @@ void vqo_fsr_easu_con(uint32_t* con, float inVpX, float inVpY, float inSzX, floa
     con[13] = f2u(4.0f * (1.0f / inSzY));
     con[14] = con[15] = 0;
 }
-// FsrRcasCon, ffx_fsr1.h:662-674: con[0] = exp2(-stops); con[1] = the same value as two packed halves
+// The CPU-side float -> half packing of ffx_a.h:482-550 (AU1_AH1_AF1, two 512-entry base/shift tables indexed by sign+exponent),
+// restated in closed form: it TRUNCATES (no round-to-nearest), flushes everything below the smallest half denormal to a signed
+// zero and maps overflow, inf and NaN to +-65504. PINNED: equal to the reference's table for all 2^32 inputs
+// (tests/test_ref_pinning.py against oracle/_ref/libvqref_fsr.so, which compiles the reference's header itself).
+uint32_t vqo_ffx_half_bits(float f) {
+    const uint32_t u = f2u(f), s = (u >> 16) & 0x8000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    if (e < 103) return s;
+    if (e < 113) return s + (1u << (e - 103)) + (m >> (126 - e));
+    if (e < 143) return s + ((e - 112) << 10) + (m >> 13);
+    return s + 0x7bffu;
+}
+// FsrRcasCon, ffx_fsr1.h:662-674: con[0] = exp2(-stops); con[1] = the same value as two packed (truncated) halves.
+// PINNED against the reference's own FsrRcasCon / FsrEasuCon (oracle/_ref, tests/golden/ref_fsr_con.json).
 void vqo_fsr_rcas_con(uint32_t* con, float sharpnessStops) {
     const float s = std::exp2(-sharpnessStops);
-    const uint32_t hbits = f32_to_f16(s);
+    const uint32_t hbits = vqo_ffx_half_bits(s);
     con[0] = f2u(s); con[1] = hbits | (hbits << 16); con[2] = 0; con[3] = 0;
 }
 

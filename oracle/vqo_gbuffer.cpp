@@ -31,52 +31,6 @@ using namespace vqo;
 
 namespace {
 
-inline float unorm8_to_float(float c) { return c * rcp(255.0f); }
-
-inline size_t tex_level_offset_px(int w0, int h0, int level) {
-    size_t off = 0;
-    for (int l = 0; l < level; ++l) off += (size_t)mip_dim(w0, l) * mip_dim(h0, l);
-    return off;
-}
-
-// bilinear WRAP of one RGBA8 level, in byte units (exact)
-inline f4 sample_2d_rgba8_wrap(const uint8_t* tex, int W, int H, float u, float v) {
-    int ix, iy; float wx, wy;
-    fixed8(u * (float)W - 0.5f, &ix, &wx);
-    fixed8(v * (float)H - 0.5f, &iy, &wy);
-    auto wrap = [](int i, int n) { int m = i % n; return m < 0 ? m + n : m; };
-    const int x0 = wrap(ix, W), x1 = wrap(ix + 1, W), y0 = wrap(iy, H), y1 = wrap(iy + 1, H);
-    auto ld = [&](int x, int y) -> f4 {
-        const uint8_t* p = tex + ((size_t)y * W + x) * 4;
-        return { (float)p[0], (float)p[1], (float)p[2], (float)p[3] };
-    };
-    return blend4(ld(x0, y0), ld(x1, y0), ld(x0, y1), ld(x1, y1), wx, wy);
-}
-
-// Texture2D.Sample / SampleBias with the quad derivatives ddx, ddy (already in uv units)
-inline f4 sample_material_tex(const vqhip_texture2d& t, f2 uv, f2 ddx, f2 ddy, float bias) {
-    if (!t.texels) return { 0, 0, 0, 0 };                                   // null SRV
-    const float W = (float)t.width, H = (float)t.height;
-    const f2 dX = { ddx.x * W, ddx.y * H }, dY = { ddy.x * W, ddy.y * H };
-    const float rx = fma_(dX.y, dX.y, dX.x * dX.x), ry = fma_(dY.y, dY.y, dY.x * dY.x);
-    const float lod = 0.5f * log2_(max_(rx, ry)) + bias;
-    const float maxl = (float)(t.mips - 1);
-    const float l = (lod > 0.0f) ? ((lod < maxl) ? lod : maxl) : 0.0f;      // NaN, -inf -> 0
-    const int fl = f2i_floor(l * 256.0f + 0.5f);
-    int lo = fl >> 8;
-    float f = (float)(fl & 255) * 0.00390625f;
-    if (lo >= t.mips - 1) { lo = t.mips - 1; f = 0.0f; }
-    const uint8_t* base = (const uint8_t*)t.texels;
-    const f4 a = sample_2d_rgba8_wrap(base + tex_level_offset_px(t.width, t.height, lo) * 4, mip_dim(t.width, lo), mip_dim(t.height, lo), uv.x, uv.y);
-    f4 r = a;
-    if (f != 0.0f) {
-        const f4 b = sample_2d_rgba8_wrap(base + tex_level_offset_px(t.width, t.height, lo + 1) * 4, mip_dim(t.width, lo + 1), mip_dim(t.height, lo + 1), uv.x, uv.y);
-        const float g = 1.0f - f;
-        r = { fma_(f, b.x, g * a.x), fma_(f, b.y, g * a.y), fma_(f, b.z, g * a.z), fma_(f, b.w, g * a.w) };
-    }
-    return { unorm8_to_float(r.x), unorm8_to_float(r.y), unorm8_to_float(r.z), unorm8_to_float(r.w) };
-}
-
 // LightingConstantBufferData.h:116-124
 inline bool has_bit(int cfg, int bit) { return (cfg & (1 << bit)) > 0; }
 
@@ -160,12 +114,7 @@ void gbuffer_pixel(const Planes& in, int x, int y, const vqhip_material* mats, i
     // :280-281  ScreenSpaceUV = (In.position.xy + 0.5) / ScreenDimensions, PointSampler = POINT_WRAP
     if (ssao && ssao->texels) {
         const float su = div_(((float)x + 0.5f) + 0.5f, (float)in.W), sv = div_(((float)y + 0.5f) + 0.5f, (float)in.H);
-        auto wrap = [](int i, int n) { int q = i % n; return q < 0 ? q + n : q; };
-        // texel = floor of the coordinate snapped to 8 fractional bits (D3D11.3 §7.18.7): these coordinates sit exactly on
-        // texel borders ((x+1)/W), the snap makes the choice (texel x+1, wrapping at the right/bottom edge) rounding-proof
-        const int tx = wrap(f2i_floor((su * (float)ssao->width) * 256.0f + 0.5f) >> 8, ssao->width);
-        const int ty = wrap(f2i_floor((sv * (float)ssao->height) * 256.0f + 0.5f) >> 8, ssao->height);
-        ao *= unorm8_to_float((float)((const uint8_t*)ssao->texels)[(size_t)ty * ssao->width + tx]);
+        ao *= fetch_r8_point_wrap((const uint8_t*)ssao->texels, ssao->width, ssao->height, su, sv);   // vqo_sampling.h
     }
 
     o0[0] = in.ip0[o]; o0[1] = in.ip0[o + 1]; o0[2] = in.ip0[o + 2]; o0[3] = ao;      // :284

@@ -206,19 +206,6 @@ inline float SpotlightIntensity(const VQ_SpotLight& l, f3 worldPos) {
 
 struct ShadowTestPCFData { f4 lightSpacePos; float depthBias, NdotL, viewDistanceOfPixel; };   // Lighting.hlsl:79-87
 
-// point-sampled (POINT_WRAP) fetch of one R32F 2D array slice: texel = floor(uv * dim) wrapped
-inline float fetch_point_wrap(const float* slice, int dim, float u, float v) {
-    int x = f2i_floor(u * (float)dim), y = f2i_floor(v * (float)dim);
-    x %= dim; if (x < 0) x += dim; y %= dim; if (y < 0) y += dim;
-    return slice[(size_t)y * dim + x];
-}
-// point-sampled fetch of an R32F cube [6][dim][dim]
-inline float fetch_cube_point(const float* cube, int dim, f3 dir) {
-    float su, sv; int f = cube_face_uv(dir, &su, &sv);
-    int x = f2i_floor(su * (float)dim), y = f2i_floor(sv * (float)dim);
-    x = x < 0 ? 0 : (x > dim - 1 ? dim - 1 : x); y = y < 0 ? 0 : (y > dim - 1 ? dim - 1 : y);
-    return cube[((size_t)f * dim + y) * dim + x];
-}
 // OmnidirectionalShadowTestPCF, Lighting.hlsl:110-174 (BIAS at :143 is computed but unused there)
 inline float OmnidirectionalShadowTestPCF(const ShadowTestPCFData& d, const float* cubeArr, int dim, int index, f3 Lw, float farPlane) {
     const float f3_ = 0.5773502691896258f, f2_ = 0.7071067811865475f;

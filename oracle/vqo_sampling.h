@@ -16,6 +16,7 @@
 #ifndef VQO_SAMPLING_H
 #define VQO_SAMPLING_H
 
+#include "../include/vqhip.h"
 #include "vqo_math.h"
 
 namespace vqo {
@@ -186,6 +187,76 @@ static inline f4 sample_equirect_lod(const float* chain, int w0, int h0, int nMi
     f4 b = sample_2d_rgba32f_wrap(chain + mip_offset_floats(w0, h0, lo + 1), mip_dim(w0, lo + 1), mip_dim(h0, lo + 1), u, v);
     float g = 1.0f - f;
     return { fma_(f, b.x, g * a.x), fma_(f, b.y, g * a.y), fma_(f, b.z, g * a.z), fma_(f, b.w, g * a.w) };
+}
+
+// ---- material textures (RGBA8_UNORM mip chains, vqo_gbuffer.cpp header) and shadow maps (R32F) ----
+static inline float unorm8_to_float(float c) { return c * rcp(255.0f); }
+
+static inline size_t tex_level_offset_px(int w0, int h0, int level) {
+    size_t off = 0;
+    for (int l = 0; l < level; ++l) off += (size_t)mip_dim(w0, l) * mip_dim(h0, l);
+    return off;
+}
+
+// bilinear WRAP of one RGBA8 level, in byte units (exact)
+static inline f4 sample_2d_rgba8_wrap(const uint8_t* tex, int W, int H, float u, float v) {
+    int ix, iy; float wx, wy;
+    fixed8(u * (float)W - 0.5f, &ix, &wx);
+    fixed8(v * (float)H - 0.5f, &iy, &wy);
+    auto wrap = [](int i, int n) { int m = i % n; return m < 0 ? m + n : m; };
+    const int x0 = wrap(ix, W), x1 = wrap(ix + 1, W), y0 = wrap(iy, H), y1 = wrap(iy + 1, H);
+    auto ld = [&](int x, int y) -> f4 {
+        const uint8_t* p = tex + ((size_t)y * W + x) * 4;
+        return { (float)p[0], (float)p[1], (float)p[2], (float)p[3] };
+    };
+    return blend4(ld(x0, y0), ld(x1, y0), ld(x0, y1), ld(x1, y1), wx, wy);
+}
+
+// Texture2D.Sample / SampleBias with the quad derivatives ddx, ddy (already in uv units)
+static inline f4 sample_material_tex(const vqhip_texture2d& t, f2 uv, f2 ddx, f2 ddy, float bias) {
+    if (!t.texels) return { 0, 0, 0, 0 };                                   // null SRV
+    const float W = (float)t.width, H = (float)t.height;
+    const f2 dX = { ddx.x * W, ddx.y * H }, dY = { ddy.x * W, ddy.y * H };
+    const float rx = fma_(dX.y, dX.y, dX.x * dX.x), ry = fma_(dY.y, dY.y, dY.x * dY.x);
+    const float lod = 0.5f * log2_(max_(rx, ry)) + bias;
+    const float maxl = (float)(t.mips - 1);
+    const float l = (lod > 0.0f) ? ((lod < maxl) ? lod : maxl) : 0.0f;      // NaN, -inf -> 0
+    const int fl = f2i_floor(l * 256.0f + 0.5f);
+    int lo = fl >> 8;
+    float f = (float)(fl & 255) * 0.00390625f;
+    if (lo >= t.mips - 1) { lo = t.mips - 1; f = 0.0f; }
+    const uint8_t* base = (const uint8_t*)t.texels;
+    const f4 a = sample_2d_rgba8_wrap(base + tex_level_offset_px(t.width, t.height, lo) * 4, mip_dim(t.width, lo), mip_dim(t.height, lo), uv.x, uv.y);
+    f4 r = a;
+    if (f != 0.0f) {
+        const f4 b = sample_2d_rgba8_wrap(base + tex_level_offset_px(t.width, t.height, lo + 1) * 4, mip_dim(t.width, lo + 1), mip_dim(t.height, lo + 1), uv.x, uv.y);
+        const float g = 1.0f - f;
+        r = { fma_(f, b.x, g * a.x), fma_(f, b.y, g * a.y), fma_(f, b.z, g * a.z), fma_(f, b.w, g * a.w) };
+    }
+    return { unorm8_to_float(r.x), unorm8_to_float(r.y), unorm8_to_float(r.z), unorm8_to_float(r.w) };
+}
+
+// texScreenSpaceAO.Sample(PointSampler, uv) of an R8_UNORM image (ForwardLighting.hlsl:280-281; POINT_WRAP): texel = floor of
+// the coordinate snapped to 8 fractional bits (D3D11.3 §7.18.7) — the shader's coordinates (x+1)/W sit exactly on texel
+// borders, the snap makes the choice (texel x+1, wrapping at the right/bottom edge) rounding-proof
+static inline float fetch_r8_point_wrap(const uint8_t* tex, int W, int H, float u, float v) {
+    auto wrap = [](int i, int n) { int q = i % n; return q < 0 ? q + n : q; };
+    const int tx = wrap(f2i_floor((u * (float)W) * 256.0f + 0.5f) >> 8, W);
+    const int ty = wrap(f2i_floor((v * (float)H) * 256.0f + 0.5f) >> 8, H);
+    return unorm8_to_float((float)tex[(size_t)ty * W + tx]);
+}
+// point-sampled (POINT_WRAP) fetch of one R32F 2D array slice: texel = floor(uv * dim) wrapped
+static inline float fetch_point_wrap(const float* slice, int dim, float u, float v) {
+    int x = f2i_floor(u * (float)dim), y = f2i_floor(v * (float)dim);
+    x %= dim; if (x < 0) x += dim; y %= dim; if (y < 0) y += dim;
+    return slice[(size_t)y * dim + x];
+}
+// point-sampled fetch of an R32F cube [6][dim][dim]
+static inline float fetch_cube_point(const float* cube, int dim, f3 dir) {
+    float su, sv; int f = cube_face_uv(dir, &su, &sv);
+    int x = f2i_floor(su * (float)dim), y = f2i_floor(sv * (float)dim);
+    x = x < 0 ? 0 : (x > dim - 1 ? dim - 1 : x); y = y < 0 ? 0 : (y > dim - 1 ? dim - 1 : y);
+    return cube[((size_t)f * dim + y) * dim + x];
 }
 
 } // namespace vqo

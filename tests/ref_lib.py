@@ -1,0 +1,109 @@
+"""ctypes bindings of oracle/_ref/*.so — the reference's OWN sources compiled here (oracle/Makefile target `ref`):
+  libvqref_fsr.so      ffx_a.h + ffx_fsr1.h with A_CPU (FsrEasuCon / FsrRcasCon, the CPU half packing)
+  libvqref_shaders.so  ForwardLighting.hlsl, BRDF.hlsl, Lighting.hlsl, ShadingMath.hlsl, ... through oracle/ref_src/hlsl_shim.h
+They exist only where /root/reference does (this container). available() gates the tests that need them; the fixtures they
+produce (tests/golden/ref_*.npz, made by tests/golden/make_ref_fixtures.py) travel to the GPU box instead."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from vqengine_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+_libs = {}
+
+
+def available(name="shaders"):
+    return os.path.exists(os.path.join(REF_DIR, f"libvqref_{name}.so"))
+
+
+def load(name="shaders"):
+    if name not in _libs:
+        lib = C.CDLL(os.path.join(REF_DIR, f"libvqref_{name}.so"))
+        vp, f32, i32, u32 = C.c_void_p, C.c_float, C.c_int32, C.c_uint32
+        if name == "fsr":
+            lib.vqref_fsr_easu_con.argtypes = [vp] + [f32] * 6
+            lib.vqref_fsr_rcas_con.argtypes = [vp, f32]
+            lib.vqref_half_bits.argtypes = [f32]
+            lib.vqref_half_bits.restype = u32
+        else:
+            lib.vqref_forward_psmain.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+            lib.vqref_forward_from_gbuffer.argtypes = [vp, vp, vp, vp, vp, vp]
+            lib.vqref_brdf.argtypes = [vp, f32, vp, f32, vp, vp, vp]
+            lib.vqref_integrate_brdf.argtypes = [f32, f32, i32, vp]
+            lib.vqref_importance_sample_ggx.argtypes = [f32, f32, vp, f32, vp]
+            lib.vqref_hammersley.argtypes = [u32, u32, vp]
+            lib.vqref_direction_to_equirect_uv.argtypes = [vp, vp]
+            lib.vqref_unpack_normal.argtypes = [vp, vp, vp, vp]
+            lib.vqref_conv_diffuse.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32]
+            lib.vqref_conv_specular.argtypes = [vp, i32, i32, i32, i32, f32, f32, f32, i32, vp]
+            lib.vqref_brdf_lut_texels.argtypes = [vp, vp, i32, vp]
+        _libs[name] = lib
+    return _libs[name]
+
+
+def _ref(x):
+    return C.byref(x) if x is not None else None
+
+
+def fsr_easu_con(in_w, in_h, out_w, out_h):
+    con = np.zeros(16, np.uint32)
+    load("fsr").vqref_fsr_easu_con(con.ctypes.data, in_w, in_h, in_w, in_h, out_w, out_h)
+    return con
+
+
+def fsr_rcas_con(stops):
+    con = np.zeros(4, np.uint32)
+    load("fsr").vqref_fsr_rcas_con(con.ctypes.data, stops)
+    return con
+
+
+def forward_from_gbuffer(gb, per_frame, per_view, env=None, shadow=None):
+    gb = [np.ascontiguousarray(g, np.float32) for g in gb]
+    h, w = gb[0].shape[:2]
+    out = np.empty((h, w, 4), np.float32)
+    g = abi.GBuffer(gb[0].ctypes.data, gb[1].ctypes.data, gb[2].ctypes.data, gb[3].ctypes.data, w, h, w)
+    rc = load().vqref_forward_from_gbuffer(C.byref(g), C.byref(per_frame), C.byref(per_view), _ref(env), _ref(shadow), out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def forward_psmain(ip, materials, per_frame, per_view, ssao=None, env=None, shadow=None):
+    ip = [np.ascontiguousarray(p, np.float32) for p in ip]
+    h, w = ip[0].shape[:2]
+    out = np.empty((h, w, 4), np.float32)
+    inter = abi.Interpolants(ip[0].ctypes.data, ip[1].ctypes.data, ip[2].ctypes.data, w, h, w)
+    s = None
+    if ssao is not None:
+        ssao = np.ascontiguousarray(ssao, np.uint8)
+        s = abi.SSAO(ssao.ctypes.data, ssao.shape[1], ssao.shape[0])
+    n = len(materials) if materials is not None else 0
+    rc = load().vqref_forward_psmain(C.byref(inter), materials if n else None, n, _ref(s), C.byref(per_frame), C.byref(per_view),
+                                     _ref(env), _ref(shadow), out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def conv_diffuse(chain, w0, h0, n_mips, res, t0=0, t1=-1):
+    """PSMain_DiffuseIrradiance (step 0.010, the shader's default) for texels [t0, t1): float32 [6,res,res,4]"""
+    chain = np.ascontiguousarray(chain, np.float32)
+    out = np.zeros((6, res, res, 4), np.float32)
+    assert load().vqref_conv_diffuse(chain.ctypes.data, w0, h0, n_mips, res, out.ctypes.data, t0, t1) == 0
+    return out
+
+
+def conv_specular_mip(chain, w0, h0, n_mips, res, roughness, mip):
+    chain = np.ascontiguousarray(chain, np.float32)
+    out = np.zeros((6, res, res, 4), np.float32)
+    assert load().vqref_conv_specular(chain.ctypes.data, w0, h0, n_mips, res, roughness, float(w0), float(h0), mip, out.ctypes.data) == 0
+    return out
+
+
+def brdf_lut_texels(xs, ys):
+    """CSMain_BRDFIntegration (1024^2 image, 2048 samples) at the given texels: float32 [n,2]"""
+    xs, ys = np.ascontiguousarray(xs, np.int32), np.ascontiguousarray(ys, np.int32)
+    out = np.zeros((len(xs), 2), np.float32)
+    assert load().vqref_brdf_lut_texels(xs.ctypes.data, ys.ctypes.data, len(xs), out.ctypes.data) == 0
+    return out

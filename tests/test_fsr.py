@@ -174,8 +174,10 @@ def test_constant_blocks():
         assert np.array_equal(con, O.fsr_rcas_con(stops))
         s = con[:1].view(F)[0]
         assert abs(float(s) - 2.0 ** -stops) < 1e-7
-        hb = np.array([s], F).astype(np.float16).view(np.uint16)[0]
-        assert con[1] == (int(hb) | (int(hb) << 16)) and con[2] == 0 == con[3]
+        # ffx_a.h:482-550 packs the CPU-side half by TRUNCATION (pinned against the reference's own table in test_ref_pinning.py)
+        hb = ((int(s.view(np.uint32)) >> 23) - 112 << 10) + ((int(s.view(np.uint32)) & 0x7fffff) >> 13)
+        assert con[1] == (hb | (hb << 16)) and con[2] == 0 == con[3]
+    assert capi.fsr_rcas_con(0.2)[1] == 0x3af63af6
     assert lib is not None
 
 

@@ -416,9 +416,11 @@ void vqhip_fsr_easu_con(uint32_t con[16], float inVpW, float inVpH, float inSzW,
 // FsrRcasCon, ffx_fsr1.h:662-674 (FFSR1_RCAS::UpdateRCASConstantBlock, PostProcess.cpp:39-45)
 void vqhip_fsr_rcas_con(uint32_t con[4], float sharpnessStops) {
     const float s = exp2f(-sharpnessStops);
-    const _Float16 hs = (_Float16)s;
-    uint16_t hb; std::memcpy(&hb, &hs, 2);
-    con[0] = fbits(s); con[1] = (uint32_t)hb | ((uint32_t)hb << 16); con[2] = 0; con[3] = 0;
+    // ffx_a.h:482-550 packs the CPU-side half by TRUNCATION (table lookup on sign+exponent, mantissa shifted right), flushing
+    // sub-denormals to zero and saturating overflow / inf / NaN to 65504 — not round-to-nearest: 0.2 stops gives 0x3af6, not 0x3af7
+    const uint32_t u = fbits(s), sg = (u >> 16) & 0x8000u, e = (u >> 23) & 0xffu, m = u & 0x7fffffu;
+    const uint32_t hb = e < 103 ? sg : e < 113 ? sg + (1u << (e - 103)) + (m >> (126 - e)) : e < 143 ? sg + ((e - 112) << 10) + (m >> 13) : sg + 0x7bffu;
+    con[0] = fbits(s); con[1] = hb | (hb << 16); con[2] = 0; con[3] = 0;
 }
 
 static bool isColorFmt(int f) { return f == VQHIP_FMT_RGBA32F || f == VQHIP_FMT_RGBA16F || f == VQHIP_FMT_RGBA8_UNORM; }
