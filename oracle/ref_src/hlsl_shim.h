@@ -200,6 +200,11 @@ VQ_HLSL_VEC(float4, 4)
 #undef VQ_HLSL_VEC
 #undef VQ_HLSL_MAP1
 #undef VQ_HLSL_MAP2
+struct bool3 { bool x, y, z; };
+inline bool3 operator<(const float3& a, float b) { return { a.x < b, a.y < b, a.z < b }; }
+inline bool3 operator>(const float3& a, float b) { return { a.x > b, a.y > b, a.z > b }; }
+inline float3 select(const bool3& c, const float3& a, const float3& b) { return float3(c.x ? a.x : b.x, c.y ? a.y : b.y, c.z ? a.z : b.z); }
+inline float3 lerp(const float3& a, float b, float t) { return float3(lerp(a.x, b, t), lerp(a.y, b, t), lerp(a.z, b, t)); }
 inline float3 cross(const float3& a, const float3& b) { return float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 
 // ---- matrices (m[row][col], HLSL element order) -------------------------------------------------------------------------
@@ -259,6 +264,7 @@ struct Texture2D {
     float4 Load(int3 p) const { return vqref_load_2d(*this, p.x, p.y, p.z); }
     float4 operator[](uint2 p) const { return vqref_load_2d(*this, (int)p.x, (int)p.y, 0); }
     float4 operator[](int2 p) const { return vqref_load_2d(*this, p.x, p.y, 0); }
+    float4 operator[](const usw_xy& p) const { return vqref_load_2d(*this, (int)p.d[0], (int)p.d[1], 0); }
     void GetDimensions(uint& w, uint& h) const { vqref_dims_2d(*this, &w, &h); }
 };
 struct TextureCube {
@@ -279,6 +285,7 @@ template <class T> struct RWTexture2D {
     T* data = nullptr; int width = 0, height = 0;
     T& operator[](uint2 p) { return data[(size_t)p.y * width + p.x]; }
     T& operator[](int2 p) { return data[(size_t)p.y * width + p.x]; }
+    T& operator[](const usw_xy& p) { return data[(size_t)p.d[1] * width + p.d[0]]; }
     void GetDimensions(uint& w, uint& h) const { w = (uint)width; h = (uint)height; }
 };
 

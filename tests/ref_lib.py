@@ -40,6 +40,11 @@ def load(name="shaders"):
             lib.vqref_conv_diffuse.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32]
             lib.vqref_conv_specular.argtypes = [vp, i32, i32, i32, i32, f32, f32, f32, i32, vp]
             lib.vqref_brdf_lut_texels.argtypes = [vp, vp, i32, vp]
+            lib.vqref_blur_pass.argtypes = [vp, i32, i32, i32, vp]
+            lib.vqref_tonemap.argtypes = [vp, i32, i32, vp, vp]
+            lib.vqref_skydome.argtypes = [vp, i32, i32, vp, i32, i32, vp]
+            lib.vqref_visualize.argtypes = [vp, i32, i32, vp, vp]
+            lib.vqref_apply_reflections.argtypes = [vp, vp, i32, i32]
         _libs[name] = lib
     return _libs[name]
 
@@ -107,3 +112,44 @@ def brdf_lut_texels(xs, ys):
     out = np.zeros((len(xs), 2), np.float32)
     assert load().vqref_brdf_lut_texels(xs.ctypes.data, ys.ctypes.data, len(xs), out.ctypes.data) == 0
     return out
+
+
+def _img32(img):
+    img = np.ascontiguousarray(img, np.float32)
+    assert img.ndim == 3 and img.shape[2] == 4
+    return img
+
+
+def blur_pass(img, direction):
+    """CSMain_X (0) / CSMain_Y (1) of GaussianBlur.hlsl on RGBA32F values; returns the float4 written to the UAV (before storage rounding)"""
+    img = _img32(img)
+    out = np.empty_like(img)
+    assert load().vqref_blur_pass(img.ctypes.data, img.shape[1], img.shape[0], direction, out.ctypes.data) == 0
+    return out
+
+
+def tonemap(img, params):
+    img = _img32(img)
+    out = np.empty_like(img)
+    assert load().vqref_tonemap(img.ctypes.data, img.shape[1], img.shape[0], C.byref(params), out.ctypes.data) == 0
+    return out
+
+
+def skydome(equirect0, params, width, height):
+    eq = _img32(equirect0)
+    out = np.empty((height, width, 4), np.float32)
+    assert load().vqref_skydome(eq.ctypes.data, eq.shape[1], eq.shape[0], C.byref(params), width, height, out.ctypes.data) == 0
+    return out
+
+
+def visualize(img, params):
+    img = _img32(img)
+    out = np.empty_like(img)
+    assert load().vqref_visualize(img.ctypes.data, img.shape[1], img.shape[0], C.byref(params), out.ctypes.data) == 0
+    return out
+
+
+def apply_reflections(refl, scene):
+    refl, scene = _img32(refl), _img32(scene).copy()
+    assert load().vqref_apply_reflections(refl.ctypes.data, scene.ctypes.data, scene.shape[1], scene.shape[0]) == 0
+    return scene

@@ -16,6 +16,7 @@ import pytest
 from tests import oracle_lib as O
 from tests import ref_lib as R
 from vqengine_amd import abi, synth
+from vqengine_amd import scene as scene_mod
 
 pytestmark = pytest.mark.skipif(not (R.available("shaders") and R.available("fsr")),
                                 reason="oracle/_ref is built only where /root/reference exists")
@@ -252,3 +253,102 @@ def test_forward_lighting_psmain_with_material_textures():
     assert valid.mean() > 0.5
     assert_close_stat(got[valid][:, :3], ref[valid][:, :3], "PSMain with textures", p99=1e-4)
     assert_close_stat(got[valid][:, 3], ref[valid][:, 3], "roughness out", p99=1e-6, worst=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# post chain: GaussianBlur.hlsl, Tonemapper.hlsl (+ HDR.hlsl), Skydome.hlsl, Visualization.hlsl, ApplyReflections.hlsl
+# ---------------------------------------------------------------------------------------------------------------------
+def _hdr_scene(w=70, h=45, seed=9):
+    rng = np.random.default_rng(seed)
+    img = (rng.random((h, w, 4), dtype=np.float32) ** 3) * rng.choice(np.array([0.05, 1.0, 8.0, 60.0], np.float32), (h, w, 1))
+    img[..., 3] = rng.random((h, w), dtype=np.float32)
+    img[3, 5, :3] = 0.0
+    return img.astype(np.float16)                                   # scene colour is an RGBA16F target
+
+
+def _halfs_apart(a16, b32):
+    """distance in fp16 ulps between stored halfs and the RNE rounding of float values"""
+    with np.errstate(over="ignore"):
+        b16 = b32.astype(np.float16)
+
+    def key(h):
+        u = h.view(np.uint16).astype(np.int32)
+        return np.where(u & 0x8000, -(u & 0x7fff), u)
+    return np.abs(key(a16) - key(b16))
+
+
+@pytest.mark.parametrize("direction", [0, 1])
+def test_gaussian_blur_pass(direction):
+    """CSMain_X / CSMain_Y (GaussianBlur.hlsl:76-130): 21 taps, ITS weight table, clamped addressing, alpha := 1. The oracle's
+    contract accumulates with one mad per tap (v2) where the HLSL writes mul + add: values agree to an ulp of fp32, i.e. the
+    stored RGBA16F texel is the same half except where the sum sits on a rounding boundary (then the neighbouring half)."""
+    img = _hdr_scene()
+    ref = R.blur_pass(img.astype(np.float32), direction)
+    got32 = O.blur_pass(img.astype(np.float32), abi.FMT_RGBA32F, direction)
+    assert (ref[..., 3] == 1).all() and (got32[..., 3] == 1).all()
+    assert_close_stat(got32[..., :3], ref[..., :3], "blur fp32", median=1e-7, p99=4e-7, worst=2e-6, floor=1e-6)
+    got16 = O.blur_pass(img, abi.FMT_RGBA16F, direction)
+    d = _halfs_apart(got16, ref)
+    assert d.max() <= 1 and np.mean(d != 0) < 2e-3, (d.max(), np.mean(d != 0))
+
+
+def test_gaussian_blur_edges_are_clamped():
+    img = np.zeros((8, 40, 4), np.float32)
+    img[:, 0, :3] = 100.0                                             # a bright first column: clamped taps re-read it
+    ref = R.blur_pass(img, 0)
+    got = O.blur_pass(img, abi.FMT_RGBA32F, 0)
+    assert_close_stat(got[..., :3], ref[..., :3], "blur clamp", median=1e-7, p99=4e-7, worst=2e-6, floor=1e-6)
+    assert ref[0, 0, 0] > ref[0, 5, 0] > ref[0, 9, 0] > 0 and ref[0, 10, 0] == 0      # the table's 11th weight is 0 (:72)
+
+
+@pytest.mark.parametrize("curve,space,gamma", [(abi.DISPLAY_CURVE_SRGB, abi.COLOR_SPACE_REC_709, 1), (abi.DISPLAY_CURVE_SRGB, abi.COLOR_SPACE_REC_709, 0),
+                                               (abi.DISPLAY_CURVE_ST2084, abi.COLOR_SPACE_REC_709, 1), (abi.DISPLAY_CURVE_ST2084, abi.COLOR_SPACE_REC_2020, 1),
+                                               (abi.DISPLAY_CURVE_LINEAR, abi.COLOR_SPACE_REC_709, 1), (7, abi.COLOR_SPACE_REC_709, 1)])
+def test_tonemapper(curve, space, gamma):
+    """Tonemapper.hlsl:CSMain (:104-151) with HDR.hlsl: Reinhard + LinearToSRGB, Rec709->Rec2020 + ST2084, linear, the yellow default."""
+    img = _hdr_scene(seed=10)
+    p = abi.TonemapperParams(space, curve, 200.0, gamma)
+    ref = R.tonemap(img.astype(np.float32), p)
+    got = O.tonemap(img, abi.FMT_RGBA16F, abi.FMT_RGBA32F, params=p)
+    assert np.array_equal(got[..., 3], ref[..., 3])                    # alpha passes through
+    st = curve == abi.DISPLAY_CURVE_ST2084                               # pow(x, m2 = 78.84) multiplies the log2's rounding by 79
+    assert_close_stat(got[..., :3], ref[..., :3], f"tonemap {curve}/{space}/{gamma}", median=2e-7, p99=3e-5 if st else 2e-6,
+                      worst=1e-4 if st else 2e-5, floor=1e-4)
+    if curve == abi.DISPLAY_CURVE_SRGB:                                  # the shipped configuration: UNORM8 back buffer
+        got8 = O.tonemap(img, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, params=p)
+        ref8 = np.empty(ref.shape, np.uint8)
+        O.load().vqo_f32_to_unorm8(ref.ctypes.data, ref8.ctypes.data, ref.size)
+        d = np.abs(got8.astype(np.int32) - ref8.astype(np.int32))
+        assert d.max() <= 1 and np.mean(d != 0) < 2e-3, (d.max(), np.mean(d != 0))
+
+
+def test_skydome():
+    eq = synth.equirect(128, 64)
+    for yaw, pitch, off in ((0.3, -0.2, 0.0), (2.5, 0.6, 1.1)):
+        sp = scene_mod.skydome_params(yaw, pitch, off, 1.0, 96, 54)
+        ref = R.skydome(eq, sp, 96, 54)
+        got = O.skydome(eq, sp, np.zeros((54, 96, 4), np.float32), abi.FMT_RGBA32F)
+        assert (ref[..., 3] == 1).all() and np.array_equal(got[..., 3], ref[..., 3])
+        # uv differences of an ulp move the 8-bit filter fraction of a few pixels by one step (1/256 of a texel difference)
+        r = rel_err(got[..., :3], ref[..., :3], 1e-3)
+        assert np.median(r) < 1e-7 and np.quantile(r, 0.99) < 5e-3 and r.max() < 5e-2, (np.median(r), np.quantile(r, 0.99), r.max())
+
+
+@pytest.mark.parametrize("mode", range(0, 10))
+def test_visualization_modes(mode):
+    img = _hdr_scene(seed=12).astype(np.float32)
+    img[..., 0] = np.clip(img[..., 0], 0, 1)
+    for unpack in (0, 1):
+        p = abi.VizParams(mode, unpack, 2.5)
+        ref = R.visualize(img, p)
+        got = O.visualize(img, abi.FMT_RGBA32F, p)
+        assert np.array_equal(got[..., 3], ref[..., 3])
+        assert_close_stat(got[..., :3], ref[..., :3], f"viz {mode}/{unpack}", median=1e-7, p99=2e-5, worst=2e-3, floor=1e-6)
+
+
+def test_apply_reflections():
+    scene, refl = _hdr_scene(seed=13).astype(np.float32), _hdr_scene(seed=14).astype(np.float32)
+    ref = R.apply_reflections(refl, scene)
+    want = scene.copy()
+    want[..., :3] = scene[..., :3] + refl[..., :3]                       # ApplyReflections.hlsl:45-57; alpha = scene roughness
+    assert np.array_equal(ref, want)
