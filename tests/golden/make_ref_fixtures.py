@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_outputs.npz: the OUTPUTS of the reference's own sources (oracle/_ref, built by `make -C oracle ref`
+from /root/reference) for every case of tests/ref_cases.py, plus a checksum of each case's (seed-built) inputs.
+Runs only where /root/reference exists; the fixture travels to the GPU box, where tests/test_ref_fixtures.py compares the
+oracle (CPU) and the HIP product (gpu) with it.   Usage: python tests/golden/make_ref_fixtures.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from tests import ref_cases, ref_lib  # noqa: E402
+
+
+def main():
+    assert ref_lib.available("shaders") and ref_lib.available("fsr"), "build oracle/_ref first: make -C oracle ref"
+    out = {}
+    for c in ref_cases.CASES:
+        inp = c.build()
+        ref = np.asarray(c.ref(inp))
+        out[c.name] = ref
+        out[c.name + "/inputs"] = np.frombuffer(ref_cases.checksum(inp).encode(), np.uint8)
+        print(f"{c.name:40s} {str(ref.shape):18s} {ref.dtype}")
+    path = os.path.join(ROOT, "tests", "golden", "ref_outputs.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
