@@ -4,8 +4,10 @@
 // FsrEasuF :315-437 with FsrEasuSetF :275-313 and FsrEasuTapF :239-273, FsrRcasCon :662-674, FsrRcasF :684-770;
 // bit-trick approximations ffx_a.h:1843-1845). SURVEY.md §8(f).4.
 //
-// ORACLE / TEST INFRASTRUCTURE ONLY (see vqo_oracle.cpp). PARITY UNPINNED: no golden image of the FSR passes exists in the
-// reference and its HLSL cannot be run here.
+// ORACLE / TEST INFRASTRUCTURE ONLY (see vqo_oracle.cpp). PARITY: FsrEasuCon / FsrRcasCon and the CPU half packing are PINNED BIT-EXACT
+// against the reference's own C++ path (ffx_a.h + ffx_fsr1.h with A_CPU compiled into oracle/_ref/libvqref_fsr.so, as PostProcess.cpp:21-75
+// does); Visualization.hlsl is pinned through the HLSL shim (oracle/_ref/libvqref_shaders.so). The EASU / RCAS FILTERS remain UNPINNED: no
+// golden image exists and ffx_a.h's A_GPU/A_HLSL macro layer is beyond the shim (restated from the header, checked by a numpy restatement).
 //
 // Contract: every operation is a separate IEEE binary32 operation in the order the header writes it (a*b+c is a multiply
 // then an add), HLSL rcp() = correctly rounded 1/x, the APrx* approximations are integer bit tricks and exact by

@@ -1,8 +1,10 @@
 // vqo_gbuffer.cpp — CPU restatement of the surface-assembly half of ForwardLighting.hlsl:PSMain (:226-287)
 // and of MipImage's 4-byte branch ("G-buffer producer").
 //
-// ORACLE / TEST INFRASTRUCTURE ONLY (see vqo_oracle.cpp). PARITY UNPINNED: the reference holds no golden
-// vectors for this path and its HLSL/D3D12 implementation cannot be run here.
+// ORACLE / TEST INFRASTRUCTURE ONLY (see vqo_oracle.cpp). PARITY: the arithmetic of PSMain's surface assembly is pinned
+// against the reference's own ForwardLighting.hlsl run on the CPU (oracle/_ref, tests/test_ref_pinning.py::test_forward_lighting_psmain_
+// with_material_textures); the texture FETCHES (filtering, LOD selection, derivatives) have no source in the reference and stay a
+// restatement of D3D's rules. MipImage (DXGIUtils.cpp) needs <Windows.h>/<dxgiformat.h> to compile: restated, not pinned.
 //
 // Contract additions of this file (DESIGN.md "G-buffer producer"):
 //   * UNORM8 texels are filtered as the integers 0..255 and the filtered value is scaled once by rcp(255)

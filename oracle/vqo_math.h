@@ -1,10 +1,10 @@
 // vqo_math.h — scalar float32 "lowering table" of the HLSL intrinsics used by the hot path.
 //
 // ORACLE / TEST INFRASTRUCTURE ONLY. Nothing under vqengine_amd/ may include, link or call this.
-// PARITY UNPINNED: the reference (vilbeyli/VQEngine) has no numeric tests, golden images or
-// known-answer vectors for this path and D3D12/WARP/DXC cannot run here, so
-// the exact bits of the reference's intrinsics (DXC's HL->DXIL lowering + WARP's JIT) are not
-// observable. This file fixes ONE legal D3D-precision lowering per intrinsic; the HIP kernels
+// PARITY: the ALGORITHM built from these intrinsics is pinned against the reference's own HLSL run on the CPU (oracle/_ref,
+// see vqo_oracle.cpp's header); the BITS of the intrinsics are not: the reference (vilbeyli/VQEngine) has no numeric tests,
+// golden images or known-answer vectors for this path and D3D12/WARP/DXC cannot run here, so what
+// DXC's HL->DXIL lowering + a driver's JIT make of them is not observable. This file fixes ONE legal D3D-precision lowering per intrinsic; the HIP kernels
 // implement the same lowering independently (vqengine_amd/csrc/vq_devmath.h) and must match these
 // bits exactly.
 //

@@ -4,10 +4,17 @@
 // `cpu_baseline` leg may load this library (as the checker / reported CPU baseline). The product
 // (vqengine_amd/, libvqhip.so) never includes, links or calls anything in oracle/.
 //
-// PARITY UNPINNED: the reference holds no golden vectors / KATs for this path
-// and its D3D12+HLSL implementation cannot be compiled or run here (Windows/DXC/WARP only), so this
-// restatement is reviewed against the HLSL line by line (citations below) but not checked against
-// outputs of the reference itself. Intrinsic lowering: vqo_math.h; sampling: vqo_sampling.h.
+// PARITY: the reference holds no golden vectors / KATs for this path and its D3D12 renderer cannot be
+// built here (Windows/DXC/WARP only). What CAN run here is the reference's shader SOURCE: oracle/_ref (Makefile target `ref`)
+// compiles ForwardLighting / BRDF / Lighting / ShadingMath / CubemapConvolution / GaussianBlur / Tonemapper / HDR / Skydome /
+// Visualization / ApplyReflections .hlsl from where they lie, through oracle/ref_src/hlsl_shim.h, and runs them on the CPU.
+//   PINNED  (tests/test_ref_pinning.py live, tests/golden/ref_outputs.npz on the GPU box): the ALGORITHM of every pass in this
+//           file — constants, branches, operand roles, loop bounds, sample sequences — against that run, to about one ulp in
+//           the median, with a tail explained by binary32 conditioning (numbers: DESIGN.md §5).
+//   NOT PINNED: the bits a DXC + driver compile of the same HLSL produces (fast-math regrouping, approximate intrinsics: the
+//           arithmetic contract of vqo_math.h picks one legal outcome), texture filtering and rasteriser interpolation (no source
+//           in the reference: vqo_sampling.h restates D3D's rules; the _ref harness uses the same statement).
+// Intrinsic lowering: vqo_math.h; sampling: vqo_sampling.h.
 //
 // Every function cites the reference file:line it follows (paths relative to the VQEngine tree).
 #include <cstdio>

@@ -1,6 +1,6 @@
 // vqo_sampling.h — software texture sampling semantics used by the oracle.
 //
-// ORACLE / TEST INFRASTRUCTURE ONLY (see vqo_math.h header). PARITY UNPINNED: D3D12/WARP filtering
+// ORACLE / TEST INFRASTRUCTURE ONLY (see vqo_math.h header). PARITY UNPINNED (fixed-function hardware, no source in the reference): D3D12/WARP filtering
 // bits are not observable here; this fixes one D3D-conformant behaviour:
 //   * texel coordinates converted to fixed point with 8 fractional bits (D3D11.3 functional spec
 //     §7.18.7 "Fixed point texture coordinates"), linear weights = those 8-bit fractions;

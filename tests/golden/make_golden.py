@@ -3,7 +3,8 @@
 
 The reference (vilbeyli/VQEngine) holds no golden vectors for this path and cannot run here, so
 these fixtures pin OUR oracle (and, through the -m gpu tests, the HIP kernels) rather than the reference's bits:
-"parity unpinned" stays true. Regenerate with:  python -m tests.golden.make_golden
+these are SELF-MADE goldens (they guard against drift); the fixtures made from the reference's own sources are
+tests/golden/ref_outputs.npz (make_ref_fixtures.py). Regenerate with:  python -m tests.golden.make_golden
 Each function returns {name: array}; inputs are regenerated from seeds by the tests, only outputs are stored."""
 import os
 import sys
