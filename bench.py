@@ -32,7 +32,7 @@ SHADE_FLOPS_PER_PX = 170 * N_LIGHTS + 160
 # HBM bytes per launch of the shade kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
 # FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950): profiles/r1b_pmc_hbm.md. Not measurable from inside
 # bench.py; the committed figure is for exactly this workload (3840x2160, 64 lights + IBL, RGBA16F out).
-SHADE_PMC_TRAFFIC_BYTES = (2 * 599481 + 64800) * 1024
+SHADE_PMC_TRAFFIC_BYTES = (2 * 598175 + 64800) * 1024   # re-measured on the round's final kernel: profiles/r1l_pmc_hbm.md
 # VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_shade.sh, committed
 # summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
 SPINUP_STEPS = 200              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
