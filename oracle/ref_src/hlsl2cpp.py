@@ -70,6 +70,9 @@ def translate(name, src):
     # 8. scalar -> vector initialisation (`float3 c = 0.0f;` splats in HLSL), typed SRVs
     src = re.sub(r"\b(float[234])\s+(\w+)\s*=\s*([-+]?\d[\w.]*)\s*;", r"\1 \2 = \1(\3);", src)
     src = re.sub(r"\bTexture2D\s*<\s*float4\s*>", "Texture2D", src)
+    # 4b. the same qualifiers hidden in macros (ffx_a.h: `#define inAF2 in AF2`, `#define outAF2 out AF2`, `#define inoutAF2 inout AF2`)
+    src = re.sub(r"^(\s*#define\s+\w+)\s+in\s+(\w+)\s*$", r"\1 \2", src, flags=re.M)
+    src = re.sub(r"^(\s*#define\s+\w+)\s+(?:inout|out)\s+(\w+)\s*$", r"\1 \2&", src, flags=re.M)
     # 5. zero casts
     src = re.sub(r"\(\s*(%s)\s*\)\s*0\b(?!\.)" % ZERO_CAST_TYPES, r"\1{}", src)
     return src
@@ -81,6 +84,7 @@ def main():
     for f in files:
         with open(os.path.join(shader_dir, f), encoding="latin-1") as fh:
             src = fh.read()
+        os.makedirs(os.path.dirname(os.path.join(out_dir, f)), exist_ok=True)
         with open(os.path.join(out_dir, f), "w", encoding="latin-1") as fh:
             fh.write("// GENERATED by oracle/ref_src/hlsl2cpp.py from the reference's Shaders/%s - never commit\n" % f)
             fh.write(translate(f, src))

@@ -49,7 +49,7 @@ struct float2 {
         struct { float r, g; };
         float d[2];
         sw2<2, 0, 1> xy; sw2<2, 1, 0> yx; sw2<2, 0, 0> xx; sw2<2, 1, 1> yy; sw2<2, 0, 1> rg;
-        sw3<2, 0, 0, 0> xxx;
+        sw3<2, 0, 0, 0> xxx; sw3<2, 1, 1, 1> yyy;
     };
     float2() : d{ 0, 0 } {}
     float2(float a, float b) : d{ a, b } {}
@@ -65,7 +65,8 @@ struct float3 {
         struct { float r, g, b; };
         float d[3];
         sw2<3, 0, 1> xy; sw2<3, 0, 2> xz; sw2<3, 1, 2> yz; sw2<3, 0, 1> rg;
-        sw3<3, 0, 1, 2> xyz; sw3<3, 0, 1, 2> rgb; sw3<3, 0, 0, 0> xxx; sw3<3, 0, 0, 0> rrr; sw3<3, 2, 1, 0> zyx;
+        sw3<3, 0, 1, 2> xyz; sw3<3, 0, 1, 2> rgb; sw3<3, 0, 0, 0> xxx; sw3<3, 0, 0, 0> rrr; sw3<3, 2, 1, 0> zyx; sw3<3, 1, 1, 1> yyy; sw3<3, 2, 2, 2> zzz;
+        sw2<3, 0, 0> xx; sw2<3, 1, 1> yy; sw2<3, 2, 2> zz;
     };
     float3() : d{ 0, 0, 0 } {}
     float3(float a, float b, float c) : d{ a, b, c } {}
@@ -108,18 +109,120 @@ template <int N, int A, int B, int C> sw3<N, A, B, C>& sw3<N, A, B, C>::operator
 template <int N, int A, int B, int C, int D> sw4<N, A, B, C, D>::operator float4() const { return float4(d[A], d[B], d[C], d[D]); }
 
 // ---- integer vectors (plain; only the members the shaders touch) ------------------------------------------------------
-struct int2 { int x, y; int2() : x(0), y(0) {} int2(int a, int b) : x(a), y(b) {} };
-struct int3 { int x, y, z; int3() : x(0), y(0), z(0) {} int3(int a, int b, int c) : x(a), y(b), z(c) {} };
-struct int4 { int x, y, z, w; int4() : x(0), y(0), z(0), w(0) {} int4(int a, int b, int c, int e) : x(a), y(b), z(c), w(e) {} };
-struct uint2 { uint x, y; uint2() : x(0), y(0) {} uint2(uint a, uint b) : x(a), y(b) {} };
+struct int2; struct int3; struct int4; struct uint2; struct uint3; struct uint4;
+template <class V, class T, int N, int A, int B> struct isw2 { T d[N]; operator V() const { return V(d[A], d[B]); } };
+struct int2 {
+    union { struct { int x, y; }; int d[2]; isw2<int2, int, 2, 0, 1> xy; };
+    int2() : d{ 0, 0 } {}
+    int& operator[](int i) { return d[i]; }
+    const int& operator[](int i) const { return d[i]; }
+    int2(int a, int b) : d{ a, b } {}
+    explicit int2(int s) : d{ s, s } {}
+    explicit int2(const uint2& o); explicit int2(const float2& o);
+    explicit operator float2() const { return float2((float)d[0], (float)d[1]); }
+};
+struct int3 {
+    union { struct { int x, y, z; }; int d[3]; isw2<int2, int, 3, 0, 1> xy; };
+    int3() : d{ 0, 0, 0 } {}
+    int& operator[](int i) { return d[i]; }
+    const int& operator[](int i) const { return d[i]; }
+    int3(int a, int b, int c) : d{ a, b, c } {}
+    int3(const int2& v, int c) : d{ v.d[0], v.d[1], c } {}
+    explicit int3(int s) : d{ s, s, s } {}
+    explicit int3(const uint3& o); explicit int3(const float3& o);
+    explicit operator float3() const { return float3((float)d[0], (float)d[1], (float)d[2]); }
+};
+struct int4 {
+    union { struct { int x, y, z, w; }; int d[4]; isw2<int2, int, 4, 0, 1> xy; isw2<int2, int, 4, 2, 3> zw; };
+    int4() : d{ 0, 0, 0, 0 } {}
+    int& operator[](int i) { return d[i]; }
+    const int& operator[](int i) const { return d[i]; }
+    int4(int a, int b, int c, int e) : d{ a, b, c, e } {}
+    explicit int4(int s) : d{ s, s, s, s } {}
+    explicit int4(const uint4& o); explicit int4(const float4& o);
+    explicit operator float4() const { return float4((float)d[0], (float)d[1], (float)d[2], (float)d[3]); }
+};
+struct uint2 {
+    union { struct { uint x, y; }; uint d[2]; isw2<uint2, uint, 2, 0, 1> xy; };
+    uint2() : d{ 0, 0 } {}
+    uint& operator[](int i) { return d[i]; }
+    const uint& operator[](int i) const { return d[i]; }
+    uint2(uint a, uint b) : d{ a, b } {}
+    explicit uint2(uint s) : d{ s, s } {}
+    explicit uint2(const int2& o) : d{ (uint)o.d[0], (uint)o.d[1] } {}
+    explicit uint2(const float2& o);
+    explicit operator float2() const { return float2((float)d[0], (float)d[1]); }
+};
+// DispatchThreadID.xy must convert to both uint2 and int2 (texture indexing takes either)
 struct usw_xy { uint d[3]; operator uint2() const { return uint2(d[0], d[1]); } operator int2() const { return int2((int)d[0], (int)d[1]); } };
 struct uint3 {
-    union { struct { uint x, y, z; }; usw_xy xy; };
-    uint3() : x(0), y(0), z(0) {}
-    uint3(uint a, uint b, uint c) : x(a), y(b), z(c) {}
+    union { struct { uint x, y, z; }; uint d[3]; usw_xy xy; };
+    uint3() : d{ 0, 0, 0 } {}
+    uint& operator[](int i) { return d[i]; }
+    const uint& operator[](int i) const { return d[i]; }
+    uint3(uint a, uint b, uint c) : d{ a, b, c } {}
+    explicit uint3(uint s) : d{ s, s, s } {}
+    explicit uint3(const int3& o) : d{ (uint)o.d[0], (uint)o.d[1], (uint)o.d[2] } {}
+    explicit uint3(const float3& o);
+    explicit operator float3() const { return float3((float)d[0], (float)d[1], (float)d[2]); }
 };
-inline int2 operator+(int2 a, int2 b) { return int2(a.x + b.x, a.y + b.y); }
-inline int2 operator-(int2 a, int2 b) { return int2(a.x - b.x, a.y - b.y); }
+struct uint4 {
+    union { struct { uint x, y, z, w; }; uint d[4]; isw2<uint2, uint, 4, 0, 1> xy; isw2<uint2, uint, 4, 2, 3> zw; };
+    uint4() : d{ 0, 0, 0, 0 } {}
+    uint& operator[](int i) { return d[i]; }
+    const uint& operator[](int i) const { return d[i]; }
+    uint4(uint a, uint b, uint c, uint e) : d{ a, b, c, e } {}
+    explicit uint4(uint s) : d{ s, s, s, s } {}
+    explicit uint4(const int4& o) : d{ (uint)o.d[0], (uint)o.d[1], (uint)o.d[2], (uint)o.d[3] } {}
+    explicit uint4(const float4& o);
+    explicit operator float4() const { return float4((float)d[0], (float)d[1], (float)d[2], (float)d[3]); }
+};
+inline int2::int2(const uint2& o) : d{ (int)o.d[0], (int)o.d[1] } {}
+inline int3::int3(const uint3& o) : d{ (int)o.d[0], (int)o.d[1], (int)o.d[2] } {}
+inline int4::int4(const uint4& o) : d{ (int)o.d[0], (int)o.d[1], (int)o.d[2], (int)o.d[3] } {}
+inline int2::int2(const float2& o) : d{ (int)o.d[0], (int)o.d[1] } {}
+inline int3::int3(const float3& o) : d{ (int)o.d[0], (int)o.d[1], (int)o.d[2] } {}
+inline int4::int4(const float4& o) : d{ (int)o.d[0], (int)o.d[1], (int)o.d[2], (int)o.d[3] } {}
+inline uint2::uint2(const float2& o) : d{ (uint)o.d[0], (uint)o.d[1] } {}
+inline uint3::uint3(const float3& o) : d{ (uint)o.d[0], (uint)o.d[1], (uint)o.d[2] } {}
+inline uint4::uint4(const float4& o) : d{ (uint)o.d[0], (uint)o.d[1], (uint)o.d[2], (uint)o.d[3] } {}
+inline float2 to_float(const uint2& v) { return float2((float)v.x, (float)v.y); }
+inline float2 to_float(const int2& v) { return float2((float)v.x, (float)v.y); }
+#define VQ_HLSL_IOPS(V, T, N)                                                                                          \
+    inline V operator+(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }    \
+    inline V operator-(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }    \
+    inline V operator*(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b.d[i]; return r; }    \
+    inline V operator&(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] & b.d[i]; return r; }    \
+    inline V operator|(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] | b.d[i]; return r; }    \
+    inline V operator^(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] ^ b.d[i]; return r; }    \
+    inline V operator<<(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] << b.d[i]; return r; }  \
+    inline V operator>>(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] >> b.d[i]; return r; }  \
+    inline V operator+(const V& a, T b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] + b; return r; }                \
+    inline V operator-(const V& a, T b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] - b; return r; }                \
+    inline V operator*(const V& a, T b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] * b; return r; }                \
+    inline V operator&(const V& a, T b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] & b; return r; }                \
+    inline V operator|(const V& a, T b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] | b; return r; }                \
+    inline V operator<<(const V& a, T b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] << b; return r; }              \
+    inline V operator>>(const V& a, T b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] >> b; return r; }              \
+    inline V operator-(T a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a - b.d[i]; return r; }                \
+    inline V operator~(const V& a) { V r; for (int i = 0; i < N; ++i) r.d[i] = ~a.d[i]; return r; }                        \
+    inline V min(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] < b.d[i] ? a.d[i] : b.d[i]; return r; } \
+    inline V max(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] > b.d[i] ? a.d[i] : b.d[i]; return r; }
+#define VQ_HLSL_ICMP(V, N) \
+    inline V operator!=(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] != b.d[i]; return r; } \
+    inline V operator==(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = a.d[i] == b.d[i]; return r; }
+VQ_HLSL_ICMP(int2, 2) VQ_HLSL_ICMP(int3, 3) VQ_HLSL_ICMP(int4, 4) VQ_HLSL_ICMP(uint2, 2) VQ_HLSL_ICMP(uint3, 3) VQ_HLSL_ICMP(uint4, 4)
+#undef VQ_HLSL_ICMP
+inline int2 abs(const int2& a) { int2 r; for (int i = 0; i < 2; ++i) r.d[i] = a.d[i] < 0 ? -a.d[i] : a.d[i]; return r; }
+inline int3 abs(const int3& a) { int3 r; for (int i = 0; i < 3; ++i) r.d[i] = a.d[i] < 0 ? -a.d[i] : a.d[i]; return r; }
+inline int4 abs(const int4& a) { int4 r; for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] < 0 ? -a.d[i] : a.d[i]; return r; }
+#define VQ_HLSL_SEL(Cnd, V, N) inline V select(const Cnd& c, const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = c.d[i] ? a.d[i] : b.d[i]; return r; }
+VQ_HLSL_SEL(uint2, uint2, 2) VQ_HLSL_SEL(uint3, uint3, 3) VQ_HLSL_SEL(uint4, uint4, 4)
+VQ_HLSL_SEL(uint2, float2, 2) VQ_HLSL_SEL(uint3, float3, 3) VQ_HLSL_SEL(uint4, float4, 4)
+#undef VQ_HLSL_SEL
+VQ_HLSL_IOPS(int2, int, 2) VQ_HLSL_IOPS(int3, int, 3) VQ_HLSL_IOPS(int4, int, 4)
+VQ_HLSL_IOPS(uint2, uint, 2) VQ_HLSL_IOPS(uint3, uint, 3) VQ_HLSL_IOPS(uint4, uint, 4)
+#undef VQ_HLSL_IOPS
 
 // ---- component-wise arithmetic ------------------------------------------------------------------------------------------
 #define VQ_HLSL_OPS(V, N)                                                                                           \
@@ -152,6 +255,17 @@ VQ_HLSL_OPS(float4, 4)
 inline float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 inline float max(float a, float b) { return fmaxf(a, b); }
 inline float min(float a, float b) { return fminf(a, b); }
+inline int max(int a, int b) { return a > b ? a : b; }
+inline int min(int a, int b) { return a < b ? a : b; }
+inline uint max(uint a, uint b) { return a > b ? a : b; }
+inline uint min(uint a, uint b) { return a < b ? a : b; }
+inline float max(float a, int b) { return fmaxf(a, (float)b); }      // HLSL promotes the int: max(L.z, 0)
+inline float min(float a, int b) { return fminf(a, (float)b); }
+inline float max(int a, float b) { return fmaxf((float)a, b); }
+inline float min(int a, float b) { return fminf((float)a, b); }
+inline int abs(int x) { return x < 0 ? -x : x; }
+inline int clamp(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+inline float trunc(float x) { return truncf(x); }
 inline float clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 inline float abs(float x) { return fabsf(x); }
 inline float sqrt(float x) { return sqrtf(x); }
@@ -175,11 +289,19 @@ inline float step(float e, float x) { return x >= e ? 1.0f : 0.0f; }
 inline float sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
 inline float asfloat(uint u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline uint asuint(float f) { uint u; std::memcpy(&u, &f, 4); return u; }
+inline float asfloat(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+inline float asfloat(float f) { return f; }
+inline uint asuint(uint u) { return u; }
+inline uint asuint(int i) { return (uint)i; }
+inline int asint(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+inline int asint(uint u) { return (int)u; }
+uint f32tof16(float f);          // RNE, defined by the harness that needs it (vqo::f32_to_f16)
+float f16tof32(uint h);
 
 #define VQ_HLSL_MAP1(V, N, FN) inline V FN(const V& a) { V r; for (int i = 0; i < N; ++i) r.d[i] = FN(a.d[i]); return r; }
 #define VQ_HLSL_MAP2(V, N, FN) inline V FN(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = FN(a.d[i], b.d[i]); return r; }
 #define VQ_HLSL_VEC(V, N)                                                                                            \
-    VQ_HLSL_MAP1(V, N, saturate) VQ_HLSL_MAP1(V, N, abs) VQ_HLSL_MAP1(V, N, sqrt) VQ_HLSL_MAP1(V, N, floor)              \
+    VQ_HLSL_MAP1(V, N, rcp) VQ_HLSL_MAP1(V, N, rsqrt) VQ_HLSL_MAP1(V, N, saturate) VQ_HLSL_MAP1(V, N, abs) VQ_HLSL_MAP1(V, N, sqrt) VQ_HLSL_MAP1(V, N, floor)              \
     VQ_HLSL_MAP1(V, N, frac) VQ_HLSL_MAP1(V, N, exp2) VQ_HLSL_MAP1(V, N, log2) VQ_HLSL_MAP1(V, N, sin) VQ_HLSL_MAP1(V, N, cos) \
     VQ_HLSL_MAP2(V, N, max) VQ_HLSL_MAP2(V, N, min) VQ_HLSL_MAP2(V, N, pow)                                               \
     inline V pow(const V& a, float b) { V r; for (int i = 0; i < N; ++i) r.d[i] = pow(a.d[i], b); return r; }             \
@@ -246,6 +368,16 @@ inline float4 mul(const float4& v, const float4x4& M) {
     return r;
 }
 
+inline float2 asfloat(const uint2& u) { return float2(asfloat(u.x), asfloat(u.y)); }
+inline float3 asfloat(const uint3& u) { return float3(asfloat(u.x), asfloat(u.y), asfloat(u.z)); }
+inline float4 asfloat(const uint4& u) { return float4(asfloat(u.x), asfloat(u.y), asfloat(u.z), asfloat(u.w)); }
+inline uint2 asuint(const float2& f) { return uint2(asuint(f.x), asuint(f.y)); }
+inline uint3 asuint(const float3& f) { return uint3(asuint(f.x), asuint(f.y), asuint(f.z)); }
+inline uint4 asuint(const float4& f) { return uint4(asuint(f.x), asuint(f.y), asuint(f.z), asuint(f.w)); }
+
+inline uint3 operator!=(const float3& a, const uint3& b) { return uint3(a.x != (float)b.x, a.y != (float)b.y, a.z != (float)b.z); }
+inline uint4 operator!=(const float4& a, const uint4& b) { return uint4(a.x != (float)b.x, a.y != (float)b.y, a.z != (float)b.z, a.w != (float)b.w); }
+
 // ---- resources: fixed-function sampling is delegated to the harness -----------------------------------------------------
 struct SamplerState { int id = 0; };
 enum { kSampleImplicit = 0, kSampleBias = 1, kSampleLevel = 2 };
@@ -255,6 +387,7 @@ float4 vqref_sample_cube(const TextureCube& t, const SamplerState& s, float3 dir
 float4 vqref_sample_2d_array(const Texture2DArray& t, const SamplerState& s, float3 uvw);
 float4 vqref_sample_cube_array(const TextureCubeArray& t, const SamplerState& s, float4 dirw);
 float4 vqref_load_2d(const Texture2D& t, int x, int y, int mip);
+float4 vqref_gather_2d(const Texture2D& t, const SamplerState& s, float2 uv, int channel);   // D3D order: (0,1) (1,1) (1,0) (0,0)
 void   vqref_dims_2d(const Texture2D& t, uint* w, uint* h);
 struct Texture2D {
     const void* res = nullptr; int kind = 0;
@@ -262,6 +395,9 @@ struct Texture2D {
     float4 SampleBias(const SamplerState& s, float2 uv, float bias) const { return vqref_sample_2d(*this, s, uv, kSampleBias, bias); }
     float4 SampleLevel(const SamplerState& s, float2 uv, float lod) const { return vqref_sample_2d(*this, s, uv, kSampleLevel, lod); }
     float4 Load(int3 p) const { return vqref_load_2d(*this, p.x, p.y, p.z); }
+    float4 GatherRed(const SamplerState& s, float2 uv, int2) const { return vqref_gather_2d(*this, s, uv, 0); }
+    float4 GatherGreen(const SamplerState& s, float2 uv, int2) const { return vqref_gather_2d(*this, s, uv, 1); }
+    float4 GatherBlue(const SamplerState& s, float2 uv, int2) const { return vqref_gather_2d(*this, s, uv, 2); }
     float4 operator[](uint2 p) const { return vqref_load_2d(*this, (int)p.x, (int)p.y, 0); }
     float4 operator[](int2 p) const { return vqref_load_2d(*this, p.x, p.y, 0); }
     float4 operator[](const usw_xy& p) const { return vqref_load_2d(*this, (int)p.d[0], (int)p.d[1], 0); }
@@ -283,9 +419,11 @@ struct TextureCubeArray {
 // RWTexture2D<T>: a plain row-major image the harness owns
 template <class T> struct RWTexture2D {
     T* data = nullptr; int width = 0, height = 0;
-    T& operator[](uint2 p) { return data[(size_t)p.y * width + p.x]; }
-    T& operator[](int2 p) { return data[(size_t)p.y * width + p.x]; }
-    T& operator[](const usw_xy& p) { return data[(size_t)p.d[1] * width + p.d[0]]; }
+    T dummy;
+    T& at(long x, long y) { return (x < 0 || y < 0 || x >= width || y >= height) ? dummy : data[(size_t)y * width + x]; }
+    T& operator[](uint2 p) { return at(p.x, p.y); }
+    T& operator[](int2 p) { return at(p.x, p.y); }
+    T& operator[](const usw_xy& p) { return at(p.d[0], p.d[1]); }
     void GetDimensions(uint& w, uint& h) const { w = (uint)width; h = (uint)height; }
 };
 

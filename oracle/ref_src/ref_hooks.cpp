@@ -77,6 +77,19 @@ float4 vqref_load_2d(const Texture2D& t, int x, int y, int) {
     const float* p = im->rgba + ((size_t)y * im->width + x) * 4;
     return float4(p[0], p[1], p[2], p[3]);
 }
+// Gather with a clamp sampler: the 2x2 footprint whose top-left texel is floor(uv*size - 0.5), texels clamped to the image
+float4 vqref_gather_2d(const Texture2D& t, const SamplerState&, float2 uv, int ch) {
+    if (t.kind != kTexImage) return float4(0, 0, 0, 0);
+    const Image* im = (const Image*)t.res;
+    const int x0 = vqo::f2i_floor(uv.x * (float)im->width - 0.5f), y0 = vqo::f2i_floor(uv.y * (float)im->height - 0.5f);
+    auto tex = [&](int x, int y) {
+        x = x < 0 ? 0 : (x > im->width - 1 ? im->width - 1 : x); y = y < 0 ? 0 : (y > im->height - 1 ? im->height - 1 : y);
+        return im->rgba[((size_t)y * im->width + x) * 4 + ch];
+    };
+    return float4(tex(x0, y0 + 1), tex(x0 + 1, y0 + 1), tex(x0 + 1, y0), tex(x0, y0));
+}
+uint f32tof16(float f) { return vqo::f32_to_f16(f); }
+float f16tof32(uint h) { return vqo::f16_to_f32((uint16_t)h); }
 void vqref_dims_2d(const Texture2D& t, uint* w, uint* h) {
     if (t.kind == kTexImage) { const Image* im = (const Image*)t.res; *w = (uint)im->width; *h = (uint)im->height; }
     else { *w = 0; *h = 0; }

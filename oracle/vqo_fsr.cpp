@@ -6,8 +6,9 @@
 //
 // ORACLE / TEST INFRASTRUCTURE ONLY (see vqo_oracle.cpp). PARITY: FsrEasuCon / FsrRcasCon and the CPU half packing are PINNED BIT-EXACT
 // against the reference's own C++ path (ffx_a.h + ffx_fsr1.h with A_CPU compiled into oracle/_ref/libvqref_fsr.so, as PostProcess.cpp:21-75
-// does); Visualization.hlsl is pinned through the HLSL shim (oracle/_ref/libvqref_shaders.so). The EASU / RCAS FILTERS remain UNPINNED: no
-// golden image exists and ffx_a.h's A_GPU/A_HLSL macro layer is beyond the shim (restated from the header, checked by a numpy restatement).
+// does); Visualization.hlsl is pinned through the HLSL shim (oracle/_ref/libvqref_shaders.so). The EASU / RCAS FILTERS are PINNED BIT-EXACT too:
+// AMDFidelityFX.hlsl + ffx_a.h (A_GPU/A_HLSL) + ffx_fsr1.h run on the CPU as dispatched (oracle/ref_src/ref_fsr.cpp); only the gather / load
+// addressing is the harness's (fixed-function).
 //
 // Contract: every operation is a separate IEEE binary32 operation in the order the header writes it (a*b+c is a multiply
 // then an add), HLSL rcp() = correctly rounded 1/x, the APrx* approximations are integer bit tricks and exact by

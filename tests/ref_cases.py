@@ -406,4 +406,45 @@ def _fsr_con_case():
 
 
 CASES.append(_fsr_con_case())
+
+
+def _ccon(a):
+    return (C.c_uint32 * len(a))(*[int(v) for v in a])
+
+
+def _fsr_filter_cases():
+    def image(iw, ih, seed):
+        rng = np.random.default_rng(seed)
+        img = rng.random((ih, iw, 4), dtype=np.float32)
+        yy, xx = np.mgrid[0:ih, 0:iw]
+        img[..., 0] = 0.5 + 0.5 * np.sin(xx * 0.7 + yy * 0.3)
+        img[ih // 3:, :, 1] = (xx[ih // 3:] > iw // 2) * 0.9
+        img[2, 3, :3] = 0.0
+        img[..., 3] = 1.0
+        return img
+    for iw, ih, ow, oh in ((48, 27, 72, 41), (33, 17, 66, 34), (17, 9, 64, 33)):
+        def build(iw=iw, ih=ih, ow=ow, oh=oh):
+            return {"img": image(iw, ih, iw * 131 + oh), "out": (ow, oh), "con": O.fsr_easu_con(iw, ih, ow, oh)}
+
+        def ref(i):
+            from tests import ref_lib as R
+            return R.fsr_easu(i["img"], i["out"][0], i["out"][1], i["con"]).view(np.uint32)
+        CASES.append(Case(f"fsr_easu_{iw}x{ih}_to_{ow}x{oh}", build, ref,
+                          lambda i: O.fsr_easu(i["img"], abi.FMT_RGBA32F, i["out"][0], i["out"][1], abi.FMT_RGBA32F, con=i["con"])[..., :3].copy().view(np.uint32),
+                          lambda ctx, i: ctx.fsr_easu(_dev(i["img"]), abi.FMT_RGBA32F, i["out"][0], i["out"][1], abi.FMT_RGBA32F,
+                                                      con=_ccon(i["con"])).cpu().numpy()[..., :3].copy().view(np.uint32), "exact"))
+    for stops in (0.0, 0.2, 1.3):
+        def build_r(stops=stops):
+            return {"img": image(45, 31, 77), "con": O.fsr_rcas_con(stops)}
+
+        def ref_r(i):
+            from tests import ref_lib as R
+            return R.fsr_rcas(i["img"], i["con"]).view(np.uint32)
+        CASES.append(Case(f"fsr_rcas_stops{stops}", build_r, ref_r,
+                          lambda i: O.fsr_rcas(i["img"], abi.FMT_RGBA32F, abi.FMT_RGBA32F, con=i["con"])[..., :3].copy().view(np.uint32),
+                          lambda ctx, i: ctx.fsr_rcas(_dev(i["img"]), abi.FMT_RGBA32F, abi.FMT_RGBA32F, con=_ccon(i["con"])).cpu().numpy()[..., :3].copy().view(np.uint32),
+                          "exact"))
+
+
+_fsr_filter_cases()
 BY_NAME = {c.name: c for c in CASES}

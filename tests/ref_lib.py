@@ -45,6 +45,8 @@ def load(name="shaders"):
             lib.vqref_skydome.argtypes = [vp, i32, i32, vp, i32, i32, vp]
             lib.vqref_visualize.argtypes = [vp, i32, i32, vp, vp]
             lib.vqref_apply_reflections.argtypes = [vp, vp, i32, i32]
+            lib.vqref_fsr_easu.argtypes = [vp, i32, i32, vp, vp, i32, i32]
+            lib.vqref_fsr_rcas.argtypes = [vp, i32, i32, vp, vp]
         _libs[name] = lib
     return _libs[name]
 
@@ -153,3 +155,20 @@ def apply_reflections(refl, scene):
     refl, scene = _img32(refl), _img32(scene).copy()
     assert load().vqref_apply_reflections(refl.ctypes.data, scene.ctypes.data, scene.shape[1], scene.shape[0]) == 0
     return scene
+
+
+def fsr_easu(img, out_w, out_h, con):
+    """FSR_EASU_CSMain over ceil(out/16)^2 workgroups of 64 lanes; returns RGB float32 [out_h, out_w, 3]"""
+    img = _img32(img)
+    con = np.ascontiguousarray(con, np.uint32)
+    out = np.zeros((out_h, out_w, 4), np.float32)
+    assert load().vqref_fsr_easu(img.ctypes.data, img.shape[1], img.shape[0], con.ctypes.data, out.ctypes.data, out_w, out_h) == 0
+    return out[..., :3]
+
+
+def fsr_rcas(img, con):
+    img = _img32(img)
+    con = np.ascontiguousarray(con, np.uint32)
+    out = np.zeros_like(img)
+    assert load().vqref_fsr_rcas(img.ctypes.data, img.shape[1], img.shape[0], con.ctypes.data, out.ctypes.data) == 0
+    return out[..., :3]

@@ -346,6 +346,31 @@ def test_visualization_modes(mode):
         assert_close_stat(got[..., :3], ref[..., :3], f"viz {mode}/{unpack}", median=1e-7, p99=2e-5, worst=2e-3, floor=1e-6)
 
 
+@pytest.mark.parametrize("sizes", [(48, 27, 72, 41), (40, 30, 52, 51), (33, 17, 66, 34), (20, 20, 20, 20), (17, 9, 64, 33)])
+def test_fsr_easu_and_rcas_are_bit_exact(sizes):
+    """FSR_EASU_CSMain / FSR_RCAS_CSMain (AMDFidelityFX.hlsl, FP32 path) with AMD's ffx_a.h + ffx_fsr1.h run as dispatched — 64-lane
+    groups, ARmp8x8 remap, 4 pixels per lane, FsrEasuF's 12-tap directional filter with its APrx* bit tricks, FsrRcasF's 5-tap
+    limiter. The oracle keeps the header's literal operation order (no regrouping on this row), so the match is BIT FOR BIT."""
+    iw, ih, ow, oh = sizes
+    rng = np.random.default_rng(iw * 131 + oh)
+    img = rng.random((ih, iw, 4), dtype=np.float32)
+    yy, xx = np.mgrid[0:ih, 0:iw]
+    img[..., 0] = 0.5 + 0.5 * np.sin(xx * 0.7 + yy * 0.3)
+    img[ih // 3:, :, 1] = (xx[ih // 3:] > iw // 2) * 0.9                 # a hard vertical edge
+    img[2, 3, :3] = 0.0
+    img[..., 3] = 1.0
+    con = O.fsr_easu_con(iw, ih, ow, oh)
+    assert np.array_equal(con, R.fsr_easu_con(iw, ih, ow, oh))
+    got = O.fsr_easu(img, abi.FMT_RGBA32F, ow, oh, abi.FMT_RGBA32F, con=con)
+    ref = R.fsr_easu(img, ow, oh, con)
+    assert np.array_equal(got[..., :3].view(np.uint32), ref.view(np.uint32))
+    for stops in (0.0, 0.2, 1.3):
+        rc = O.fsr_rcas_con(stops)
+        got2 = O.fsr_rcas(got, abi.FMT_RGBA32F, abi.FMT_RGBA32F, con=rc)
+        ref2 = R.fsr_rcas(got, rc)
+        assert np.array_equal(got2[..., :3].view(np.uint32), ref2.view(np.uint32)), stops
+
+
 def test_apply_reflections():
     scene, refl = _hdr_scene(seed=13).astype(np.float32), _hdr_scene(seed=14).astype(np.float32)
     ref = R.apply_reflections(refl, scene)
