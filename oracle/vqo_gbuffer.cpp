@@ -4,7 +4,7 @@
 // ORACLE / TEST INFRASTRUCTURE ONLY (see vqo_oracle.cpp). PARITY: the arithmetic of PSMain's surface assembly is pinned
 // against the reference's own ForwardLighting.hlsl run on the CPU (oracle/_ref, tests/test_ref_pinning.py::test_forward_lighting_psmain_
 // with_material_textures); the texture FETCHES (filtering, LOD selection, derivatives) have no source in the reference and stay a
-// restatement of D3D's rules. MipImage (DXGIUtils.cpp) needs <Windows.h>/<dxgiformat.h> to compile: restated, not pinned.
+// restatement of D3D's rules. MipImage's 4-byte branch is pinned BIT-EXACT against the reference's own DXGIUtils.cpp (oracle/_ref/libvqref_mip.so).
 //
 // Contract additions of this file (DESIGN.md "G-buffer producer"):
 //   * UNORM8 texels are filtered as the integers 0..255 and the filtered value is scaled once by rcp(255)

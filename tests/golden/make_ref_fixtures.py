@@ -15,7 +15,7 @@ from tests import ref_cases, ref_lib  # noqa: E402
 
 
 def main():
-    assert ref_lib.available("shaders") and ref_lib.available("fsr"), "build oracle/_ref first: make -C oracle ref"
+    assert ref_lib.available("shaders") and ref_lib.available("fsr") and ref_lib.available("mip"), "build oracle/_ref first: make -C oracle ref"
     out = {}
     for c in ref_cases.CASES:
         inp = c.build()

@@ -447,4 +447,37 @@ def _fsr_filter_cases():
 
 
 _fsr_filter_cases()
+
+
+def _mip_cases():
+    def build_f():
+        rng = np.random.default_rng(64032)
+        return {"l0": (rng.random((32, 64, 4), dtype=np.float32) * 20).astype(np.float32)}
+
+    def build_u():
+        rng = np.random.default_rng(12816)
+        return {"l0": rng.integers(0, 256, (128, 16, 4), dtype=np.uint8)}
+
+    def ref(i):
+        from tests import ref_lib as R
+        return np.concatenate([lv.reshape(-1, 4) for lv in R.mip_chain(i["l0"])])
+
+    def n_px(i):                 # texels of the levels the reference function produces (both dimensions >= 2 going in)
+        h, w = i["l0"].shape[:2]
+        n = 0
+        while h >= 2 and w >= 2:
+            h, w = h // 2, w // 2
+            n += h * w
+        return n
+
+    def cut(chain, i):
+        h, w = i["l0"].shape[:2]
+        return chain[w * h: w * h + n_px(i)]
+    CASES.append(Case("mipimage_min_rgba32f", build_f, lambda i: ref(i).view(np.uint32), lambda i: cut(O.mip_chain(i["l0"])[0], i).view(np.uint32),
+                      lambda ctx, i: cut(ctx.mip_chain(_dev(i["l0"]))[0].cpu().numpy(), i).view(np.uint32), "exact"))
+    CASES.append(Case("mipimage_box_rgba8", build_u, ref, lambda i: cut(O.mip_chain_rgba8(i["l0"])[0], i),
+                      lambda ctx, i: cut(ctx.mip_chain_rgba8(_dev(i["l0"]))[0].cpu().numpy(), i), "exact"))
+
+
+_mip_cases()
 BY_NAME = {c.name: c for c in CASES}

@@ -23,7 +23,9 @@ def load(name="shaders"):
     if name not in _libs:
         lib = C.CDLL(os.path.join(REF_DIR, f"libvqref_{name}.so"))
         vp, f32, i32, u32 = C.c_void_p, C.c_float, C.c_int32, C.c_uint32
-        if name == "fsr":
+        if name == "mip":
+            lib.vqref_mip_image.argtypes = [vp, vp, C.c_uint, C.c_uint, C.c_uint]
+        elif name == "fsr":
             lib.vqref_fsr_easu_con.argtypes = [vp] + [f32] * 6
             lib.vqref_fsr_rcas_con.argtypes = [vp, f32]
             lib.vqref_half_bits.argtypes = [f32]
@@ -172,3 +174,19 @@ def fsr_rcas(img, con):
     out = np.zeros_like(img)
     assert load().vqref_fsr_rcas(img.ctypes.data, img.shape[1], img.shape[0], con.ctypes.data, out.ctypes.data) == 0
     return out[..., :3]
+
+
+def mip_chain(level0):
+    """VQ_DXGI_UTILS::MipImage applied level by level (as TextureManager::GenerateMips does) while both dimensions are >= 2.
+    level0: float32 [H,W,4] (16-byte MIN filter) or uint8 [H,W,4] (4-byte box filter). Returns the list of levels 1.. as [h,w,4]."""
+    lib = load("mip")
+    cur = np.ascontiguousarray(level0)
+    bpp = 16 if cur.dtype == np.float32 else 4
+    levels = []
+    while cur.shape[0] >= 2 and cur.shape[1] >= 2:
+        h, w = cur.shape[0] // 2, cur.shape[1] // 2
+        dst = np.zeros((h, w, 4), cur.dtype)
+        lib.vqref_mip_image(cur.ctypes.data, dst.ctypes.data, cur.shape[1], cur.shape[0], bpp)
+        levels.append(dst)
+        cur = dst
+    return levels

@@ -18,7 +18,7 @@ from tests import ref_lib as R
 from vqengine_amd import abi, synth
 from vqengine_amd import scene as scene_mod
 
-pytestmark = pytest.mark.skipif(not (R.available("shaders") and R.available("fsr")),
+pytestmark = pytest.mark.skipif(not (R.available("shaders") and R.available("fsr") and R.available("mip")),
                                 reason="oracle/_ref is built only where /root/reference exists")
 
 
@@ -377,3 +377,29 @@ def test_apply_reflections():
     want = scene.copy()
     want[..., :3] = scene[..., :3] + refl[..., :3]                       # ApplyReflections.hlsl:45-57; alpha = scene roughness
     assert np.array_equal(ref, want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# VQ_DXGI_UTILS::MipImage (DXGIUtils.cpp:250-318), the reference's C++ compiled as is
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(32, 64), (128, 16), (256, 256), (8, 8), (2, 2)])
+def test_mip_chains_equal_the_reference_mipimage(shape):
+    """The HDR equirect chain (16-byte branch: MIN filter, alpha := 1) and the material-texture chain (4-byte branch: per-channel
+    integer box filter, truncating) — bit for bit, for every level the reference function can produce (both dimensions >= 2)."""
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    l0 = (rng.random((h, w, 4), dtype=np.float32) * 20).astype(np.float32)
+    l0[0, 0, :3] = (np.inf, 0.0, -3.0)
+    chain, n = O.mip_chain(l0)
+    off = w * h
+    for lv in R.mip_chain(l0):
+        px = lv.shape[0] * lv.shape[1]
+        assert np.array_equal(chain[off: off + px].view(np.uint32), lv.reshape(-1, 4).view(np.uint32))
+        off += px
+    t0 = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    c8, n8 = O.mip_chain_rgba8(t0)
+    off = w * h
+    for lv in R.mip_chain(t0):
+        px = lv.shape[0] * lv.shape[1]
+        assert np.array_equal(c8[off: off + px], lv.reshape(-1, 4))
+        off += px
