@@ -30,13 +30,13 @@ VALU_PEAK_TFLOPS = 157.3        # :40
 SHADE_BYTES_PER_PX = 64 + 8     # 4 float4 G-buffer planes in + RGBA16F out
 SHADE_FLOPS_PER_PX = 170 * N_LIGHTS + 160
 # HBM bytes per launch of the shade kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
-# FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950): profiles/r1b_pmc_hbm.md. Not measurable from inside
+# FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950): profiles/r1l_pmc_hbm.md (calibration: r1b_pmc_hbm.md). Not measurable from inside
 # bench.py; the committed figure is for exactly this workload (3840x2160, 64 lights + IBL, RGBA16F out).
 SHADE_PMC_TRAFFIC_BYTES = (2 * 598175 + 64800) * 1024   # re-measured on the round's final kernel: profiles/r1l_pmc_hbm.md
 # VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_shade.sh, committed
 # summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
 SPINUP_STEPS = 200              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
-SHADE_PMC_VALU_PER_WAVE = 6480
+SHADE_PMC_VALU_PER_WAVE = 5142
 SHADE_TRANS_PER_WAVE = 273      # quarter-rate v_rcp_f32 / v_rsq_f32 per wave: 5 per executed light (81.7 % of 64) + ~12 in set-up / IBL
 VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip;
                                 # the single-shot figure of round 1a-1e, 52.7, was taken on cold clocks)
@@ -260,7 +260,7 @@ def main():
                        "post": "blur X, then blur Y + tonemap in one kernel (identical bits to three dispatches)" if args.post == "fused" else "blur X, blur Y, tonemap"},
             "roofline": {"bound": "hbm", "kernel": "k_forward_lighting<env,nocasters,RGBA16F>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": SHADE_PMC_TRAFFIC_BYTES, "traffic_unit": "bytes/launch",
-                         "traffic_source": "profiles/r1b_pmc_hbm.md (rocprofv3 PMC, 2*FETCH_SIZE + WRITE_SIZE); algorithmic = %d" % (SHADE_BYTES_PER_PX * px_tile),
+                         "traffic_source": "profiles/r1l_pmc_hbm.md (rocprofv3 PMC, separate passes, 2*FETCH_SIZE + WRITE_SIZE); algorithmic = %d" % (SHADE_BYTES_PER_PX * px_tile),
                          "bytes_per_px": SHADE_BYTES_PER_PX, "ms": round(t_shade * 1e3, 4),
                          "note": "64-light shading is VALU-bound by construction (SURVEY.md 8d): see valu"},
             "valu": {"achieved_tflops_model": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12, 2), "peak": VALU_PEAK_TFLOPS,

@@ -79,12 +79,12 @@ inline float GeometryEnvironmentMap(f3 N, f3 V, f3 L, float k) {
 }
 // Fresnel_Schlick, BRDF.hlsl:132-136 — called as Fresnel_Schlick(H, V, F0) (:183): "N" is H, V is the caller's V
 inline f3 Fresnel_Schlick(f3 N, f3 V, f3 F0) {
-    const float p = pow_(1.0f - max_(0.0f, dot(N, V)), 5.0f);
+    const float p = pow5_(1.0f - max_(0.0f, dot(N, V)));
     return { fma_(1.0f - F0.x, p, F0.x), fma_(1.0f - F0.y, p, F0.y), fma_(1.0f - F0.z, p, F0.z) };      // F0 + (1-F0)*p, mad
 }
 // FresnelWithRoughness, BRDF.hlsl:152-156
 inline f3 FresnelWithRoughness(float cosTheta, f3 F0, float roughness) {
-    const float p = pow_(1.0f - cosTheta, 5.0f);
+    const float p = pow5_(1.0f - cosTheta);
     const float omr = 1.0f - roughness;
     return { fma_(max_(omr, F0.x) - F0.x, p, F0.x), fma_(max_(omr, F0.y) - F0.y, p, F0.y), fma_(max_(omr, F0.z) - F0.z, p, F0.z) };
 }
@@ -190,7 +190,7 @@ inline f2 IntegrateBRDF(float NdotV, float roughness, int count) {
         if (NdotL > 0.0f) {
             const float G = GeometryEnvironmentMap(N, V, L, roughness);
             const float G_Vis = max_(div_(G * VdotH, NdotH * NdotV), 0.0001f);
-            const float Fc = pow_(1.0f - VdotH, 5.0f);
+            const float Fc = pow5_(1.0f - VdotH);
             F0Scale += (1.0f - Fc) * G_Vis;
             F0Bias += Fc * G_Vis;
         }

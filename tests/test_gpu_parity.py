@@ -304,11 +304,10 @@ def test_forward_full_size_properties(ctx):
     base = ctx.forward_lighting(gb_full, synth.per_frame()[0], pv, out_fmt=abi.FMT_RGBA32F)
     s = (a[..., :3].double() + b[..., :3].double() - base[..., :3].double())
     rel = ((s - out32[..., :3].double()).abs() / out32[..., :3].double().abs().clamp_min(1e-6))
-    # The HLSL itself yields NaN where dot(H,V) rounds above 1 (pow(negative, 5) == exp2(5*log2(x)), BRDF.hlsl:135):
-    # a handful of pixels per 531 M light-pixel pairs. They must be NaN in BOTH (crop check above) and stay rare.
-    finite = torch.isfinite(out32).all(dim=-1)
-    assert (~finite).sum().item() < 1e-4 * W * H, (~finite).sum().item()   # ~2e-5 observed on this scene
-    assert rel[finite].max().item() < 2e-5, rel[finite].max().item()
+    # pow(1 - dot(H,V), 5.0) is the compiler's mul-only pattern (contract v4): a dot product that rounds a hair above 1 gives a tiny
+    # negative product, not the NaN exp2(5*log2(x)) produced under contracts v1-v3 (~2e-5 of the pixels of this scene)
+    assert torch.isfinite(out32).all()
+    assert rel.max().item() < 2e-5, rel.max().item()
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_brdf_lut(void* __restrict__ out, int si
             if (NdotL > 0.0f) {
                 const float G = G1_env(N, V, roughness) * G1_env(N, L, roughness);
                 const float G_Vis = max_(div_(G * VdotH, NdotH * NdotV), 0.0001f);
-                const float Fc = pow_(1.0f - VdotH, 5.0f);
+                const float Fc = pow5(1.0f - VdotH);
                 F0Scale += (1.0f - Fc) * G_Vis;
                 F0Bias += Fc * G_Vis;
             }

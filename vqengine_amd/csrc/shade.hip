@@ -41,25 +41,6 @@ struct Pixel {
 
 VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
 
-// pow_(x, 5.0f) == exp2_(5 * log2_(x)) for the Fresnel terms, where x = 1 - max(0, cos) is either 0, negative by a
-// rounding hair, or in [2^-24, 1]. On [2^-24, 1] none of log2_/exp2_'s special cases (zero, negative, denormal,
-// inf, NaN, overflow, underflow: 5*log2(x) >= -120) can fire, so the same arithmetic runs without their selects;
-// anything else (rare) goes through the general routine. Bit-identical to pow_(x, 5.0f) for every x.
-VQD float pow5(float x) {
-    if (__builtin_expect(!(x >= 5.9604644775390625e-8f && x <= 1.0f), 0)) return pow_(x, 5.0f);
-    const float t = 5.0f * log2_normal_bits(__float_as_uint(x), 0);      // in [-120, 0]
-    const float n = __builtin_rintf(t);                                   // v_rndne_f32
-    const float g = t - n;
-    float q = 1.535336188319500E-4f;
-    q = fma_(q, g, 1.339887440266574E-3f);
-    q = fma_(q, g, 9.618437357674640E-3f);
-    q = fma_(q, g, 5.550332471162809E-2f);
-    q = fma_(q, g, 2.402264791363012E-1f);
-    q = fma_(q, g, 6.931472028550421E-1f);
-    const float s = fma_(q, g, 1.0f);
-    return s * __uint_as_float((uint32_t)((int)n + 127) << 23);
-}
-
 VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.P = mk3(g0.x, g0.y, g0.z);
     px.Nraw = mk3(g1.x, g1.y, g1.z);
