@@ -97,6 +97,34 @@ def cpu_baseline(pre, lut, pf, pv, frame_h, target_s=12.0):
                       f"frame ({W * rows / 1e6:.1f} Mpix): shade 64 lights + IBL, blur X/Y, tonemap; {t:.1f} s"}
 
 
+def cpu_reference_source(pre, lut, pf, pv, frame_h, target_s=8.0):
+    """The REFERENCE'S OWN shader source (ForwardLighting.hlsl:PSMain, GaussianBlur.hlsl, Tonemapper.hlsl) run on one host core
+    through oracle/_ref (oracle/ref_src/hlsl_shim.h) on rows of the same frame, when that library travelled with the tree. A second
+    reported baseline next to `cpu_baseline`: scalar, single-threaded (the translated shaders keep their globals), literal IEEE."""
+    from tests import oracle_lib as O, ref_lib as R
+    if not R.available("shaders"):
+        return None
+    d_np, s_np, l_np = pre["diffuse_blurred"].cpu().numpy(), pre["specular"].cpu().numpy(), lut.cpu().numpy()
+    env = O.host_envmap(d_np, s_np, 128, pre["spec_mips"], l_np)
+    rows_per = 22                                           # one blur kernel height: the band is a (small) image of its own
+    t, rows, k = 0.0, 0, 0
+    while t < target_s and k < 64:
+        gb = synth.gbuffer_rows(W, frame_h, (k * 97) % (frame_h - rows_per), (k * 97) % (frame_h - rows_per) + rows_per, seed=0x6400)
+        n = gb[1][..., :3].astype(np.float64)
+        gb[1][..., :3] = (n / np.linalg.norm(n, axis=-1, keepdims=True)).astype(np.float32)
+        t0 = time.perf_counter()
+        sc = R.forward_from_gbuffer(gb, pf, pv, env=env).astype(np.float16).astype(np.float32)
+        x = R.blur_pass(sc, 0).astype(np.float16).astype(np.float32)
+        y = R.blur_pass(x, 1).astype(np.float16).astype(np.float32)
+        R.tonemap(y, abi.TonemapperParams.default())
+        t += time.perf_counter() - t0
+        rows += rows_per
+        k += 1
+    return {"value": round(W * rows / t / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "reference",
+            "sample": f"the reference's HLSL (PSMain 64 lights + IBL, CSMain_X/_Y, tonemapper CSMain) compiled to C++ through oracle/ref_src/hlsl_shim.h, "
+                      f"1 thread, {k} bands of {W}x{rows_per} rows of the same frame ({W * rows / 1e6:.2f} Mpix); {t:.1f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -280,6 +308,12 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pre, lut, pf, pv, frame_h)
+            try:                                             # optional second baseline: only where oracle/_ref exists
+                ref_line = cpu_reference_source(pre, lut, pf, pv, frame_h)
+                if ref_line is not None:
+                    out["cpu_reference_source"] = ref_line
+            except Exception as e:                           # never let the optional leg break the bench line
+                out["cpu_reference_source"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
