@@ -20,9 +20,6 @@ namespace {
 constexpr float PI_      = 3.14159265359f;    // ShadingMath.hlsl:25
 constexpr float EPSILON_ = 0.000000000001f;   // BRDF.hlsl:21
 
-#ifndef VQ_ABLATE
-#define VQ_ABLATE 0                           // timing-only ablations (scripts/bench_variants.sh); 0 = the product
-#endif
 #ifndef VQ_SHADE_WAVES
 #define VQ_SHADE_WAVES 1
 #endif
@@ -79,11 +76,7 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const float dNL = dot(px.Nn, Wi);
     const float NdotL = saturate(dNL);
     // Fresnel_Schlick(H, V, F0) :132-136
-#if VQ_ABLATE == 1
-    const float p5 = 0.25f + 1e-9f * dot(H, px.V);           // ablation: no pow
-#else
-    const float p5 = pow5(1.0f - max_(0.0f, dot(H, px.V)));
-#endif
+    const float p5 = pow5(1.0f - max_(0.0f, dot(H, px.V)));      // x*((x*x)*(x*x)): the compiler's mul-only pattern (contract v4)
     const f3 F = mk3(fma_(px.omF0.x, p5, px.F0.x), fma_(px.omF0.y, p5, px.F0.y), fma_(px.omF0.z, p5, px.F0.z));
     // D*G/denom with the three divisions merged into one (contract v3):
     //   D = a2/(PI t^2) (NormalDistributionGGX :65-79; 1 when PI t^2 < EPSILON), G = G1V * NL/(NL(1-k)+k+1e-4) (Geometry_Smith :118-121)
@@ -166,11 +159,7 @@ VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
         ok = ok & (dot(Hs, Hs) >= 0x1p-100f);
         const float NdotL = saturate(dot(px.Nraw, Wi));
         const float w = (rD * rD) * NdotL;
-#if VQ_ABLATE == 3
-        const f3 b = mk3(Wi.x * px.k, Wi.y * px.a2, Wi.z * px.omk);   // ablation: no BRDF
-#else
         const f3 b = brdf_t(px, Wi, rc);
-#endif
         I = lit(I, b, cb, w);
     }
     if (__builtin_expect(!ok, 0)) { RcpIEEE ieee; I = point_light_t(px, lpos, l.range, cb, Iprev, ieee); }
