@@ -35,7 +35,7 @@ SHADE_FLOPS_PER_PX = 170 * N_LIGHTS + 160
 SHADE_PMC_TRAFFIC_BYTES = (2 * 598175 + 64800) * 1024   # re-measured on the round's final kernel: profiles/r1l_pmc_hbm.md
 # VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_shade.sh, committed
 # summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
-SPINUP_STEPS = 200              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
+SPINUP_STEPS = int(os.environ.get("VQ_BENCH_SPINUP", "200"))              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
 SHADE_PMC_VALU_PER_WAVE = 5142
 SHADE_TRANS_PER_WAVE = 273      # quarter-rate v_rcp_f32 / v_rsq_f32 per wave: 5 per executed light (81.7 % of 64) + ~12 in set-up / IBL
 VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip;
@@ -150,11 +150,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # VQ_BENCH_SHARE_GPU=1 (debug aid for single-GPU boxes): every rank uses the visible GPUs round-robin and the collectives run
+    # over gloo, so that the N > 1 control flow (tiles, halo exchange, double-buffered composite, drain) can be exercised on real
+    # kernels without N GPUs. Never set by the driver; the product configuration is one GPU per rank over RCCL.
+    share = os.environ.get("VQ_BENCH_SHARE_GPU") == "1"
+    device_ordinal = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(device_ordinal)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctx = capi.Context(local_rank)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_ordinal))
+    ctx = capi.Context(device_ordinal)
 
     frame_h = TILE_H * world
     tl = tiling.RowTiling(W, frame_h, world, rank)
@@ -270,6 +278,21 @@ def main():
     drain()
     barrier()
 
+    verify = None
+    if world > 1 and os.environ.get("VQ_BENCH_VERIFY") == "1":
+        # debug aid: rank 0 recomputes the WHOLE frame on its own GPU (no tiles, no halos) and compares it byte for byte with the
+        # composite of the last step — the row tiling + halo exchange + composite on real kernels (tests/test_gpu_bench_flow.py)
+        last = (args.steps + n_detail + (args.steps & 1) - 1) & 1
+        if rank == 0:
+            gb_full = upload_tile(frame_h, 0, frame_h)
+            sc = ctx.forward_lighting(gb_full, pf, pv, out_fmt=F16, extra_point=extra, env=env)
+            xb = ctx.gaussian_blur_x(sc, F16)
+            want = ctx.gaussian_blur_y_tonemap(xb, F16, R8)
+            torch.cuda.synchronize()
+            verify = {"mismatching_bytes": int((want != frame[last]).sum().item()), "frame": [W, frame_h]}
+            del gb_full, sc, xb, want
+        dist.barrier()
+
     if rank == 0:
         px_tile, px_frame = W * TILE_H, W * frame_h
         t_shade = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) * 1e-3
@@ -306,6 +329,8 @@ def main():
                            "blur_y_tonemap_ms": round(t_tm * 1e3, 4), "blur_y_tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1),
                            "post_algorithmic_GBps_split_equivalent": round(px_tile * 44 / (t_blur + t_tm) / 1e9, 1)})},
         }
+        if verify is not None:
+            out["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pre, lut, pf, pv, frame_h)
             try:                                             # optional second baseline: only where oracle/_ref exists
