@@ -21,14 +21,16 @@ VQD float APrxLoRsq(float a) { return __uint_as_float(0x5f347d74u - (__float_as_
 VQD float min3(float a, float b, float c) { return min_(a, min_(b, c)); }
 VQD float max3(float a, float b, float c) { return max_(a, max_(b, c)); }
 
-template <int FMT> VQD f3 texel_clamp(const void* __restrict__ p, int W, int H, int x, int y) {
-    x = min(max(x, 0), W - 1); y = min(max(y, 0), H - 1);
-    const uint32_t i = __umul24(y, W) + (uint32_t)x;
+template <int FMT> VQD f3 texel_at(const void* __restrict__ p, uint32_t i) {
     if (FMT == VQHIP_FMT_RGBA32F) { const float4 q = ((const float4*)p)[i]; return mk3(q.x, q.y, q.z); }
     if (FMT == VQHIP_FMT_RGBA16F) { const float4 q = load_rgba16f(p, i); return mk3(q.x, q.y, q.z); }
     const uint32_t q = ((const uint32_t*)p)[i];
     const float s = 0.0039215688593685627f;                     // rcp(255.0f)
     return mk3((float)(q & 255u) * s, (float)((q >> 8) & 255u) * s, (float)((q >> 16) & 255u) * s);
+}
+template <int FMT> VQD f3 texel_clamp(const void* __restrict__ p, int W, int H, int x, int y) {
+    x = min(max(x, 0), W - 1); y = min(max(y, 0), H - 1);
+    return texel_at<FMT>(p, __umul24(y, W) + (uint32_t)x);
 }
 template <int FMT> VQD void store_rgb1(void* __restrict__ p, uint32_t i, f3 c) {
     if (FMT == VQHIP_FMT_RGBA32F) ((float4*)p)[i] = make_float4(c.x, c.y, c.z, 1.0f);
@@ -80,12 +82,21 @@ __global__ __launch_bounds__(256) void k_fsr_easu(const void* __restrict__ in, i
     const float fpx = __builtin_floorf(ppx), fpy = __builtin_floorf(ppy);
     ppx = ppx - fpx; ppy = ppy - fpy;
     const int fx = f2i_trunc(fpx), fy = f2i_trunc(fpy);
-    const f3 b = texel_clamp<INFMT>(in, inW, inH, fx, fy - 1), c = texel_clamp<INFMT>(in, inW, inH, fx + 1, fy - 1);
-    const f3 e = texel_clamp<INFMT>(in, inW, inH, fx - 1, fy), f = texel_clamp<INFMT>(in, inW, inH, fx, fy),
-             g = texel_clamp<INFMT>(in, inW, inH, fx + 1, fy), h = texel_clamp<INFMT>(in, inW, inH, fx + 2, fy);
-    const f3 i = texel_clamp<INFMT>(in, inW, inH, fx - 1, fy + 1), j = texel_clamp<INFMT>(in, inW, inH, fx, fy + 1),
-             k = texel_clamp<INFMT>(in, inW, inH, fx + 1, fy + 1), l = texel_clamp<INFMT>(in, inW, inH, fx + 2, fy + 1);
-    const f3 n = texel_clamp<INFMT>(in, inW, inH, fx, fy + 2), o = texel_clamp<INFMT>(in, inW, inH, fx + 1, fy + 2);
+    f3 b, c, e, f, g, h, i, j, k, l, n, o;
+    if (fx >= 1 && fy >= 1 && fx + 2 < inW && fy + 2 < inH) {    // whole 4x4 footprint inside the image: one base index, no clamps
+        const uint32_t p0 = __umul24(fy, inW) + (uint32_t)fx, W1 = (uint32_t)inW;
+        b = texel_at<INFMT>(in, p0 - W1);     c = texel_at<INFMT>(in, p0 - W1 + 1);
+        e = texel_at<INFMT>(in, p0 - 1);      f = texel_at<INFMT>(in, p0);          g = texel_at<INFMT>(in, p0 + 1);      h = texel_at<INFMT>(in, p0 + 2);
+        i = texel_at<INFMT>(in, p0 + W1 - 1); j = texel_at<INFMT>(in, p0 + W1);     k = texel_at<INFMT>(in, p0 + W1 + 1); l = texel_at<INFMT>(in, p0 + W1 + 2);
+        n = texel_at<INFMT>(in, p0 + 2 * W1); o = texel_at<INFMT>(in, p0 + 2 * W1 + 1);
+    } else {
+        b = texel_clamp<INFMT>(in, inW, inH, fx, fy - 1); c = texel_clamp<INFMT>(in, inW, inH, fx + 1, fy - 1);
+        e = texel_clamp<INFMT>(in, inW, inH, fx - 1, fy); f = texel_clamp<INFMT>(in, inW, inH, fx, fy);
+        g = texel_clamp<INFMT>(in, inW, inH, fx + 1, fy); h = texel_clamp<INFMT>(in, inW, inH, fx + 2, fy);
+        i = texel_clamp<INFMT>(in, inW, inH, fx - 1, fy + 1); j = texel_clamp<INFMT>(in, inW, inH, fx, fy + 1);
+        k = texel_clamp<INFMT>(in, inW, inH, fx + 1, fy + 1); l = texel_clamp<INFMT>(in, inW, inH, fx + 2, fy + 1);
+        n = texel_clamp<INFMT>(in, inW, inH, fx, fy + 2); o = texel_clamp<INFMT>(in, inW, inH, fx + 1, fy + 2);
+    }
     #define VQ_LUMA(t) ((t).z * 0.5f + ((t).x * 0.5f + (t).y))
     const float bL = VQ_LUMA(b), cL = VQ_LUMA(c), eL = VQ_LUMA(e), fL = VQ_LUMA(f), gL = VQ_LUMA(g), hL = VQ_LUMA(h), iL = VQ_LUMA(i),
                 jL = VQ_LUMA(j), kL = VQ_LUMA(k), lL = VQ_LUMA(l), nL = VQ_LUMA(n), oL = VQ_LUMA(o);
