@@ -135,12 +135,12 @@ static inline float exp2_(float x) {
 }
 
 static inline float pow_(float x, float y) { return exp2_(y * log2_(x)); }
-// pow(x, n) with a LITERAL integral exponent is a product, not exp2(n*log2 x): DXC reproduces FXC's "mul-only pattern" for such
-// calls (lib/HLSL/HLOperationLower.cpp: CanUseFxcMulOnlyPatternForPow / TranslatePowUsingFxcMulOnlyPattern — a scalar pow may cost up
-// to 3 multiplies, which covers n = 2, 3, 4, 5, 6, 8) by square-and-multiply: x^5 = x * ((x*x) * (x*x)). The path's uses: pow(.,2) in
-// the GGX / Smith terms (written as products throughout this file) and pow(1 - cos, 5.0) in the three Fresnel terms (BRDF.hlsl:135,
-// :155, :274). Besides being what the reference's compiler emits, the product form has no NaN for a base that rounding pushed a hair
-// below zero (dot(H,V) = 1 + ulp), where exp2(5*log2(x)) would poison the pixel. (Contract v4; v1-v3 used exp2(5*log2 x) here.)
+// pow(1 - cos, 5.0) of the three Fresnel terms (BRDF.hlsl:135, :155, :274) is evaluated as the product x * ((x*x) * (x*x)): FXC's
+// "mul-only pattern" for a literal integral exponent (square-and-multiply, up to 3 multiplies for a scalar), which DXC reproduces only
+// in FXC-compatibility mode (lib/HLSL/HLOperationLower.cpp: TranslatePowImpl, isFXCCompatMode; otherwise only exponent 2 becomes a
+// multiply). The engine's own flags do NOT enable that mode, its binary evaluates exp2(5*log2 x) — contract v4 takes the product
+// deliberately: more accurate on [0,1], inside D3D's pow tolerance, 23 fewer instructions per light, and finite
+// where rounding pushes the base a hair below zero (dot(H,V) = 1 + ulp), where the log/exp form is NaN. v1-v3 used exp2(5*log2 x).
 static inline float pow5_(float x) { const float x2 = x * x; return x * (x2 * x2); }
 
 // sin/cos: Cody-Waite reduction by pi/4 octants (3-part constant), Cephes sinf/cosf kernels on

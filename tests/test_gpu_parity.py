@@ -304,8 +304,8 @@ def test_forward_full_size_properties(ctx):
     base = ctx.forward_lighting(gb_full, synth.per_frame()[0], pv, out_fmt=abi.FMT_RGBA32F)
     s = (a[..., :3].double() + b[..., :3].double() - base[..., :3].double())
     rel = ((s - out32[..., :3].double()).abs() / out32[..., :3].double().abs().clamp_min(1e-6))
-    # pow(1 - dot(H,V), 5.0) is the compiler's mul-only pattern (contract v4): a dot product that rounds a hair above 1 gives a tiny
-    # negative product, not the NaN exp2(5*log2(x)) produced under contracts v1-v3 (~2e-5 of the pixels of this scene)
+    # pow(1 - dot(H,V), 5.0) is the product x*((x*x)*(x*x)) (contract v4): a dot product that rounds a hair above 1 gives
+    # a tiny negative product, not the NaN that exp2(5*log2(x)) — contracts v1-v3, and the engine's own compile — produces (~2e-5 of the pixels)
     assert torch.isfinite(out32).all()
     assert rel.max().item() < 2e-5, rel.max().item()
 

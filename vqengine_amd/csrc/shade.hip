@@ -76,7 +76,7 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const float dNL = dot(px.Nn, Wi);
     const float NdotL = saturate(dNL);
     // Fresnel_Schlick(H, V, F0) :132-136
-    const float p5 = pow5(1.0f - max_(0.0f, dot(H, px.V)));      // x*((x*x)*(x*x)): the compiler's mul-only pattern (contract v4)
+    const float p5 = pow5(1.0f - max_(0.0f, dot(H, px.V)));      // x*((x*x)*(x*x)): FXC's mul-only pattern (contract v4)
     const f3 F = mk3(fma_(px.omF0.x, p5, px.F0.x), fma_(px.omF0.y, p5, px.F0.y), fma_(px.omF0.z, p5, px.F0.z));
     // D*G/denom with the three divisions merged into one (contract v3):
     //   D = a2/(PI t^2) (NormalDistributionGGX :65-79; 1 when PI t^2 < EPSILON), G = G1V * NL/(NL(1-k)+k+1e-4) (Geometry_Smith :118-121)

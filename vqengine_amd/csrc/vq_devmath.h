@@ -147,9 +147,9 @@ VQD float exp2_(float x) {
     return out;
 }
 VQD float pow_(float x, float y) { return exp2_(y * log2_(x)); }
-// pow(x, 5.0) with a literal exponent = DXC's (FXC's) mul-only pattern, square-and-multiply: x * ((x*x) * (x*x)) (contract v4, the
-// three Fresnel terms of BRDF.hlsl). Three full-rate multiplies instead of a log2 and an exp2 polynomial, and no NaN for a base that
-// rounding pushed a hair below zero.
+// pow(1 - cos, 5.0) of the three Fresnel terms as FXC's mul-only pattern, square-and-multiply: x * ((x*x) * (x*x)) (contract v4 — a
+// deliberate choice: the engine's DXC flags give exp2(5*log2 x)). Three full-rate multiplies instead of a log2 and an
+// exp2 polynomial, and no NaN for a base that rounding pushed a hair below zero.
 VQD float pow5(float x) { const float x2 = x * x; return x * (x2 * x2); }
 // pow_(x, y) for x in [0,1] known to be +0 or a positive NORMAL number and y > 0 with y*log2(x) >= -126 (e.g. UNORM8 data,
 // y = 2.2): the same operations as pow_ with the special-case selects that cannot trigger removed — identical bits.
