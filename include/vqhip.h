@@ -427,6 +427,16 @@ VQHIP_API int vqhip_skydome(vqhip_ctx* ctx, void* stream, const void* equirect_l
         const VQ_SkydomeParams* params, const vqhip_interpolants* coverage,
         void* color, int width, int height, int row_pitch_px, vqhip_format fmt);
 
+/* Light gizmo meshes — the other half of SURVEY.md §8(f).2 — are drawn by the reference with Unlit.hlsl (SceneRendering.cpp:1787-1819):
+ * VSMain transforms the mesh, PSMain (:58-61) returns the light's colour for every covered, depth-tested pixel. Rasterisation stays
+ * with the engine; what crosses the boundary is its result, in the same plane the skydome reads: a pixel whose ip2.w index is
+ * -(2+k) is covered by gizmo k (index -1 = sky, >= 0 = material). Those pixels receive colors[k] (all four channels, as PSMain
+ * returns float4(color)); every other pixel is left untouched. colors is a HOST array of numColors <= VQHIP_MAX_UNLIT_COLORS entries
+ * (FFrameConstantBufferUnlit::color of each FLightRenderData, SceneRendering.cpp:1799). */
+#define VQHIP_MAX_UNLIT_COLORS 64
+VQHIP_API int vqhip_unlit_composite(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* coverage,
+        const VQ_float4* colors, int numColors, void* color, int width, int height, int row_pitch_px, vqhip_format fmt);
+
 /* ---- HDRI ingest -------------------------------------------------------------------
  * Replaces Image::LoadFromFile -> stbi_loadf for Radiance .hdr files (call site TextureManager.cpp:566; the decoder
  * itself lives in stb_image inside the un-vendored Libs/VQUtils submodule — its published algorithm, stb_image.h

@@ -25,6 +25,9 @@ namespace reflections {
 namespace viz {
 #include "Visualization.hlsl"
 }
+namespace unlit {
+#include "Unlit.hlsl"
+}
 } // namespace hlsl
 
 using namespace hlsl;
@@ -95,6 +98,15 @@ int vqref_visualize(const float* in, int W, int H, const VQ_VizParams* p, float*
         for (int x = 0; x < W; ++x) { const uint3 z(0, 0, 0); viz::CSMain(z, z, uint3((uint)x, (uint)y, 0)); }
     std::memcpy(out, dst.data(), sizeof(float4) * dst.size());
     return 0;
+}
+
+// Unlit.hlsl: VSMain carries the cbuffer colour to PSMain, PSMain returns it. One invocation for cbuffer colour `rgba`.
+void vqref_unlit_color(const float* rgba, float* out4) {
+    unlit::color = float4(rgba[0], rgba[1], rgba[2], rgba[3]);
+    unlit::VSInput v;
+    const unlit::PSInput in = unlit::VSMain(v, 0);
+    const float4 c = unlit::PSMain(in);
+    out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = c.w;
 }
 
 // scene (RGBA32F values, in place) += reflections

@@ -19,6 +19,7 @@
 // Every function cites the reference file:line it follows (paths relative to the VQEngine tree).
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include <omp.h>
 
@@ -797,6 +798,21 @@ int vqo_skydome(const float* equirect0, int w0, int h0, const VQ_SkydomeParams* 
             const f2 uv = DirectionToEquirectUV(normalize(d));
             const f4 c = sample_2d_rgba32f_wrap(equirect0, w0, h0, uv.x, uv.y);
             store_px(color, (size_t)y * pitch + x, fmt, { c.x, c.y, c.z, 1.0f });
+        }
+    return 0;
+}
+
+// Unlit.hlsl:PSMain :58-61 (light gizmo meshes, SceneRendering.cpp:1787-1819) over the engine's coverage plane: ip2.w == -(2+k) -> colors[k]
+int vqo_unlit_composite(const float* coverage_ip2, int cov_pitch, const float* colors, int numColors, void* color, int W, int H, int pitch, int fmt) {
+    if (!coverage_ip2 || !color || (numColors > 0 && !colors)) return -1;
+    if (fmt != VQHIP_FMT_RGBA32F && fmt != VQHIP_FMT_RGBA16F) return -3;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int32_t idx; std::memcpy(&idx, coverage_ip2 + ((size_t)y * cov_pitch + x) * 4 + 3, 4);
+            if (idx > -2) continue;
+            const long k = -2L - (long)idx;
+            if (k >= numColors) continue;
+            store_px(color, (size_t)y * pitch + x, fmt, { colors[4 * k], colors[4 * k + 1], colors[4 * k + 2], colors[4 * k + 3] });
         }
     return 0;
 }

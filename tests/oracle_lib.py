@@ -316,3 +316,14 @@ def bits_equal(a, b):
         ne = a != b
     idx = np.argwhere(ne)
     return int(ne.sum()), idx[:5]
+
+
+def unlit_composite(coverage_ip2, colors, color, fmt):
+    """Writes colors[k] into pixels of `color` (numpy image of `fmt`, in place) whose coverage index is -(2+k)."""
+    lib = load()
+    lib.vqo_unlit_composite.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+    cov = np.ascontiguousarray(coverage_ip2, np.float32)
+    cols = np.ascontiguousarray(np.asarray(colors, np.float32).reshape(-1, 4))
+    h, w = color.shape[:2]
+    assert lib.vqo_unlit_composite(_p(cov), w, _p(cols), len(cols), _p(color), w, h, w, fmt) == 0
+    return color

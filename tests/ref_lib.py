@@ -47,6 +47,7 @@ def load(name="shaders"):
             lib.vqref_skydome.argtypes = [vp, i32, i32, vp, i32, i32, vp]
             lib.vqref_visualize.argtypes = [vp, i32, i32, vp, vp]
             lib.vqref_apply_reflections.argtypes = [vp, vp, i32, i32]
+            lib.vqref_unlit_color.argtypes = [vp, vp]
             lib.vqref_fsr_easu.argtypes = [vp, i32, i32, vp, vp, i32, i32]
             lib.vqref_fsr_rcas.argtypes = [vp, i32, i32, vp, vp]
         _libs[name] = lib

@@ -61,6 +61,7 @@ def load_library():
                                                C.POINTER(abi.SSAO), C.POINTER(abi.GBuffer)]),
         "vqhip_mip_chain_bytes_rgba8": (sz, [i32, i32, i32]),
         "vqhip_mip_chain_box_rgba8": (i32, [vp, vp, vp, i32, i32, i32]),
+        "vqhip_unlit_composite": (i32, [vp, vp, C.POINTER(abi.Interpolants), vp, i32, vp, i32, i32, i32, i32]),
         "vqhip_skydome": (i32, [vp, vp, vp, i32, i32, C.POINTER(abi.SkydomeParams), C.POINTER(abi.Interpolants), vp, i32, i32, i32, i32]),
         "vqhip_hdr_parse_header": (i32, [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]),
         "vqhip_hdr_decode_rgba32f": (i32, [vp, vp, C.c_char_p, sz, vp, i32, i32]),
@@ -86,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
-    "vqhip_skydome", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
+    "vqhip_skydome", "vqhip_unlit_composite", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
     "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections",
 ]
 
@@ -354,6 +355,18 @@ class Context:
             cov = abi.Interpolants(coverage_ip[0].data_ptr(), coverage_ip[1].data_ptr(), coverage_ip[2].data_ptr(), w, h, w)
         self._ck(self.lib.vqhip_skydome(self._h, self._stream(stream), _ptr(equirect_level0), equirect_level0.shape[1], equirect_level0.shape[0],
                                         C.byref(params), C.byref(cov) if cov is not None else None, _ptr(color), w, h, w, fmt))
+        return color
+
+    def unlit_composite(self, coverage_ip, colors, color, fmt, stream=None):
+        """Light gizmo meshes (Unlit.hlsl:PSMain, SceneRendering.cpp:1787-1819): pixels whose ip2.w index is -(2+k) get colors[k]
+        (sequence of 4-tuples); `color` is written in place."""
+        _check_img(color, fmt, "color")
+        h, w = color.shape[0], color.shape[1]
+        for i, t in enumerate(coverage_ip):
+            _check_img(t, FMT_RGBA32F, f"ip{i}")
+        cov = abi.Interpolants(coverage_ip[0].data_ptr(), coverage_ip[1].data_ptr(), coverage_ip[2].data_ptr(), w, h, w)
+        arr = (abi.float4 * max(len(colors), 1))(*[abi.float4(*[float(v) for v in c]) for c in colors])
+        self._ck(self.lib.vqhip_unlit_composite(self._h, self._stream(stream), C.byref(cov), C.cast(arr, C.c_void_p), len(colors), _ptr(color), w, h, w, fmt))
         return color
 
     def conv_diffuse(self, chain, w0, h0, n_mips, res=64, step=0.010, order=CONV_WAVE64, fmt=FMT_RGBA16F, stream=None):

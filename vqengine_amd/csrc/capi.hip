@@ -369,6 +369,24 @@ int vqhip_skydome(vqhip_ctx* ctx, void* stream, const void* equirect_level0, int
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "skydome launch");
 }
 
+int vqhip_unlit_composite(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* coverage, const VQ_float4* colors, int numColors,
+                          void* color, int width, int height, int row_pitch_px, vqhip_format fmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "unlit_composite: ctx is NULL");
+    if (!coverage || !coverage->ip2 || !color || width <= 0 || height <= 0 || row_pitch_px < width || numColors < 0 || (numColors > 0 && !colors))
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "unlit_composite: bad argument");
+    if (numColors > VQHIP_MAX_UNLIT_COLORS) return fail(ctx, VQHIP_ERR_INVALID_ARG, "unlit_composite: more than VQHIP_MAX_UNLIT_COLORS gizmos");
+    if (coverage->width != width || coverage->height != height || coverage->row_pitch_px < width)
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "unlit_composite: coverage planes do not match the colour target");
+    if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "unlit_composite: fmt must be RGBA32F or RGBA16F");
+    if (numColors == 0) return VQHIP_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    UnlitColors cols;
+    for (int i = 0; i < numColors; ++i) cols.c[i] = make_float4(colors[i].x, colors[i].y, colors[i].z, colors[i].w);
+    hipError_t e = launch_unlit_composite((hipStream_t)stream, (const float4*)coverage->ip2, coverage->row_pitch_px, cols, numColors,
+                                          color, width, height, row_pitch_px, fmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "unlit_composite launch");
+}
+
 // ---- HDRI ingest --------------------------------------------------------------------
 int vqhip_hdr_parse_header(const void* file, size_t bytes, int* width, int* height, size_t* data_offset) {
     if (!file || !width || !height) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "hdr_parse_header: NULL argument");

@@ -226,6 +226,25 @@ hipError_t launch_skydome(hipStream_t s, const float4* eq0, int w0, int h0, cons
     return hipGetLastError();
 }
 
+// Unlit.hlsl:PSMain :58-61 over the engine's coverage plane: pixels covered by light gizmo k (ip2.w == -(2+k)) get its colour
+template <int FMT>
+__global__ __launch_bounds__(256) void k_unlit_composite(const float4* __restrict__ cov, int covPitch, UnlitColors cols, int n,
+                                                         void* __restrict__ color, int W, int H, int pitch) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int idx = __float_as_int(cov[(size_t)y * covPitch + x].w);
+    if (idx > -2) return;
+    const long k = -2L - (long)idx;
+    if (k >= n) return;
+    store_px<FMT>(color, (size_t)y * pitch + x, cols.c[k]);
+}
+hipError_t launch_unlit_composite(hipStream_t s, const float4* cov, int covPitch, const UnlitColors& cols, int n, void* color, int W, int H, int pitch, int fmt) {
+    dim3 grid((W + 255) / 256, H);
+    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_unlit_composite<0>), grid, dim3(256), 0, s, cov, covPitch, cols, n, color, W, H, pitch);
+    else                          hipLaunchKernelGGL((k_unlit_composite<1>), grid, dim3(256), 0, s, cov, covPitch, cols, n, color, W, H, pitch);
+    return hipGetLastError();
+}
+
 hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt) {
     dim3 grid((size + 255) / 256, size);
     if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut<3>), grid, dim3(256), 0, s, out, size, samples);

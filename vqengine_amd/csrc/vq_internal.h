@@ -58,6 +58,9 @@ hipError_t launch_mip_box_rgba8(hipStream_t s, const void* src, void* dst, int s
 hipError_t launch_skydome(hipStream_t s, const float4* eq0, int w0, int h0, const VQ_SkydomeParams& sp, const float4* cov, int covPitch,
                           void* color, int W, int H, int pitch, int fmt);
 
+struct UnlitColors { float4 c[VQHIP_MAX_UNLIT_COLORS]; };
+hipError_t launch_unlit_composite(hipStream_t s, const float4* cov, int covPitch, const UnlitColors& cols, int n, void* color, int W, int H, int pitch, int fmt);
+
 // HDRI ingest (§8f.3, hdri.hip): host-side header parse / run expansion (0 or -1 with *err set), device conversion
 int hdr_parse_header(const uint8_t* f, size_t n, int* w, int* h, size_t* off, const char** err);
 int hdr_expand_rgbe(const uint8_t* f, size_t n, size_t off, int w, int h, uint8_t* rgbe, const char** err);

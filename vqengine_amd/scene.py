@@ -222,3 +222,44 @@ def skydome_params(camera_yaw, camera_pitch, hdri_yaw_offset, fov_y, viewport_wi
     sp_.tanHalfFovY = t
     sp_.tanHalfFovX = t * float(viewport_width) / float(viewport_height)
     return sp_
+
+
+# ---- which HDRI file an environment map is loaded from (Source/Engine/EnvironmentMap.cpp) ----------------------
+HDRI_DIMENSIONS = {8: (8192, 4096), 4: (4096, 2048), 2: (2048, 1024), 1: (1024, 512)}   # LookupResolutionX/Y, EnvironmentMap.cpp:163-164
+
+
+def determine_resolution_hdri(file_path, monitor_resolution_y):
+    """DetermineResolution_HDRI (EnvironmentMap.cpp:69-91): the `%resolution%` token of an environment-map path is replaced by
+    1k / 2k / 4k / 8k after the height of the monitor the swap chain is on (<720, <1080, <=1440, else 8k). A path without a token is
+    returned unchanged with the default "1k". Returns (resolution, path)."""
+    resolution = "1k"
+    i = file_path.find("%")
+    if i >= 0:
+        if monitor_resolution_y < 720:
+            resolution = "1k"
+        elif monitor_resolution_y < 1080:
+            resolution = "2k"
+        elif monitor_resolution_y <= 1440:
+            resolution = "4k"
+        else:
+            resolution = "8k"
+        j = file_path.rfind("%")
+        file_path = file_path[:i] + resolution + file_path[j + 1:]
+    return resolution, file_path
+
+
+def find_environment_map_to_downsize_from(files_in_folder, env_map_name, target_resolution):
+    """FindEnvironmentMapToDownsizeFrom (EnvironmentMap.cpp:92-136): when the file of the chosen resolution is missing, the first file of
+    the HDRI folder whose name contains the map's name and ends in a `_<n>k` resolution token is the source to downsize from ("" when
+    the next higher resolution would exceed 8k or nothing matches). The resize itself (`Image::CreateResizedImage`, stb_image_resize in
+    the un-vendored VQUtils submodule) and the write-back to disk are outside this build — DESIGN.md §7.3."""
+    assert len(target_resolution) >= 2
+    if (ord(target_resolution[0]) - ord("0")) * 2 > 8:
+        return ""
+    for path in files_in_folder:
+        name = path.replace("\\", "/").rsplit("/", 1)[-1].rsplit(".", 1)[0]
+        if env_map_name in name:
+            tok = name.split("_")[-1]
+            if len(tok) >= 2 and tok[-2].isalnum() and tok[0].isalnum() and tok[-1] == "k":
+                return path
+    return ""
