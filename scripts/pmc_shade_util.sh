@@ -1,0 +1,19 @@
+#!/bin/bash
+# Where the shade kernel's cycles go (run on the GPU box): SQ busy / wave / instruction-issue counters, one rocprofv3 pass per group.
+cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
+i=0
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY"; do
+  i=$((i+1)); rm -rf gpurun_out/pmc_util_$i
+  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmc_util_$i -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>gpurun_out/pmc_util_$i.err
+  echo "group $i rc=$? : $grp"
+done
+python - <<PY
+import csv, glob, statistics as st, collections
+vals = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/pmc_util_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "k_forward_lighting" in r["Kernel_Name"]:
+            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k in sorted(vals):
+    print(f"{k:24s} median {st.median(vals[k]):16.0f}  (n={len(vals[k])})")
+PY
