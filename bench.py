@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--composite", choices=["gather", "allgather"], default="gather",
                     help="final composite of the RGBA8 tiles: gather on rank 0 (the presenting GPU; 1/N of the traffic, rank 0 receives over its "
                          "N-1 direct xGMI links) or all-gather on every rank")
+    ap.add_argument("--fresnel-pow", choices=["product", "exp2_log2"], default="product",
+                    help="pow(1 - cos, 5) of the Fresnel terms: the product x*((x*x)*(x*x)) (default, contract v4) or exp2(5*log2 x), the engine's own "
+                         "DXC lowering (vqhip_set_fresnel_pow; DESIGN.md 3.2)")
     ap.add_argument("--overlap", action="store_true",
                     help="post chain of frame n on a second (high-priority) HIP stream overlapping the shading of frame n+1. Measured "
                          "+1 %% only (the 32 400-workgroup shade dispatch starves the second queue), so the default is ONE stream, "
@@ -164,6 +167,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_ordinal))
     ctx = capi.Context(device_ordinal)
 
+    ctx.set_fresnel_pow(args.fresnel_pow == "exp2_log2")
+    global SHADE_PMC_VALU_PER_WAVE
+    if args.fresnel_pow == "exp2_log2":
+        SHADE_PMC_VALU_PER_WAVE = 6480                # PMC count of that form (profiles/r1g_shade_valu.md, contract v3 row)
+    if args.fresnel_pow == "exp2_log2":
+        from tests import oracle_lib as _O
+        _O.load().vqo_set_fresnel_pow(1)          # keeps the cpu_baseline leg on the same arithmetic
     frame_h = TILE_H * world
     tl = tiling.RowTiling(W, frame_h, world, rank)
     pre, lut = build_ibl(ctx)
@@ -307,7 +317,7 @@ def main():
                                    "21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8" + ("" if world == 1 else f"; frame 3840x{frame_h} row-tiled, RCCL halo ({args.halo}) + composite ({args.composite}{' on rank 0' if args.composite == 'gather' else ''})"),
                        "width": W, "frame_height": frame_h, "lights": N_LIGHTS, "parallelism": f"rows{world}",
                        "streams": "2: post chain of frame n overlaps shading of frame n+1" if args.overlap else "1",
-                       "untimed_spinup_steps": SPINUP_STEPS,
+                       "untimed_spinup_steps": SPINUP_STEPS, "fresnel_pow": args.fresnel_pow,
                        "post": "blur X, then blur Y + tonemap in one kernel (identical bits to three dispatches)" if args.post == "fused" else "blur X, blur Y, tonemap"},
             "roofline": {"bound": "hbm", "kernel": "k_forward_lighting<env,nocasters,RGBA16F>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": SHADE_PMC_TRAFFIC_BYTES, "traffic_unit": "bytes/launch",

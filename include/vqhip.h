@@ -296,6 +296,15 @@ VQHIP_API int  vqhip_create(int device_ordinal, vqhip_ctx** out_ctx);
 VQHIP_API void vqhip_destroy(vqhip_ctx* ctx);
 VQHIP_API const char* vqhip_last_error(const vqhip_ctx* ctx);   /* ctx may be NULL: process-wide last error */
 VQHIP_API int  vqhip_abi_version(void);                          /* == VQHIP_ABI_VERSION */
+
+/* How pow(1 - cos, 5.0) of the three Fresnel terms (BRDF.hlsl:135, :155, :274) is evaluated by vqhip_forward_lighting and
+ * vqhip_brdf_lut issued through this context (contract v4):
+ *   VQHIP_FRESNEL_POW_PRODUCT   (default) x*((x*x)*(x*x)) — FXC's / DXC -Gec's mul-only pattern: 21 % fewer instructions in the
+ *                               light loop, finite where dot(H,V) rounds a hair above 1;
+ *   VQHIP_FRESNEL_POW_EXP2_LOG2 exp2(5*log2(x)) — what DXC emits with the engine's own flags (no -Gec): NaN for a negative base,
+ *                               values within ~3 binary32 ulps of the product elsewhere (the contract of rounds v1-v3). */
+typedef enum vqhip_fresnel_pow { VQHIP_FRESNEL_POW_PRODUCT = 0, VQHIP_FRESNEL_POW_EXP2_LOG2 = 1 } vqhip_fresnel_pow;
+VQHIP_API int  vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode);
 #define VQHIP_ABI_VERSION 1
 
 /* Replaces VQRenderer::RenderSceneColor's lit draw loop (SceneRendering.cpp:1619-1785, hot part :1730-1784)

@@ -31,6 +31,10 @@ using namespace vqo;
 
 namespace {
 
+// vqo_set_fresnel_pow: 0 = the product x*((x*x)*(x*x)) (contract v4, default), 1 = exp2(5*log2 x) (the engine's DXC flags; v1-v3)
+int g_pow5ExpLog = 0;
+inline float fresnel_pow5(float x) { return g_pow5ExpLog ? pow_(x, 5.0f) : pow5_(x); }
+
 const float PI_         = 3.14159265359f;   // Shaders/ShadingMath.hlsl:25
 const float TWO_PI_     = 6.28318530718f;   // :26
 const float PI_OVER_TWO = 1.5707963268f;    // :27
@@ -80,12 +84,12 @@ inline float GeometryEnvironmentMap(f3 N, f3 V, f3 L, float k) {
 }
 // Fresnel_Schlick, BRDF.hlsl:132-136 — called as Fresnel_Schlick(H, V, F0) (:183): "N" is H, V is the caller's V
 inline f3 Fresnel_Schlick(f3 N, f3 V, f3 F0) {
-    const float p = pow5_(1.0f - max_(0.0f, dot(N, V)));
+    const float p = fresnel_pow5(1.0f - max_(0.0f, dot(N, V)));
     return { fma_(1.0f - F0.x, p, F0.x), fma_(1.0f - F0.y, p, F0.y), fma_(1.0f - F0.z, p, F0.z) };      // F0 + (1-F0)*p, mad
 }
 // FresnelWithRoughness, BRDF.hlsl:152-156
 inline f3 FresnelWithRoughness(float cosTheta, f3 F0, float roughness) {
-    const float p = pow5_(1.0f - cosTheta);
+    const float p = fresnel_pow5(1.0f - cosTheta);
     const float omr = 1.0f - roughness;
     return { fma_(max_(omr, F0.x) - F0.x, p, F0.x), fma_(max_(omr, F0.y) - F0.y, p, F0.y), fma_(max_(omr, F0.z) - F0.z, p, F0.z) };
 }
@@ -191,7 +195,7 @@ inline f2 IntegrateBRDF(float NdotV, float roughness, int count) {
         if (NdotL > 0.0f) {
             const float G = GeometryEnvironmentMap(N, V, L, roughness);
             const float G_Vis = max_(div_(G * VdotH, NdotH * NdotV), 0.0001f);
-            const float Fc = pow5_(1.0f - VdotH);
+            const float Fc = fresnel_pow5(1.0f - VdotH);
             F0Scale += (1.0f - Fc) * G_Vis;
             F0Bias += Fc * G_Vis;
         }
@@ -801,6 +805,8 @@ int vqo_skydome(const float* equirect0, int w0, int h0, const VQ_SkydomeParams* 
         }
     return 0;
 }
+
+void vqo_set_fresnel_pow(int expLog) { g_pow5ExpLog = expLog ? 1 : 0; }
 
 // Unlit.hlsl:PSMain :58-61 (light gizmo meshes, SceneRendering.cpp:1787-1819) over the engine's coverage plane: ip2.w == -(2+k) -> colors[k]
 int vqo_unlit_composite(const float* coverage_ip2, int cov_pitch, const float* colors, int numColors, void* color, int W, int H, int pitch, int fmt) {

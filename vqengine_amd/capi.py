@@ -61,6 +61,7 @@ def load_library():
                                                C.POINTER(abi.SSAO), C.POINTER(abi.GBuffer)]),
         "vqhip_mip_chain_bytes_rgba8": (sz, [i32, i32, i32]),
         "vqhip_mip_chain_box_rgba8": (i32, [vp, vp, vp, i32, i32, i32]),
+        "vqhip_set_fresnel_pow": (i32, [vp, i32]),
         "vqhip_unlit_composite": (i32, [vp, vp, C.POINTER(abi.Interpolants), vp, i32, vp, i32, i32, i32, i32]),
         "vqhip_skydome": (i32, [vp, vp, vp, i32, i32, C.POINTER(abi.SkydomeParams), C.POINTER(abi.Interpolants), vp, i32, i32, i32, i32]),
         "vqhip_hdr_parse_header": (i32, [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]),
@@ -87,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
-    "vqhip_skydome", "vqhip_unlit_composite", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
+    "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
     "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections",
 ]
 
@@ -356,6 +357,10 @@ class Context:
         self._ck(self.lib.vqhip_skydome(self._h, self._stream(stream), _ptr(equirect_level0), equirect_level0.shape[1], equirect_level0.shape[0],
                                         C.byref(params), C.byref(cov) if cov is not None else None, _ptr(color), w, h, w, fmt))
         return color
+
+    def set_fresnel_pow(self, exp2_log2):
+        """False (default): pow(1 - cos, 5) as the product x*((x*x)*(x*x)); True: exp2(5*log2 x), the engine's own DXC lowering."""
+        self._ck(self.lib.vqhip_set_fresnel_pow(self._h, 1 if exp2_log2 else 0))
 
     def unlit_composite(self, coverage_ip, colors, color, fmt, stream=None):
         """Light gizmo meshes (Unlit.hlsl:PSMain, SceneRendering.cpp:1787-1819): pixels whose ip2.w index is -(2+k) get colors[k]

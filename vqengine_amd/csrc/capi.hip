@@ -24,6 +24,7 @@ struct vqhip_ctx {
     bool slotBusy[kSlots] = {};
     int nextSlot = 0;
     void* scratch = nullptr; size_t scratchBytes = 0;
+    int pow5ExpLog = 0;            // vqhip_set_fresnel_pow
     void* tonemapLut = nullptr;    // 128 KB: 65536-entry tonemap table (post.hip:k_tonemap_lut)
     std::string lastError;
 };
@@ -182,6 +183,7 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
     if (env) fc->env = *env;
     if (sm) fc->sm = *sm;
     fc->hasEnv = env ? 1 : 0;
+    fc->pow5ExpLog = ctx->pow5ExpLog;
     vqd::sincos_(-perFrame->fHDRIOffsetInRadians, &fc->hdriSin, &fc->hdriCos);      // GetHDRIRotationMatrix, Lighting.hlsl:348-358
     // pack the non-shadowing point lights for the hot loop: cbuffer array first, then the extension array, in index order
     DevPointLight* pts = (DevPointLight*)(fc + 1);
@@ -258,12 +260,19 @@ int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int w
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "tonemap launch");
 }
 
+int vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "set_fresnel_pow: ctx is NULL");
+    if (mode != VQHIP_FRESNEL_POW_PRODUCT && mode != VQHIP_FRESNEL_POW_EXP2_LOG2) return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_fresnel_pow: unknown mode");
+    ctx->pow5ExpLog = mode == VQHIP_FRESNEL_POW_EXP2_LOG2 ? 1 : 0;
+    return VQHIP_OK;
+}
+
 int vqhip_brdf_lut(vqhip_ctx* ctx, void* stream, void* outRG, int size, int samples, vqhip_format fmt) {
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "brdf_lut: ctx is NULL");
     if (!outRG || size <= 0 || samples <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "brdf_lut: bad argument");
     if (fmt != VQHIP_FMT_RG16F && fmt != VQHIP_FMT_RG32F) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "brdf_lut: fmt must be RG16F or RG32F");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = launch_brdf_lut((hipStream_t)stream, outRG, size, samples, fmt);
+    hipError_t e = launch_brdf_lut((hipStream_t)stream, outRG, size, samples, fmt, ctx->pow5ExpLog);
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "brdf_lut launch");
 }
 

@@ -63,7 +63,7 @@ VQD f3 ImportanceSampleGGX(float Xiy, float sinPhi, float cosPhi, f3 N, float ro
 // Block = 256 texels of one row; the per-sample (sin phi, cos phi, Xi.y) table is shared through LDS
 // (every lane reads the same entry: LDS broadcast). 4 KB chunks of 512 samples bound the LDS use.
 template <int FMT>
-__global__ __launch_bounds__(256) void k_brdf_lut(void* __restrict__ out, int size, int samples) {
+__global__ __launch_bounds__(256) void k_brdf_lut(void* __restrict__ out, int size, int samples, int p5ExpLog) {
     __shared__ float sSin[512], sCos[512], sXy[512];
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     const float NdotV = div_((float)x + 0.5f, (float)size);     // CubemapConvolution.hlsl:233-236
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_brdf_lut(void* __restrict__ out, int si
             if (NdotL > 0.0f) {
                 const float G = G1_env(N, V, roughness) * G1_env(N, L, roughness);
                 const float G_Vis = max_(div_(G * VdotH, NdotH * NdotV), 0.0001f);
-                const float Fc = pow5(1.0f - VdotH);
+                const float Fc = p5ExpLog ? pow5_explog(1.0f - VdotH) : pow5(1.0f - VdotH);
                 F0Scale += (1.0f - Fc) * G_Vis;
                 F0Bias += Fc * G_Vis;
             }
@@ -245,10 +245,10 @@ hipError_t launch_unlit_composite(hipStream_t s, const float4* cov, int covPitch
     return hipGetLastError();
 }
 
-hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt) {
+hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt, int p5ExpLog) {
     dim3 grid((size + 255) / 256, size);
-    if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut<3>), grid, dim3(256), 0, s, out, size, samples);
-    else                        hipLaunchKernelGGL((k_brdf_lut<4>), grid, dim3(256), 0, s, out, size, samples);
+    if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut<3>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
+    else                        hipLaunchKernelGGL((k_brdf_lut<4>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
     return hipGetLastError();
 }
 

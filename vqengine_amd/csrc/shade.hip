@@ -33,6 +33,7 @@ struct Pixel {
     float k, omk;                         // k = (roughness+1)^2/8, omk = 1-k
     float a2, a2m1;                       // GGX alpha^2, alpha^2 - 1
     float a2G1V;                          // a2 * G1V: the light-independent part of the merged D*G numerator
+    bool p5ExpLog;                        // wave-uniform: Fresnel pow as exp2(5*log2 x) instead of the product (vqhip_set_fresnel_pow)
     bool fastOK;                          // roughness in [0,1]: precondition of the unchecked fast reciprocals (add_point_light)
 };
 
@@ -76,7 +77,8 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const float dNL = dot(px.Nn, Wi);
     const float NdotL = saturate(dNL);
     // Fresnel_Schlick(H, V, F0) :132-136
-    const float p5 = pow5(1.0f - max_(0.0f, dot(H, px.V)));      // x*((x*x)*(x*x)): FXC's mul-only pattern (contract v4)
+    const float x5 = 1.0f - max_(0.0f, dot(H, px.V));
+    const float p5 = px.p5ExpLog ? pow5_explog(x5) : pow5(x5);   // default: x*((x*x)*(x*x)), FXC's mul-only pattern (contract v4)
     const f3 F = mk3(fma_(px.omF0.x, p5, px.F0.x), fma_(px.omF0.y, p5, px.F0.y), fma_(px.omF0.z, p5, px.F0.z));
     // D*G/denom with the three divisions merged into one (contract v3):
     //   D = a2/(PI t^2) (NormalDistributionGGX :65-79; 1 when PI t^2 < EPSILON), G = G1V * NL/(NL(1-k)+k+1e-4) (Geometry_Smith :118-121)
@@ -220,7 +222,7 @@ VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
         spec = mk3(sp.x, sp.y, sp.z);
         sb = sample_2d_rg16f_clamp(fc->env.brdf_lut, fc->env.lut_size, fc->env.lut_size, NdotV, px.roughness);
     }
-    const float p5 = pow5(1.0f - NdotV);                                         // FresnelWithRoughness :152-156
+    const float p5 = px.p5ExpLog ? pow5_explog(1.0f - NdotV) : pow5(1.0f - NdotV);   // FresnelWithRoughness :152-156
     const float omr = 1.0f - px.roughness;
     const f3 Ks = mk3(fma_(max_(omr, px.F0.x) - px.F0.x, p5, px.F0.x), fma_(max_(omr, px.F0.y) - px.F0.y, p5, px.F0.y), fma_(max_(omr, px.F0.z) - px.F0.z, p5, px.F0.z));
     const f3 Kd = mk3((1.0f - Ks.x) * px.omm, (1.0f - Ks.y) * px.omm, (1.0f - Ks.z) * px.omm);
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     Pixel px;
     const f3 cam = ld3(fc->perView.CameraPosition);
     setup_pixel(px, g0, g1, g2, cam);
+    px.p5ExpLog = fc->pow5ExpLog != 0;
     const float ao = g0.w;
     // illumination accumulators, ForwardLighting.hlsl:290-293: diffuse*ao + emissive*intensity (mad)
     f3 I = mk3(fma_(g3.x, g3.w, px.albedo.x * ao), fma_(g3.y, g3.w, px.albedo.y * ao), fma_(g3.z, g3.w, px.albedo.z * ao));

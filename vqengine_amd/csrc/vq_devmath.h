@@ -151,6 +151,23 @@ VQD float pow_(float x, float y) { return exp2_(y * log2_(x)); }
 // deliberate choice: the engine's DXC flags give exp2(5*log2 x)). Three full-rate multiplies instead of a log2 and an
 // exp2 polynomial, and no NaN for a base that rounding pushed a hair below zero.
 VQD float pow5(float x) { const float x2 = x * x; return x * (x2 * x2); }
+// The engine-compile form (vqhip_set_fresnel_pow(EXP2_LOG2)): pow_(x, 5.0f) == exp2_(5 * log2_(x)), where x = 1 - max(0, cos) is either
+// 0, negative by a rounding hair, or in [2^-24, 1]. On [2^-24, 1] none of log2_/exp2_'s special cases can fire (5*log2(x) >= -120), so the
+// same arithmetic runs without their selects; anything else (rare) takes the general routine. Bit-identical to pow_(x, 5.0f) for every x.
+VQD float pow5_explog(float x) {
+    if (__builtin_expect(!(x >= 5.9604644775390625e-8f && x <= 1.0f), 0)) return pow_(x, 5.0f);
+    const float t = 5.0f * log2_normal_bits(__float_as_uint(x), 0);
+    const float n = __builtin_rintf(t);
+    const float g = t - n;
+    float q = 1.535336188319500E-4f;
+    q = fma_(q, g, 1.339887440266574E-3f);
+    q = fma_(q, g, 9.618437357674640E-3f);
+    q = fma_(q, g, 5.550332471162809E-2f);
+    q = fma_(q, g, 2.402264791363012E-1f);
+    q = fma_(q, g, 6.931472028550421E-1f);
+    const float s = fma_(q, g, 1.0f);
+    return s * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
 // pow_(x, y) for x in [0,1] known to be +0 or a positive NORMAL number and y > 0 with y*log2(x) >= -126 (e.g. UNORM8 data,
 // y = 2.2): the same operations as pow_ with the special-case selects that cannot trigger removed — identical bits.
 VQD float pow_unit(float x, float y) {

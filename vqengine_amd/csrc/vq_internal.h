@@ -17,6 +17,7 @@ struct alignas(16) FrameConstants {
     vqhip_shadowmaps       sm;             // device pointers
     int32_t                hasEnv;
     int32_t                numPointAll;    // numPointLights + numExtraPoint
+    int32_t                pow5ExpLog;     // vqhip_set_fresnel_pow: 0 = product (default), 1 = exp2(5*log2 x)
     float                  hdriSin, hdriCos;   // vqd::sincos_(-fHDRIOffsetInRadians): frame-uniform, evaluated once on the host by the
                                                // very same routine (IEEE ops only, so host and device agree bit for bit)
     // DevPointLight pts[numPointAll] follows
@@ -79,7 +80,7 @@ hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* h
 hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, void* lutScratch);
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
                                  const VQ_TonemapperParams& p, int fmt, int outFmt, void* lutScratch);
-hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt);
+hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt, int pow5ExpLog);
 hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw, int sh, int dw, int dh);
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
                                       const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt);
