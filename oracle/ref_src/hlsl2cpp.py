@@ -8,7 +8,8 @@ The rewrites are purely syntactic — no expression is reordered, no constant to
   1. `: register(x)` bindings and `: SEMANTIC` annotations are dropped; `cbuffer X { T v; }` becomes `T v;`
   2. `[numthreads(..)]`, `[unroll]`, `[loop]`, `[branch]`, `[flatten]` attributes are dropped
   3. unsuffixed floating literals get an `f` suffix (HLSL literals are float, C++ ones double)
-  4. `in` parameter qualifiers are dropped, `out` / `inout` parameters become references
+  4. `in` parameter qualifiers are dropped, `out` / `inout` parameters become references — also where a macro hides them
+     (ffx_a.h: `#define inAF2 in AF2`, `#define outAF2 out AF2`)
   5. `(Type)0` zero-initialisation casts become `Type{}`
   6. swizzles of scalars (`0.5f.xx`, `(1.0f - r).xxx`) become vector constructors
   7. per-file patches listed in PATCHES below (each one says why)
