@@ -36,7 +36,7 @@ SHADE_PMC_TRAFFIC_BYTES = (2 * 598175 + 64800) * 1024   # re-measured on the rou
 # VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_shade.sh, committed
 # summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
 SPINUP_STEPS = int(os.environ.get("VQ_BENCH_SPINUP", "200"))              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
-SHADE_PMC_VALU_PER_WAVE = 5142
+SHADE_PMC_VALU_PER_WAVE = 5149
 SHADE_TRANS_PER_WAVE = 273      # quarter-rate v_rcp_f32 / v_rsq_f32 per wave: 5 per executed light (81.7 % of 64) + ~12 in set-up / IBL
 VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip;
                                 # the single-shot figure of round 1a-1e, 52.7, was taken on cold clocks)
