@@ -26,6 +26,9 @@ ZERO_CAST_TYPES = r"PSOutput|PSInput|BRDF_Surface|ShadowTestPCFData|float[234]|f
 PATCHES = [
     ("ForwardLighting.hlsl", '#include "Tessellation.hlsl"', "", "hull/domain stages are not on the path (and are not C++-expressible)"),
     ("ForwardLighting.hlsl", "Surface.roughness.r)", "Surface.roughness)", "swizzle of a scalar member: `.r` of a float is the float"),
+    ("LightingConstantBufferData.h", "#define NUM_LIGHTS__POINT 100", "#ifndef NUM_LIGHTS__POINT\n#define NUM_LIGHTS__POINT 100\n#endif",
+     "the engine's light cap stays 100 in libvqref_shaders.so; BASELINE cfg5 (256 point lights) exceeds it, so a SECOND build "
+     "(libvqref_shaders_l256.so, -DNUM_LIGHTS__POINT=256) raises the cap the way the header's own comment describes — nothing else differs"),
 ]
 # (file, start marker, end marker): text from the first marker up to (not including) the second is dropped
 CUTS = [

@@ -141,10 +141,15 @@ int vqref_forward_psmain(const vqhip_interpolants* in, const vqhip_material* mat
 // PSMain driven from a G-buffer (the product's boundary for the lighting half): each pixel becomes a texture-less material
 // (textureConfig 0, null SRVs) whose constants are the G-buffer values, ao arrives as fAmbientLightingFactor with a white SSAO
 // texture, the normal as the interpolated WorldSpaceNormal. out = RGBA32F [H][W][4].
+//   extra / nExtra: point lights beyond the cbuffer's 100 (the product's extension array, include/vqhip.h). Only the build with the
+//   cap raised (-DNUM_LIGHTS__POINT=256, libvqref_shaders_l256.so) has room for them: they continue point_lights[] at index 100.
 int vqref_forward_from_gbuffer(const vqhip_gbuffer* gb, const VQ_PerFrameData* pf, const VQ_PerViewLightingData* pv,
-                               const vqhip_envmap* env, const vqhip_shadowmaps* sm, float* out) {
+                               const VQ_PointLight* extra, int nExtra, const vqhip_envmap* env, const vqhip_shadowmaps* sm, float* out) {
     if (!gb || !pf || !pv || !out) return -1;
+    if (nExtra < 0 || (nExtra > 0 && (!extra || pf->Lights.numPointLights != VQ_NUM_LIGHTS__POINT || VQ_NUM_LIGHTS__POINT + nExtra > NUM_LIGHTS__POINT))) return -2;
     fillFrame(*pf, *pv);
+    for (int i = 0; i < nExtra; ++i) cbPerFrame.Lights.point_lights[VQ_NUM_LIGHTS__POINT + i] = toPoint(extra[i]);
+    cbPerFrame.Lights.numPointLights += nExtra;
     bindScene(env, sm);
     texScreenSpaceAO.kind = kTexOne;
     Texture2D* mts[] = { &texDiffuse, &texNormals, &texEmissive, &texMetalness, &texRoughness, &texOcclRoughMetal, &texLocalAO };

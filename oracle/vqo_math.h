@@ -34,6 +34,14 @@
 //                            Cephes-style single-precision kernels, evaluated with explicit FMA Horner
 //                            steps; accuracy vs libm double is measured in tests/test_oracle_math.py).
 //   (int)x                   truncation toward zero; NaN -> 0; saturating.
+//
+// Contract v5 (round 2): the table above is the FAST-MATH lowering; it is now used only where the result is insensitive to it. Everything
+// ForwardLighting.hlsl:PSMain evaluates once per pixel, and inside the light loops the chain that feeds the GGX denominator and the range
+// cull (Lw - P, its length, Wi, H, dot(N,H), nh2*(a2-1)+1), is evaluated AS WRITTEN: products and sums rounded one by one, left to right,
+// a/b = the IEEE quotient (fdiv_), dot / length / normalize / lerp / reflect / mul(v,M) in their textbook expansion (the *_lit functions
+// below) — the evaluation the reference's own HLSL gets when it is run through oracle/ref_src/hlsl_shim.h. Reason: at roughness < 0.2 a
+// 1-ulp change of dot(N,H) moves a highlight pixel by tens of RGBA16F ulps (measured on the BASELINE-shape fixtures: up to 62), so only
+// the same rounding sequence keeps the product within 1 storage ulp of the reference source everywhere.
 #ifndef VQO_MATH_H
 #define VQO_MATH_H
 
@@ -53,6 +61,7 @@ static inline float    u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return
 static inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 static inline float rcp(float b) { return 1.0f / b; }
 static inline float div_(float a, float b) { return a * rcp(b); }
+static inline float fdiv_(float a, float b) { return a / b; }          // IEEE-754 correctly rounded quotient (load-time passes, see below)
 static inline float sqrt_(float x) { return __builtin_sqrtf(x); }
 static inline float rsqrt(float x) { return rcp(sqrt_(x)); }
 static inline float max_(float a, float b) { return __builtin_fmaxf(a, b); }
@@ -68,6 +77,15 @@ static inline f3 neg(f3 a) { return { -a.x, -a.y, -a.z }; }
 static inline float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 static inline float dot4(f4 a, f4 b) { return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x))); }
 static inline f3 normalize(f3 v) { return mul(v, rsqrt(dot(v, v))); }
+// The HLSL AS WRITTEN, for the ill-conditioned chain of the lighting functions (contract v5): dot = x*x' + y*y' + z*z'
+// left to right with every product and sum rounded on its own, normalize(v) = v / length(v) with one IEEE division per component.
+static inline float dot_lit(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float dot4_lit(f4 a, f4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+static inline f3 div_lit(f3 v, float l) { return { fdiv_(v.x, l), fdiv_(v.y, l), fdiv_(v.z, l) }; }
+static inline float length_lit(f3 v) { return sqrt_(dot_lit(v, v)); }
+static inline f3 normalize_lit(f3 v) { return div_lit(v, length_lit(v)); }
+static inline float lerp_lit(float a, float b, float t) { return a + t * (b - a); }
+static inline f3 reflect_lit(f3 i, f3 n) { const float t = 2.0f * dot_lit(n, i); return { i.x - t * n.x, i.y - t * n.y, i.z - t * n.z }; }
 static inline float length(f3 v) { return sqrt_(dot(v, v)); }
 static inline f3 cross(f3 a, f3 b) { return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x }; }
 static inline float lerp(float a, float b, float t) { return fma_(t, b - a, a); }

@@ -88,42 +88,50 @@ inline f3 Fresnel_Schlick(f3 N, f3 V, f3 F0) {
     return { fma_(1.0f - F0.x, p, F0.x), fma_(1.0f - F0.y, p, F0.y), fma_(1.0f - F0.z, p, F0.z) };      // F0 + (1-F0)*p, mad
 }
 // FresnelWithRoughness, BRDF.hlsl:152-156
-inline f3 FresnelWithRoughness(float cosTheta, f3 F0, float roughness) {
+inline f3 FresnelWithRoughness(float cosTheta, f3 F0, float roughness) {     // per pixel: as written (contract v5)
     const float p = fresnel_pow5(1.0f - cosTheta);
     const float omr = 1.0f - roughness;
-    return { fma_(max_(omr, F0.x) - F0.x, p, F0.x), fma_(max_(omr, F0.y) - F0.y, p, F0.y), fma_(max_(omr, F0.z) - F0.z, p, F0.z) };
+    return { F0.x + (max_(omr, F0.x) - F0.x) * p, F0.y + (max_(omr, F0.y) - F0.y) * p, F0.z + (max_(omr, F0.z) - F0.z) * p };
 }
 // F_LambertDiffuse, BRDF.hlsl:158-161
 inline f3 F_LambertDiffuse(f3 kd) { return { div_(kd.x, PI_), div_(kd.y, PI_), div_(kd.z, PI_) }; }
 
-// BRDF, BRDF.hlsl:163-194. Expression tree = the HLSL's value with the scalar factors of the two vector products
-// gathered (what an optimising D3D compiler emits; DXC runs without IEEE strictness, ShaderCompileUtils.cpp:56):
-//   specular = D*F*G/denom          ->  F * sG,  sG = (D*G) * rcp(denom)           (scalar)
-//   diffuse  = (1-F)*(1-metal)*albedo/PI -> (1-F) * kA,  kA = ((1-metal)*albedo) * rcp(PI)   (light independent)
-//   result   = Id + Is              ->  fma(F, sG, (1-F)*kA)
+// BRDF, BRDF.hlsl:163-194 (contract v5). Two kinds of expressions:
+//  (1) AS WRITTEN — everything that depends on the pixel only (Wo, N, NdotV, F0, k, G1(N,V), a2: the product hoists them out of the light
+//      loop) and, per light, the chain into the GGX denominator: H = normalize(Wo + Wi), NdotH = saturate(dot(N,H)), nh2*(a2-1)+1.
+//      At roughness < 0.2 that denominator cancels down to a2 ~ 1e-5..1e-3, so one ulp of NdotH is up to several per cent of D: only the
+//      reference's own rounding sequence keeps a highlight pixel within one RGBA16F ulp of the reference's output.
+//  (2) REGROUPED (contract v3/v4, what a fast-math D3D compile may emit; each insensitive to an ulp of its inputs):
+//      specular = D*F*G/denom          ->  F * sG,  sG = (D*G) * rcp(denom)           (scalar)
+//      diffuse  = (1-F)*(1-metal)*albedo/PI -> (1-F) * kA,  kA = ((1-metal)*albedo) * rcp(PI)   (light independent)
+//      result   = Id + Is              ->  fma(F, sG - kA, kA)
 inline f3 BRDF(const Surface& s, f3 Wi, f3 V) {
-    const f3 Wo = normalize(V);
-    const f3 N = normalize(s.N);
-    const f3 H = normalize(add(Wo, Wi));
-    const float NdotH = saturate(dot(N, H));
-    const float NdotV = saturate(dot(N, Wo));
-    const float NdotL = saturate(dot(N, Wi));
+    // (1) per pixel, as written
+    const f3 Wo = normalize_lit(V);                                          // :166
+    const f3 N = normalize_lit(s.N);                                         // :167
+    const float NdotV = saturate(dot_lit(N, Wo));                            // :171
     const f3 albedo = s.diffuseColor;
     const float roughness = s.roughness, metalness = s.metalness;
-    const f3 F0 = { lerp(0.04f, albedo.x, metalness), lerp(0.04f, albedo.y, metalness), lerp(0.04f, albedo.z, metalness) };
+    const f3 F0 = { lerp_lit(0.04f, albedo.x, metalness), lerp_lit(0.04f, albedo.y, metalness), lerp_lit(0.04f, albedo.z, metalness) };   // :178
+    const float rp1 = roughness + 1.0f;
+    const float k = fdiv_(rp1 * rp1, 8.0f);                                  // :91
+    const float NV = max_(0.0f, dot_lit(N, Wo));
+    const float G1V = fdiv_(NV, (NV * (1.0f - k) + k) + 0.0001f);            // Geometry_Smiths_SchlickGGX(N, Wo, roughness) :92-95
+    const float a = roughness * roughness, a2 = a * a;                       // :74-75
+    // (1) per light, as written: the half vector and the GGX denominator
+    const f3 H = normalize_lit(add(Wo, Wi));                                 // :168
+    const float NdotH = saturate(dot_lit(N, H));                             // :169
+    const float t = (NdotH * NdotH) * (a2 - 1.0f) + 1.0f;                    // :77  nh2 * (a2 - 1) + 1
+    const float dd = PI_ * (t * t);                                          //      PI * pow(., 2)
+    // (2) regrouped
+    const float NdotL = saturate(dot(N, Wi));
     const f3 F = Fresnel_Schlick(H, V, F0);
     // D*G/denom with its three divisions merged into one (contract v3; fast-math arcp + reassoc):
     //   D  = a2 / (PI t^2)                      NormalDistributionGGX :65-79 (returns 1 when PI t^2 < EPSILON)
     //   G  = G1(N,V) * NL / (NL(1-k) + k + 1e-4) Geometry_Smith :118-121, Geometry_Smiths_SchlickGGX :82-97
     //   sG = ((a2*G1V) * NL) * rcp((PI t^2 * gL) * denom)          [ (G1V*NL) * rcp(gL*denom) on the EPSILON branch ]
-    const float rp1 = roughness + 1.0f;
-    const float k = div_(rp1 * rp1, 8.0f);
-    const float G1V = Geometry_Smiths_SchlickGGX(N, Wo, roughness);          // per pixel: keeps its own division
     const float NL = max_(0.0f, dot(N, Wi));
     const float gL = fma_(NL, 1.0f - k, k) + 0.0001f;
-    const float a = roughness * roughness, a2 = a * a;
-    const float t = fma_(NdotH * NdotH, a2 - 1.0f, 1.0f);
-    const float dd = PI_ * (t * t);
     const float denom = max_((4.0f * NdotV) * NdotL, 0.0001f);
     const float sG = (dd < EPSILON_) ? (G1V * NL) * rcp(gL * denom) : ((a2 * G1V) * NL) * rcp((dd * gL) * denom);
     const float omm = 1.0f - metalness, invPI = rcp(PI_);
@@ -133,15 +141,16 @@ inline f3 BRDF(const Surface& s, f3 Wi, f3 V) {
 }
 // EnvironmentBRDF, BRDF.hlsl:196-207
 inline f3 EnvironmentBRDF(float NdotV, float roughness, float metallic, f3 diffuseColor, f3 diffuseIrradiance, f3 preFilteredSpecular, f2 F0ScaleBias) {
-    const f3 F0 = { lerp(0.04f, diffuseColor.x, metallic), lerp(0.04f, diffuseColor.y, metallic), lerp(0.04f, diffuseColor.z, metallic) };
+    // once per pixel: every expression as written (contract v5)
+    const f3 F0 = { lerp_lit(0.04f, diffuseColor.x, metallic), lerp_lit(0.04f, diffuseColor.y, metallic), lerp_lit(0.04f, diffuseColor.z, metallic) };
     const f3 Ks = FresnelWithRoughness(NdotV, F0, roughness);
     const float omm = 1.0f - metallic;
     const f3 Kd = { (1.0f - Ks.x) * omm, (1.0f - Ks.y) * omm, (1.0f - Ks.z) * omm };
     const f3 diffuse = mul(diffuseIrradiance, diffuseColor);
-    const f3 specular = { preFilteredSpecular.x * fma_(Ks.x, F0ScaleBias.x, F0ScaleBias.y),
-                          preFilteredSpecular.y * fma_(Ks.y, F0ScaleBias.x, F0ScaleBias.y),
-                          preFilteredSpecular.z * fma_(Ks.z, F0ScaleBias.x, F0ScaleBias.y) };
-    return { fma_(Kd.x, diffuse.x, specular.x), fma_(Kd.y, diffuse.y, specular.y), fma_(Kd.z, diffuse.z, specular.z) };   // Kd*diffuse + specular, mad
+    const f3 specular = { preFilteredSpecular.x * (Ks.x * F0ScaleBias.x + F0ScaleBias.y),
+                          preFilteredSpecular.y * (Ks.y * F0ScaleBias.x + F0ScaleBias.y),
+                          preFilteredSpecular.z * (Ks.z * F0ScaleBias.x + F0ScaleBias.y) };
+    return { Kd.x * diffuse.x + specular.x, Kd.y * diffuse.y + specular.y, Kd.z * diffuse.z + specular.z };
 }
 
 // ---- Shaders/ShadingMath.hlsl -----------------------------------------------------------------
@@ -168,7 +177,7 @@ inline f2 Hammersley(uint32_t i, uint32_t count) { return { div_((float)i, (floa
 inline f3 ImportanceSampleGGX(f2 Xi, f3 N, float roughness) {
     const float a = roughness * roughness;
     const float phi = (2.0f * PI_) * Xi.x;
-    const float cosTheta = sqrt_(div_(1.0f - Xi.y, 1.0f + (a * a - 1.0f) * Xi.y));
+    const float cosTheta = sqrt_(fdiv_(1.0f - Xi.y, 1.0f + (a * a - 1.0f) * Xi.y));
     const float sinTheta = sqrt_(1.0f - cosTheta * cosTheta);
     float sp, cp; sincos_(phi, &sp, &cp);
     f3 H = { cp * sinTheta, sp * sinTheta, cosTheta };
@@ -208,12 +217,12 @@ inline float AttenuationBRDF(float dist) { return rcp(dist * dist); }   // Light
 
 // SpotlightIntensity, Lighting.hlsl:57-73
 inline float SpotlightIntensity(const VQ_SpotLight& l, f3 worldPos) {
-    const f3 pixelDir = normalize(sub(worldPos, to3(l.position)));
-    const f3 spotDir = normalize(to3(l.spotDir));
-    const float theta = acos_(dot(pixelDir, spotDir));
+    const f3 pixelDir = normalize_lit(sub(worldPos, to3(l.position)));       // as written (contract v5): acos near 1 amplifies every ulp
+    const f3 spotDir = normalize_lit(to3(l.spotDir));
+    const float theta = acos_(dot_lit(pixelDir, spotDir));
     if (theta > l.outerConeAngle) return 0.0f;
     if (theta <= l.innerConeAngle) return 1.0f;
-    return 1.0f - div_(theta - l.innerConeAngle, l.outerConeAngle - l.innerConeAngle);
+    return 1.0f - fdiv_(theta - l.innerConeAngle, l.outerConeAngle - l.innerConeAngle);
 }
 
 struct ShadowTestPCFData { f4 lightSpacePos; float depthBias, NdotL, viewDistanceOfPixel; };   // Lighting.hlsl:79-87
@@ -228,21 +237,20 @@ inline float OmnidirectionalShadowTestPCF(const ShadowTestPCFData& d, const floa
         { f2_, 0, f2_ }, { -f2_, 0, f2_ }, { f2_, 0, -f2_ }, { -f2_, 0, -f2_ },
         { 0, f2_, f2_ }, { 0, -f2_, f2_ }, { 0, -f2_, -f2_ }, { 0, f2_, -f2_ } };
     float shadow = 0.0f;
-    const float diskRadius = (1.0f + div_(d.viewDistanceOfPixel, farPlane)) * div_(1.0f, 8.0f);
+    const float diskRadius = (1.0f + fdiv_(d.viewDistanceOfPixel, farPlane)) * fdiv_(1.0f, 8.0f);
     const float* cube = cubeArr + (size_t)index * 6 * dim * dim;
-    const float lenLw = length(Lw);
+    const float lenLw = length_lit(Lw);
     for (int i = 0; i < 20; ++i) {
         const f3 sv = { -(Lw.x + DIRS[i].x * diskRadius), -(Lw.y + DIRS[i].y * diskRadius), -(Lw.z + DIRS[i].z * diskRadius) };
         const float closest = fetch_cube_point(cube, dim, sv) * farPlane;
         shadow += (lenLw > (closest + d.depthBias) + 0.001f) ? 1.0f : 0.0f;
     }
-    shadow = div_(shadow, 20.0f);
+    shadow = fdiv_(shadow, 20.0f);
     return 1.0f - shadow;
 }
 // ShadowTestPCF, Lighting.hlsl:177-218
 inline float ShadowTestPCF(const ShadowTestPCFData& d, const float* arr, int dim, f2 smDims, int index) {
-    const float rw = rcp(d.lightSpacePos.w);
-    const f3 p = { d.lightSpacePos.x * rw, d.lightSpacePos.y * rw, d.lightSpacePos.z * rw };
+    const f3 p = { fdiv_(d.lightSpacePos.x, d.lightSpacePos.w), fdiv_(d.lightSpacePos.y, d.lightSpacePos.w), fdiv_(d.lightSpacePos.z, d.lightSpacePos.w) };
     if (p.x < -1.0f || p.x > 1.0f || p.y < -1.0f || p.y > 1.0f || p.z < 0.0f || p.z > 1.0f) return 0.0f;
     const float BIAS = d.depthBias * tan_(acos_(d.NdotL));
     float shadow = 0.0f;
@@ -254,13 +262,12 @@ inline float ShadowTestPCF(const ShadowTestPCFData& d, const float* arr, int dim
             const float closest = fetch_point_wrap(slice, dim, uv.x + (float)x * texel.x, uv.y + (float)y * texel.y);
             shadow += (p.z - BIAS > closest) ? 1.0f : 0.0f;
         }
-    shadow = div_(shadow, 25.0f);
+    shadow = fdiv_(shadow, 25.0f);
     return 1.0f - shadow;
 }
 // ShadowTestPCF_Directional, Lighting.hlsl:222-272 (uses the raw depthBias, :263)
 inline float ShadowTestPCF_Directional(const ShadowTestPCFData& d, const float* map, int dim, f2 smDims) {
-    const float rw = rcp(d.lightSpacePos.w);
-    const f3 p = { d.lightSpacePos.x * rw, d.lightSpacePos.y * rw, d.lightSpacePos.z * rw };
+    const f3 p = { fdiv_(d.lightSpacePos.x, d.lightSpacePos.w), fdiv_(d.lightSpacePos.y, d.lightSpacePos.w), fdiv_(d.lightSpacePos.z, d.lightSpacePos.w) };
     if (p.x < -1.0f || p.x > 1.0f || p.y < -1.0f || p.y > 1.0f || p.z < 0.0f || p.z > 1.0f) return 0.0f;
     float shadow = 0.0f;
     const f2 texel = { rcp(smDims.x), rcp(smDims.y) };
@@ -270,7 +277,7 @@ inline float ShadowTestPCF_Directional(const ShadowTestPCFData& d, const float* 
             const float closest = fetch_point_wrap(map, dim, uv.x + (float)x * texel.x, uv.y + (float)y * texel.y);
             shadow += (p.z - d.depthBias > closest) ? 1.0f : 0.0f;
         }
-    shadow = div_(shadow, 25.0f);
+    shadow = fdiv_(shadow, 25.0f);
     return 1.0f - shadow;
 }
 
@@ -286,19 +293,20 @@ inline f3 lit(f3 acc, f3 b, f3 cb, float w) { return { fma_(b.x, cb.x * w, acc.x
 inline f3 CalculatePointLightIllumination(const VQ_PointLight& l, const Surface& s, f3 P, f3 V, f3 acc = { 0, 0, 0 }) {
     const f3 Lw = to3(l.position);
     const f3 d = sub(Lw, P);
-    const float D = length(d);
-    const float rD = rcp(D);                                 // normalize(d) = d * rsqrt(dot(d,d)) = d * rcp(D): one reciprocal ...
-    const f3 Wi = mul(d, rD);
+    const float D = length_lit(d);                           // as written (contract v5): D decides the range cull, Wi feeds the GGX denominator
+    const f3 Wi = div_lit(d, D);                             // normalize(Lw - P) = (Lw - P) / length(Lw - P), one IEEE quotient per component
+    const float rD = rcp(D);
     const float NdotL = saturate(dot(s.N, Wi));
-    const float w = (rD * rD) * NdotL;                       // ... shared with AttenuationBRDF: 1/(D*D) as (1/D)*(1/D) (contract v3)
+    const float w = (rD * rD) * NdotL;                       // AttenuationBRDF: 1/(D*D) as (1/D)*(1/D) (contract v3, insensitive)
     if (D < l.range) return lit(acc, BRDF(s, Wi, V), light_cb(l.color, l.brightness), w);
     return acc;
 }
 // CalculateSpotLightIllumination, Lighting.hlsl:323-333 (no range cull)
 inline f3 CalculateSpotLightIllumination(const VQ_SpotLight& l, const Surface& s, f3 P, f3 V, f3 acc = { 0, 0, 0 }) {
     const f3 d = sub(to3(l.position), P);
-    const float rD = rcp(length(d));
-    const f3 Wi = mul(d, rD);
+    const float D = length_lit(d);
+    const f3 Wi = div_lit(d, D);
+    const float rD = rcp(D);
     const float cone = SpotlightIntensity(l, P);
     const float NdotL = saturate(dot(s.N, Wi));
     const float w = (cone * (rD * rD)) * NdotL;
@@ -306,21 +314,24 @@ inline f3 CalculateSpotLightIllumination(const VQ_SpotLight& l, const Surface& s
 }
 // CalculateDirectionalLightIllumination, Lighting.hlsl:334-345
 inline f3 CalculateDirectionalLightIllumination(const VQ_DirectionalLight& l, const Surface& s, f3 V) {
-    const f3 Wi = normalize(neg(to3(l.lightDirection)));
+    const f3 Wi = normalize_lit(neg(to3(l.lightDirection)));
     const float NdotL = saturate(dot(s.N, Wi));
     return lit({ 0, 0, 0 }, BRDF(s, Wi, V), light_cb(l.color, l.brightness), NdotL);
 }
 
 // GetHDRIRotationMatrix, Lighting.hlsl:348-358; mul(v, m) = row vector times matrix
 struct M3 { float m[3][3]; };
+// The matrix depends on the frame only (the shader's own TODO: "pass m with cbuffer"): cos / sin are taken CORRECTLY ROUNDED (double
+// libm rounded to float) — the product's host side does the same and hands the kernel the two numbers. The contract's polynomial cos_
+// is 1 ulp off at the bench's offset 0.3, which moved the 8-bit filter fraction of two taps next to a sun in the cfg3 band (3 RGBA16F ulps).
 inline M3 GetHDRIRotationMatrix(float offs) {
-    float s, c; sincos_(-offs, &s, &c);
+    const float c = (float)std::cos((double)-offs), s = (float)std::sin((double)-offs);
     return { { { c, 0, s }, { 0, 1, 0 }, { -s, 0, c } } };
 }
-inline f3 mul_v_m(f3 v, const M3& m) {
-    return { fma_(v.z, m.m[2][0], fma_(v.y, m.m[1][0], v.x * m.m[0][0])),
-             fma_(v.z, m.m[2][1], fma_(v.y, m.m[1][1], v.x * m.m[0][1])),
-             fma_(v.z, m.m[2][2], fma_(v.y, m.m[1][2], v.x * m.m[0][2])) };
+inline f3 mul_v_m(f3 v, const M3& m) {          // as written: products and sums rounded one by one, left to right (contract v5)
+    return { (v.x * m.m[0][0] + v.y * m.m[1][0]) + v.z * m.m[2][0],
+             (v.x * m.m[0][1] + v.y * m.m[1][1]) + v.z * m.m[2][1],
+             (v.x * m.m[0][2] + v.y * m.m[1][2]) + v.z * m.m[2][2] };
 }
 inline size_t cube_mip_offset_halfs(int res0, int mip) {   // packed [mip][6][r][r] RGBA16F
     size_t off = 0;
@@ -330,12 +341,12 @@ inline size_t cube_mip_offset_halfs(int res0, int mip) {   // packed [mip][6][r]
 // CalculateEnvironmentMapIllumination, Lighting.hlsl:360-380 ; _DiffuseOnly :382-395
 inline f3 CalculateEnvironmentMapIllumination(const Surface& s, f3 V, int MAX_REFLECTION_LOD, const vqhip_envmap& env, float hdriOffset, bool diffuseOnly) {
     const M3 m = GetHDRIRotationMatrix(hdriOffset);
-    const float NdotV = saturate(dot(s.N, V));
+    const float NdotV = saturate(dot_lit(s.N, V));
     const f3 N = mul_v_m(s.N, m);
     const f4 irr = sample_cube_rgba16f((const uint16_t*)env.diffuse_cube, env.diffuse_res, N);
     if (diffuseOnly)
         return EnvironmentBRDF(NdotV, s.roughness, s.metalness, s.diffuseColor, { irr.x, irr.y, irr.z }, { 0, 0, 0 }, { 0, 0 });
-    const f3 R = mul_v_m(reflect(neg(V), s.N), m);
+    const f3 R = mul_v_m(reflect_lit(neg(V), s.N), m);
     int MIP_LEVEL = f2i_trunc(s.roughness * (float)MAX_REFLECTION_LOD);
     if (MIP_LEVEL < 0) MIP_LEVEL = 0;
     if (MIP_LEVEL > env.spec_mips - 1) MIP_LEVEL = env.spec_mips - 1;           // sampler clamps the LOD
@@ -349,7 +360,7 @@ inline f4 mul_M_v(const VQ_matrix& M, f4 v) {   // HLSL mul(M, v) with column-ma
     f4 r;
     float* o = &r.x;
     for (int j = 0; j < 4; ++j)
-        o[j] = fma_(v.w, M.m[3][j], fma_(v.z, M.m[2][j], fma_(v.y, M.m[1][j], v.x * M.m[0][j])));
+        o[j] = ((v.x * M.m[0][j] + v.y * M.m[1][j]) + v.z * M.m[2][j]) + v.w * M.m[3][j];      // as written (contract v5)
     return r;
 }
 
@@ -363,10 +374,10 @@ inline f4 ShadePixel(f4 g0, f4 g1, f4 g2, f4 g3, const VQ_PerFrameData& F, const
     const float ao = g0.w;
     const f3 P = { g0.x, g0.y, g0.z };                                   // :284
     const f3 cam = to3(Vw.CameraPosition);
-    const f3 V = normalize(sub(cam, P));                                  // :285
-    f3 I = { fma_(S.emissiveColor.x, S.emissiveIntensity, S.diffuseColor.x * ao),     // :290-293, diffuse*ao + emissive*intensity (mad)
-             fma_(S.emissiveColor.y, S.emissiveIntensity, S.diffuseColor.y * ao),
-             fma_(S.emissiveColor.z, S.emissiveIntensity, S.diffuseColor.z * ao) };
+    const f3 V = normalize_lit(sub(cam, P));                              // :285
+    f3 I = { S.diffuseColor.x * ao + S.emissiveColor.x * S.emissiveIntensity,          // :290-293 as written
+             S.diffuseColor.y * ao + S.emissiveColor.y * S.emissiveIntensity,
+             S.diffuseColor.z * ao + S.emissiveColor.z * S.emissiveIntensity };
     if (env) {                                                            // :299-306 (NULL == NullCubemap: adds 0)
         const f3 e = CalculateEnvironmentMapIllumination(S, V, f2i_trunc(Vw.MaxEnvMapLODLevels), *env, F.fHDRIOffsetInRadians,
                                                          Vw.EnvironmentMapDiffuseOnlyIllumination != 0);
@@ -379,13 +390,13 @@ inline f4 ShadePixel(f4 g0, f4 g1, f4 g2, f4 g3, const VQ_PerFrameData& F, const
     for (int pc = 0; pc < L.numPointCasters; ++pc) {                      // :321-339
         const VQ_PointLight& l = L.point_casters[pc];
         const f3 Lw = sub(to3(l.position), P);
-        const float D = length(Lw);
+        const float D = length_lit(Lw);
         if (D < l.range) {
-            const f3 Ln = normalize(Lw);
+            const f3 Ln = normalize_lit(Lw);
             ShadowTestPCFData d{};
             d.depthBias = l.depthBias;
-            d.NdotL = saturate(dot(S.N, Ln));
-            d.viewDistanceOfPixel = length(sub(P, cam));
+            d.NdotL = saturate(dot_lit(S.N, Ln));
+            d.viewDistanceOfPixel = length_lit(sub(P, cam));
             const f3 c = CalculatePointLightIllumination(l, S, P, V);
             const float sh = OmnidirectionalShadowTestPCF(d, sm->point, sm->point_dim, pc, Lw, l.range);
             I = { fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z) };
@@ -393,12 +404,12 @@ inline f4 ShadePixel(f4 g0, f4 g1, f4 g2, f4 g3, const VQ_PerFrameData& F, const
     }
     for (int sc = 0; sc < L.numSpotCasters; ++sc) {                       // :342-356
         const VQ_SpotLight& l = L.spot_casters[sc];
-        const f3 Ln = normalize(sub(to3(l.position), P));
+        const f3 Ln = normalize_lit(sub(to3(l.position), P));
         ShadowTestPCFData d{};
         d.depthBias = l.depthBias;
-        d.NdotL = saturate(dot(S.N, Ln));
+        d.NdotL = saturate(dot_lit(S.N, Ln));
         d.lightSpacePos = mul_M_v(L.shadowViews[sc], { P.x, P.y, P.z, 1.0f });
-        d.viewDistanceOfPixel = length(sub(P, cam));
+        d.viewDistanceOfPixel = length_lit(sub(P, cam));
         const f3 c = CalculateSpotLightIllumination(l, S, P, V);
         const float sh = ShadowTestPCF(d, sm->spot, sm->spot_dim, { F.f2SpotLightShadowMapDimensions.x, F.f2SpotLightShadowMapDimensions.y }, sc);
         I = { fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z) };
@@ -409,9 +420,9 @@ inline f4 ShadePixel(f4 g0, f4 g1, f4 g2, f4 g3, const VQ_PerFrameData& F, const
             float ShadowingFactor = 1.0f;
             if (l.shadowing) {
                 ShadowTestPCFData d{};
-                const f3 Ln = normalize(neg(to3(l.lightDirection)));
+                const f3 Ln = normalize_lit(neg(to3(l.lightDirection)));
                 d.lightSpacePos = mul_M_v(L.shadowViewDirectional, { P.x, P.y, P.z, 1.0f });
-                d.NdotL = saturate(dot(S.N, Ln));
+                d.NdotL = saturate(dot_lit(S.N, Ln));
                 d.depthBias = l.depthBias;
                 ShadowingFactor = ShadowTestPCF_Directional(d, sm->directional, sm->dir_dim,
                                       { F.f2DirectionalLightShadowMapDimensions.x, F.f2DirectionalLightShadowMapDimensions.y });

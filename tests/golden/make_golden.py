@@ -84,8 +84,18 @@ def gbuffer_small():
     return {"gb0": gb[0], "gb1": gb[1], "gb2": gb[2], "gb3": gb[3], "mat0_first_chain_tail": first[0][first[1] * first[2]:]}
 
 
+def shade_small_exp2log2():
+    """shade_small with the Fresnel pow evaluated as exp2(5*log2 x), the engine's own DXC lowering (vqo_set_fresnel_pow(1))"""
+    lib = O.load()
+    lib.vqo_set_fresnel_pow(1)
+    try:
+        return shade_small()
+    finally:
+        lib.vqo_set_fresnel_pow(0)
+
+
 if __name__ == "__main__":
-    for fn in (ibl_small, shade_small, post_small, gbuffer_small):
+    for fn in (ibl_small, shade_small, shade_small_exp2log2, post_small, gbuffer_small):
         out = fn()
         path = os.path.join(HERE, fn.__name__ + ".npz")
         np.savez_compressed(path, **out)

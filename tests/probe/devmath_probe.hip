@@ -54,3 +54,35 @@ extern "C" __attribute__((visibility("default"))) long long vqprobe_exhaustive(i
     (void)hipFree(d); (void)hipFree(f);
     return (long long)h;
 }
+
+// fdiv_rcp(a, b, rcp(b)) vs the IEEE quotient a / b for EVERY pair of significands: a = 1.ma, b = 1.mb, ma, mb in [0, 2^23). Rounding of a
+// quotient depends on the significands only (scaling by powers of two is exact while nothing under/overflows), so the 2^46 pairs are a
+// proof for all normal-range operands. One thread per mb, looping over a slice of ma; `mb0`/`nb` select the divisors of one launch.
+__global__ void k_fdiv_exhaust(uint32_t mb0, uint32_t ma0, uint32_t na, unsigned long long* bad, uint32_t* first) {
+    const uint32_t mb = mb0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const float b = __uint_as_float(0x3f800000u | mb);
+    const float r = rcp_newton(b);
+    unsigned long long nbad = 0; uint32_t fa = 0;
+    for (uint32_t ma = ma0; ma < ma0 + na; ++ma) {
+        const float a = __uint_as_float(0x3f800000u | ma);
+        const float got = fdiv_rcp(a, b, r), ref = a / b;
+        if (__float_as_uint(got) != __float_as_uint(ref)) { if (!nbad) fa = ma; ++nbad; }
+    }
+    if (nbad) { if (atomicAdd(bad, nbad) == 0) { first[0] = fa; first[1] = mb; } }
+}
+// returns the number of mismatching pairs among ma in [ma0, ma0+na) x mb in [mb0, mb0+nb); first_bad = {ma, mb} of one of them
+extern "C" __attribute__((visibility("default"))) long long vqprobe_fdiv_exhaustive(uint32_t mb0, uint32_t nb, uint32_t ma0, uint32_t na, uint32_t* first_bad) {
+    unsigned long long* d; uint32_t* f;
+    if (hipMalloc(&d, 8) != hipSuccess || hipMalloc(&f, 8) != hipSuccess) return -1;
+    (void)hipMemset(d, 0, 8); (void)hipMemset(f, 0, 8);
+    for (uint32_t o = 0; o < nb; o += 1u << 17) {                      // launches of 2^17 divisors (~0.3 s each for all 2^23 numerators)
+        const uint32_t n = (nb - o) < (1u << 17) ? (nb - o) : (1u << 17);
+        hipLaunchKernelGGL(k_fdiv_exhaust, dim3(n / 256), dim3(256), 0, 0, mb0 + o, ma0, na, d, f);
+        if (hipDeviceSynchronize() != hipSuccess) return -2;
+    }
+    unsigned long long h = 0;
+    if (hipMemcpy(&h, d, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    (void)hipMemcpy(first_bad, f, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d); (void)hipFree(f);
+    return (long long)h;
+}

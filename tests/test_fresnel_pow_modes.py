@@ -1,5 +1,5 @@
 """vqhip_set_fresnel_pow: pow(1 - cos, 5.0) of the Fresnel terms as the product (default, contract v4) or as exp2(5*log2 x) — the engine's own
-DXC lowering and the contract of rounds v1-v3. Mode 1 must reproduce the golden fixture that was made BEFORE contract v4."""
+DXC lowering. Both modes have a self-made golden (tests/golden/make_golden.py); the HIP path is bit-exact in both."""
 import os
 
 import numpy as np
@@ -20,9 +20,9 @@ def exp2_log2_oracle():
     lib.vqo_set_fresnel_pow(0)
 
 
-def test_oracle_mode1_reproduces_the_pre_v4_golden(exp2_log2_oracle):
+def test_oracle_mode1_reproduces_its_golden(exp2_log2_oracle):
     got = make_golden.shade_small()
-    want = np.load(os.path.join(GOLD, "shade_small_v3.npz"))
+    want = np.load(os.path.join(GOLD, "shade_small_exp2log2.npz"))
     for k in ("noenv_rgba32f", "env_rgba16f"):
         n, where = O.bits_equal(got[k], want[k])
         assert n == 0, (k, n, where)
@@ -30,7 +30,7 @@ def test_oracle_mode1_reproduces_the_pre_v4_golden(exp2_log2_oracle):
 
 def test_the_two_forms_differ_by_ulps_and_by_the_nan_corner():
     now = np.load(os.path.join(GOLD, "shade_small.npz"))["noenv_rgba32f"]
-    v3 = np.load(os.path.join(GOLD, "shade_small_v3.npz"))["noenv_rgba32f"]
+    v3 = np.load(os.path.join(GOLD, "shade_small_exp2log2.npz"))["noenv_rgba32f"]
     both = np.isfinite(now) & np.isfinite(v3)
     rel = np.abs(now[both].astype(np.float64) - v3[both]) / np.maximum(np.abs(v3[both]), 1e-6)
     assert rel.max() < 2e-6 and (now != v3).any()            # a few binary32 ulps of a sum over 28 lights

@@ -103,3 +103,14 @@ def test_fast_paths_exhaustive(ctx, which, name):
     first = C.c_uint32(0)
     n = lib.vqprobe_exhaustive(which, C.byref(first))
     assert n == 0, f"{name}: {n} mismatching inputs, first 0x{first.value:08x}"
+
+
+def test_fdiv_rcp_exhaustive_significands(ctx):
+    """fdiv_rcp (q = a*r, one exact-residual correction with the correctly rounded reciprocal r) == IEEE a / b for ALL 2^23 x 2^23
+    significand pairs (7.0e13 quotients, ~20 s of GPU time): the quotients of normalize() in the light loop are the reference's."""
+    lib = C.CDLL(PROBE)
+    lib.vqprobe_fdiv_exhaustive.restype = C.c_longlong
+    lib.vqprobe_fdiv_exhaustive.argtypes = [C.c_uint32] * 4 + [C.POINTER(C.c_uint32)]
+    first = (C.c_uint32 * 2)()
+    n = lib.vqprobe_fdiv_exhaustive(0, 1 << 23, 0, 1 << 23, first)
+    assert n == 0, f"{n} mismatching significand pairs, e.g. a=1+{first[0]}*2^-23, b=1+{first[1]}*2^-23"

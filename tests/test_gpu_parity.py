@@ -83,6 +83,21 @@ def test_ibl_reference_sizes_cfg4(ctx):
     assert np.isfinite(f).all() and (f[:, :3] >= 0).all() and np.all(f[:, 3] == 1.0)
 
 
+def test_cfg4_env_matches_golden(ctx):
+    """The WHOLE of BASELINE config 4 (2048^2 equirect -> 6x64^2 diffuse irradiance at 99 382 taps per texel -> blur -> 128^2 x 7-mip
+    specular; 1024^2 x 2048-sample BRDF LUT) computed by the HIP product == tests/golden/cfg4_env.npz, the same thing computed by the CPU
+    oracle (tests/golden/make_cfg4_env.py), bit for bit in the reference's storage formats: every texel, not a sample of them."""
+    from tests import ref_cases
+    g = ref_cases.cfg4_env()
+    eq = synth.equirect(2048, 2048)
+    chain, n = ctx.mip_chain(dev(eq))
+    pre = ctx.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_WAVE64)
+    assert pre["spec_mips"] == g["spec_mips"] == 7
+    assert_bits(pre["diffuse_blurred"], g["diffuse"], "cfg4 diffuse irradiance (blurred) 6x64^2")
+    assert_bits(pre["specular"], g["specular"], "cfg4 specular 128^2 x 7 mips")
+    assert_bits(ctx.brdf_lut(1024, 2048, abi.FMT_RG16F), g["lut"], "cfg4 BRDF LUT 1024^2 x 2048")
+
+
 def test_envmap_prefilter(env_small):
     for k in ("diffuse_unblurred", "diffuse_blurred", "specular"):
         assert_bits(env_small["pre_g"][k], env_small["pre_o"][k], f"prefilter {k}")
@@ -308,6 +323,35 @@ def test_forward_full_size_properties(ctx):
     # a tiny negative product, not the NaN that exp2(5*log2(x)) — contracts v1-v3, and the engine's own compile — produces (~2e-5 of the pixels)
     assert torch.isfinite(out32).all()
     assert rel.max().item() < 2e-5, rel.max().item()
+
+
+def test_forward_cfg3_full_frame_with_ibl(ctx):
+    """The bench's own dispatch — 3840x2160, 64 point lights + the full-size cfg4 IBL, k_forward_lighting<env,nocasters,RGBA16F> — against
+    the oracle on five 40-row bands spread over the frame (768 000 pixels), bit for bit, plus the 256-light cfg5 shape on one band."""
+    from tests import ref_cases
+    W, H = 3840, 2160
+    g = ref_cases.cfg4_env()
+    keep = []
+    env_g = ref_cases.dev_env(g, keep)
+    env_o = ref_cases.host_env(g)
+    pf, _ = synth.per_frame(points=synth.point_lights(64, seed=0x6400), hdri_offset=0.3)
+    pv = synth.per_view(W, H, max_env_lod=g["spec_mips"])
+    gb_full = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
+    for r0 in range(0, H, 240):
+        part = synth.gbuffer_rows(W, H, r0, r0 + 240, seed=0x6400)
+        for k in range(4):
+            gb_full[k][r0:r0 + 240].copy_(torch.from_numpy(part[k]))
+    out = ctx.forward_lighting(gb_full, pf, pv, out_fmt=abi.FMT_RGBA16F, env=env_g)
+    for r0 in (0, 517, 1060, 1603, 2120):
+        gb = synth.gbuffer_rows(W, H, r0, r0 + 40, seed=0x6400)
+        assert_bits(out[r0:r0 + 40], O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F, env=env_o), f"cfg3 rows {r0}..{r0 + 40}")
+    del gb_full, out
+    W5, H5 = 7680, 4320
+    pf5, extra = synth.per_frame(points=synth.point_lights(256, seed=0x2560))
+    pv5 = synth.per_view(W5, H5)
+    gb = synth.gbuffer_rows(W5, H5, 3000, 3024, seed=0x2560)
+    got = ctx.forward_lighting([dev(x) for x in gb], pf5, pv5, out_fmt=abi.FMT_RGBA16F, extra_point=extra)
+    assert_bits(got, O.forward_lighting(gb, pf5, pv5, abi.FMT_RGBA16F, extra_point=extra), "cfg5 band, 256 lights")
 
 
 # ---------------------------------------------------------------------------------------------------

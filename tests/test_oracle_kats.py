@@ -74,7 +74,7 @@ def test_forward_lighting_structure():
     pv = synth.per_view(W, H)
     base = O.forward_lighting(gb, synth.per_frame()[0], pv, abi.FMT_RGBA32F)
     exp = gb[2][..., :3].astype(np.float64) * gb[0][..., 3:4] + gb[3][..., :3].astype(np.float64) * gb[3][..., 3:4]
-    assert np.allclose(base[..., :3], exp, rtol=2e-7, atol=0)            # fma(emissive, intensity, diffuse*ao): two roundings
+    assert np.allclose(base[..., :3], exp, rtol=2e-7, atol=0)            # diffuse*ao + emissive*intensity as written: three roundings
     pts = synth.point_lights(4, seed=6)
     for p in pts:
         p.range = 1e-3                                                    # D < range never true -> contributes nothing
@@ -84,7 +84,9 @@ def test_forward_lighting_structure():
     pf, extra = synth.per_frame(points=many)
     full = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F, extra_point=extra)
     acc = ref64.shade(gb, (0.0, 10.0, -60.0), light_dicts(many)[0])
-    assert np.abs(full - acc).max() / np.abs(acc).max() < 1e-4     # fp32 oracle vs float64 restatement
+    # fp32 oracle vs float64 restatement. A transcription slip shows up as a gross mismatch; the bound is what binary32 allows: at
+    # roughness ~0.05 the GGX denominator nh2*(a2-1)+1 cancels to ~1e-5, so one ulp of dot(N,H) is ~1 % of a highlight pixel
+    assert np.abs(full - acc).max() / np.abs(acc).max() < 2e-3
     # NullCubemap path: env=None adds exactly nothing (SceneRendering.cpp:1698-1709)
     pf0, _ = synth.per_frame(hdri_offset=1.0)
     assert np.array_equal(O.forward_lighting(gb, pf0, pv, abi.FMT_RGBA32F), base)

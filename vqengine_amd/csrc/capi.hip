@@ -184,7 +184,10 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
     if (sm) fc->sm = *sm;
     fc->hasEnv = env ? 1 : 0;
     fc->pow5ExpLog = ctx->pow5ExpLog;
-    vqd::sincos_(-perFrame->fHDRIOffsetInRadians, &fc->hdriSin, &fc->hdriCos);      // GetHDRIRotationMatrix, Lighting.hlsl:348-358
+    // GetHDRIRotationMatrix, Lighting.hlsl:348-358: a per-frame constant (the shader's own TODO: "pass m with cbuffer") — sin / cos are taken
+    // correctly rounded (double libm rounded to float), like the oracle; the contract's polynomial cos is 1 ulp off at e.g. 0.3 rad
+    fc->hdriSin = (float)std::sin((double)-perFrame->fHDRIOffsetInRadians);
+    fc->hdriCos = (float)std::cos((double)-perFrame->fHDRIOffsetInRadians);
     // pack the non-shadowing point lights for the hot loop: cbuffer array first, then the extension array, in index order
     DevPointLight* pts = (DevPointLight*)(fc + 1);
     const int nPts = L.numPointLights + numExtraPoint;

@@ -47,7 +47,7 @@ VQD float G1_env(f3 N, f3 V, float roughness) {                 // Geometry_Smit
 // ImportanceSampleGGX, BRDF.hlsl:217-238, with sin/cos(phi) supplied by the caller
 VQD f3 ImportanceSampleGGX(float Xiy, float sinPhi, float cosPhi, f3 N, float roughness) {
     const float a = roughness * roughness;
-    const float cosTheta = sqrt_(div_(1.0f - Xiy, 1.0f + (a * a - 1.0f) * Xiy));
+    const float cosTheta = sqrt_(fdiv_(1.0f - Xiy, 1.0f + (a * a - 1.0f) * Xiy));
     const float sinTheta = sqrt_(1.0f - cosTheta * cosTheta);
     const f3 H = mk3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
     const f3 up = abs_(N.z) < 0.999f ? mk3(0, 0, 1) : mk3(1, 0, 0);

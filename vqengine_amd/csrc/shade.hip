@@ -3,9 +3,11 @@
 // loads (16 B/lane, fully coalesced), light records read through the scalar cache (wave-uniform index),
 // every light-invariant term hoisted to per-pixel setup.
 //
-// Arithmetic follows the contract in DESIGN.md §3 (intrinsic lowering: vq_devmath.h; expression trees of the
-// lighting functions: "contract v2/v3" — scalar factors of vector products gathered, a*b+c written as one mad, the three
-// divisions of D*G/denom merged into one reciprocal, 1/(D*D) formed from the reciprocal that normalises Lw - P):
+// Arithmetic follows the contract in DESIGN.md §3 (intrinsic lowering: vq_devmath.h). Contract v5: everything evaluated once per
+// pixel, and per light the chain into the GGX denominator and the range cull (Lw - P, its length, Wi, H, dot(N,H), nh2*(a2-1)+1), is
+// the HLSL AS WRITTEN (products / sums rounded one by one, IEEE quotients: the *_lit functions) — one ulp there is tens of RGBA16F
+// ulps of a highlight pixel. The insensitive rest of the light loop keeps the regrouped trees of contract v2-v4 (scalar factors of
+// vector products gathered, a*b+c as one mad, the three divisions of D*G/denom merged into one reciprocal, 1/(D*D) = (1/D)^2):
 //   Shaders/BRDF.hlsl:65-79,82-97,118-121,132-136,152-161,163-207
 //   Shaders/Lighting.hlsl:29-32,57-73,110-174,177-272,308-395
 //   Shaders/ForwardLighting.hlsl:284-380
@@ -45,21 +47,22 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.roughness = g1.w;
     px.albedo = mk3(g2.x, g2.y, g2.z);
     px.metalness = g2.w;
-    px.V = normalize(sub(cam, px.P));                        // ForwardLighting.hlsl:285
-    px.Wo = normalize(px.V);                                 // BRDF.hlsl:166
-    px.Nn = normalize(px.Nraw);                              // :167
-    px.F0 = mk3(lerp(0.04f, px.albedo.x, px.metalness), lerp(0.04f, px.albedo.y, px.metalness), lerp(0.04f, px.albedo.z, px.metalness));   // :178
+    // once per pixel: as written (contract v5)
+    px.V = normalize_lit(sub(cam, px.P));                    // ForwardLighting.hlsl:285
+    px.Wo = normalize_lit(px.V);                             // BRDF.hlsl:166
+    px.Nn = normalize_lit(px.Nraw);                          // :167
+    px.F0 = mk3(lerp_lit(0.04f, px.albedo.x, px.metalness), lerp_lit(0.04f, px.albedo.y, px.metalness), lerp_lit(0.04f, px.albedo.z, px.metalness));   // :178
     px.omF0 = mk3(1.0f - px.F0.x, 1.0f - px.F0.y, 1.0f - px.F0.z);
     px.omm = 1.0f - px.metalness;
     const float invPI = rcp(PI_);
     px.kA = mk3((px.omm * px.albedo.x) * invPI, (px.omm * px.albedo.y) * invPI, (px.omm * px.albedo.z) * invPI);     // (1-metal)*albedo/PI
-    const float NdotV = saturate(dot(px.Nn, px.Wo));         // :171
+    const float NdotV = saturate(dot_lit(px.Nn, px.Wo));     // :171
     px.NdotV4 = 4.0f * NdotV;
     const float rp1 = px.roughness + 1.0f;                   // Geometry_Smiths_SchlickGGX :92-96
-    px.k = div_(rp1 * rp1, 8.0f);
+    px.k = (rp1 * rp1) * 0.125f;                             // / 8.0f: exact either way
     px.omk = 1.0f - px.k;
-    const float NV = max_(0.0f, dot(px.Nn, px.Wo));
-    px.G1V = div_(NV, fma_(NV, px.omk, px.k) + 0.0001f);
+    const float NV = max_(0.0f, dot_lit(px.Nn, px.Wo));
+    px.G1V = fdiv_(NV, (NV * px.omk + px.k) + 0.0001f);
     const float a = px.roughness * px.roughness;             // NormalDistributionGGX :74-75
     px.a2 = a * a;
     px.a2m1 = px.a2 - 1.0f;
@@ -67,13 +70,16 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.fastOK = (px.roughness >= 0.04f) & (px.roughness <= 1.0f);     // below 0.04 the GGX EPSILON early-out may fire: IEEE path
 }
 
-// BRDF(s, Wi, V), BRDF.hlsl:163-194 (contract v2 tree): fma(F, sG, (1-F)*kA) with sG = (D*G)*rcp(denom) and the
-// per-pixel kA = ((1-metal)*albedo)*rcp(PI). `rc` is the reciprocal / sqrt policy (vq_devmath.h).
+// BRDF(s, Wi, V), BRDF.hlsl:163-194. As written: H = normalize(Wo + Wi) (IEEE quotients through rc.div), NdotH, nh2*(a2-1)+1.
+// Regrouped (contract v2-v4): fma(F, sG - kA, kA) with sG = (D*G)*rcp(denom) and the per-pixel kA = ((1-metal)*albedo)*rcp(PI).
+// `rc` is the reciprocal / sqrt / quotient policy (vq_devmath.h).
 template <class R>
 VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const f3 Hs = add(px.Wo, Wi);
-    const f3 H = mul(Hs, rc(rc.sqrt(dot(Hs, Hs))));          // normalize(Wo + Wi)
-    const float NdotH = saturate(dot(px.Nn, H));
+    const float Hl = rc.sqrt(dot_lit(Hs, Hs));               // length(Wo + Wi)
+    const float rH = rc(Hl);
+    const f3 H = mk3(rc.div(Hs.x, Hl, rH), rc.div(Hs.y, Hl, rH), rc.div(Hs.z, Hl, rH));     // :168
+    const float NdotH = saturate(dot_lit(px.Nn, H));         // :169
     const float dNL = dot(px.Nn, Wi);
     const float NdotL = saturate(dNL);
     // Fresnel_Schlick(H, V, F0) :132-136
@@ -86,7 +92,7 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const float NL = max_(0.0f, dNL);
     const float gL = fma_(NL, px.omk, px.k) + 0.0001f;
     const float nh2 = NdotH * NdotH;
-    const float t = fma_(nh2, px.a2m1, 1.0f);
+    const float t = nh2 * px.a2m1 + 1.0f;                    // :77 as written: the product is rounded before the sum
     const float dd = PI_ * (t * t);
     const float den = max_(px.NdotV4 * NdotL, 0.0001f);
     float sG;
@@ -110,10 +116,10 @@ VQD f3 light_cb(const VQ_float3& color, float brightness) { return mk3(color.x *
 template <class R>
 VQD f3 point_light_t(const Pixel& px, f3 lpos, float range, f3 cb, f3 acc, R& rc) {
     const f3 d = sub(lpos, px.P);
-    const float D = rc.sqrt(dot(d, d));                      // length(Lw - P); normalize() shares the sqrt
+    const float D = rc.sqrt(dot_lit(d, d));                  // length(Lw - P) as written; normalize() shares the sqrt
     if (D < range) {
-        const float rD = rc(D);                              // one reciprocal for normalize(Lw - P) and for AttenuationBRDF :29-32,
-        const f3 Wi = mul(d, rD);
+        const float rD = rc(D);                              // one reciprocal for the quotients of normalize(Lw - P) and for AttenuationBRDF :29-32
+        const f3 Wi = mk3(rc.div(d.x, D, rD), rc.div(d.y, D, rD), rc.div(d.z, D, rD));
         const float NdotL = saturate(dot(px.Nraw, Wi));
         const float w = (rD * rD) * NdotL;                   // 1/(D*D) as (1/D)*(1/D) (contract v3)
         return lit(acc, brdf_t(px, Wi, rc), cb, w);
@@ -137,6 +143,9 @@ VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op va
 //              => the merged reciprocal's operand (pi t^2 * gL) * denom in [2.4e-16, 17.6]: operand and result normal
 //   light  : dd = |Lw-P|^2 in [2^-60, 2^60] =>  D in [2^-30, 2^30], 1/D normal (and (1/D)^2 is a plain product)
 //   light  : hh = |Wo+Wi|^2 >= 2^-100 (and not NaN; it is <= ~4 for unit Wo, Wi) => sqrt and 1/sqrt normal
+//   light  : every component of Lw-P and of Wo+Wi has magnitude >= 2^-78 (one v_min3 each) => the corrected quotients d/D, Hs/|Hs|
+//            (fdiv_rcp: exhaustively equal to IEEE division when nothing underflows) are the IEEE quotients; a zero or denormal
+//            component (a light exactly above the pixel on one axis) takes the IEEE path for that light
 // all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
 // degenerate geometry, roughness outside [0,1]) redoes that light with IEEE operations; results are identical bits.
 struct RcpTrust {
@@ -145,20 +154,23 @@ struct RcpTrust {
     static constexpr bool kGgxDenomAboveEps = true;
     VQD float operator()(float b) const { return rcp_newton(b); }
     VQD float sqrt(float x) const { return sqrt_newton(x); }
+    VQD float div(float a, float b, float r) const { return fdiv_rcp(a, b, r); }
 };
+VQD float min3abs(f3 v) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)); }   // one v_min3_f32 with |.| modifiers
 VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
     const f3 Iprev = I;
     const f3 lpos = mk3(l.px, l.py, l.pz), cb = mk3(l.cbx, l.cby, l.cbz);
     const f3 d = sub(lpos, px.P);
-    const float dd = dot(d, d);
-    bool ok = px.fastOK & (dd >= 0x1p-60f) & (dd <= 0x1p60f);
+    const float dd = dot_lit(d, d);                          // as written: D decides the range cull
+    bool ok = px.fastOK & (dd >= 0x1p-60f) & (dd <= 0x1p60f) & (min3abs(d) >= 0x1p-78f);
     if (dd < l.rangeSq) {                                    // == (length(Lw - P) < l.range), exactly (host-made threshold): culled lights
         RcpTrust rc;                                         // need no square root; wave-coherent (execz skip)
         const float D = sqrt_newton(dd);
         const float rD = rc(D);
-        const f3 Wi = mul(d, rD);
+        const f3 Wi = mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P)
         const f3 Hs = add(px.Wo, Wi);
-        ok = ok & (dot(Hs, Hs) >= 0x1p-100f);
+        const bool okH = (dot_lit(Hs, Hs) >= 0x1p-100f) & (min3abs(Hs) >= 0x1p-78f);
+        ok = ok & okH;
         const float NdotL = saturate(dot(px.Nraw, Wi));
         const float w = (rD * rD) * NdotL;
         const f3 b = brdf_t(px, Wi, rc);
@@ -170,16 +182,16 @@ VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
 // SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333 (no range cull)
 VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, f3 acc) {
     const f3 d = sub(ld3(l.position), px.P);
-    const float D = sqrt_(dot(d, d));
+    const float D = length_lit(d);
+    const f3 Wi = div_lit(d, D);                             // normalize(l.position - P) as written
     const float rD = rcp(D);
-    const f3 Wi = mul(d, rD);
-    const f3 pd = normalize(sub(px.P, ld3(l.position)));
-    const f3 sd = normalize(ld3(l.spotDir));
-    const float theta = acos_(dot(pd, sd));
+    const f3 pd = normalize_lit(sub(px.P, ld3(l.position))); // SpotlightIntensity as written: acos near 1 amplifies every ulp
+    const f3 sd = normalize_lit(ld3(l.spotDir));
+    const float theta = acos_(dot_lit(pd, sd));
     float cone;
     if (theta > l.outerConeAngle) cone = 0.0f;
     else if (theta <= l.innerConeAngle) cone = 1.0f;
-    else cone = 1.0f - div_(theta - l.innerConeAngle, l.outerConeAngle - l.innerConeAngle);
+    else cone = 1.0f - fdiv_(theta - l.innerConeAngle, l.outerConeAngle - l.innerConeAngle);
     const float NdotL = saturate(dot(px.Nraw, Wi));
     const float w = (cone * (rD * rD)) * NdotL;
     RcpIEEE rc;
@@ -188,27 +200,27 @@ VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, f3 acc) {
 
 // CalculateDirectionalLightIllumination :334-345
 VQD f3 directional_light(const Pixel& px, const VQ_DirectionalLight& l) {
-    const f3 Wi = normalize(neg(ld3(l.lightDirection)));
+    const f3 Wi = normalize_lit(neg(ld3(l.lightDirection)));
     const float NdotL = saturate(dot(px.Nraw, Wi));
     RcpIEEE rc;
     return lit(mk3(0.0f, 0.0f, 0.0f), brdf_t(px, Wi, rc), light_cb(l.color, l.brightness), NdotL);
 }
 
-VQD f3 mul_v_m3(f3 v, float c, float s) {     // mul(v, GetHDRIRotationMatrix) with m = {c,0,s; 0,1,0; -s,0,c}
-    return mk3(fma_(v.z, -s, fma_(v.y, 0.0f, v.x * c)),
-               fma_(v.z, 0.0f, fma_(v.y, 1.0f, v.x * 0.0f)),
-               fma_(v.z, c, fma_(v.y, 0.0f, v.x * s)));
+VQD f3 mul_v_m3(f3 v, float c, float s) {     // mul(v, GetHDRIRotationMatrix) with m = {c,0,s; 0,1,0; -s,0,c}, as written (zero terms kept)
+    return mk3((v.x * c + v.y * 0.0f) + v.z * -s,
+               (v.x * 0.0f + v.y * 1.0f) + v.z * 0.0f,
+               (v.x * s + v.y * 0.0f) + v.z * c);
 }
 
 // CalculateEnvironmentMapIllumination(+_DiffuseOnly), Lighting.hlsl:348-395 ; EnvironmentBRDF BRDF.hlsl:196-207
 VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
-    const float sn = fc->hdriSin, cs = fc->hdriCos;          // sincos_(-fHDRIOffsetInRadians), hoisted to the host (capi.hip)
-    const float NdotV = saturate(dot(px.Nraw, px.V));
+    const float sn = fc->hdriSin, cs = fc->hdriCos;          // sin / cos(-fHDRIOffsetInRadians), correctly rounded, from the host (capi.hip)
+    const float NdotV = saturate(dot_lit(px.Nraw, px.V));    // everything here runs once per pixel: as written (contract v5)
     const f3 N = mul_v_m3(px.Nraw, cs, sn);
     const float4 irr = sample_cube_rgba16f(fc->env.diffuse_cube, fc->env.diffuse_res, N);
     f3 spec = mk3(0, 0, 0); float2 sb = make_float2(0, 0);
     if (!fc->perView.EnvironmentMapDiffuseOnlyIllumination) {
-        const f3 R = mul_v_m3(reflect(neg(px.V), px.Nraw), cs, sn);
+        const f3 R = mul_v_m3(reflect_lit(neg(px.V), px.Nraw), cs, sn);
         const int maxLod = f2i_trunc(fc->perView.MaxEnvMapLODLevels);
         int mip = f2i_trunc(px.roughness * (float)maxLod);
         mip = min(max(mip, 0), fc->env.spec_mips - 1);
@@ -224,16 +236,16 @@ VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
     }
     const float p5 = px.p5ExpLog ? pow5_explog(1.0f - NdotV) : pow5(1.0f - NdotV);   // FresnelWithRoughness :152-156
     const float omr = 1.0f - px.roughness;
-    const f3 Ks = mk3(fma_(max_(omr, px.F0.x) - px.F0.x, p5, px.F0.x), fma_(max_(omr, px.F0.y) - px.F0.y, p5, px.F0.y), fma_(max_(omr, px.F0.z) - px.F0.z, p5, px.F0.z));
+    const f3 Ks = mk3(px.F0.x + (max_(omr, px.F0.x) - px.F0.x) * p5, px.F0.y + (max_(omr, px.F0.y) - px.F0.y) * p5, px.F0.z + (max_(omr, px.F0.z) - px.F0.z) * p5);
     const f3 Kd = mk3((1.0f - Ks.x) * px.omm, (1.0f - Ks.y) * px.omm, (1.0f - Ks.z) * px.omm);
     const f3 diffuse = mk3(irr.x * px.albedo.x, irr.y * px.albedo.y, irr.z * px.albedo.z);
-    const f3 specular = mk3(spec.x * fma_(Ks.x, sb.x, sb.y), spec.y * fma_(Ks.y, sb.x, sb.y), spec.z * fma_(Ks.z, sb.x, sb.y));
-    return mk3(fma_(Kd.x, diffuse.x, specular.x), fma_(Kd.y, diffuse.y, specular.y), fma_(Kd.z, diffuse.z, specular.z));
+    const f3 specular = mk3(spec.x * (Ks.x * sb.x + sb.y), spec.y * (Ks.y * sb.x + sb.y), spec.z * (Ks.z * sb.x + sb.y));
+    return mk3(Kd.x * diffuse.x + specular.x, Kd.y * diffuse.y + specular.y, Kd.z * diffuse.z + specular.z);
 }
 
 VQD float4 mul_M_v(const VQ_matrix& M, f3 P) {     // HLSL mul(M, float4(P,1)) == row vector * M_cpu
     float o[4];
-    for (int j = 0; j < 4; ++j) o[j] = fma_(1.0f, M.m[3][j], fma_(P.z, M.m[2][j], fma_(P.y, M.m[1][j], P.x * M.m[0][j])));
+    for (int j = 0; j < 4; ++j) o[j] = ((P.x * M.m[0][j] + P.y * M.m[1][j]) + P.z * M.m[2][j]) + 1.0f * M.m[3][j];   // as written
     return make_float4(o[0], o[1], o[2], o[3]);
 }
 
@@ -247,21 +259,20 @@ __device__ const float DZ[20] = {  PA,  PA,  PA,  PA, -PA, -PA, -PA, -PA,  0,  0
 #undef PB
 // OmnidirectionalShadowTestPCF, Lighting.hlsl:110-174
 VQD float omni_pcf(const float* cubeArr, int dim, int index, f3 Lw, float farPlane, float depthBias, float viewDist) {
-    const float diskRadius = (1.0f + div_(viewDist, farPlane)) * 0.125f;
+    const float diskRadius = (1.0f + fdiv_(viewDist, farPlane)) * 0.125f;
     const float* cube = cubeArr + (size_t)index * 6 * dim * dim;
-    const float lenLw = length(Lw);
+    const float lenLw = length_lit(Lw);
     float shadow = 0.0f;
     for (int i = 0; i < 20; ++i) {
         const f3 sv = mk3(-(Lw.x + DX[i] * diskRadius), -(Lw.y + DY[i] * diskRadius), -(Lw.z + DZ[i] * diskRadius));
         const float closest = fetch_cube_point(cube, dim, sv) * farPlane;
         shadow += (lenLw > (closest + depthBias) + 0.001f) ? 1.0f : 0.0f;
     }
-    return 1.0f - div_(shadow, 20.0f);
+    return 1.0f - fdiv_(shadow, 20.0f);
 }
 // ShadowTestPCF :177-218 (useTanBias) / ShadowTestPCF_Directional :222-272 (raw bias)
 VQD float pcf_2d(const float* slice, int dim, float2 smDims, float4 lsp, float bias) {
-    const float rw = rcp(lsp.w);
-    const f3 p = mk3(lsp.x * rw, lsp.y * rw, lsp.z * rw);
+    const f3 p = mk3(fdiv_(lsp.x, lsp.w), fdiv_(lsp.y, lsp.w), fdiv_(lsp.z, lsp.w));
     if (p.x < -1.0f || p.x > 1.0f || p.y < -1.0f || p.y > 1.0f || p.z < 0.0f || p.z > 1.0f) return 0.0f;
     const float tx = rcp(smDims.x), ty = rcp(smDims.y);
     const float u = 0.5f + p.x * 0.5f, v = 0.5f + p.y * -0.5f;
@@ -272,7 +283,7 @@ VQD float pcf_2d(const float* slice, int dim, float2 smDims, float4 lsp, float b
             const float closest = fetch_point_wrap(slice, dim, u + (float)x * tx, v + (float)y * ty);
             shadow += (ref > closest) ? 1.0f : 0.0f;
         }
-    return 1.0f - div_(shadow, 25.0f);
+    return 1.0f - fdiv_(shadow, 25.0f);
 }
 
 template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT>
@@ -289,8 +300,8 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     setup_pixel(px, g0, g1, g2, cam);
     px.p5ExpLog = fc->pow5ExpLog != 0;
     const float ao = g0.w;
-    // illumination accumulators, ForwardLighting.hlsl:290-293: diffuse*ao + emissive*intensity (mad)
-    f3 I = mk3(fma_(g3.x, g3.w, px.albedo.x * ao), fma_(g3.y, g3.w, px.albedo.y * ao), fma_(g3.z, g3.w, px.albedo.z * ao));
+    // illumination accumulators, ForwardLighting.hlsl:290-293: diffuse*ao + emissive*intensity, as written
+    f3 I = mk3(px.albedo.x * ao + g3.x * g3.w, px.albedo.y * ao + g3.y * g3.w, px.albedo.z * ao + g3.z * g3.w);
 
     if (HAS_ENV) I = add(I, environment(px, fc));                                             // :299-306
 
@@ -324,9 +335,9 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
         for (int pc = 0; pc < nPC; ++pc) {                                                    // :321-339
             const VQ_PointLight& l = L.point_casters[pc];
             const f3 Lw = sub(ld3(l.position), px.P);
-            const float D = length(Lw);
+            const float D = length_lit(Lw);
             if (D < l.range) {
-                const float viewDist = length(sub(px.P, cam));
+                const float viewDist = length_lit(sub(px.P, cam));
                 const f3 c = point_light(px, l);
                 const float sh = omni_pcf(fc->sm.point, fc->sm.point_dim, pc, Lw, l.range, l.depthBias, viewDist);
                 I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
@@ -335,8 +346,8 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
         const int nSC = L.numSpotCasters;
         for (int sc = 0; sc < nSC; ++sc) {                                                    // :342-356
             const VQ_SpotLight& l = L.spot_casters[sc];
-            const f3 Ln = normalize(sub(ld3(l.position), px.P));
-            const float NdotL = saturate(dot(px.Nraw, Ln));
+            const f3 Ln = normalize_lit(sub(ld3(l.position), px.P));
+            const float NdotL = saturate(dot_lit(px.Nraw, Ln));
             const float4 lsp = mul_M_v(L.shadowViews[sc], px.P);
             const f3 c = spot_light(px, l, mk3(0.0f, 0.0f, 0.0f));
             const float bias = l.depthBias * tan_(acos_(NdotL));

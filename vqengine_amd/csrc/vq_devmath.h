@@ -49,19 +49,35 @@ VQD float sqrt_(float x) {
     if (__builtin_expect(!sqrt_fast_ok(x), 0)) s = __builtin_sqrtf(x);
     return s;
 }
+// IEEE-754 correctly rounded quotient (v_div_scale/v_div_fmas/v_div_fixup under -fhip-fp32-correctly-rounded-divide-sqrt). Used where
+// the reference's x/x must be EXACTLY 1 (ImportanceSampleGGX at roughness 0, BRDF.hlsl:222): a*rcp(b) gives 1 - 2^-24 there.
+VQD float fdiv_(float a, float b) { return a / b; }
+// The same quotient from an already available correctly rounded reciprocal r = RN(1/b): q = a*r, one exact-residual correction
+// q' = fma(fma(-b,q,a), r, q) (Markstein). 3 VALU per quotient instead of the ~10 of the IEEE expansion when several numerators share
+// one divisor (normalize: 3 components). Equal to a/b for ALL 2^23 x 2^23 significand pairs — checked exhaustively on gfx950
+// (tests/probe/devmath_probe.hip `fdiv`, tests/test_gpu_devmath.py::test_fdiv_rcp_exhaustive_significands) — whenever nothing underflows:
+// callers guarantee |a| in [2^-78, 2^100], b and r normal (the residual a - b*q is a multiple of ulp(b)*ulp(q) ~ 2^-47 |a|).
+// NOT valid for a = -0 (gives +0), denormals, inf/NaN: hot loops test their operands once and redo the light with fdiv_ otherwise.
+VQD float fdiv_rcp(float a, float b, float r) {
+    const float q = a * r;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
 // Arithmetic policies for hot loops: Fast runs reciprocals / square roots unchecked and accumulates ONE validity
 // flag; when it drops (operand outside the validated fast range — rare) the caller redoes the whole block with
 // IEEE. Results are bit-identical to rcp() / sqrt_() either way.
+VQD bool fdiv_rcp_ok(float a) { const float m = __builtin_fabsf(a); return (m >= 0x1p-78f) & (m <= 0x1p100f); }
 struct RcpFast {
     static constexpr bool kGgxDenomAboveEps = false;         // policies that make no claim about the GGX denominator keep its EPSILON test
     bool ok = true;
     VQD float operator()(float b) { const float r = rcp_newton(b); ok = ok & is_normal(r); return r; }
     VQD float sqrt(float x) { ok = ok & sqrt_fast_ok(x); return sqrt_newton(x); }
+    VQD float div(float a, float b, float r) { ok = ok & fdiv_rcp_ok(a); return fdiv_rcp(a, b, r); }       // r = (*this)(b)
 };
 struct RcpIEEE {
     static constexpr bool kGgxDenomAboveEps = false;
     VQD float operator()(float b) const { return 1.0f / b; }
     VQD float sqrt(float x) const { return __builtin_sqrtf(x); }
+    VQD float div(float a, float b, float) const { return a / b; }
 };
 VQD float rsqrt(float x) { return rcp(sqrt_(x)); }
 VQD float div_(float a, float b) { return a * rcp(b); }     // HLSL a / b
@@ -86,6 +102,15 @@ VQD float length(f3 v) { return sqrt_(dot(v, v)); }
 VQD f3 cross(f3 a, f3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
 VQD float lerp(float a, float b, float t) { return fma_(t, b - a, a); }       // a + t*(b-a) as one mad
 VQD f3 reflect(f3 i, f3 n) { float t = 2.0f * dot(n, i); return mk3(i.x - n.x * t, i.y - n.y * t, i.z - n.z * t); }
+// The HLSL AS WRITTEN (arithmetic contract v5): every product and sum rounded on its own, left to right, a/b the IEEE
+// quotient. Used for everything ForwardLighting.hlsl:PSMain evaluates once per pixel and, inside the light loops, for the chain that
+// feeds the GGX denominator and the range cull — where one ulp of an operand is worth tens of RGBA16F ulps of a highlight pixel.
+VQD float dot_lit(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+VQD float length_lit(f3 v) { return sqrt_(dot_lit(v, v)); }
+VQD f3 div_lit(f3 v, float l) { return mk3(fdiv_(v.x, l), fdiv_(v.y, l), fdiv_(v.z, l)); }
+VQD f3 normalize_lit(f3 v) { return div_lit(v, length_lit(v)); }
+VQD float lerp_lit(float a, float b, float t) { return a + t * (b - a); }
+VQD f3 reflect_lit(f3 i, f3 n) { const float t = 2.0f * dot_lit(n, i); return mk3(i.x - t * n.x, i.y - t * n.y, i.z - t * n.z); }
 
 // float -> int: truncation, NaN -> 0, saturating
 VQD int f2i_trunc(float x) {

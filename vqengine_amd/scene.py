@@ -74,6 +74,50 @@ class Light:
         return s                                             # `range` is NOT set by the CPU side (:108-121)
 
 
+def quat_mul(a, b):
+    """Quaternion::operator* (Quaternion.cpp:151-164): (s1 s2 - v1.v2, s1 v2 + s2 v1 + v1 x v2), quaternions as (w, x, y, z)."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    v = a[0] * b[1:] + b[0] * a[1:] + np.cross(a[1:], b[1:])
+    return (float(a[0] * b[0] - a[1:] @ b[1:]), float(v[0]), float(v[1]), float(v[2]))
+
+
+def quat_from_axis_angle(axis, angle_rad):
+    """Quaternion::FromAxisAngle (Quaternion.cpp:54-61): (cos(a/2), axis * sin(a/2)); the axis is NOT normalised by the engine."""
+    h = 0.5 * float(angle_rad)
+    return (math.cos(h),) + tuple(float(c) * math.sin(h) for c in axis)
+
+
+def rotation_from_xml_euler_degrees(x_deg, y_deg, z_deg):
+    """A scene file's `<Rotation> x y z </Rotation>` (FileParser.cpp:543-549): RotateAroundGlobalX, then Y, then Z axis, each
+    `_rotation = q * _rotation` (Transform.h:62-74) starting from the identity."""
+    q = (1.0, 0.0, 0.0, 0.0)
+    for axis, deg in (((1, 0, 0), x_deg), ((0, 1, 0), y_deg), ((0, 0, 1), z_deg)):
+        q = quat_mul(quat_from_axis_angle(axis, deg * DEG2RAD), q)
+    return q
+
+
+def default_scene_lights():
+    """The <Light> elements of Data/Levels/Default.xml:202-308 (BASELINE config 1's light set) as the parser leaves them
+    (FileParser.cpp:676-720): every element has a <Shadows> child, whose mere presence sets bCastingShadows (:710-713), so the
+    directional light is shadowing and both spot lights land in spot_casters[]; the two point lights are disabled and
+    GatherSceneLightData skips them. Mobility defaults to DYNAMIC where the element has none."""
+    rot = rotation_from_xml_euler_degrees
+    return [
+        Light(Type=Light.DIRECTIONAL, Mobility=Light.STATIONARY, Color=(1.0, 1.0, 1.0), Range=100.0, Brightness=0.90, DepthBias=0.00045,
+              RotationQuaternion=rot(0, 0, 40), bCastingShadows=True),                                                   # :202-221
+        Light(Type=Light.POINT, Mobility=Light.DYNAMIC, Position=(12.5, 5.0, 5.0), bEnabled=False, Color=(0.4, 0.4, 0.85), Range=20.0,
+              Brightness=1500.0, DepthBias=0.001, bCastingShadows=True),                                                 # :223-242
+        Light(Type=Light.POINT, Mobility=Light.DYNAMIC, Position=(-12.5, 3.0, 0.0), bEnabled=False, Color=(0.4, 0.4, 0.15), Range=200.0,
+              Brightness=35.0, DepthBias=0.05, bCastingShadows=True),                                                    # :243-262
+        Light(Type=Light.SPOT, Mobility=Light.STATIC, Color=(0.9, 0.9, 0.9), Range=35.0, Brightness=1500.0, DepthBias=0.000009,
+              Position=(22.0, 26.0, 4.0), RotationQuaternion=rot(90, 0, -15), SpotOuterConeAngleDegrees=22.0,
+              SpotInnerConeAngleDegrees=20.0, bCastingShadows=True),                                                     # :264-284
+        Light(Type=Light.SPOT, Mobility=Light.STATIC, Color=(0.4, 0.4, 0.15), Range=35.0, Brightness=1000.0, DepthBias=0.000005,
+              Position=(-18.0, 20.0, 4.0), RotationQuaternion=rot(90, 0, 15), SpotOuterConeAngleDegrees=32.0,
+              SpotInnerConeAngleDegrees=28.0, bCastingShadows=True),                                                     # :285-305
+    ]
+
+
 def _set_matrix(dst, m):
     m = np.asarray(m, np.float32).reshape(4, 4)
     for i in range(4):
