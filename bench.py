@@ -1,15 +1,24 @@
 #!/usr/bin/env python3
-"""bench.py — forward-PBR hot path on MI355X (BASELINE.json metric: Mpixels/s forward-PBR @4K, 64 lights).
+"""bench.py — forward-PBR hot path on MI355X (BASELINE.json metric: Mpixels/s forward-PBR @4K, 64 lights; 1/2/4/8 GPUs).
 
-A "step" is one pass of BASELINE config 3 over one synthetic frame tile that is already resident in HBM:
-    forward lighting (64 point lights + IBL sample)  -> RGBA16F scene colour   [vqhip_forward_lighting]
-    21-tap Gaussian blur X, Y                        -> RGBA16F                 [vqhip_gaussian_blur_x/_y]
-    tonemap (Reinhard + sRGB OETF)                   -> RGBA8_UNORM             [vqhip_tonemap]
-N = 1: one 3840x2160 frame. N > 1 (weak scaling): the frame is 3840 x (2160*N), row-tiled one tile per GPU, with
-the RCCL halo exchange before the Y blur and the composite of the RGBA8 tiles (gather on rank 0, or --composite allgather)
-inside the timed region.
-`value` = pixels of the whole frame / max-over-ranks wall time. Prints ONE JSON line on rank 0."""
+A "step" is one pass of the hot path over one synthetic frame (tile) that is already resident in HBM:
+    forward lighting (point lights [+ IBL sample])   -> RGBA16F scene colour   [vqhip_forward_lighting]
+    21-tap Gaussian blur X                            -> RGBA16F                 [vqhip_gaussian_blur_x]
+    (N > 1) 10-row halo exchange with the neighbours                             [vqhip_exchange_blur_halos, RCCL send/recv]
+    blur Y + tonemap (Reinhard + sRGB OETF)           -> RGBA8_UNORM             [vqhip_gaussian_blur_y_tonemap]
+    (N > 1) composite of the RGBA8 tiles on rank 0                               [vqhip_composite_tiles, RCCL send/recv]
+
+--config cfg3 (default; BASELINE config 3, the configuration the metric is quoted on): 3840x2160 tile per GPU, 64 point lights + the
+    full-size cfg4 IBL. N > 1 is WEAK scaling: the frame is 3840 x (2160*N), one 4K tile per GPU.
+--config cfg5 (BASELINE config 5): ONE 7680x4320 frame, 256 point lights (100 in the cbuffer + 156 through the extension array),
+    row-tiled over the N GPUs (4320/N rows each): STRONG scaling. At N = 1 the whole 2.1 GB G-buffer is shaded by one GPU.
+
+Every byte that crosses GPUs goes through the C ABI (include/vqhip.h, vqengine_amd/csrc/mgpu.hip); torch.distributed is the control
+plane only (communicator-id broadcast, barriers, the max-over-ranks reduction of the wall time).
+`value` = pixels of the whole frame * steps / max-over-ranks wall time. Prints ONE JSON line on rank 0."""
 import argparse
+import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -24,22 +33,47 @@ sys.path.insert(0, ROOT)
 
 from vqengine_amd import abi, capi, synth, tiling  # noqa: E402
 
-W, TILE_H, N_LIGHTS = 3840, 2160, 64
+CONFIGS = {
+    "cfg3": dict(width=3840, height=2160, lights=64, env=True, seed=0x6400, scaling="weak",
+                 metric="Mpixels/s forward-PBR @4K,64 lights",
+                 workload="BASELINE cfg3: 3840x2160 float4 G-buffer tile per GPU, 64 point lights + IBL sample -> RGBA16F, 21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8"),
+    "cfg5": dict(width=7680, height=4320, lights=256, env=False, seed=0x2560, scaling="strong",
+                 metric="Mpixels/s forward-PBR @8K,256 lights (BASELINE cfg5, one frame row-tiled over the GPUs)",
+                 workload="BASELINE cfg5: ONE 7680x4320 float4 G-buffer, 256 point lights (100 cbuffer + 156 extension) -> RGBA16F, 21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8"),
+}
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec); 6290 measured copy ceiling
 VALU_PEAK_TFLOPS = 157.3        # :40
 SHADE_BYTES_PER_PX = 64 + 8     # 4 float4 G-buffer planes in + RGBA16F out
-SHADE_FLOPS_PER_PX = 170 * N_LIGHTS + 160
-# HBM bytes per launch of the shade kernel from the PMC counters (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes,
-# FETCH doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950): profiles/r1l_pmc_hbm.md (calibration: r1b_pmc_hbm.md). Not measurable from inside
-# bench.py; the committed figure is for exactly this workload (3840x2160, 64 lights + IBL, RGBA16F out).
-SHADE_PMC_TRAFFIC_BYTES = (2 * 598175 + 64800) * 1024   # re-measured on the round's final kernel: profiles/r1l_pmc_hbm.md
-# VALU instructions per wave of the same kernel from `rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES` (scripts/pmc_shade.sh, committed
-# summary profiles/r1e_valu_issue_rates.md + r1g note) and the measured issue ceiling of the chip (v_fma_f32 ubench).
-SPINUP_STEPS = int(os.environ.get("VQ_BENCH_SPINUP", "200"))              # untimed steady-state spin-up before the W warm-up steps (~0.28 s of GPU work)
-SHADE_PMC_VALU_PER_WAVE = 5149
-SHADE_TRANS_PER_WAVE = 273      # quarter-rate v_rcp_f32 / v_rsq_f32 per wave: 5 per executed light (81.7 % of 64) + ~12 in set-up / IBL
-VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip;
-                                # the single-shot figure of round 1a-1e, 52.7, was taken on cold clocks)
+SPINUP_STEPS = int(os.environ.get("VQ_BENCH_SPINUP", "200"))     # untimed steady-state spin-up before the W warm-up steps (~0.25 s of GPU work)
+COLD_STEPS = 20                 # the first steps after the idle set-up phase, timed on their own ("cold_start")
+VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
+PMC_SOURCES = ["vqengine_amd/csrc/shade.hip", "vqengine_amd/csrc/vq_devmath.h", "vqengine_amd/csrc/vq_sampling.h"]
+
+
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in PMC_SOURCES:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc_constants(config, fresnel_pow):
+    """Counter-derived constants of the shade kernel (HBM bytes per launch, VALU instructions per wave) cannot be measured from inside
+    bench.py: they are read from profiles/pmc_constants.json, which records the sha256 of the kernel sources they were measured on
+    (scripts/pmc_refresh.sh). If the sources changed since, the constants are NOT used: the fields they feed are null and `stale` is set."""
+    try:
+        d = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None, {"stale": True, "why": "profiles/pmc_constants.json missing"}
+    entry = d.get(f"{config}/{fresnel_pow}")
+    meta = {"file": "profiles/pmc_constants.json", "kernel_sources_sha256": d.get("kernel_sources_sha256"), "measured_at_commit": d.get("measured_at_commit"),
+            "profile": d.get("profile")}
+    if entry is None:
+        return None, dict(meta, stale=True, why=f"no entry for {config}/{fresnel_pow}")
+    if d.get("kernel_sources_sha256") != kernel_source_hash():
+        return None, dict(meta, stale=True, why="shade.hip / vq_devmath.h / vq_sampling.h changed since the counters were collected", now=kernel_source_hash())
+    return entry, dict(meta, stale=False)
 
 
 def build_ibl(ctx):
@@ -53,20 +87,17 @@ def build_ibl(ctx):
     return pre, lut
 
 
-def upload_tile(frame_h, row0, row1):
+def upload_tile(cfg, frame_h, row0, row1):
+    W = cfg["width"]
     gb = [torch.empty((row1 - row0, W, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
     for r in range(row0, row1, 240):
-        part = synth.gbuffer_rows(W, frame_h, r, min(r + 240, row1), seed=0x6400)
+        part = synth.gbuffer_rows(W, frame_h, r, min(r + 240, row1), seed=cfg["seed"])
         for k in range(4):
             gb[k][r - row0:r - row0 + part[k].shape[0]].copy_(torch.from_numpy(part[k]))
     return gb
 
 
-def cpu_baseline(pre, lut, pf, pv, frame_h, target_s=12.0):
-    """The CPU oracle (a scalar C++ port of the HLSL, OpenMP over rows) timed on the host cores on a bounded row
-    band of the SAME workload. Reported baseline only — never the thing measured as `value`."""
-    from tests import oracle_lib as O
-    O.load()
+def host_cores():
     cores = len(os.sched_getaffinity(0))
     try:                                                     # honour a cgroup CPU quota if the box has one
         q, p = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -74,14 +105,23 @@ def cpu_baseline(pre, lut, pf, pv, frame_h, target_s=12.0):
             cores = max(1, min(cores, int(float(q) / float(p))))
     except (OSError, ValueError):
         pass
-    d_np, s_np, l_np = pre["diffuse_blurred"].cpu().numpy(), pre["specular"].cpu().numpy(), lut.cpu().numpy()
-    env = O.host_envmap(d_np, s_np, 128, pre["spec_mips"], l_np)
-    band = 540                                               # quarter-frame bands of the SAME synthetic frame
+    return cores
+
+
+def cpu_baseline(cfg, env_np, pf, extra, pv, frame_h, target_s=10.0):
+    """The CPU oracle (a scalar C++ port of the HLSL, OpenMP over rows) timed on the host cores on a bounded row
+    band of the SAME workload. Reported baseline only — never the thing measured as `value`."""
+    from tests import oracle_lib as O
+    O.load()
+    cores = host_cores()
+    W = cfg["width"]
+    env = O.host_envmap(*env_np) if env_np is not None else None
+    band = 540 if cfg["lights"] <= 64 else 135               # bands of the SAME synthetic frame
 
     def run(row0, rows):
-        gb = synth.gbuffer_rows(W, frame_h, row0, row0 + rows, seed=0x6400)
+        gb = synth.gbuffer_rows(W, frame_h, row0, row0 + rows, seed=cfg["seed"])
         t0 = time.perf_counter()
-        sc = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F, env=env, nthreads=cores)
+        sc = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F, extra_point=extra, env=env, nthreads=cores)
         x = O.blur_pass(sc, abi.FMT_RGBA16F, 0, nthreads=cores)
         y = O.blur_pass(x, abi.FMT_RGBA16F, 1, nthreads=cores)
         O.tonemap(y, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, nthreads=cores)
@@ -94,26 +134,25 @@ def cpu_baseline(pre, lut, pf, pv, frame_h, target_s=12.0):
         k += 1
     return {"value": round(W * rows / t / 1e6, 4), "unit": "Mpix/s", "cores": int(cores), "kind": "port",
             "sample": f"oracle (scalar C++ port of the HLSL, OpenMP static over rows, {cores} threads) on {k} bands of {W}x{band} rows of the same "
-                      f"frame ({W * rows / 1e6:.1f} Mpix): shade 64 lights + IBL, blur X/Y, tonemap; {t:.1f} s"}
+                      f"frame ({W * rows / 1e6:.1f} Mpix): shade {cfg['lights']} lights{' + IBL' if env is not None else ''}, blur X/Y, tonemap; {t:.1f} s"}
 
 
-def cpu_reference_source(pre, lut, pf, pv, frame_h, target_s=8.0):
+def cpu_reference_source(cfg, env_np, pf, extra, pv, frame_h, target_s=6.0):
     """The REFERENCE'S OWN shader source (ForwardLighting.hlsl:PSMain, GaussianBlur.hlsl, Tonemapper.hlsl) run on one host core
     through oracle/_ref (oracle/ref_src/hlsl_shim.h) on rows of the same frame, when that library travelled with the tree. A second
     reported baseline next to `cpu_baseline`: scalar, single-threaded (the translated shaders keep their globals), literal IEEE."""
     from tests import oracle_lib as O, ref_lib as R
-    if not R.available("shaders"):
+    if not R.available("shaders") or (extra is not None and not R.available("shaders_l256")):
         return None
-    d_np, s_np, l_np = pre["diffuse_blurred"].cpu().numpy(), pre["specular"].cpu().numpy(), lut.cpu().numpy()
-    env = O.host_envmap(d_np, s_np, 128, pre["spec_mips"], l_np)
-    rows_per = 22                                           # one blur kernel height: the band is a (small) image of its own
+    W = cfg["width"]
+    env = O.host_envmap(*env_np) if env_np is not None else None
+    rows_per = 22 if cfg["lights"] <= 64 else 4              # one blur kernel height: the band is a (small) image of its own
     t, rows, k = 0.0, 0, 0
     while t < target_s and k < 64:
-        gb = synth.gbuffer_rows(W, frame_h, (k * 97) % (frame_h - rows_per), (k * 97) % (frame_h - rows_per) + rows_per, seed=0x6400)
-        n = gb[1][..., :3].astype(np.float64)
-        gb[1][..., :3] = (n / np.linalg.norm(n, axis=-1, keepdims=True)).astype(np.float32)
+        r0 = (k * 97) % (frame_h - rows_per)
+        gb = synth.gbuffer_rows(W, frame_h, r0, r0 + rows_per, seed=cfg["seed"])
         t0 = time.perf_counter()
-        sc = R.forward_from_gbuffer(gb, pf, pv, env=env).astype(np.float16).astype(np.float32)
+        sc = R.forward_from_gbuffer(gb, pf, pv, env=env, extra=extra).astype(np.float16).astype(np.float32)
         x = R.blur_pass(sc, 0).astype(np.float16).astype(np.float32)
         y = R.blur_pass(x, 1).astype(np.float16).astype(np.float32)
         R.tonemap(y, abi.TonemapperParams.default())
@@ -121,30 +160,30 @@ def cpu_reference_source(pre, lut, pf, pv, frame_h, target_s=8.0):
         rows += rows_per
         k += 1
     return {"value": round(W * rows / t / 1e6, 4), "unit": "Mpix/s", "cores": 1, "kind": "reference",
-            "sample": f"the reference's HLSL (PSMain 64 lights + IBL, CSMain_X/_Y, tonemapper CSMain) compiled to C++ through oracle/ref_src/hlsl_shim.h, "
-                      f"1 thread, {k} bands of {W}x{rows_per} rows of the same frame ({W * rows / 1e6:.2f} Mpix); {t:.1f} s"}
+            "sample": f"the reference's HLSL (PSMain {cfg['lights']} lights{' + IBL' if env is not None else ''}, CSMain_X/_Y, tonemapper CSMain) compiled to C++ through "
+                      f"oracle/ref_src/hlsl_shim.h, 1 thread, {k} bands of {W}x{rows_per} rows of the same frame ({W * rows / 1e6:.2f} Mpix); {t:.1f} s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)       # a step is ~1.4 ms: 50 + 10 keep the clocks ramped, the run stays setup-dominated
+    ap.add_argument("--steps", type=int, default=50)       # a step is ~1.1 ms: 50 + 10 keep the clocks ramped, the run stays setup-dominated
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--halo", choices=["p2p", "allgather"], default="p2p")
     ap.add_argument("--post", choices=["fused", "split"], default="fused",
                     help="post chain after the X blur: Y blur and tonemapper as two dispatches (split) or one kernel (fused); identical bits")
-    ap.add_argument("--composite", choices=["gather", "allgather"], default="gather",
-                    help="final composite of the RGBA8 tiles: gather on rank 0 (the presenting GPU; 1/N of the traffic, rank 0 receives over its "
-                         "N-1 direct xGMI links) or all-gather on every rank")
+    ap.add_argument("--composite", choices=["root", "all"], default="root",
+                    help="final composite of the RGBA8 tiles: on rank 0 only (the presenting GPU; it receives over its N-1 direct xGMI links) or on every rank")
+    ap.add_argument("--composite-overlap", choices=["on", "off"], default="on",
+                    help="on: the composite of frame n runs on a second stream / second communicator and overlaps the shading of frame n+1 (drained "
+                         "inside the timed region); off: everything in one stream order")
     ap.add_argument("--fresnel-pow", choices=["product", "exp2_log2"], default="product",
                     help="pow(1 - cos, 5) of the Fresnel terms: the product x*((x*x)*(x*x)) (default, contract v4) or exp2(5*log2 x), the engine's own "
-                         "DXC lowering (vqhip_set_fresnel_pow; DESIGN.md 3.2)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="post chain of frame n on a second (high-priority) HIP stream overlapping the shading of frame n+1. Measured "
-                         "+1 %% only (the 32 400-workgroup shade dispatch starves the second queue), so the default is ONE stream, "
-                         "which also keeps the per-kernel event timings clean.")
+                         "DXC lowering (vqhip_set_fresnel_pow; DESIGN.md 3.2). The other mode is timed too and reported as `engine_lowering`.")
+    ap.add_argument("--no-second-mode", action="store_true", help="skip the timing of the other Fresnel-pow mode")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -153,133 +192,132 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # VQ_BENCH_SHARE_GPU=1 (debug aid for single-GPU boxes): every rank uses the visible GPUs round-robin and the collectives run
-    # over gloo, so that the N > 1 control flow (tiles, halo exchange, double-buffered composite, drain) can be exercised on real
-    # kernels without N GPUs. Never set by the driver; the product configuration is one GPU per rank over RCCL.
+    # VQ_BENCH_SHARE_GPU=1 (debug aid for single-GPU boxes): every rank uses the visible GPUs round-robin, the control plane runs over
+    # gloo and the C ABI's RCCL calls are served by tests/cpp/libmock_rccl.so (shared memory), so that the N > 1 control flow — tiles,
+    # halo exchange, double-buffered composite, drain — can be exercised on real kernels without N GPUs. Never set by the driver.
     share = os.environ.get("VQ_BENCH_SHARE_GPU") == "1"
     device_ordinal = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(device_ordinal)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
+            os.environ["VQHIP_RCCL_LIBRARY"] = os.path.join(ROOT, "tests", "cpp", "libmock_rccl.so")
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_ordinal))
     ctx = capi.Context(device_ordinal)
-
     ctx.set_fresnel_pow(args.fresnel_pow == "exp2_log2")
-    global SHADE_PMC_VALU_PER_WAVE
-    if args.fresnel_pow == "exp2_log2":
-        SHADE_PMC_VALU_PER_WAVE = 6480                # PMC count of that form (profiles/r1g_shade_valu.md, contract v3 row)
-    if args.fresnel_pow == "exp2_log2":
-        from tests import oracle_lib as _O
-        _O.load().vqo_set_fresnel_pow(1)          # keeps the cpu_baseline leg on the same arithmetic
-    frame_h = TILE_H * world
+
+    W, L = cfg["width"], cfg["lights"]
+    frame_h = cfg["height"] * world if cfg["scaling"] == "weak" else cfg["height"]
     tl = tiling.RowTiling(W, frame_h, world, rank)
-    pre, lut = build_ibl(ctx)
-    env = capi.make_envmap(pre["diffuse_blurred"], pre["specular"], 128, pre["spec_mips"], lut)
-    pf, extra = synth.per_frame(points=synth.point_lights(N_LIGHTS, seed=0x6400), hdri_offset=0.3)
-    pv = synth.per_view(W, frame_h, max_env_lod=pre["spec_mips"])
-    gb = upload_tile(frame_h, tl.row0, tl.row1)
+    rows = tl.tile_rows
+    env = pre = lut = None
+    if cfg["env"]:
+        pre, lut = build_ibl(ctx)
+        env = capi.make_envmap(pre["diffuse_blurred"], pre["specular"], 128, pre["spec_mips"], lut)
+    pf, extra = synth.per_frame(points=synth.point_lights(L, seed=cfg["seed"]), hdri_offset=0.3 if cfg["env"] else 0.0)
+    pv = synth.per_view(W, frame_h, max_env_lod=pre["spec_mips"] if pre else 0)
+    gb = upload_tile(cfg, frame_h, tl.row0, tl.row1)
+
+    # communicators of the data path (C ABI): one for the halo exchange (critical path, main stream), one for the composite
+    comm_halo = comm_comp = None
+    if world > 1:
+        ids = [capi.comm_unique_id(), capi.comm_unique_id()] if rank == 0 else [None, None]
+        dist.broadcast_object_list(ids, src=0)               # control plane: 2 x 128 bytes
+        comm_halo = capi.Comm(ids[0], world, rank)
+        comm_comp = capi.Comm(ids[1], world, rank)
 
     F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
-    scene = [capi.empty_image(TILE_H, W, F16, ctx.device) for _ in range(2)]
-    xblur = capi.empty_image(TILE_H, W, F16, ctx.device)
-    yblur = capi.empty_image(TILE_H, W, F16, ctx.device)
-    sdr = [capi.empty_image(TILE_H, W, R8, ctx.device) for _ in range(2)]
-    need_frame = world > 1 and (args.composite == "allgather" or rank == 0)
+    scene = [capi.empty_image(rows, W, F16, ctx.device) for _ in range(2)]
+    xblur = capi.empty_image(rows, W, F16, ctx.device)
+    yblur = capi.empty_image(rows, W, F16, ctx.device) if args.post == "split" else None
+    sdr = [capi.empty_image(rows, W, R8, ctx.device) for _ in range(2)]
+    root = 0 if args.composite == "root" else capi.ALL_RANKS
+    need_frame = world > 1 and (root == capi.ALL_RANKS or rank == 0)
     frame = [torch.empty((frame_h, W, 4), dtype=torch.uint8, device=ctx.device) for _ in range(2)] if need_frame else [None, None]
-    pending = [None, None]
-    halo_fn = tiling.exchange_halos_p2p if args.halo == "p2p" else tiling.exchange_halos_allgather
-    # Two HIP streams, like the reference's GFX + async-compute queues (SceneRendering.cpp:605-606,629): the VALU-bound
-    # shading of frame n+1 runs on `s_shade` while the HBM-bound post chain (+ halo exchange + composite) of frame n runs
-    # on `s_post`. Every frame still does all of its work inside the timed region; scene colour is double-buffered.
-    s_shade = torch.cuda.current_stream(ctx.device)
-    s_post = torch.cuda.Stream(ctx.device, priority=-1) if args.overlap else s_shade   # high priority: its short kernels slot in
-    e_scene = [torch.cuda.Event(), torch.cuda.Event()]
-    e_post = [None, None]
+    halo_top = capi.empty_image(capi.HALO_ROWS, W, F16, ctx.device) if world > 1 and rank > 0 else None
+    halo_bottom = capi.empty_image(capi.HALO_ROWS, W, F16, ctx.device) if world > 1 and rank < world - 1 else None
+    overlap = world > 1 and args.composite_overlap == "on"
+    s_main = torch.cuda.current_stream(ctx.device)
+    s_comp = torch.cuda.Stream(ctx.device) if overlap else s_main
+    h_main, h_comp = C.c_void_p(s_main.cuda_stream), C.c_void_p(s_comp.cuda_stream)
+    e_post = [torch.cuda.Event(), torch.cuda.Event()]
+    e_comp = [None, None]
 
     def step(i, ev=None):
         b = i & 1
-        if e_post[b] is not None and args.overlap:    # scene[b] was last read by the post chain of step i-2
-            s_shade.wait_event(e_post[b])
+        if overlap and e_comp[b] is not None:        # sdr[b] / frame[b] were last touched by the composite of step i-2
+            s_main.wait_event(e_comp[b])
         if ev:
-            ev[0].record(s_shade)
+            ev[0].record(s_main)
         ctx.forward_lighting(gb, pf, pv, out=scene[b], out_fmt=F16, extra_point=extra, env=env)
         if ev:
-            ev[1].record(s_shade)
-        if args.overlap:
-            e_scene[b].record(s_shade)
-        with torch.cuda.stream(s_post):
-            if args.overlap:
-                s_post.wait_event(e_scene[b])
-            if world > 1 and pending[b] is not None:  # composite of step i-2 must have drained before sdr[b]/frame[b] are reused
-                pending[b].wait()
-                pending[b] = None
+            ev[1].record(s_main)
+        if ev and len(ev) == 5:
+            ev[4].record(s_main)
+        ctx.gaussian_blur_x(scene[b], F16, out=xblur)
+        if world > 1:
+            comm_halo.exchange_blur_halos(xblur, F16, halo_top, halo_bottom, stream=h_main)
+        if args.post == "fused":
+            # CSMain_Y + Tonemapper in one kernel (register-window Y pass whose store goes through the 64 KB tonemap table in
+            # LDS): bit-identical to the two dispatches, BlurOutput never touches HBM. ev[2] then closes the X pass (+ halo exchange).
             if ev and len(ev) == 5:
-                ev[4].record(s_post)
-            ctx.gaussian_blur_x(scene[b], F16, out=xblur)
-            top = bottom = None
-            if world > 1:
-                top, bottom = halo_fn(xblur)
-            if args.post == "fused":
-                # CSMain_Y + Tonemapper in one kernel (register-window Y pass whose store goes through the 64 KB tonemap table in
-                # LDS): bit-identical to the two dispatches, BlurOutput never touches HBM. ev[2] then closes the X pass only.
-                if ev and len(ev) == 5:
-                    ev[2].record(s_post)
-                ctx.gaussian_blur_y_tonemap(xblur, F16, R8, out=sdr[b], halo_top=top, halo_bottom=bottom)
-            else:
-                ctx.gaussian_blur_y(xblur, F16, out=yblur, halo_top=top, halo_bottom=bottom)
-                if ev and len(ev) == 5:
-                    ev[2].record(s_post)
-                ctx.tonemap(yblur, F16, R8, out=sdr[b])
+                ev[2].record(s_main)
+            ctx.gaussian_blur_y_tonemap(xblur, F16, R8, out=sdr[b], halo_top=halo_top, halo_bottom=halo_bottom)
+        else:
+            ctx.gaussian_blur_y(xblur, F16, out=yblur, halo_top=halo_top, halo_bottom=halo_bottom)
             if ev and len(ev) == 5:
-                ev[3].record(s_post)
-            if world > 1:                              # all-gather on RCCL's own stream, drained two steps later
-                if args.composite == "gather":
-                    _, pending[b] = tiling.composite_to_root(sdr[b], out=frame[b], dst=0, async_op=True)
-                else:
-                    _, pending[b] = tiling.composite(sdr[b], out=frame[b], async_op=True)
-            if args.overlap:
-                e_post[b] = torch.cuda.Event()
-                e_post[b].record(s_post)
+                ev[2].record(s_main)
+            ctx.tonemap(yblur, F16, R8, out=sdr[b])
+        if ev and len(ev) == 5:
+            ev[3].record(s_main)
+        if world > 1:
+            if overlap:
+                e_post[b].record(s_main)
+                s_comp.wait_event(e_post[b])
+            comm_comp.composite_tiles(sdr[b], R8, frame_h, root, frame[b], stream=h_comp)
+            if overlap:
+                e_comp[b] = torch.cuda.Event()
+                e_comp[b].record(s_comp)
 
     def drain():
-        with torch.cuda.stream(s_post):
-            for b in (0, 1):
-                if pending[b] is not None:
-                    pending[b].wait()
-                    pending[b] = None
-        s_shade.wait_stream(s_post)
+        if overlap:
+            s_main.wait_stream(s_comp)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Untimed spin-up: the chip needs ~0.2-0.3 s of sustained load to reach its steady-state clocks (measured: the same
-    # kernel runs 1.33 ms right after the idle set-up phase and 1.25 ms once ramped), so a fixed number of extra untimed steps
-    # precedes the W warm-up steps whatever W is. The timed region is still exactly K steps.
-    for i in range(SPINUP_STEPS):
+    def timed(n_steps, evs=None, first=0):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            step(first + i, evs[i] if evs else None)
+        drain()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    # 1. cold start: the very first steps after the idle set-up phase, timed on their own (the chip has not ramped its clocks yet)
+    dt_cold = timed(COLD_STEPS)
+    # 2. untimed spin-up: the chip needs ~0.2-0.3 s of sustained load to reach its steady-state clocks, so a fixed number of extra
+    #    untimed steps precedes the W warm-up steps whatever W is. The timed region is still exactly K steps.
+    for i in range(max(0, SPINUP_STEPS - COLD_STEPS)):
         step(i)
     drain()
     for i in range(args.warmup):
         step(i)
     drain()
-    # timed region: only the dominant kernel is bracketed by HIP events (2 records per step); the per-stage timings of the
-    # HBM-bound post kernels are taken in a separate, untimed pass afterwards so their instrumentation does not sit in `value`
+    # 3. timed region: only the dominant kernel is bracketed by HIP events (2 records per step); the per-stage timings of the
+    #    HBM-bound post kernels are taken in a separate, untimed pass afterwards so their instrumentation does not sit in `value`
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, evs[i])
-    drain()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = timed(args.steps, evs)
 
     n_detail = min(args.steps, 10)
     evd = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n_detail)]
@@ -287,14 +325,28 @@ def main():
         step(args.steps + i + (args.steps & 1), evd[i])
     drain()
     barrier()
+    # 4. frame latency: one step at a time, nothing in flight before or after it (the throughput figure pipelines the composite)
+    lat = []
+    for i in range(5):
+        barrier()
+        t0 = time.perf_counter()
+        step(i)
+        drain()
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    lat_t = torch.tensor([float(np.median(lat))], dtype=torch.float64, device=ctx.device)
+    if world > 1:
+        dist.all_reduce(lat_t, op=dist.ReduceOp.MAX)
+    frame_latency = float(lat_t.item())
 
     verify = None
     if world > 1 and os.environ.get("VQ_BENCH_VERIFY") == "1":
         # debug aid: rank 0 recomputes the WHOLE frame on its own GPU (no tiles, no halos) and compares it byte for byte with the
         # composite of the last step — the row tiling + halo exchange + composite on real kernels (tests/test_gpu_bench_flow.py)
-        last = (args.steps + n_detail + (args.steps & 1) - 1) & 1
+        torch.cuda.synchronize()
+        last = 4 & 1
         if rank == 0:
-            gb_full = upload_tile(frame_h, 0, frame_h)
+            gb_full = upload_tile(cfg, frame_h, 0, frame_h)
             sc = ctx.forward_lighting(gb_full, pf, pv, out_fmt=F16, extra_point=extra, env=env)
             xb = ctx.gaussian_blur_x(sc, F16)
             want = ctx.gaussian_blur_y_tonemap(xb, F16, R8)
@@ -303,48 +355,81 @@ def main():
             del gb_full, sc, xb, want
         dist.barrier()
 
+    # 5. the other Fresnel-pow lowering, same invocation, same clocks: `engine_lowering` is the engine-faithful exp2(5*log2 x) form
+    second = None
+    if not args.no_second_mode:
+        other = "exp2_log2" if args.fresnel_pow == "product" else "product"
+        ctx.set_fresnel_pow(other == "exp2_log2")
+        for i in range(20):
+            step(i)
+        drain()
+        evs2 = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
+        dt2 = timed(args.steps, evs2)
+        ctx.set_fresnel_pow(args.fresnel_pow == "exp2_log2")
+        second = {"fresnel_pow": other, "value": round(W * frame_h * args.steps / dt2 / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                  "shade_ms": round(float(np.mean([e[0].elapsed_time(e[1]) for e in evs2])), 4)}
+
     if rank == 0:
-        px_tile, px_frame = W * TILE_H, W * frame_h
+        px_tile, px_frame = W * rows, W * frame_h
         t_shade = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) * 1e-3
         t_blur = float(np.mean([e[4].elapsed_time(e[2]) for e in evd])) * 1e-3
         t_tm = float(np.mean([e[2].elapsed_time(e[3]) for e in evd])) * 1e-3
         ach = SHADE_BYTES_PER_PX * px_tile / t_shade / 1e9
+        flops_px = 170 * L + 160
+        pmc, pmc_meta = load_pmc_constants(args.config, args.fresnel_pow)
+        if pmc_meta.get("stale"):
+            print(f"bench.py: PMC constants not used: {pmc_meta.get('why')}", file=sys.stderr)
         out = {
-            "metric": "Mpixels/s forward-PBR @4K,64 lights", "value": round(px_frame * args.steps / dt / 1e6, 2), "unit": "Mpix/s",
+            "metric": cfg["metric"], "value": round(px_frame * args.steps / dt / 1e6, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg3: 3840x2160 float4 G-buffer tile per GPU, 64 point lights + IBL sample -> RGBA16F, "
-                                   "21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8" + ("" if world == 1 else f"; frame 3840x{frame_h} row-tiled, RCCL halo ({args.halo}) + composite ({args.composite}{' on rank 0' if args.composite == 'gather' else ''})"),
-                       "width": W, "frame_height": frame_h, "lights": N_LIGHTS, "parallelism": f"rows{world}",
-                       "streams": "2: post chain of frame n overlaps shading of frame n+1" if args.overlap else "1",
-                       "untimed_spinup_steps": SPINUP_STEPS, "fresnel_pow": args.fresnel_pow,
+            "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["workload"] + ("" if world == 1 else f"; frame {W}x{frame_h} row-tiled {rows} rows per GPU, RCCL p2p halo exchange + composite on "
+                                                       f"{'rank 0' if root == 0 else 'every rank'} through the C ABI"),
+                       "name": args.config, "width": W, "frame_height": frame_h, "tile_rows": rows, "lights": L, "parallelism": f"rows{world}",
+                       "composite_overlap": overlap, "untimed_spinup_steps": SPINUP_STEPS, "fresnel_pow": args.fresnel_pow,
                        "post": "blur X, then blur Y + tonemap in one kernel (identical bits to three dispatches)" if args.post == "fused" else "blur X, blur Y, tonemap"},
-            "roofline": {"bound": "hbm", "kernel": "k_forward_lighting<env,nocasters,RGBA16F>", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5), "traffic": SHADE_PMC_TRAFFIC_BYTES, "traffic_unit": "bytes/launch",
-                         "traffic_source": "profiles/r1l_pmc_hbm.md (rocprofv3 PMC, separate passes, 2*FETCH_SIZE + WRITE_SIZE); algorithmic = %d" % (SHADE_BYTES_PER_PX * px_tile),
+            "roofline": {"bound": "hbm", "kernel": f"k_forward_lighting<{'env' if env is not None else 'noenv'},nocasters,RGBA16F>", "achieved": round(ach, 2),
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
+                         "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "traffic_unit": "bytes/launch",
+                         "traffic_source": "rocprofv3 PMC, separate passes, 2*FETCH_SIZE + WRITE_SIZE (profiles/pmc_constants.json); algorithmic = %d" % (SHADE_BYTES_PER_PX * px_tile),
                          "bytes_per_px": SHADE_BYTES_PER_PX, "ms": round(t_shade * 1e3, 4),
-                         "note": "64-light shading is VALU-bound by construction (SURVEY.md 8d): see valu"},
-            "valu": {"achieved_tflops_model": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
-                     "frac": round(SHADE_FLOPS_PER_PX * px_tile / t_shade / 1e12 / VALU_PEAK_TFLOPS, 4), "flops_per_px_model": SHADE_FLOPS_PER_PX},
-            "valu_issue": {"achieved_T_lane_instr_s": round(SHADE_PMC_VALU_PER_WAVE * px_tile / t_shade / 1e12, 2),
-                           "ceiling": VALU_ISSUE_CEILING_TLIS, "frac": round(SHADE_PMC_VALU_PER_WAVE * px_tile / t_shade / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
-                           "frac_slot_weighted": round((SHADE_PMC_VALU_PER_WAVE + 3 * SHADE_TRANS_PER_WAVE) * px_tile / t_shade / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
-                           "valu_instr_per_wave": SHADE_PMC_VALU_PER_WAVE, "quarter_rate_instr_per_wave": SHADE_TRANS_PER_WAVE,
-                           "note": "the binding roof: VALU instructions issued per second (PMC count x live kernel time) vs the steady-state v_fma_f32 "
-                                   "issue rate of the chip (scripts/ubench/valu_ceiling.hip); slot-weighted counts each quarter-rate v_rcp/v_rsq as 4 slots"},
+                         "note": f"{L}-light shading is VALU-bound by construction (SURVEY.md 8d): see valu / valu_issue"},
+            "valu": {"achieved_tflops_model": round(flops_px * px_tile / t_shade / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
+                     "frac": round(flops_px * px_tile / t_shade / 1e12 / VALU_PEAK_TFLOPS, 4), "flops_per_px_model": flops_px},
+            "pmc_constants": pmc_meta,
             "stages": {"shade_Mpix_s": round(px_tile / t_shade / 1e6, 1), "shade_ms": round(t_shade * 1e3, 4),
                        **({"blur_xy_ms": round(t_blur * 1e3, 4), "blur_xy_GBps": round(px_tile * 32 / t_blur / 1e9, 1),
                            "tonemap_ms": round(t_tm * 1e3, 4), "tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1)} if args.post == "split" else
                           {"blur_x_ms": round(t_blur * 1e3, 4), "blur_x_GBps": round(px_tile * 16 / t_blur / 1e9, 1),
                            "blur_y_tonemap_ms": round(t_tm * 1e3, 4), "blur_y_tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1),
-                           "post_algorithmic_GBps_split_equivalent": round(px_tile * 44 / (t_blur + t_tm) / 1e9, 1)})},
+                           "post_chain_ms": round((t_blur + t_tm) * 1e3, 4), "post_chain_GBps": round(px_tile * 28 / (t_blur + t_tm) / 1e9, 1),
+                           "post_chain_frac_of_hbm_peak": round(px_tile * 28 / (t_blur + t_tm) / 1e9 / HBM_PEAK_GBPS, 4)}),
+                       **({"blur_x_includes": "halo exchange"} if world > 1 else {})},
+            "frame_latency_ms": round(frame_latency * 1e3, 4),
+            "cold_start": {"steps": COLD_STEPS, "ms_per_step": round(dt_cold / COLD_STEPS * 1e3, 4), "value": round(px_frame * COLD_STEPS / dt_cold / 1e6, 2),
+                           "note": "the first steps after the idle set-up phase, before the clocks ramp; `value` is the steady-state figure"},
         }
+        if pmc:
+            vw, tw = pmc["valu_instr_per_wave"], pmc.get("quarter_rate_instr_per_wave", 0)
+            waves = px_tile / 64.0
+            out["valu_issue"] = {"achieved_T_lane_instr_s": round(vw * 64 * waves / t_shade / 1e12, 2), "ceiling": VALU_ISSUE_CEILING_TLIS,
+                                 "frac": round(vw * 64 * waves / t_shade / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
+                                 "frac_slot_weighted": round((vw + 3 * tw) * 64 * waves / t_shade / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
+                                 "valu_instr_per_wave": vw, "quarter_rate_instr_per_wave": tw,
+                                 "note": "the binding roof: VALU instructions issued per second (PMC count x live kernel time) vs the steady-state v_fma_f32 "
+                                         "issue rate of the chip (scripts/ubench/valu_ceiling.hip); slot-weighted counts each quarter-rate v_rcp/v_rsq as 4 slots"}
+        if second is not None:
+            out["engine_lowering" if second["fresnel_pow"] == "exp2_log2" else "product_lowering"] = second
         if verify is not None:
             out["verify"] = verify
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pre, lut, pf, pv, frame_h)
+            env_np = (pre["diffuse_blurred"].cpu().numpy(), pre["specular"].cpu().numpy(), 128, pre["spec_mips"], lut.cpu().numpy()) if pre else None
+            if args.fresnel_pow == "exp2_log2":
+                from tests import oracle_lib as _O
+                _O.load().vqo_set_fresnel_pow(1)             # keeps the cpu_baseline leg on the same arithmetic
+            out["cpu_baseline"] = cpu_baseline(cfg, env_np, pf, extra, pv, frame_h)
             try:                                             # optional second baseline: only where oracle/_ref exists
-                ref_line = cpu_reference_source(pre, lut, pf, pv, frame_h)
+                ref_line = cpu_reference_source(cfg, env_np, pf, extra, pv, frame_h)
                 if ref_line is not None:
                     out["cpu_reference_source"] = ref_line
             except Exception as e:                           # never let the optional leg break the bench line
@@ -352,6 +437,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        comm_halo.close()
+        comm_comp.close()
         dist.destroy_process_group()
     ctx.close()
 

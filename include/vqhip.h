@@ -45,7 +45,8 @@ typedef enum vqhip_status {
     VQHIP_ERR_INVALID_ARG   = -1,
     VQHIP_ERR_HIP           = -2,   /* a HIP runtime call failed; see vqhip_last_error()            */
     VQHIP_ERR_UNSUPPORTED   = -3,   /* format / parameter combination not implemented              */
-    VQHIP_ERR_NO_DEVICE     = -4    /* no gfx950 device visible — there is NO CPU fallback          */
+    VQHIP_ERR_NO_DEVICE     = -4,   /* no gfx950 device visible — there is NO CPU fallback          */
+    VQHIP_ERR_RCCL          = -5    /* RCCL could not be loaded or a collective call failed (row-tiled multi-GPU mode) */
 } vqhip_status;
 
 /* Storage formats of the reference render targets:
@@ -492,6 +493,42 @@ VQHIP_API int vqhip_apply_reflections(vqhip_ctx* ctx, void* stream, const void* 
 typedef struct VQ_VizParams { int32_t iDrawMode; int32_t iUnpackNormals; float fInputStrength; } VQ_VizParams;
 VQHIP_API int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
         const VQ_VizParams* params, vqhip_format inFmt, vqhip_format outFmt);
+
+/* ---- one frame row-tiled over the GPUs of a node ------------------------------------------------------
+ * No reference analogue (VQEngine renders on one adapter; the limit being exceeded is the single command queue of
+ * SceneRendering.cpp:2507). One process per GPU; rank r owns rows [row0, row0+rows) of the frame and only that part of the
+ * G-buffer, lights / env maps / LUT are replicated. vqhip_forward_lighting, vqhip_gaussian_blur_x and the tonemapper need
+ * no communication; the two exchanges below are the whole multi-GPU data path:
+ *
+ *   vqhip_gaussian_blur_x(tile) -> vqhip_exchange_blur_halos -> vqhip_gaussian_blur_y[_tonemap](tile, halo_top, halo_bottom)
+ *                                                            -> vqhip_composite_tiles
+ *
+ * A vqhip_comm wraps an RCCL communicator (one rank per GPU, xGMI point-to-point). RCCL is loaded at run time
+ * (librccl.so.1, or the library named by $VQHIP_RCCL_LIBRARY): single-GPU hosts never touch it. Like every other entry point
+ * the two exchanges enqueue on `stream` and return without synchronising.
+ *   vqhip_comm_unique_id : rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks out of band
+ *   vqhip_comm_create    : every rank, collectively (ncclCommInitRank on the calling thread's current HIP device)
+ *   vqhip_comm_adopt     : wrap an ncclComm_t the host already owns (not destroyed by vqhip_comm_destroy) */
+#define VQHIP_HALO_ROWS      10        /* KERNEL_RANGE - 1, Shaders/GaussianBlur.hlsl:54-55 */
+#define VQHIP_COMM_ID_BYTES  128       /* sizeof(ncclUniqueId) */
+#define VQHIP_ALL_RANKS      (-1)
+typedef struct vqhip_comm vqhip_comm;
+/* rows of rank `rank`: frame_height / world each, the first frame_height % world ranks one more. world > 1 needs >= 10 rows per tile. */
+VQHIP_API int  vqhip_rowtile(int frame_height, int world, int rank, int* row0, int* rows);
+VQHIP_API int  vqhip_comm_unique_id(void* id128);
+VQHIP_API int  vqhip_comm_create(const void* id128, int world, int rank, vqhip_comm** out_comm);
+VQHIP_API int  vqhip_comm_adopt(void* nccl_comm, int world, int rank, vqhip_comm** out_comm);
+VQHIP_API void vqhip_comm_destroy(vqhip_comm* comm);
+/* Exchange 1. xblur_tile: this rank's X-blurred tile (tile_rows x width, row_pitch_px pixels per row, fmt RGBA16F | RGBA32F).
+ * Sends its first 10 rows to rank-1 and its last 10 rows to rank+1 and receives theirs into halo_top / halo_bottom (dense
+ * 10 x width buffers, the layout vqhip_gaussian_blur_y takes; ignored — may be NULL — at the frame's top / bottom edge). */
+VQHIP_API int  vqhip_exchange_blur_halos(vqhip_comm* comm, void* stream, const void* xblur_tile, int width, int tile_rows,
+        int row_pitch_px, vqhip_format fmt, void* halo_top, void* halo_bottom);
+/* Exchange 2. tile: this rank's finished tile (dense rows, fmt e.g. RGBA8_UNORM). root >= 0: only that rank receives the
+ * frame (frame_height x width, dense; NULL elsewhere) — the GPU that presents, like the reference's one swap chain;
+ * root == VQHIP_ALL_RANKS: every rank receives it. Transfers are grouped point-to-point messages straight into the frame. */
+VQHIP_API int  vqhip_composite_tiles(vqhip_comm* comm, void* stream, const void* tile, int width, int frame_height,
+        vqhip_format fmt, int root, void* frame);
 
 #ifdef __cplusplus
 }

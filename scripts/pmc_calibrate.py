@@ -11,9 +11,10 @@ ctx = capi.Context(0)
 pre, lut = bench.build_ibl(ctx)
 env = capi.make_envmap(pre["diffuse_blurred"], pre["specular"], 128, pre["spec_mips"], lut)
 pf, extra = synth.per_frame(points=synth.point_lights(64, seed=0x6400), hdri_offset=0.3)
-pv = synth.per_view(bench.W, bench.TILE_H, max_env_lod=pre["spec_mips"])
-gb = bench.upload_tile(bench.TILE_H, 0, bench.TILE_H)
-out = capi.empty_image(bench.TILE_H, bench.W, abi.FMT_RGBA16F, ctx.device)
+cfg = bench.CONFIGS["cfg3"]
+pv = synth.per_view(cfg["width"], cfg["height"], max_env_lod=pre["spec_mips"])
+gb = bench.upload_tile(cfg, cfg["height"], 0, cfg["height"])
+out = capi.empty_image(cfg["height"], cfg["width"], abi.FMT_RGBA16F, ctx.device)
 for _ in range(3):
     ctx.forward_lighting(gb, pf, pv, out=out, out_fmt=abi.FMT_RGBA16F)              # k_forward_lighting<false,false,1>
     ctx.forward_lighting(gb, pf, pv, out=out, out_fmt=abi.FMT_RGBA16F, env=env)     # k_forward_lighting<true,false,1>

@@ -1,0 +1,132 @@
+// mock_rccl.cpp — TEST INFRASTRUCTURE: a stand-in for librccl.so that moves the bytes of ncclSend / ncclRecv through POSIX shared
+// memory between the processes of ONE machine. It exists because the row-tiled multi-GPU path of the product
+// (vqengine_amd/csrc/mgpu.hip: vqhip_exchange_blur_halos, vqhip_composite_tiles) calls RCCL through the C ABI, and the boxes tests run on
+// have at most one GPU (RCCL refuses two ranks on one device) or none. Loaded through $VQHIP_RCCL_LIBRARY; never shipped, never used
+// by bench.py outside its single-GPU debug mode (VQ_BENCH_SHARE_GPU).
+//   * no GPU visible (this container): buffers are HOST memory, bytes move with memcpy           (tests/test_mgpu_mock.py)
+//   * a GPU is visible: buffers are DEVICE memory; the stream is drained, bytes move with hipMemcpy(Default) through the mailbox
+//     (tests/test_gpu_bench_flow.py: N ranks sharing one GPU)
+// Semantics kept from RCCL: sends / receives between GroupStart and GroupEnd are posted together and progress concurrently (no ordering
+// deadlock), messages between one ordered pair of ranks match in posting order.
+#include <fcntl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <hip/hip_runtime_api.h>
+
+extern "C" {
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef struct MockComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+}
+
+namespace {
+constexpr int kMaxRanks = 8;
+constexpr size_t kSlotBytes = 4u << 20;                    // one in-flight chunk per ordered pair
+struct Mailbox { std::atomic<uint64_t> produced, consumed; std::atomic<uint64_t> bytes; char pad[40]; };
+struct Shared { std::atomic<int> arrived; char pad[60]; Mailbox box[kMaxRanks][kMaxRanks]; };   // payload slots follow
+size_t sharedBytes() { return sizeof(Shared) + (size_t)kMaxRanks * kMaxRanks * kSlotBytes; }
+char* slot(Shared* s, int src, int dst) { return (char*)(s + 1) + ((size_t)src * kMaxRanks + dst) * kSlotBytes; }
+bool haveGpu() { static int n = -1; if (n < 0) { int c = 0; n = (hipGetDeviceCount(&c) == hipSuccess && c > 0) ? 1 : 0; } return n == 1; }
+
+struct Op { bool send; char* buf; size_t bytes, done; int peer; hipStream_t st; };
+thread_local int g_depth = 0;
+thread_local std::vector<Op> g_ops;
+thread_local MockComm* g_comm = nullptr;
+}
+
+struct MockComm { Shared* sh; int world, rank; char name[64]; };
+
+namespace {
+void copyIn(void* dst, const void* src, size_t n) { if (haveGpu()) (void)hipMemcpy(dst, src, n, hipMemcpyDefault); else std::memcpy(dst, src, n); }
+size_t elemSize(ncclDataType_t t) { switch (t) { case 0: case 1: return 1; case 2: case 3: case 7: return 4; case 4: case 5: case 8: return 8; case 6: case 9: return 2; } return 1; }
+
+// one non-blocking step of an operation; returns true when it has finished
+bool progress(MockComm* c, Op& op) {
+    if (op.done == op.bytes) return true;
+    const int src = op.send ? c->rank : op.peer, dst = op.send ? op.peer : c->rank;
+    Mailbox& m = c->sh->box[src][dst];
+    if (op.send) {
+        if (m.produced.load(std::memory_order_acquire) != m.consumed.load(std::memory_order_acquire)) return false;     // slot still full
+        const size_t n = std::min(kSlotBytes, op.bytes - op.done);
+        copyIn(slot(c->sh, src, dst), op.buf + op.done, n);
+        m.bytes.store(n, std::memory_order_relaxed);
+        m.produced.fetch_add(1, std::memory_order_release);
+        op.done += n;
+    } else {
+        if (m.produced.load(std::memory_order_acquire) == m.consumed.load(std::memory_order_acquire)) return false;     // nothing there yet
+        const size_t n = m.bytes.load(std::memory_order_relaxed);
+        if (n > op.bytes - op.done) { std::fprintf(stderr, "mock_rccl: message larger than the posted receive\n"); std::abort(); }
+        copyIn(op.buf + op.done, slot(c->sh, src, dst), n);
+        m.consumed.fetch_add(1, std::memory_order_release);
+        op.done += n;
+    }
+    return op.done == op.bytes;
+}
+void runGroup() {
+    if (!g_comm) { g_ops.clear(); return; }
+    if (haveGpu()) for (const Op& op : g_ops) (void)hipStreamSynchronize(op.st);       // the data was produced on the caller's stream
+    // per ordered pair only the oldest unfinished operation may progress (messages match in posting order)
+    for (bool all = false; !all;) {
+        all = true;
+        bool blockedSend[kMaxRanks] = {}, blockedRecv[kMaxRanks] = {};
+        for (Op& op : g_ops) {
+            if (op.done == op.bytes && op.bytes) continue;
+            bool& blocked = op.send ? blockedSend[op.peer] : blockedRecv[op.peer];
+            if (blocked) { all = false; continue; }
+            if (!progress(g_comm, op)) { blocked = true; all = false; }
+            else if (op.done != op.bytes) { blocked = true; all = false; }
+        }
+        if (!all) sched_yield();
+    }
+    g_ops.clear();
+}
+}
+
+extern "C" {
+__attribute__((visibility("default"))) int vqmock_rccl_host_buffers() { return haveGpu() ? 0 : 1; }
+__attribute__((visibility("default"))) const char* ncclGetErrorString(ncclResult_t) { return "mock_rccl error"; }
+__attribute__((visibility("default"))) ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+    std::memset(id, 0, sizeof(*id));
+    std::snprintf(id->internal, sizeof(id->internal), "/vqmock_%d_%ld", (int)getpid(), (long)random());
+    const int fd = shm_open(id->internal, O_CREAT | O_EXCL | O_RDWR, 0600);
+    if (fd < 0 || ftruncate(fd, (off_t)sharedBytes()) != 0) return 2;
+    close(fd);                                              // zero-filled: counters start at 0
+    return 0;
+}
+__attribute__((visibility("default"))) ncclResult_t ncclCommInitRank(ncclComm_t* out, int world, ncclUniqueId id, int rank) {
+    if (world > kMaxRanks) return 4;
+    const int fd = shm_open(id.internal, O_RDWR, 0600);
+    if (fd < 0) return 2;
+    void* p = mmap(nullptr, sharedBytes(), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return 2;
+    MockComm* c = new MockComm{ (Shared*)p, world, rank, {} };
+    std::strncpy(c->name, id.internal, sizeof(c->name) - 1);
+    c->sh->arrived.fetch_add(1);
+    while (c->sh->arrived.load() < world) sched_yield();    // collective, like the real one
+    if (rank == 0) shm_unlink(c->name);                     // every rank has it mapped: the name can go
+    *out = c;
+    return 0;
+}
+__attribute__((visibility("default"))) ncclResult_t ncclCommDestroy(ncclComm_t c) { if (c) { munmap(c->sh, sharedBytes()); delete c; } return 0; }
+__attribute__((visibility("default"))) ncclResult_t ncclGroupStart() { ++g_depth; return 0; }
+__attribute__((visibility("default"))) ncclResult_t ncclGroupEnd() { if (--g_depth == 0) runGroup(); return 0; }
+__attribute__((visibility("default"))) ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st) {
+    g_comm = c; g_ops.push_back({ true, (char*)buf, count * elemSize(t), 0, peer, st });
+    if (g_depth == 0) runGroup();
+    return 0;
+}
+__attribute__((visibility("default"))) ncclResult_t ncclRecv(void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st) {
+    g_comm = c; g_ops.push_back({ false, (char*)buf, count * elemSize(t), 0, peer, st });
+    if (g_depth == 0) runGroup();
+    return 0;
+}
+}

@@ -100,9 +100,10 @@ def test_row_tiled_chain_equals_full_frame(world, halo_mode, comp):
 def test_row_tiling_geometry():
     t = tiling.RowTiling(3840, 2160 * 8, 8, 3)
     assert (t.tile_rows, t.row0, t.row1) == (2160, 6480, 8640)
-    with pytest.raises(ValueError):
-        tiling.RowTiling(64, 100, 3, 0)
-    with pytest.raises(ValueError):
+    t = tiling.RowTiling(64, 100, 3, 0)        # uneven heights: the first frame_height % world ranks own one row more (vqhip_rowtile)
+    assert (t.row0, t.tile_rows) == (0, 34) and tiling.RowTiling(64, 100, 3, 2).row1 == 100
+    from vqengine_amd import capi
+    with pytest.raises(capi.VQHipError):
         tiling.RowTiling(64, 16, 2, 0)         # tiles shorter than the 10-row halo
     assert tiling.HALO_ROWS == 10              # KERNEL_RANGE - 1, GaussianBlur.hlsl:54-55
 

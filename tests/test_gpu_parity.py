@@ -357,6 +357,25 @@ def test_forward_cfg3_full_frame_with_ibl(ctx):
 # ---------------------------------------------------------------------------------------------------
 # post chain
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows", [270, 135, 27])
+def test_blur_y_halo_at_the_end_of_an_allocation(ctx, rows):
+    """Tile heights that are no multiple of the 16-row groups of the Y kernels (270 = 2160/8, 135): the register window of the last
+    group extends past the 10 halo rows the filter needs. Those reads must stay inside the caller's 10-row halo buffer: here each
+    halo is the LAST 10 rows of its own exact-size allocation and the result must still equal the untiled blur (all three Y kernels)."""
+    W = 192
+    img = synth.hdr_image(W, rows + 20, seed=0x4A10).astype(np.float16)
+    full = O.blur_pass(img, abi.FMT_RGBA16F, 1)
+    top = dev(img[:10].copy())
+    mid = dev(img[10:10 + rows].copy())
+    bottom = dev(img[10 + rows:].copy())
+    got = ctx.gaussian_blur_y(mid, abi.FMT_RGBA16F, halo_top=top, halo_bottom=bottom)
+    assert_bits(got, full[10:10 + rows], f"blur Y {rows}-row tile with exact-size halos")
+    sdr = ctx.gaussian_blur_y_tonemap(mid, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, halo_top=top, halo_bottom=bottom)
+    assert_bits(sdr, O.tonemap(full[10:10 + rows], abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM), "fused blur Y + tonemap (table kernel or LDS tile)")
+    hdr = ctx.gaussian_blur_y_tonemap(mid, abi.FMT_RGBA16F, abi.FMT_RGBA16F, halo_top=top, halo_bottom=bottom)
+    assert_bits(hdr, O.tonemap(full[10:10 + rows], abi.FMT_RGBA16F, abi.FMT_RGBA16F), "fused blur Y + tonemap, LDS-tile kernel")
+
+
 @pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
 @pytest.mark.parametrize("shape", [(97, 301), (1, 5), (64, 64), (40, 1)])
 def test_blur(ctx, fmt, shape):

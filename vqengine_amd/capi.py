@@ -72,6 +72,13 @@ def load_library():
         "vqhip_fsr_rcas": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(C.c_uint32), i32, i32]),
         "vqhip_visualize": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.VizParams), i32, i32]),
         "vqhip_apply_reflections": (i32, [vp, vp, vp, vp, i32, i32, i32]),
+        "vqhip_rowtile": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
+        "vqhip_comm_unique_id": (i32, [vp]),
+        "vqhip_comm_create": (i32, [vp, i32, i32, C.POINTER(vp)]),
+        "vqhip_comm_adopt": (i32, [vp, i32, i32, C.POINTER(vp)]),
+        "vqhip_comm_destroy": (None, [vp]),
+        "vqhip_exchange_blur_halos": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+        "vqhip_composite_tiles": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
@@ -90,6 +97,8 @@ EXPORTED_SYMBOLS = [
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
     "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
     "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections",
+    "vqhip_rowtile", "vqhip_comm_unique_id", "vqhip_comm_create", "vqhip_comm_adopt", "vqhip_comm_destroy", "vqhip_exchange_blur_halos",
+    "vqhip_composite_tiles",
 ]
 
 
@@ -116,6 +125,71 @@ def hdr_parse_header(data):
         raise VQHipError(rc, (lib.vqhip_last_error(None) or b"").decode())
     return w.value, h.value, off.value
 
+HALO_ROWS = 10            # VQHIP_HALO_ROWS
+ALL_RANKS = -1            # VQHIP_ALL_RANKS
+COMM_ID_BYTES = 128       # VQHIP_COMM_ID_BYTES
+
+
+def _global_error(rc):
+    raise VQHipError(rc, (load_library().vqhip_last_error(None) or b"").decode())
+
+
+def rowtile(frame_height, world, rank):
+    """(row0, rows) of rank `rank` (vqhip_rowtile)."""
+    r0, n = C.c_int(), C.c_int()
+    rc = load_library().vqhip_rowtile(frame_height, world, rank, C.byref(r0), C.byref(n))
+    if rc != 0:
+        _global_error(rc)
+    return r0.value, n.value
+
+
+def comm_unique_id():
+    """bytes(128): ncclGetUniqueId through the C ABI; made on rank 0 and handed to the other ranks out of band."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load_library().vqhip_comm_unique_id(buf)
+    if rc != 0:
+        _global_error(rc)
+    return buf.raw
+
+
+def _addr(x):
+    """device pointer of a torch tensor, or host pointer of a numpy array (the mock-RCCL tests); None -> NULL"""
+    if x is None:
+        return C.c_void_p(None)
+    return C.c_void_p(x.data_ptr()) if hasattr(x, "data_ptr") else C.c_void_p(x.ctypes.data)
+
+
+class Comm:
+    """vqhip_comm: the RCCL communicator of the row-tiled multi-GPU mode (include/vqhip.h). Collective constructor."""
+
+    def __init__(self, unique_id, world, rank):
+        self.lib = load_library()
+        self.world, self.rank = world, rank
+        h = C.c_void_p()
+        rc = self.lib.vqhip_comm_create(unique_id, world, rank, C.byref(h))
+        if rc != 0:
+            _global_error(rc)
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vqhip_comm_destroy(self._h)
+            self._h = None
+
+    def exchange_blur_halos(self, x_tile, fmt, halo_top, halo_bottom, stream=None):
+        """x_tile [rows, W, 4]; halo_top / halo_bottom: preallocated [10, W, 4] buffers (None at the frame's edges)."""
+        rows, w = x_tile.shape[0], x_tile.shape[1]
+        rc = self.lib.vqhip_exchange_blur_halos(self._h, stream, _addr(x_tile), w, rows, w, fmt, _addr(halo_top), _addr(halo_bottom))
+        if rc != 0:
+            _global_error(rc)
+
+    def composite_tiles(self, tile, fmt, frame_height, root, frame, stream=None):
+        """tile [rows, W, C] -> frame [frame_height, W, C] on `root` (or every rank: ALL_RANKS)."""
+        rc = self.lib.vqhip_composite_tiles(self._h, stream, _addr(tile), tile.shape[1], frame_height, fmt, root, _addr(frame))
+        if rc != 0:
+            _global_error(rc)
+
+
 _TORCH_DTYPE = {FMT_RGBA32F: (torch.float32, 4), FMT_RGBA16F: (torch.float16, 4), FMT_RGBA8_UNORM: (torch.uint8, 4),
                 FMT_RG16F: (torch.float16, 2), FMT_RG32F: (torch.float32, 2)}
 
@@ -129,10 +203,26 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
 
 
-def _check_img(t, fmt, name):
+def _check_img(t, fmt, name, hw=None):
+    """contiguous cuda image of `fmt`; hw = (rows, width) it must have (the C ABI takes raw pointers: a smaller `out` would be an
+    out-of-bounds device write)."""
     dt, ch = _TORCH_DTYPE[fmt]
     if not (t.is_cuda and t.is_contiguous() and t.dtype == dt and t.shape[-1] == ch):
         raise ValueError(f"{name}: expected contiguous cuda tensor [...,{ch}] of {dt}, got {tuple(t.shape)} {t.dtype} {t.device}")
+    if hw is not None and tuple(t.shape[:2]) != tuple(hw):
+        raise ValueError(f"{name}: expected {hw[0]} x {hw[1]} pixels, got {tuple(t.shape[:2])}")
+
+
+def _halo_rows(halo_top, halo_bottom, fmt, width):
+    """Both halos of a tile have the same row count (>= 10) and the tile's width and format."""
+    rows = 0
+    for hh in (halo_top, halo_bottom):
+        if hh is not None:
+            _check_img(hh, fmt, "halo", (hh.shape[0], width))
+            if rows and hh.shape[0] != rows:
+                raise ValueError(f"halo_top and halo_bottom must have the same number of rows, got {rows} and {hh.shape[0]}")
+            rows = hh.shape[0]
+    return rows
 
 
 class Context:
@@ -170,12 +260,12 @@ class Context:
     def forward_lighting(self, gb, per_frame, per_view, out=None, out_fmt=FMT_RGBA16F, extra_point=None, env=None, shadow=None, stream=None):
         """gb: tuple of 4 float32 cuda tensors [H,W,4] (gb0..gb3). env: abi.EnvMap or None. Returns out tensor."""
         g0, g1, g2, g3 = gb
-        for i, g in enumerate(gb):
-            _check_img(g, FMT_RGBA32F, f"gb{i}")
         h, w = g0.shape[0], g0.shape[1]
+        for i, g in enumerate(gb):
+            _check_img(g, FMT_RGBA32F, f"gb{i}", (h, w))             # all four planes share one shape
         if out is None:
             out = empty_image(h, w, out_fmt, self.device)
-        _check_img(out, out_fmt, "out")
+        _check_img(out, out_fmt, "out", (h, w))
         gbuf = abi.GBuffer(g0.data_ptr(), g1.data_ptr(), g2.data_ptr(), g3.data_ptr(), w, h, w)
         n_extra = 0
         extra_ptr = C.c_void_p(None)
@@ -194,6 +284,7 @@ class Context:
         h, w = src.shape[0], src.shape[1]
         tmp = tmp if tmp is not None else torch.empty_like(src)
         out = out if out is not None else torch.empty_like(src)
+        _check_img(tmp, fmt, "tmp", (h, w)); _check_img(out, fmt, "out", (h, w))
         p = abi.BlurParams(w, h)
         self._ck(self.lib.vqhip_gaussian_blur(self._h, self._stream(stream), _ptr(src), _ptr(tmp), _ptr(out), C.byref(p), fmt))
         return out
@@ -201,6 +292,7 @@ class Context:
     def gaussian_blur_x(self, src, fmt, out=None, stream=None):
         _check_img(src, fmt, "src")
         out = out if out is not None else torch.empty_like(src)
+        _check_img(out, fmt, "out", src.shape[:2])
         p = abi.BlurParams(src.shape[1], src.shape[0])
         self._ck(self.lib.vqhip_gaussian_blur_x(self._h, self._stream(stream), _ptr(src), _ptr(out), C.byref(p), fmt))
         return out
@@ -208,11 +300,8 @@ class Context:
     def gaussian_blur_y(self, src, fmt, out=None, halo_top=None, halo_bottom=None, stream=None):
         _check_img(src, fmt, "src")
         out = out if out is not None else torch.empty_like(src)
-        rows = 0
-        for hh in (halo_top, halo_bottom):
-            if hh is not None:
-                _check_img(hh, fmt, "halo")
-                rows = hh.shape[0]
+        _check_img(out, fmt, "out", src.shape[:2])
+        rows = _halo_rows(halo_top, halo_bottom, fmt, src.shape[1])
         p = abi.BlurParams(src.shape[1], src.shape[0])
         self._ck(self.lib.vqhip_gaussian_blur_y(self._h, self._stream(stream), _ptr(src), _ptr(out), _ptr(halo_top), _ptr(halo_bottom), rows, C.byref(p), fmt))
         return out
@@ -222,12 +311,8 @@ class Context:
         _check_img(src, fmt, "src")
         h, w = src.shape[0], src.shape[1]
         out = out if out is not None else empty_image(h, w, out_fmt, self.device)
-        _check_img(out, out_fmt, "out")
-        rows = 0
-        for hh in (halo_top, halo_bottom):
-            if hh is not None:
-                _check_img(hh, fmt, "halo")
-                rows = hh.shape[0]
+        _check_img(out, out_fmt, "out", (h, w))
+        rows = _halo_rows(halo_top, halo_bottom, fmt, w)
         params = params if params is not None else abi.TonemapperParams.default()
         p = abi.BlurParams(w, h)
         self._ck(self.lib.vqhip_gaussian_blur_y_tonemap(self._h, self._stream(stream), _ptr(src), _ptr(out), _ptr(halo_top), _ptr(halo_bottom), rows,
@@ -238,7 +323,7 @@ class Context:
         _check_img(src, in_fmt, "src")
         h, w = src.shape[0], src.shape[1]
         out = out if out is not None else empty_image(h, w, out_fmt, self.device)
-        _check_img(out, out_fmt, "out")
+        _check_img(out, out_fmt, "out", (h, w))
         params = params if params is not None else abi.TonemapperParams.default()
         self._ck(self.lib.vqhip_tonemap(self._h, self._stream(stream), _ptr(src), _ptr(out), w, h, C.byref(params), in_fmt, out_fmt))
         return out
@@ -300,7 +385,7 @@ class Context:
         con = fsr_easu_con(w, h, out_w, out_h) if con is None else con
         if out is None:
             out = empty_image(out_h, out_w, out_fmt, self.device)
-        _check_img(out, out_fmt, "out")
+        _check_img(out, out_fmt, "out", (out_h, out_w))
         self._ck(self.lib.vqhip_fsr_easu(self._h, self._stream(stream), _ptr(src), w, h, in_fmt, con, _ptr(out), out_w, out_h, out_fmt))
         return out
 
@@ -311,7 +396,7 @@ class Context:
         con = fsr_rcas_con() if con is None else con
         if out is None:
             out = empty_image(h, w, out_fmt, self.device)
-        _check_img(out, out_fmt, "out")
+        _check_img(out, out_fmt, "out", (h, w))
         self._ck(self.lib.vqhip_fsr_rcas(self._h, self._stream(stream), _ptr(src), _ptr(out), w, h, con, in_fmt, out_fmt))
         return out
 

@@ -25,7 +25,12 @@ struct vqhip_ctx {
     int nextSlot = 0;
     void* scratch = nullptr; size_t scratchBytes = 0;
     int pow5ExpLog = 0;            // vqhip_set_fresnel_pow
-    void* tonemapLut = nullptr;    // 128 KB: 65536-entry tonemap table (post.hip:k_tonemap_lut)
+    // 65536-entry tonemap tables (post.hip:k_tonemap_lut), cached per (TonemapperParams, output format): the table is built once
+    // per parameter set instead of once per frame, and two streams of one context can no longer race on a shared scratch table.
+    static constexpr int kLuts = 4;
+    struct TonemapLut { void* table = nullptr; VQ_TonemapperParams key{}; int outFmt = -1; bool valid = false;
+                        hipEvent_t built = nullptr, lastUse = nullptr; bool used = false; } lut[kLuts];
+    int nextLut = 0;
     std::string lastError;
 };
 
@@ -75,6 +80,36 @@ int ensureScratch(vqhip_ctx* ctx, size_t bytes) {
     return VQHIP_OK;
 }
 
+// The tonemap table of (p, outFmt), ready to be read by work enqueued on `st` after this call: a cached table makes `st` wait for the
+// event of its build (it may have happened on another stream); a miss rebuilds the least recently claimed slot on `st`, after the
+// last reader of the table that is being replaced. The caller records the slot's lastUse event once its kernel is enqueued.
+int acquireTonemapLut(vqhip_ctx* ctx, hipStream_t st, const VQ_TonemapperParams& p, int outFmt, int* slotOut) {
+    for (int i = 0; i < vqhip_ctx::kLuts; ++i) {
+        auto& L = ctx->lut[i];
+        if (L.valid && L.outFmt == outFmt && std::memcmp(&L.key, &p, sizeof(p)) == 0) {
+            HIP_TRY(ctx, hipStreamWaitEvent(st, L.built, 0));
+            *slotOut = i;
+            return VQHIP_OK;
+        }
+    }
+    const int i = ctx->nextLut;
+    ctx->nextLut = (i + 1) % vqhip_ctx::kLuts;
+    auto& L = ctx->lut[i];
+    if (L.used) HIP_TRY(ctx, hipStreamWaitEvent(st, L.lastUse, 0));
+    L.valid = false;
+    hipError_t e = launch_tonemap_lut_build(st, L.table, p, outFmt);
+    if (e != hipSuccess) return failHip(ctx, e, "tonemap table build launch");
+    HIP_TRY(ctx, hipEventRecord(L.built, st));
+    L.key = p; L.outFmt = outFmt; L.valid = true; L.used = false;
+    *slotOut = i;
+    return VQHIP_OK;
+}
+int releaseTonemapLut(vqhip_ctx* ctx, hipStream_t st, int slot) {
+    HIP_TRY(ctx, hipEventRecord(ctx->lut[slot].lastUse, st));
+    ctx->lut[slot].used = true;
+    return VQHIP_OK;
+}
+
 int mipDim(int d0, int l) { int d = d0 >> l; return d < 1 ? 1 : d; }
 
 // Smallest float t >= 0 with sqrtf(t) >= range: `length(Lw - P) < range` (Lighting.hlsl:318) <=> `dot(d,d) < t` exactly, because the
@@ -91,6 +126,8 @@ float rangeCullThreshold(float range) {
 }
 
 } // namespace
+
+namespace vqk { int fail_global(int code, const std::string& msg) { return fail(nullptr, code, msg); } }     // for mgpu.hip (no context)
 
 extern "C" {
 
@@ -119,7 +156,9 @@ int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
         vqhip_destroy(ctx);
         return rc;
     }
-    if ((e = hipMalloc(&ctx->tonemapLut, 131072)) != hipSuccess) { int rc = failHip(nullptr, e, "vqhip_create: tonemap table"); vqhip_destroy(ctx); return rc; }
+    for (int i = 0; i < vqhip_ctx::kLuts; ++i)
+        if ((e = hipMalloc(&ctx->lut[i].table, 131072)) != hipSuccess || (e = hipEventCreateWithFlags(&ctx->lut[i].built, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->lut[i].lastUse, hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "vqhip_create: tonemap tables"); vqhip_destroy(ctx); return rc; }
     for (int i = 0; i < vqhip_ctx::kSlots; ++i)
         if ((e = hipEventCreateWithFlags(&ctx->slotEvent[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->copyEvent[i], hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "hipEventCreate"); vqhip_destroy(ctx); return rc; }
@@ -137,7 +176,11 @@ void vqhip_destroy(vqhip_ctx* ctx) {
     if (ctx->hostRing) (void)hipHostFree(ctx->hostRing);
     if (ctx->devRing) (void)hipFree(ctx->devRing);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->tonemapLut) (void)hipFree(ctx->tonemapLut);
+    for (int i = 0; i < vqhip_ctx::kLuts; ++i) {
+        if (ctx->lut[i].table) (void)hipFree(ctx->lut[i].table);
+        if (ctx->lut[i].built) (void)hipEventDestroy(ctx->lut[i].built);
+        if (ctx->lut[i].lastUse) (void)hipEventDestroy(ctx->lut[i].lastUse);
+    }
     delete ctx;
 }
 
@@ -241,8 +284,12 @@ int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const void* in, 
     if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: in-place is not supported");
     if ((halo_top || halo_bottom) && halo_rows < 10) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: halo_rows must be >= 10");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = launch_blur_y_tonemap((hipStream_t)stream, in, out, halo_top, halo_bottom, halo_rows, p->iImageSizeX, p->iImageSizeY, *tm, blurFmt, outFmt, ctx->tonemapLut);
-    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "blur_y_tonemap launch");
+    int slot = -1;
+    if (blur_y_tonemap_uses_lut(*tm, blurFmt, outFmt, (size_t)p->iImageSizeX * p->iImageSizeY)) { const int rc = acquireTonemapLut(ctx, (hipStream_t)stream, *tm, outFmt, &slot); if (rc) return rc; }
+    hipError_t e = launch_blur_y_tonemap((hipStream_t)stream, in, out, halo_top, halo_bottom, halo_rows, p->iImageSizeX, p->iImageSizeY, *tm, blurFmt, outFmt,
+                                         slot >= 0 ? ctx->lut[slot].table : nullptr);
+    if (e != hipSuccess) return failHip(ctx, e, "blur_y_tonemap launch");
+    return slot >= 0 ? releaseTonemapLut(ctx, (hipStream_t)stream, slot) : VQHIP_OK;
 }
 
 int vqhip_gaussian_blur(vqhip_ctx* ctx, void* stream, const void* in, void* tmp, void* out, const VQ_BlurParams* p, vqhip_format fmt) {
@@ -259,8 +306,11 @@ int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int w
     if (!isImageFmt(inFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "tonemap: inFmt must be RGBA32F or RGBA16F");
     if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "tonemap: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = launch_tonemap((hipStream_t)stream, in, out, width, height, *p, inFmt, outFmt, ctx->tonemapLut);
-    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "tonemap launch");
+    int slot = -1;
+    if (tonemap_uses_lut(*p, inFmt, outFmt, (size_t)width * height)) { const int rc = acquireTonemapLut(ctx, (hipStream_t)stream, *p, outFmt, &slot); if (rc) return rc; }
+    hipError_t e = launch_tonemap((hipStream_t)stream, in, out, width, height, *p, inFmt, outFmt, slot >= 0 ? ctx->lut[slot].table : nullptr);
+    if (e != hipSuccess) return failHip(ctx, e, "tonemap launch");
+    return slot >= 0 ? releaseTonemapLut(ctx, (hipStream_t)stream, slot) : VQHIP_OK;
 }
 
 int vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode) {

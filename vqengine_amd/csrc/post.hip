@@ -156,8 +156,10 @@ __global__ __launch_bounds__(256) void k_blur_y(const void* __restrict__ in, voi
     for (int i = 0; i < ROWS + 2 * R; ++i) {
         int sy = yBase - R + i;
         float4 s;
-        if (sy < 0 && haloTop)              s = load_px<FMT>(haloTop, (size_t)(haloRows + sy) * W + x);
-        else if (sy > H - 1 && haloBottom)  s = load_px<FMT>(haloBottom, (size_t)(sy - H) * W + x);
+        // window rows beyond the 10 the filter reaches (tile heights that are no multiple of ROWS) feed no valid output: their index is
+        // clamped into the halo buffer so that no row outside the caller's haloRows-row allocation is ever touched
+        if (sy < 0 && haloTop)              s = load_px<FMT>(haloTop, (size_t)(haloRows + max(sy, -haloRows)) * W + x);
+        else if (sy > H - 1 && haloBottom)  s = load_px<FMT>(haloBottom, (size_t)min(sy - H, haloRows - 1) * W + x);
         else { sy = min(max(sy, 0), H - 1); s = load_px<FMT>(in, (size_t)sy * W + x); }      // clamp :178
         wx[i] = s.x; wy[i] = s.y; wz[i] = s.z;
     }
@@ -238,8 +240,8 @@ __global__ __launch_bounds__(256) void k_blur_y_tonemap(const void* __restrict__
     for (int i = g; i < TR + 2 * R; i += 4) {                 // 4 waves stream the rows, 64 contiguous pixels each
         int sy = y0 - R + i;
         const void* src = in; size_t idx;
-        if (sy < 0 && haloTop)             { src = haloTop;    idx = (size_t)(haloRows + sy) * W + xc; }
-        else if (sy > H - 1 && haloBottom) { src = haloBottom; idx = (size_t)(sy - H) * W + xc; }
+        if (sy < 0 && haloTop)             { src = haloTop;    idx = (size_t)(haloRows + max(sy, -haloRows)) * W + xc; }      // never outside the halo buffer
+        else if (sy > H - 1 && haloBottom) { src = haloBottom; idx = (size_t)min(sy - H, haloRows - 1) * W + xc; }
         else                               { sy = min(max(sy, 0), H - 1); idx = (size_t)sy * W + xc; }            // clamp :178
         if (FMT == 0) ((float4*)tile)[i * 64 + c] = ((const float4*)src)[idx];
         else          ((h4*)tile)[i * 64 + c] = ((const h4*)src)[idx];
@@ -337,8 +339,8 @@ __global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restri
         for (int i = 0; i < ROWS + 2 * R; ++i) {
             int sy = yBase - R + i;
             float4 s;
-            if (sy < 0 && haloTop)              s = load_px<1>(haloTop, (size_t)(haloRows + sy) * W + x);
-            else if (sy > H - 1 && haloBottom)  s = load_px<1>(haloBottom, (size_t)(sy - H) * W + x);
+            if (sy < 0 && haloTop)              s = load_px<1>(haloTop, (size_t)(haloRows + max(sy, -haloRows)) * W + x);      // never outside the halo buffer
+            else if (sy > H - 1 && haloBottom)  s = load_px<1>(haloBottom, (size_t)min(sy - H, haloRows - 1) * W + x);
             else { sy = min(max(sy, 0), H - 1); s = load_px<1>(in, (size_t)sy * W + x); }      // clamp :178
             wx[i] = s.x; wy[i] = s.y; wz[i] = s.z;
         }
@@ -408,23 +410,34 @@ hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* h
     return hipGetLastError();
 }
 
-hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, void* lutScratch) {
+static bool perChannelCurve(const VQ_TonemapperParams& p) {
+    return p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_SRGB || p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_LINEAR ||
+           (p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_ST2084 && p.ContentColorSpaceEnum != VQ_COLOR_SPACE_REC_709);
+}
+// the table path applies: RGBA16F in, a curve that does not mix channels, an 8-bit or fp16 target and enough pixels to pay for the table load
+bool tonemap_uses_lut(const VQ_TonemapperParams& p, int inFmt, int outFmt, size_t nPixels) {
+    return perChannelCurve(p) && inFmt == VQHIP_FMT_RGBA16F && (outFmt == VQHIP_FMT_RGBA8_UNORM || outFmt == VQHIP_FMT_RGBA16F) && nPixels >= (size_t)1 << 16;
+}
+bool blur_y_tonemap_uses_lut(const VQ_TonemapperParams& p, int blurFmt, int outFmt, size_t nPixels) {
+    return perChannelCurve(p) && blurFmt == VQHIP_FMT_RGBA16F && outFmt == VQHIP_FMT_RGBA8_UNORM && nPixels >= (size_t)1 << 16;
+}
+hipError_t launch_tonemap_lut_build(hipStream_t s, void* table, const VQ_TonemapperParams& p, int outFmt) {
+    if (outFmt == VQHIP_FMT_RGBA8_UNORM) hipLaunchKernelGGL((k_tonemap_lut_build<2>), dim3(256), dim3(256), 0, s, table, p);
+    else                                 hipLaunchKernelGGL((k_tonemap_lut_build<1>), dim3(256), dim3(256), 0, s, table, p);
+    return hipGetLastError();
+}
+
+// lutTable: NULL, or the table of (p, outFmt) built by launch_tonemap_lut_build (the context caches it per parameter set, capi.hip)
+hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, const void* lutTable) {
     const size_t n = (size_t)W * H;
-    const bool perChannel = p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_SRGB || p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_LINEAR ||
-                            (p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_ST2084 && p.ContentColorSpaceEnum != VQ_COLOR_SPACE_REC_709);
-    if (lutScratch && perChannel && inFmt == VQHIP_FMT_RGBA16F && (outFmt == VQHIP_FMT_RGBA8_UNORM || outFmt == VQHIP_FMT_RGBA16F) && n >= (size_t)1 << 16) {
+    if (lutTable && tonemap_uses_lut(p, inFmt, outFmt, n)) {
         if (outFmt == VQHIP_FMT_RGBA8_UNORM) {
-            hipLaunchKernelGGL((k_tonemap_lut_build<2>), dim3(256), dim3(256), 0, s, lutScratch, p);
-            hipLaunchKernelGGL((k_tonemap_lut<2>), dim3(512), dim3(1024), 65536, s, (const uint2*)in, out, n, (const void*)lutScratch);
+            hipLaunchKernelGGL((k_tonemap_lut<2>), dim3(512), dim3(1024), 65536, s, (const uint2*)in, out, n, lutTable);
         } else {
-            static bool attrSet = false;                      // > 64 KB of dynamic LDS needs the opt-in once per process
-            if (!attrSet) {
-                hipError_t e = hipFuncSetAttribute((const void*)k_tonemap_lut<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-                if (e != hipSuccess) return e;
-                attrSet = true;
-            }
-            hipLaunchKernelGGL((k_tonemap_lut_build<1>), dim3(256), dim3(256), 0, s, lutScratch, p);
-            hipLaunchKernelGGL((k_tonemap_lut<1>), dim3(256), dim3(1024), 131072, s, (const uint2*)in, out, n, (const void*)lutScratch);
+            // > 64 KB of dynamic LDS needs the opt-in; it is a per-device function attribute and cheap, so it is simply set on every launch
+            hipError_t e = hipFuncSetAttribute((const void*)k_tonemap_lut<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((k_tonemap_lut<1>), dim3(256), dim3(1024), 131072, s, (const uint2*)in, out, n, lutTable);
         }
         return hipGetLastError();
     }
@@ -440,14 +453,11 @@ hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H
 }
 
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
-                                 const VQ_TonemapperParams& p, int fmt, int outFmt, void* lutScratch) {
-    const bool perChannel = p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_SRGB || p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_LINEAR ||
-                            (p.OutputDisplayCurveEnum == VQ_DISPLAY_CURVE_ST2084 && p.ContentColorSpaceEnum != VQ_COLOR_SPACE_REC_709);
-    if (lutScratch && perChannel && fmt == VQHIP_FMT_RGBA16F && outFmt == VQHIP_FMT_RGBA8_UNORM && (size_t)W * H >= (size_t)1 << 16) {
+                                 const VQ_TonemapperParams& p, int fmt, int outFmt, const void* lutTable) {
+    if (lutTable && blur_y_tonemap_uses_lut(p, fmt, outFmt, (size_t)W * H)) {
         const int tilesX = (W + 63) / 64, tilesY = (H + 127) / 128, nTiles = tilesX * tilesY;
-        hipLaunchKernelGGL((k_tonemap_lut_build<2>), dim3(256), dim3(256), 0, s, lutScratch, p);
         hipLaunchKernelGGL((k_blur_y_tonemap_lut<16>), dim3(nTiles < 512 ? nTiles : 512), dim3(512), 0, s, in, out, haloTop, haloBottom, haloRows, W, H,
-                           (const void*)lutScratch, tilesX, nTiles);
+                           lutTable, tilesX, nTiles);
         return hipGetLastError();
     }
 #ifndef VQ_FUSED_TR

@@ -169,8 +169,8 @@ VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
         const float rD = rc(D);
         const f3 Wi = mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P)
         const f3 Hs = add(px.Wo, Wi);
-        const bool okH = (dot_lit(Hs, Hs) >= 0x1p-100f) & (min3abs(Hs) >= 0x1p-78f);
-        ok = ok & okH;
+        const bool okHh = dot_lit(Hs, Hs) >= 0x1p-100f, okHm = min3abs(Hs) >= 0x1p-78f;
+        ok = ok & okHh & okHm;
         const float NdotL = saturate(dot(px.Nraw, Wi));
         const float w = (rD * rD) * NdotL;
         const f3 b = brdf_t(px, Wi, rc);

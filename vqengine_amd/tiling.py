@@ -6,24 +6,51 @@ light arrays / env cubemaps / LUT are replicated, and only two exchanges touch t
                   has its own xGMI link), or — as BASELINE.json words it — one small all-gather of boundary rows;
   2. composite  — all-gather of the tonemapped tiles so every rank holds the whole frame.
 
-Works on any torch.distributed backend: "nccl" (= RCCL over xGMI) with CUDA tensors on the GPU box, "gloo" with
-CPU tensors in the unit tests. There is no collective in the shade / X-blur / tonemap stages."""
+The PRODUCT data path is the C ABI: vqhip_exchange_blur_halos / vqhip_composite_tiles (vqengine_amd/csrc/mgpu.hip, RCCL
+send/recv on the caller's stream), bound here as `RowTiledFrame`; bench.py uses nothing else between its kernels. The
+torch.distributed functions further down state the same two exchanges on any backend ("gloo" with CPU tensors): they are the
+independent second statement the CPU tests compare the tiling against (tests/test_distributed_cpu.py), not the product path.
+There is no collective in the shade / X-blur / tonemap stages."""
 import torch
 import torch.distributed as dist
 
-HALO_ROWS = 10  # KERNEL_RANGE_MINUS1, Shaders/GaussianBlur.hlsl:54-55
+from . import capi
+
+HALO_ROWS = capi.HALO_ROWS  # KERNEL_RANGE_MINUS1, Shaders/GaussianBlur.hlsl:54-55
 
 
 class RowTiling:
+    """Rows of rank `rank` == vqhip_rowtile: frame_height // world each, the first frame_height % world ranks one more."""
+
     def __init__(self, width, frame_height, world_size, rank):
-        if frame_height % world_size:
-            raise ValueError(f"frame height {frame_height} is not divisible by world size {world_size}")
         self.width, self.frame_height, self.world, self.rank = width, frame_height, world_size, rank
-        self.tile_rows = frame_height // world_size
-        if world_size > 1 and self.tile_rows < HALO_ROWS:
-            raise ValueError("tiles must be at least 10 rows tall (the halo comes from the direct neighbour only)")
-        self.row0 = rank * self.tile_rows
+        self.row0, self.tile_rows = capi.rowtile(frame_height, world_size, rank)
         self.row1 = self.row0 + self.tile_rows
+
+
+class RowTiledFrame:
+    """The two exchanges of a row-tiled frame through the C ABI (RCCL). `unique_id` comes from capi.comm_unique_id() on rank 0 and
+    reaches the other ranks out of band (bench.py broadcasts it with torch.distributed — control plane only). Buffers are the caller's:
+    device tensors, or numpy arrays with the shared-memory mock RCCL of the tests (tests/cpp/mock_rccl.cpp)."""
+
+    def __init__(self, unique_id, width, frame_height, world, rank):
+        self.tiling = RowTiling(width, frame_height, world, rank)
+        self.comm = capi.Comm(unique_id, world, rank)
+
+    def close(self):
+        self.comm.close()
+
+    def exchange_blur_halos(self, x_tile, fmt, halo_top, halo_bottom, stream=None):
+        """halo_top / halo_bottom: caller-owned [10, W, 4] buffers; returns the pair with None for a frame edge."""
+        t = self.tiling
+        top = halo_top if t.rank > 0 else None
+        bottom = halo_bottom if t.rank < t.world - 1 else None
+        self.comm.exchange_blur_halos(x_tile, fmt, top, bottom, stream)
+        return top, bottom
+
+    def composite(self, tile, fmt, frame, root=0, stream=None):
+        self.comm.composite_tiles(tile, fmt, self.tiling.frame_height, root, frame, stream)
+        return frame
 
 
 def exchange_halos_p2p(x_tile, group=None):
