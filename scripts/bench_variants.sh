@@ -3,6 +3,6 @@
 cp vqengine_amd/lib/libvqhip.so /tmp/base.so
 for v in base "$@"; do
   if [ $v = base ]; then cp /tmp/base.so vqengine_amd/lib/libvqhip.so; else cp scripts/variants/libvqhip_$v.so vqengine_amd/lib/libvqhip.so; fi
-  python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['stages'])"
+  python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-second-mode 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', d['value'], d['stages'])"
 done
 cp /tmp/base.so vqengine_amd/lib/libvqhip.so

@@ -35,11 +35,14 @@ struct Pixel {
     float k, omk;                         // k = (roughness+1)^2/8, omk = 1-k
     float a2, a2m1;                       // GGX alpha^2, alpha^2 - 1
     float a2G1V;                          // a2 * G1V: the light-independent part of the merged D*G numerator
-    bool p5ExpLog;                        // wave-uniform: Fresnel pow as exp2(5*log2 x) instead of the product (vqhip_set_fresnel_pow)
+    bool p5ExpLog;                        // wave-uniform: Fresnel pow as exp2(5*log2 x) instead of the product (vqhip_set_fresnel_pow). Kept a RUN-TIME
+                                          // flag on purpose: with the mode as a template parameter (no branch in the light loop) the same arithmetic ran
+                                          // 9 % slower on the same box (profiles/r2c_shade_variants.md) — the scheduler's choice for the longer block
     bool fastOK;                          // roughness in [0,1]: precondition of the unchecked fast reciprocals (add_point_light)
 };
 
 VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
+VQD float min3abs(f3 v) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)); }   // one v_min3_f32 with |.| modifiers
 
 VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.P = mk3(g0.x, g0.y, g0.z);
@@ -67,7 +70,9 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.a2 = a * a;
     px.a2m1 = px.a2 - 1.0f;
     px.a2G1V = px.a2 * px.G1V;
-    px.fastOK = (px.roughness >= 0.04f) & (px.roughness <= 1.0f);     // below 0.04 the GGX EPSILON early-out may fire: IEEE path
+    // preconditions of the unchecked fast path of add_point_light that depend on the pixel only: roughness in [0.04, 1] (below 0.04 the GGX
+    // EPSILON early-out may fire) and a finite Wo (with a finite Wi it makes Wo + Wi free of NaN, which the min3 test there cannot see)
+    px.fastOK = (px.roughness >= 0.04f) & (px.roughness <= 1.0f) & (dot_lit(px.Wo, px.Wo) <= 4.0f);      // the comparison is false for a NaN component
 }
 
 // BRDF(s, Wi, V), BRDF.hlsl:163-194. As written: H = normalize(Wo + Wi) (IEEE quotients through rc.div), NdotH, nh2*(a2-1)+1.
@@ -141,11 +146,11 @@ VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op va
 //              pi t^2 in [1.9e-11, pi] (t = fma(nh2, a2-1, 1) in [a2 - 2^-25, 1], nh2 saturated)
 //              denom = max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
 //              => the merged reciprocal's operand (pi t^2 * gL) * denom in [2.4e-16, 17.6]: operand and result normal
-//   light  : dd = |Lw-P|^2 in [2^-60, 2^60] =>  D in [2^-30, 2^30], 1/D normal (and (1/D)^2 is a plain product)
-//   light  : hh = |Wo+Wi|^2 >= 2^-100 (and not NaN; it is <= ~4 for unit Wo, Wi) => sqrt and 1/sqrt normal
-//   light  : every component of Lw-P and of Wo+Wi has magnitude >= 2^-78 (one v_min3 each) => the corrected quotients d/D, Hs/|Hs|
-//            (fdiv_rcp: exhaustively equal to IEEE division when nothing underflows) are the IEEE quotients; a zero or denormal
-//            component (a light exactly above the pixel on one axis) takes the IEEE path for that light
+//   light  : every component of Lw-P has magnitude >= 2^-40 (one v_min3) and dd = |Lw-P|^2 <= 2^60 (false for NaN / inf operands too)
+//            => dd in [2^-80, 2^60], D in [2^-40, 2^30]: sqrt, 1/D normal ((1/D)^2 is a plain product), quotients d/D free of underflow
+//   light  : every component of Wo+Wi has magnitude >= 2^-40 (one v_min3; Wo, Wi finite => no NaN) => hh = |Wo+Wi|^2 in [2^-80, ~4]
+//   => the corrected quotients d/D, Hs/|Hs| (fdiv_rcp: exhaustively equal to IEEE division when nothing underflows) are the IEEE
+//      quotients; a zero or tiny component (a light exactly above the pixel on one axis) takes the IEEE path for that light
 // all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
 // degenerate geometry, roughness outside [0,1]) redoes that light with IEEE operations; results are identical bits.
 struct RcpTrust {
@@ -156,21 +161,20 @@ struct RcpTrust {
     VQD float sqrt(float x) const { return sqrt_newton(x); }
     VQD float div(float a, float b, float r) const { return fdiv_rcp(a, b, r); }
 };
-VQD float min3abs(f3 v) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)); }   // one v_min3_f32 with |.| modifiers
 VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
     const f3 Iprev = I;
     const f3 lpos = mk3(l.px, l.py, l.pz), cb = mk3(l.cbx, l.cby, l.cbz);
     const f3 d = sub(lpos, px.P);
     const float dd = dot_lit(d, d);                          // as written: D decides the range cull
-    bool ok = px.fastOK & (dd >= 0x1p-60f) & (dd <= 0x1p60f) & (min3abs(d) >= 0x1p-78f);
+    bool ok = px.fastOK & (dd <= 0x1p60f) & (min3abs(d) >= 0x1p-40f);
     if (dd < l.rangeSq) {                                    // == (length(Lw - P) < l.range), exactly (host-made threshold): culled lights
         RcpTrust rc;                                         // need no square root; wave-coherent (execz skip)
         const float D = sqrt_newton(dd);
         const float rD = rc(D);
         const f3 Wi = mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P)
         const f3 Hs = add(px.Wo, Wi);
-        const bool okHh = dot_lit(Hs, Hs) >= 0x1p-100f, okHm = min3abs(Hs) >= 0x1p-78f;
-        ok = ok & okHh & okHm;
+        const bool okH = min3abs(Hs) >= 0x1p-40f;
+        ok = ok & okH;
         const float NdotL = saturate(dot(px.Nraw, Wi));
         const float w = (rD * rD) * NdotL;
         const f3 b = brdf_t(px, Wi, rc);
@@ -297,8 +301,8 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
 
     Pixel px;
     const f3 cam = ld3(fc->perView.CameraPosition);
-    setup_pixel(px, g0, g1, g2, cam);
     px.p5ExpLog = fc->pow5ExpLog != 0;
+    setup_pixel(px, g0, g1, g2, cam);
     const float ao = g0.w;
     // illumination accumulators, ForwardLighting.hlsl:290-293: diffuse*ao + emissive*intensity, as written
     f3 I = mk3(px.albedo.x * ao + g3.x * g3.w, px.albedo.y * ao + g3.y * g3.w, px.albedo.z * ao + g3.z * g3.w);
