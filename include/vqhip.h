@@ -240,8 +240,14 @@ typedef struct vqhip_envmap_out {
  *          (Renderer_Resources.cpp:385-387): every sample returns 0. */
 typedef struct vqhip_texture2d {
     const void* texels;
-    int32_t width, height, mips, reserved;
+    int32_t width, height, mips, reserved;   /* reserved: 0, except vqhip_material.texDiffuse.reserved = material flags (below) */
 } vqhip_texture2d;
+/* vqhip_material.texDiffuse.reserved bit 0: the material is drawn with the "_AlphaMasked" PSO permutation, i.e. PSMain compiled with
+ * ENABLE_ALPHA_MASK (PipelineStateObjects.cpp:1477,1571) — chosen by Material::IsAlphaMasked (Material.cpp:39: an alpha-mask map is
+ * bound, or the diffuse map uses its alpha channel). Then `if (HasDiffuseMap(TEX_CFG) && AlbedoAlpha.a < 0.01f) discard;`
+ * (ForwardLighting.hlsl:237-240): vqhip_gbuffer_from_materials gives such a pixel an all-zero record AND rewrites its material index in
+ * ip2.w to -1 (in place), so that it reads as "no geometry" to vqhip_skydome / vqhip_unlit_composite, like a discarded fragment. */
+#define VQHIP_MATERIAL_ALPHA_MASKED 1
 
 /* cbPerObject.materialData + the descriptor table t0..t7 of ForwardLighting.hlsl:84-92 that
  * AssetLoader.cpp:406-420 fills per material (t3 texAlphaMask and t8 texHeightmap are not read by
@@ -398,7 +404,8 @@ VQHIP_API int vqhip_envmap_prefilter(vqhip_ctx* ctx, void* stream, const void* e
  * multiplies — for every pixel of the interpolant planes at once, each pixel using
  * materials[materialIndex] (the reference binds one material per draw: SceneRendering.cpp:1744-1750).
  * Writes the four planes of `out` (their pointers are written through despite the const in
- * vqhip_gbuffer); pixels without geometry get all-zero records.
+ * vqhip_gbuffer); pixels without geometry get all-zero records, and so do the fragments an alpha-masked material discards
+ * (VQHIP_MATERIAL_ALPHA_MASKED: their index in in->ip2 is overwritten with -1).
  *   materials : HOST array (copied; numMaterials <= vqhip_max_materials())
  *   fAmbientLightingFactor : cbPerFrame.fAmbientLightingFactor (:247)
  *   ssao : NULL or a descriptor with texels == NULL => factor 1.0

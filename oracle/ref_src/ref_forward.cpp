@@ -18,6 +18,12 @@
 #include "../vqo_sampling.h"
 #include "ref_hooks.h"
 
+#if ENABLE_ALPHA_MASK
+// the "_AlphaMasked" PSO permutation (PipelineStateObjects.cpp:1571) — built as its own library, libvqref_shaders_am.so. HLSL's `discard`
+// ends the invocation: here it flags the pixel and returns from PSMain (the only function that uses it, ForwardLighting.hlsl:239).
+#define discard do { vqref::g_ctx.discarded = true; return PSOutput{}; } while (0)
+#endif
+
 namespace hlsl {
 // ---- the reference's shader, verbatim apart from hlsl2cpp.py's syntactic rewrites ------------------------------------
 namespace fwd {
@@ -132,7 +138,9 @@ int vqref_forward_psmain(const vqhip_interpolants* in, const vqhip_material* mat
             In.WorldSpaceNormal = float3(ip1[o], ip1[o + 1], ip1[o + 2]);
             In.WorldSpaceTangent = float3(ip2[o], ip2[o + 1], ip2[o + 2]);
             In.uv = float2(ip0[o + 3], ip1[o + 3]);
+            g_ctx.discarded = false;
             const PSOutput r = PSMain(In);
+            if (g_ctx.discarded) { dst[0] = dst[1] = dst[2] = dst[3] = -1.0f; continue; }      // sentinel: no colour is negative
             dst[0] = r.color.x; dst[1] = r.color.y; dst[2] = r.color.z; dst[3] = r.color.w;
         }
     return 0;

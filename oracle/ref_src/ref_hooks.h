@@ -28,6 +28,7 @@ struct Ctx {
     vqo::f2 ddx{ 0, 0 }, ddy{ 0, 0 };
     const vqhip_envmap* env = nullptr;
     const vqhip_shadowmaps* sm = nullptr;
+    bool discarded = false;             // set by the `discard` statement of an ENABLE_ALPHA_MASK build (ref_forward.cpp)
 };
 extern Ctx g_ctx;
 

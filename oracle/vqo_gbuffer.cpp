@@ -23,6 +23,7 @@
 //   * Everything else keeps the HLSL's literal operation order (this is not one of the v2 lighting functions).
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <omp.h>
 
 #include "../include/vqhip.h"
@@ -37,15 +38,18 @@ namespace {
 inline bool has_bit(int cfg, int bit) { return (cfg & (1 << bit)) > 0; }
 
 // ShadingMath.hlsl:44-52
+// Evaluated once per pixel: AS WRITTEN (contract v5) — the normal it returns steers the cube-map taps of the lighting pass, whose 8-bit
+// filter fractions turn an ulp of the direction into a step of 1/256 of a texel difference.
 inline f3 UnpackNormal(f3 S, f3 worldNormal, f3 worldTangent) {
-    S = normalize(f3{ S.x * 2.0f - 1.0f, S.y * 2.0f - 1.0f, S.z * 2.0f - 1.0f });
-    const f3 T = normalize(sub(worldTangent, mul(worldNormal, dot(worldNormal, worldTangent))));
-    const f3 N = normalize(worldNormal);
-    const f3 B = normalize(cross(T, N));
+    S = normalize_lit(f3{ S.x * 2.0f - 1.0f, S.y * 2.0f - 1.0f, S.z * 2.0f - 1.0f });
+    const float nt = dot_lit(worldNormal, worldTangent);
+    const f3 T = normalize_lit(sub(worldTangent, f3{ nt * worldNormal.x, nt * worldNormal.y, nt * worldNormal.z }));
+    const f3 N = normalize_lit(worldNormal);
+    const f3 B = normalize_lit(cross(T, N));
     // mul(SampledNormal, float3x3(T, B, N)): row vector times matrix with rows T, B, N
-    return { fma_(S.z, N.x, fma_(S.y, B.x, S.x * T.x)),
-             fma_(S.z, N.y, fma_(S.y, B.y, S.x * T.y)),
-             fma_(S.z, N.z, fma_(S.y, B.z, S.x * T.z)) };
+    return { (S.x * T.x + S.y * B.x) + S.z * N.x,
+             (S.x * T.y + S.y * B.y) + S.z * N.y,
+             (S.x * T.z + S.y * B.z) + S.z * N.z };
 }
 
 inline f3 SRGBToLinear(f3 c) { return { pow_(c.x, 2.2f), pow_(c.y, 2.2f), pow_(c.z, 2.2f) }; }   // ShadingMath.hlsl:65
@@ -60,12 +64,13 @@ inline f2 uv_transformed(const Planes& p, int x, int y, const VQ_MaterialData& m
     return { p.ip0[o + 3] * m.uvScaleOffset.x + m.uvScaleOffset.z, p.ip1[o + 3] * m.uvScaleOffset.y + m.uvScaleOffset.w };
 }
 
-void gbuffer_pixel(const Planes& in, int x, int y, const vqhip_material* mats, int nMats, float ambient,
+// returns true when the fragment is discarded (ENABLE_ALPHA_MASK permutation, ForwardLighting.hlsl:237-240)
+bool gbuffer_pixel(const Planes& in, int x, int y, const vqhip_material* mats, int nMats, float ambient,
                    const vqhip_ssao* ssao, float* o0, float* o1, float* o2, float* o3) {
     const int idx = mat_index(in, x, y);
     if (idx < 0 || idx >= nMats) {
         for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = o3[k] = 0.0f;
-        return;
+        return false;
     }
     const vqhip_material& mt = mats[idx];
     const VQ_MaterialData& m = mt.data;
@@ -94,6 +99,11 @@ void gbuffer_pixel(const Planes& in, int x, int y, const vqhip_material* mats, i
     const f4 ORM     = sample_material_tex(mt.texOcclRoughMetal, uv, ddx, ddy, 0.0f);
     const float LocalAO   = sample_material_tex(mt.texLocalAO,   uv, ddx, ddy, 0.0f).x;
 
+    // :237-240  #if ENABLE_ALPHA_MASK (the "_AlphaMasked" PSO permutation == VQHIP_MATERIAL_ALPHA_MASKED): discard
+    if ((mt.texDiffuse.reserved & VQHIP_MATERIAL_ALPHA_MASKED) && has_bit(TEX_CFG, 0) && AlbedoAlpha.w < 0.01f) {
+        for (int k = 0; k < 4; ++k) o0[k] = o1[k] = o2[k] = o3[k] = 0.0f;
+        return true;
+    }
     const f3 Albedo   = SRGBToLinear({ AlbedoAlpha.x, AlbedoAlpha.y, AlbedoAlpha.z });     // :243
     const f3 Emissive = SRGBToLinear({ Emis4.x, Emis4.y, Emis4.z });                       // :244
 
@@ -103,10 +113,10 @@ void gbuffer_pixel(const Planes& in, int x, int y, const vqhip_material* mats, i
     const f3 emissiveColor = has_bit(TEX_CFG, 7) ? mul(Emissive, memis) : memis;       // :250
     float roughness = m.roughness, metalness = m.metalness;                            // :252-253
 
-    const f3 N = normalize(f3{ in.ip1[o], in.ip1[o + 1], in.ip1[o + 2] });             // :265
-    const f3 T = normalize(f3{ in.ip2[o], in.ip2[o + 1], in.ip2[o + 2] });             // :266
+    const f3 N = normalize_lit(f3{ in.ip1[o], in.ip1[o + 1], in.ip1[o + 2] });         // :265
+    const f3 T = normalize_lit(f3{ in.ip2[o], in.ip2[o + 1], in.ip2[o + 2] });         // :266
     const f3 Nrm = { Normal4.x, Normal4.y, Normal4.z };
-    const f3 SurfN = (length(Nrm) < 0.01f) ? N : UnpackNormal(Nrm, N, T);              // :267
+    const f3 SurfN = (length_lit(Nrm) < 0.01f) ? N : UnpackNormal(Nrm, N, T);          // :267
 
     if (has_bit(TEX_CFG, 2)) ao *= LocalAO;                                            // :269
     if (has_bit(TEX_CFG, 4)) roughness *= Roughness;                                   // :270
@@ -123,6 +133,7 @@ void gbuffer_pixel(const Planes& in, int x, int y, const vqhip_material* mats, i
     o1[0] = SurfN.x; o1[1] = SurfN.y; o1[2] = SurfN.z; o1[3] = roughness;
     o2[0] = diffuseColor.x; o2[1] = diffuseColor.y; o2[2] = diffuseColor.z; o2[3] = metalness;
     o3[0] = emissiveColor.x; o3[1] = emissiveColor.y; o3[2] = emissiveColor.z; o3[3] = m.emissiveIntensity;   // :251
+    return false;
 }
 
 } // namespace
@@ -136,12 +147,18 @@ int vqo_gbuffer_from_materials(const vqhip_interpolants* in, const vqhip_materia
     if (nthreads <= 0) nthreads = omp_get_max_threads();
     const Planes p = { (const float*)in->ip0, (const float*)in->ip1, (const float*)in->ip2, in->width, in->height, in->row_pitch_px };
     float* g0 = (float*)out->gb0; float* g1 = (float*)out->gb1; float* g2 = (float*)out->gb2; float* g3 = (float*)out->gb3;
+    std::vector<uint8_t> discarded((size_t)in->width * in->height, 0);
     #pragma omp parallel for schedule(static) num_threads(nthreads)
     for (int y = 0; y < in->height; ++y)
         for (int x = 0; x < in->width; ++x) {
             const size_t q = ((size_t)y * out->row_pitch_px + x) * 4;
-            gbuffer_pixel(p, x, y, materials, numMaterials, fAmbientLightingFactor, ssao, g0 + q, g1 + q, g2 + q, g3 + q);
+            discarded[(size_t)y * in->width + x] = gbuffer_pixel(p, x, y, materials, numMaterials, fAmbientLightingFactor, ssao, g0 + q, g1 + q, g2 + q, g3 + q);
         }
+    // discarded fragments read as "no geometry" afterwards: index -1 in the coverage plane (after the pass: quad partners needed the old index)
+    float* ip2 = (float*)in->ip2;
+    for (int y = 0; y < in->height; ++y)
+        for (int x = 0; x < in->width; ++x)
+            if (discarded[(size_t)y * in->width + x]) { const int32_t m1 = -1; std::memcpy(ip2 + ((size_t)y * in->row_pitch_px + x) * 4 + 3, &m1, 4); }
     return 0;
 }
 

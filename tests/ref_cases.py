@@ -249,12 +249,23 @@ for _k in ("ambient", "points64", "spots8", "directional", "mixed_env", "env_dif
     CASES.append(_forward_case(_k))
 
 
-def _psmain_case():
+def _psmain_case(alpha_masked=False):
+    """alpha_masked: every material drawn with the "_AlphaMasked" PSO permutation (ENABLE_ALPHA_MASK, ForwardLighting.hlsl:237-240;
+    VQHIP_MATERIAL_ALPHA_MASKED): the diffuse maps get holes of alpha 0 and the discarded fragments must be the same set on both sides."""
     W, H, NM = 48, 32, 5
 
     def build():
         ip = synth.interpolants(W, H, NM)
         datas, texsets = synth.material_set(NM, max_dim=64)
+        if alpha_masked:
+            for k, d in enumerate(datas):                     # magnified textures: low LODs, where whole texels are transparent
+                d.uvScaleOffset = abi.float4(0.02 * (k + 1), 0.015 * (k + 2), d.uvScaleOffset.z, d.uvScaleOffset.w)
+            for ts in texsets:
+                if "texDiffuse" in ts:
+                    img = ts["texDiffuse"]
+                    h = img.shape[0]
+                    img[: (3 * h) // 4, :, 3] = 0         # transparent upper three quarters: the filtered alpha crosses 0.01 near the seam, at low LODs
+                    img[(3 * h) // 4:, :, 3] = np.maximum(img[(3 * h) // 4:, :, 3], 2)
         env = small_env()
         pf, _ = synth.per_frame(points=synth.point_lights(10, seed=3), spots=synth.spot_lights(2, seed=3), directional=synth.directional_light(),
                                 hdri_offset=-0.4)
@@ -269,20 +280,33 @@ def _psmain_case():
                 chain, n = O.mip_chain_rgba8(img)
                 cs[slot] = (chain, img.shape[1], img.shape[0], n)
             hc.append(cs)
-        return O.host_materials(i["datas"], hc)
+        m = O.host_materials(i["datas"], hc)
+        for k in range(NM):
+            m[k].texDiffuse.reserved = abi.MATERIAL_ALPHA_MASKED if alpha_masked else 0
+        return m
 
     def valid(i):
         idx = i["ip"][2][..., 3].view(np.int32)
         return (idx >= 0) & (idx < NM)
 
+    def masked(rgba, discarded):
+        """lit colours of the valid pixels with the discarded ones replaced by the sentinel -1 (same encoding on all three sides)"""
+        out = np.asarray(rgba, np.float32).copy()
+        out[discarded] = -1.0
+        return out
+
     def ref(i):
         from tests import ref_lib as R
-        out = R.forward_psmain(i["ip"], host_mats(i), i["pf"], i["pv"], ssao=i["ssao"], env=host_env(i["env"]))
+        out = R.forward_psmain([p.copy() for p in i["ip"]], host_mats(i), i["pf"], i["pv"], ssao=i["ssao"], env=host_env(i["env"]), alpha_masked=alpha_masked)
         return out[valid(i)]
 
     def oracle(i):
-        gb = O.gbuffer_from_materials(i["ip"], host_mats(i), i["pf"].fAmbientLightingFactor, ssao=i["ssao"])
-        return O.forward_lighting(gb, i["pf"], i["pv"], F16, env=host_env(i["env"]))[valid(i)]
+        ip = [p.copy() for p in i["ip"]]                      # the producer rewrites the index of discarded fragments in ip2.w
+        gb = O.gbuffer_from_materials(ip, host_mats(i), i["pf"].fAmbientLightingFactor, ssao=i["ssao"])
+        lit = O.forward_lighting(gb, i["pf"], i["pv"], F16, env=host_env(i["env"]))
+        gone = valid(i) & (ip[2][..., 3].view(np.int32) == -1)
+        assert alpha_masked or not gone.any()
+        return masked(lit, gone)[valid(i)]
 
     def product(ctx, i):
         keep = []
@@ -293,13 +317,19 @@ def _psmain_case():
                 chain, n = ctx.mip_chain_rgba8(_dev(img))
                 keep.append(chain)
                 setattr(dm[k], slot, abi.Texture2D(chain.data_ptr(), img.shape[1], img.shape[0], n, 0))
-        gb = ctx.gbuffer_from_materials([_dev(p) for p in i["ip"]], dm, i["pf"].fAmbientLightingFactor, _dev(i["ssao"]))
+            dm[k].texDiffuse.reserved = abi.MATERIAL_ALPHA_MASKED if alpha_masked else 0
+        ipd = [_dev(p) for p in i["ip"]]
+        gb = ctx.gbuffer_from_materials(ipd, dm, i["pf"].fAmbientLightingFactor, _dev(i["ssao"]))
         out = ctx.forward_lighting(gb, i["pf"], i["pv"], out_fmt=F16, env=dev_env(i["env"], keep))
-        return out.cpu().numpy()[valid(i)]
+        gone = valid(i) & (ipd[2].cpu().numpy()[..., 3].view(np.int32) == -1)
+        return masked(out.cpu().numpy(), gone)[valid(i)]
+    if alpha_masked:
+        return Case("psmain_alpha_masked", build, ref, oracle, product, ("ulp16", 1, 0.003))
     return Case("psmain_textured", build, ref, oracle, product, ("ulp16", 1, 0.003))         # measured: max 1, 0.07 % of channels
 
 
 CASES.append(_psmain_case())
+CASES.append(_psmain_case(alpha_masked=True))
 
 
 def _lut_case():

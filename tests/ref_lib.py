@@ -32,6 +32,8 @@ def load(name="shaders"):
             lib.vqref_half_bits.restype = u32
         elif name == "shaders_l256":
             lib.vqref_forward_from_gbuffer.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
+        elif name == "shaders_am":
+            lib.vqref_forward_psmain.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
         else:
             lib.vqref_forward_psmain.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
             lib.vqref_forward_from_gbuffer.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
@@ -87,7 +89,9 @@ def forward_from_gbuffer(gb, per_frame, per_view, env=None, shadow=None, extra=N
     return out
 
 
-def forward_psmain(ip, materials, per_frame, per_view, ssao=None, env=None, shadow=None):
+def forward_psmain(ip, materials, per_frame, per_view, ssao=None, env=None, shadow=None, alpha_masked=False):
+    """PSMain per pixel of the interpolant planes. alpha_masked: the ENABLE_ALPHA_MASK permutation (libvqref_shaders_am.so) — every material
+    is then drawn with the alpha-masked PSO; discarded pixels come back as -1 in all four channels."""
     ip = [np.ascontiguousarray(p, np.float32) for p in ip]
     h, w = ip[0].shape[:2]
     out = np.empty((h, w, 4), np.float32)
@@ -97,7 +101,7 @@ def forward_psmain(ip, materials, per_frame, per_view, ssao=None, env=None, shad
         ssao = np.ascontiguousarray(ssao, np.uint8)
         s = abi.SSAO(ssao.ctypes.data, ssao.shape[1], ssao.shape[0])
     n = len(materials) if materials is not None else 0
-    rc = load().vqref_forward_psmain(C.byref(inter), materials if n else None, n, _ref(s), C.byref(per_frame), C.byref(per_view),
+    rc = load("shaders_am" if alpha_masked else "shaders").vqref_forward_psmain(C.byref(inter), materials if n else None, n, _ref(s), C.byref(per_frame), C.byref(per_view),
                                      _ref(env), _ref(shadow), out.ctypes.data)
     assert rc == 0
     return out

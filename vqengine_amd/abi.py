@@ -120,6 +120,7 @@ class Texture2D(C.Structure):  # vqhip_texture2d: RGBA8_UNORM mip chain, texels 
     _fields_ = [("texels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("mips", C.c_int32), ("reserved", C.c_int32)]
 
 
+MATERIAL_ALPHA_MASKED = 1   # VQHIP_MATERIAL_ALPHA_MASKED: flag in vqhip_material.texDiffuse.reserved (the "_AlphaMasked" PSO permutation)
 MATERIAL_TEXTURE_SLOTS = ("texDiffuse", "texNormals", "texEmissive", "texMetalness", "texRoughness", "texOcclRoughMetal", "texLocalAO")
 
 

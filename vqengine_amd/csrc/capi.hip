@@ -5,7 +5,9 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <string>
 #include <vector>
 #include "vq_internal.h"
@@ -129,6 +131,31 @@ float rangeCullThreshold(float range) {
 
 namespace vqk { int fail_global(int code, const std::string& msg) { return fail(nullptr, code, msg); } }     // for mgpu.hip (no context)
 
+namespace vqk {
+namespace {
+struct Roctx { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; };
+const Roctx& roctx() {
+    static const Roctx r = [] {
+        Roctx x;
+        const char* env = std::getenv("VQHIP_ROCTX");
+        if (env && env[0] == '0') return x;
+        for (const char* n : { "librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so" }) {
+            if (void* lib = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                x.push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+                x.pop = (int (*)())dlsym(lib, "roctxRangePop");
+                if (x.push && x.pop) return x;
+                x = Roctx{};
+            }
+        }
+        return x;
+    }();
+    return r;
+}
+} // namespace
+Range::Range(const char* name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+Range::~Range() { if (on) roctx().pop(); }
+} // namespace vqk
+
 extern "C" {
 
 int vqhip_abi_version(void) { return VQHIP_ABI_VERSION; }
@@ -189,6 +216,7 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
         const VQ_PointLight* extraPoint, int numExtraPoint,
         const vqhip_envmap* env, const vqhip_shadowmaps* sm,
         void* out, int out_row_pitch_px, vqhip_format outFmt) {
+    vqk::Range range_("RenderSceneColor");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "forward_lighting: ctx is NULL");
     if (!gb || !perFrame || !perView || !out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: NULL argument");
     if (!gb->gb0 || !gb->gb1 || !gb->gb2 || !gb->gb3) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: NULL G-buffer plane");
@@ -254,6 +282,7 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
 }
 
 int vqhip_gaussian_blur_x(vqhip_ctx* ctx, void* stream, const void* in, void* out, const VQ_BlurParams* p, vqhip_format fmt) {
+    vqk::Range range_("BlurX");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur_x: ctx is NULL");
     if (!in || !out || !p || p->iImageSizeX <= 0 || p->iImageSizeY <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_x: bad argument");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_x: fmt must be RGBA32F or RGBA16F");
@@ -265,6 +294,7 @@ int vqhip_gaussian_blur_x(vqhip_ctx* ctx, void* stream, const void* in, void* ou
 
 int vqhip_gaussian_blur_y(vqhip_ctx* ctx, void* stream, const void* in, void* out, const void* halo_top, const void* halo_bottom, int halo_rows,
                           const VQ_BlurParams* p, vqhip_format fmt) {
+    vqk::Range range_("BlurY");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y: ctx is NULL");
     if (!in || !out || !p || p->iImageSizeX <= 0 || p->iImageSizeY <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y: bad argument");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_y: fmt must be RGBA32F or RGBA16F");
@@ -277,6 +307,7 @@ int vqhip_gaussian_blur_y(vqhip_ctx* ctx, void* stream, const void* in, void* ou
 
 int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, const void* halo_top, const void* halo_bottom, int halo_rows,
                                   const VQ_BlurParams* p, const VQ_TonemapperParams* tm, vqhip_format blurFmt, vqhip_format outFmt) {
+    vqk::Range range_("BlurY+TonemapperCS");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: ctx is NULL");
     if (!in || !out || !p || !tm || p->iImageSizeX <= 0 || p->iImageSizeY <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: bad argument");
     if (!isImageFmt(blurFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_y_tonemap: blurFmt must be RGBA32F or RGBA16F");
@@ -301,6 +332,7 @@ int vqhip_gaussian_blur(vqhip_ctx* ctx, void* stream, const void* in, void* tmp,
 
 int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
                   const VQ_TonemapperParams* p, vqhip_format inFmt, vqhip_format outFmt) {
+    vqk::Range range_("TonemapperCS");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "tonemap: ctx is NULL");
     if (!in || !out || !p || width <= 0 || height <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "tonemap: bad argument");
     if (!isImageFmt(inFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "tonemap: inFmt must be RGBA32F or RGBA16F");
@@ -321,6 +353,7 @@ int vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode) {
 }
 
 int vqhip_brdf_lut(vqhip_ctx* ctx, void* stream, void* outRG, int size, int samples, vqhip_format fmt) {
+    vqk::Range range_("CreateBRDFIntegralLUT");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "brdf_lut: ctx is NULL");
     if (!outRG || size <= 0 || samples <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "brdf_lut: bad argument");
     if (fmt != VQHIP_FMT_RG16F && fmt != VQHIP_FMT_RG32F) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "brdf_lut: fmt must be RG16F or RG32F");
@@ -338,6 +371,7 @@ size_t vqhip_mip_level_offset_bytes(int w0, int h0, int level) {
 size_t vqhip_mip_chain_bytes(int w0, int h0, int nMips) { return vqhip_mip_level_offset_bytes(w0, h0, nMips); }
 
 int vqhip_mip_chain_min_rgba32f(vqhip_ctx* ctx, void* stream, void* mips, int w0, int h0, int nMips) {
+    vqk::Range range_("GenerateMips");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "mip_chain: ctx is NULL");
     if (!mips || w0 <= 0 || h0 <= 0 || nMips <= 0 || nMips > vqhip_mip_level_count(w0, h0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "mip_chain: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -354,6 +388,7 @@ int vqhip_mip_chain_min_rgba32f(vqhip_ctx* ctx, void* stream, void* mips, int w0
 size_t vqhip_mip_chain_bytes_rgba8(int w0, int h0, int nMips) { return vqhip_mip_level_offset_bytes(w0, h0, nMips) / 4; }
 
 int vqhip_mip_chain_box_rgba8(vqhip_ctx* ctx, void* stream, void* mips, int w0, int h0, int nMips) {
+    vqk::Range range_("GenerateMips");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "mip_chain_box_rgba8: ctx is NULL");
     if (!mips || w0 <= 0 || h0 <= 0 || nMips <= 0 || nMips > vqhip_mip_level_count(w0, h0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "mip_chain_box_rgba8: bad argument");
     if ((w0 & (w0 - 1)) || (h0 & (h0 - 1))) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "mip_chain_box_rgba8: w0 and h0 must be powers of two");
@@ -375,6 +410,7 @@ static bool badTexture(const vqhip_texture2d& t) {
 
 int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
                                  float fAmbientLightingFactor, const vqhip_ssao* ssao, const vqhip_gbuffer* out) {
+    vqk::Range range_("Geometry");                       // :1723 (surface assembly half of the lit draws)
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: ctx is NULL");
     if (!in || !out || !in->ip0 || !in->ip1 || !in->ip2 || !out->gb0 || !out->gb1 || !out->gb2 || !out->gb3)
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: NULL plane");
@@ -418,6 +454,7 @@ int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_inter
 // ---- skydome ------------------------------------------------------------------------
 int vqhip_skydome(vqhip_ctx* ctx, void* stream, const void* equirect_level0, int w0, int h0, const VQ_SkydomeParams* params,
                   const vqhip_interpolants* coverage, void* color, int width, int height, int row_pitch_px, vqhip_format fmt) {
+    vqk::Range range_("EnvironmentMap");                 // SceneRendering.cpp:1824
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "skydome: ctx is NULL");
     if (!equirect_level0 || !params || !color || w0 <= 0 || h0 <= 0 || width <= 0 || height <= 0 || row_pitch_px < width)
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "skydome: bad argument");
@@ -433,6 +470,7 @@ int vqhip_skydome(vqhip_ctx* ctx, void* stream, const void* equirect_level0, int
 
 int vqhip_unlit_composite(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* coverage, const VQ_float4* colors, int numColors,
                           void* color, int width, int height, int row_pitch_px, vqhip_format fmt) {
+    vqk::Range range_("Lights");                         // :1790
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "unlit_composite: ctx is NULL");
     if (!coverage || !coverage->ip2 || !color || width <= 0 || height <= 0 || row_pitch_px < width || numColors < 0 || (numColors > 0 && !colors))
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "unlit_composite: bad argument");
@@ -459,6 +497,7 @@ int vqhip_hdr_parse_header(const void* file, size_t bytes, int* width, int* heig
 }
 
 int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, size_t bytes, void* out_rgba32f, int width, int height) {
+    vqk::Range range_("LoadHDRI");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "hdr_decode: ctx is NULL");
     if (!file || !out_rgba32f) return fail(ctx, VQHIP_ERR_INVALID_ARG, "hdr_decode: NULL argument");
     const char* err = nullptr; int w = 0, h = 0; size_t off = 0;
@@ -507,6 +546,7 @@ static bool isColorFmt(int f) { return f == VQHIP_FMT_RGBA32F || f == VQHIP_FMT_
 
 int vqhip_fsr_easu(vqhip_ctx* ctx, void* stream, const void* in, int inW, int inH, vqhip_format inFmt, const uint32_t con[16],
                    void* out, int outW, int outH, vqhip_format outFmt) {
+    vqk::Range range_("FSR-EASU CS");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "fsr_easu: ctx is NULL");
     if (!in || !out || !con || inW <= 0 || inH <= 0 || outW <= 0 || outH <= 0 || inW >= (1 << 24) || outW >= (1 << 24))
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "fsr_easu: bad argument");
@@ -519,6 +559,7 @@ int vqhip_fsr_easu(vqhip_ctx* ctx, void* stream, const void* in, int inW, int in
 
 int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height, const uint32_t con[4],
                    vqhip_format inFmt, vqhip_format outFmt) {
+    vqk::Range range_("FSR-RCAS CS");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "fsr_rcas: ctx is NULL");
     if (!in || !out || !con || width <= 0 || height <= 0 || width >= (1 << 24)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "fsr_rcas: bad argument");
     if (!isColorFmt(inFmt) || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "fsr_rcas: formats must be RGBA8_UNORM, RGBA16F or RGBA32F");
@@ -530,6 +571,7 @@ int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void* out, int 
 
 int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height, const VQ_VizParams* params,
                     vqhip_format inFmt, vqhip_format outFmt) {
+    vqk::Range range_("RenderPostProcess_DebugViz");      // :2543
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "visualize: ctx is NULL");
     if (!in || !out || !params || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "visualize: bad argument");
     if (!isColorFmt(inFmt) || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "visualize: formats must be RGBA8_UNORM, RGBA16F or RGBA32F");
@@ -539,6 +581,7 @@ int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int
 }
 
 int vqhip_apply_reflections(vqhip_ctx* ctx, void* stream, const void* reflectionRadiance, void* sceneColor, int width, int height, vqhip_format fmt) {
+    vqk::Range range_("CompositeReflections");            // :2374
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "apply_reflections: ctx is NULL");
     if (!reflectionRadiance || !sceneColor || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "apply_reflections: bad argument");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "apply_reflections: fmt must be RGBA32F or RGBA16F");
@@ -563,6 +606,7 @@ static int checkChain(vqhip_ctx* ctx, const void* chain, int w0, int h0, int nMi
 
 int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
                        int diffuseRes, float step, vqhip_conv_order order, void* outCube, vqhip_format fmt) {
+    vqk::Range range_("DiffuseIrradianceCubemap");
     int rc = checkChain(ctx, equirect_mips, w0, h0, nMips, "conv_diffuse");
     if (rc) return rc;
     if (!outCube || diffuseRes <= 0 || !(step > 0.0f)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_diffuse: bad argument");
@@ -591,6 +635,7 @@ int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, 
 
 int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
                         int specRes0, vqhip_conv_order order, void* outCubeMips, vqhip_format fmt) {
+    vqk::Range range_("SpecularIrradianceCubemap");
     int rc = checkChain(ctx, equirect_mips, w0, h0, nMips, "conv_specular");
     if (rc) return rc;
     const int MIPS = vqhip_specular_mip_count(specRes0);
@@ -611,6 +656,7 @@ int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equirect_mips,
 
 int vqhip_envmap_prefilter(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
                            int diffuseRes, float diffuseStep, int specRes0, vqhip_conv_order order, const vqhip_envmap_out* out) {
+    vqk::Range range_("RenderEnvironmentMapCubeFaces");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "envmap_prefilter: ctx is NULL");
     if (!out || !out->diffuse_blurred || !out->blur_tmp || !out->specular) return fail(ctx, VQHIP_ERR_INVALID_ARG, "envmap_prefilter: missing output buffer");
     void* diff = out->diffuse_unblurred;

@@ -117,14 +117,16 @@ VQD float4 fetch(const void* texels, const Footprint& fp) {
     return make_float4(r.x * s, r.y * s, r.z * s, r.w * s);
 }
 
+// once per pixel: as written (contract v5) — this normal steers the cube-map taps of the lighting pass
 VQD f3 UnpackNormal(f3 S, f3 worldNormal, f3 worldTangent) {          // ShadingMath.hlsl:44-52
-    S = normalize(mk3(S.x * 2.0f - 1.0f, S.y * 2.0f - 1.0f, S.z * 2.0f - 1.0f));
-    const f3 T = normalize(sub(worldTangent, mul(worldNormal, dot(worldNormal, worldTangent))));
-    const f3 N = normalize(worldNormal);
-    const f3 B = normalize(cross(T, N));
-    return mk3(fma_(S.z, N.x, fma_(S.y, B.x, S.x * T.x)),
-               fma_(S.z, N.y, fma_(S.y, B.y, S.x * T.y)),
-               fma_(S.z, N.z, fma_(S.y, B.z, S.x * T.z)));
+    S = normalize_lit(mk3(S.x * 2.0f - 1.0f, S.y * 2.0f - 1.0f, S.z * 2.0f - 1.0f));
+    const float nt = dot_lit(worldNormal, worldTangent);
+    const f3 T = normalize_lit(sub(worldTangent, mk3(nt * worldNormal.x, nt * worldNormal.y, nt * worldNormal.z)));
+    const f3 N = normalize_lit(worldNormal);
+    const f3 B = normalize_lit(cross(T, N));
+    return mk3((S.x * T.x + S.y * B.x) + S.z * N.x,
+               (S.x * T.y + S.y * B.y) + S.z * N.y,
+               (S.x * T.z + S.y * B.z) + S.z * N.z);
 }
 
 VQD bool has_bit(int cfg, int bit) { return (cfg & (1 << bit)) > 0; }   // LightingConstantBufferData.h:116-124
@@ -215,6 +217,17 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
                 }
             }
 
+            // :237-240  #if ENABLE_ALPHA_MASK  if (HasDiffuseMap(TEX_CFG) && AlbedoAlpha.a < 0.01f) discard;
+            // the fragment is gone: zero record, and the pixel's index in the coverage plane becomes "no geometry" (quad partners keep the
+            // index they read before, like the helper lanes of a discarded fragment keep serving derivatives)
+            if ((mt.texDiffuse.reserved & VQHIP_MATERIAL_ALPHA_MASKED) && has_bit(TEX_CFG, 0) && AlbedoAlpha.w < 0.01f) {
+                const float4 z = make_float4(0, 0, 0, 0);
+                *(float4*)((char*)a.gb0 + q) = z; *(float4*)((char*)a.gb1 + q) = z; *(float4*)((char*)a.gb2 + q) = z; *(float4*)((char*)a.gb3 + q) = z;
+                ((float*)((char*)a.ip2 + o))[3] = __int_as_float(-1);
+                todo = false;
+                continue;
+            }
+
             float ao = gc->ambient;                                                        // :247
             const f3 mdiff = mk3(m.diffuse.x, m.diffuse.y, m.diffuse.z), memis = mk3(m.emissiveColor.x, m.emissiveColor.y, m.emissiveColor.z);
             f3 diffuseColor = mdiff, emissiveColor = memis;
@@ -224,12 +237,12 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
                 emissiveColor = mul(mk3(pow_unit(Emis4.x, 2.2f), pow_unit(Emis4.y, 2.2f), pow_unit(Emis4.z, 2.2f)), memis);
             float roughness = m.roughness, metalness = m.metalness;                        // :252-253
 
-            const f3 N = normalize(mk3(i1.x, i1.y, i1.z));                                 // :265
+            const f3 N = normalize_lit(mk3(i1.x, i1.y, i1.z));                             // :265
             const f3 Nrm = mk3(Normal4.x, Normal4.y, Normal4.z);
             f3 SurfN = N;                                                                  // :267  length(Normal) < 0.01 ? N : UnpackNormal(...)
-            const bool unpack = !(length(Nrm) < 0.01f);
+            const bool unpack = !(length_lit(Nrm) < 0.01f);
             if (__builtin_amdgcn_ballot_w64(unpack) != 0) {                                // a real branch: most waves of a normal-map-less material skip it
-                const f3 T = normalize(mk3(i2.x, i2.y, i2.z));                             // :266
+                const f3 T = normalize_lit(mk3(i2.x, i2.y, i2.z));                         // :266
                 const f3 U = UnpackNormal(Nrm, N, T);
                 if (unpack) SurfN = U;
             }

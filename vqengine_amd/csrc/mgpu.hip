@@ -166,6 +166,7 @@ int vqhip_exchange_blur_halos(vqhip_comm* c, void* stream, const void* xblur_til
     if ((up && !halo_top) || (down && !halo_bottom)) return vqk::fail_global(VQHIP_ERR_INVALID_ARG, "vqhip_exchange_blur_halos: a halo buffer of an inner tile edge is NULL");
     if ((up || down) && tile_rows < VQHIP_HALO_ROWS) return vqk::fail_global(VQHIP_ERR_INVALID_ARG, "vqhip_exchange_blur_halos: tile shorter than the halo");
     if (!up && !down) return VQHIP_OK;
+    vqk::Range range_("BlurHaloExchange");
     Rccl& r = rccl();
     hipStream_t st = (hipStream_t)stream;
     const size_t bpp = bytesPerPixel(fmt), rowB = (size_t)width * bpp, pitchB = (size_t)row_pitch_px * bpp;
@@ -188,6 +189,7 @@ int vqhip_composite_tiles(vqhip_comm* c, void* stream, const void* tile, int wid
         return vqk::fail_global(VQHIP_ERR_INVALID_ARG, "vqhip_composite_tiles: bad arguments");
     const size_t bpp = bytesPerPixel(fmt);
     if (!bpp) return vqk::fail_global(VQHIP_ERR_UNSUPPORTED, "vqhip_composite_tiles: unknown format");
+    vqk::Range range_("CompositeTiles");
     const bool receiver = root == VQHIP_ALL_RANKS || root == c->rank;
     if (receiver && !frame) return vqk::fail_global(VQHIP_ERR_INVALID_ARG, "vqhip_composite_tiles: frame is NULL on a receiving rank");
     Rccl& r = rccl();

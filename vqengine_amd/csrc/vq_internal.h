@@ -6,6 +6,17 @@
 
 namespace vqk {
 
+// roctx range around the host side of an entry point, named after the GPU marker the reference opens at the call it replaces
+// (SCOPED_GPU_MARKER, e.g. SceneRendering.cpp:1630 "RenderSceneColor"), so a rocprofv3 --marker-trace timeline reads like a PIX capture of
+// the engine. The marker library (librocprofiler-sdk-roctx / libroctx64) is bound at run time; absent library or VQHIP_ROCTX=0: no-op.
+struct Range {
+    explicit Range(const char* name);
+    ~Range();
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+    bool on;
+};
+
 // Device-resident per-call constant block == the cbuffers b0/b1 of ForwardLighting.hlsl:76-77 plus the
 // resource descriptors that replace its SRV tables. Uploaded once per vqhip_forward_lighting call into a
 // slot of the context's constant ring (the analogue of the reference's DynamicBufferHeap bump allocation,

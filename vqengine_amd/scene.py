@@ -206,6 +206,11 @@ class Material:
                 cfg |= 1 << bit
         return cfg
 
+    def is_alpha_masked(self, diffuse_map_uses_alpha_channel=False):
+        """Material::IsAlphaMasked (Material.cpp:39): an alpha-mask map is bound, or the diffuse map's alpha channel is in use
+        (TextureManager.cpp:835 HasAlphaValuesSIMD). Selects the "_AlphaMasked" PSO == abi.MATERIAL_ALPHA_MASKED in texDiffuse.reserved."""
+        return self.TexAlphaMaskMap != INVALID_ID or (self.TexDiffuseMap != INVALID_ID and bool(diffuse_map_uses_alpha_channel))
+
     def get_cbuffer_data(self):
         """Material::GetCBufferData, Material.h:120-127: memcpy of the first 80 bytes + textureConfig as a FLOAT."""
         d = abi.MaterialData()
