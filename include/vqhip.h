@@ -468,6 +468,14 @@ VQHIP_API int vqhip_unlit_composite(vqhip_ctx* ctx, void* stream, const vqhip_in
 VQHIP_API int vqhip_hdr_parse_header(const void* file, size_t bytes, int* width, int* height, size_t* data_offset);
 VQHIP_API int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, size_t bytes,
         void* out_rgba32f, int width, int height);
+/* Replaces Image::CreateResizedImage as CreateEnvironmentMapTextureFromHiResAndSaveToDisk uses it (EnvironmentMap.cpp:142-209, call :167):
+ * when the HDRI of the chosen resolution is missing, the next higher one (8k / 4k / 2k of LookupResolutionX/Y :163-164) is downsized to it.
+ * The resampler itself (stb_image_resize inside the un-vendored Libs/VQUtils submodule, version and filter not pinned by the reference tree)
+ * is NOT restated — PARITY UNPINNED for this entry point: every target texel is the plain mean of its k x k source block, k = width /
+ * out_width = height / out_height an integer (2, 4, 8 for the engine's table) — which is also what the engine's alternative branch (:183-200,
+ * repeated CreateHalfResolutionFromImage) converges to. Any other ratio returns VQHIP_ERR_UNSUPPORTED. RGBA32F device images, alpha := 1. */
+VQHIP_API int vqhip_hdr_downsize_rgba32f(vqhip_ctx* ctx, void* stream, const void* in_rgba32f, int width, int height,
+        void* out_rgba32f, int out_width, int out_height);
 
 /* ---- FidelityFX Super Resolution 1.0 (post chain tail) ------------------------------
  * Replace the FSR-EASU and FSR-RCAS dispatches of VQRenderer::RenderPostProcess (SceneRendering.cpp:2695-2784):

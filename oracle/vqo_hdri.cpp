@@ -108,4 +108,25 @@ int vqo_hdr_decode_rgba32f(const uint8_t* file, size_t n, float* out, int w, int
     return 0;
 }
 
+// Integer-ratio downsize (vqhip_hdr_downsize_rgba32f; EnvironmentMap.cpp:142-209 — the reference's resampler is stb_image_resize in the absent
+// submodule: PARITY UNPINNED, plain k x k mean restated): block summed row by row, left to right, scaled by 1/(k*k), alpha 1.
+int vqo_hdr_downsize_rgba32f(const float* in, int w, int h, float* out, int ow, int oh) {
+    if (!in || !out || w <= 0 || h <= 0 || ow <= 0 || oh <= 0) return -1;
+    const int k = w / ow;
+    if (k < 1 || ow * k != w || oh * k != h) return -3;
+    const float inv = 1.0f / (float)(k * k);
+    for (int y = 0; y < oh; ++y)
+        for (int x = 0; x < ow; ++x) {
+            float a[3] = { 0, 0, 0 };
+            for (int j = 0; j < k; ++j)
+                for (int i = 0; i < k; ++i) {
+                    const float* p = in + ((size_t)(y * k + j) * w + (size_t)x * k + i) * 4;
+                    a[0] = a[0] + p[0]; a[1] = a[1] + p[1]; a[2] = a[2] + p[2];
+                }
+            float* o = out + ((size_t)y * ow + x) * 4;
+            o[0] = a[0] * inv; o[1] = a[1] * inv; o[2] = a[2] * inv; o[3] = 1.0f;
+        }
+    return 0;
+}
+
 } // extern "C"

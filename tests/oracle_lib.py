@@ -59,6 +59,7 @@ def load():
     lib.vqo_skydome.argtypes = [vp, i32, i32, C.POINTER(abi.SkydomeParams), vp, i32, vp, i32, i32, i32, i32, i32]
     lib.vqo_hdr_parse_header.argtypes = [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]
     lib.vqo_hdr_decode_rgba32f.argtypes = [C.c_char_p, sz, vp, i32, i32]
+    lib.vqo_hdr_downsize_rgba32f.argtypes = [vp, i32, i32, vp, i32, i32]
     lib.vqo_fsr_easu_con.argtypes = [vp, f32, f32, f32, f32, f32, f32]
     lib.vqo_fsr_rcas_con.argtypes = [vp, f32]
     lib.vqo_fsr_easu.argtypes = [vp, i32, i32, i32, vp, vp, i32, i32, i32, i32]
@@ -327,3 +328,14 @@ def unlit_composite(coverage_ip2, colors, color, fmt):
     h, w = color.shape[:2]
     assert lib.vqo_unlit_composite(_p(cov), w, _p(cols), len(cols), _p(color), w, h, w, fmt) == 0
     return color
+
+
+def hdr_downsize(img, out_w, out_h):
+    """float32 [H,W,4] -> [out_h,out_w,4] (k x k mean, integer ratios); raises ValueError(code) otherwise."""
+    lib = load()
+    img = np.ascontiguousarray(img, np.float32)
+    out = np.empty((out_h, out_w, 4), np.float32)
+    rc = lib.vqo_hdr_downsize_rgba32f(_p(img), img.shape[1], img.shape[0], _p(out), out_w, out_h)
+    if rc != 0:
+        raise ValueError(rc)
+    return out

@@ -62,3 +62,21 @@ def test_full_frame_chain_matches_oracle(ctx):
     sky = np.ascontiguousarray(ip[2][..., 3]).view(np.int32) < 0
     assert sky.sum() > 1000 and np.isfinite(col_o[sky].astype(np.float32)).all()       # sky pixels were overwritten (no NaN records left)
     assert fin_o.shape == (OH, OW, 4) and fin_o[..., :3].std() > 5
+
+
+def test_hdri_downsize_matches_oracle_and_reports_unsupported(ctx):
+    """vqhip_hdr_downsize_rgba32f: the engine's 8k -> 4k / 2k / 1k fallback shapes at 1/8 scale (1024x512 -> 512x256 / 256x128 / 128x64) bit for
+    bit against the oracle; any non-integer or anisotropic ratio is VQHIP_ERR_UNSUPPORTED, not an approximation."""
+    import torch
+    from tests import oracle_lib as O
+    from vqengine_amd import abi, capi, synth
+    img = synth.equirect(1024, 512)
+    dev = torch.from_numpy(img).cuda()
+    for k in (1, 2, 4, 8):
+        got = ctx.hdr_downsize(dev, 1024 // k, 512 // k).cpu().numpy()
+        n, idx = O.bits_equal(got, O.hdr_downsize(img, 1024 // k, 512 // k))
+        assert n == 0, (k, n, idx)
+    for ow, oh in ((1000, 500), (512, 128), (2048, 1024)):
+        with pytest.raises(capi.VQHipError) as e:
+            ctx.hdr_downsize(dev, ow, oh)
+        assert e.value.code == abi.VQHIP_ERR_UNSUPPORTED

@@ -101,3 +101,16 @@ def test_product_header_parser_matches_oracle():
         ow, oh, ooff = C.c_int(), C.c_int(), C.c_size_t()
         assert lib.vqo_hdr_parse_header(head, len(head), C.byref(ow), C.byref(oh), C.byref(ooff)) == 0
         assert (pw, ph, poff) == (ow.value, oh.value, ooff.value) == (w, h, len(head) - 2)
+
+
+def test_downsize_oracle_is_the_block_mean_and_rejects_other_ratios():
+    """vqo_hdr_downsize_rgba32f (the fallback of EnvironmentMap.cpp:142-209 restated as a k x k mean — PARITY UNPINNED, the reference's
+    resampler is stb_image_resize in the absent submodule): against a float64 block mean; non-integer / anisotropic ratios are refused."""
+    img = synth.equirect(256, 128)
+    for k in (1, 2, 4, 8):
+        got = O.hdr_downsize(img, 256 // k, 128 // k)
+        want = img.astype(np.float64).reshape(128 // k, k, 256 // k, k, 4).mean((1, 3))
+        assert np.allclose(got[..., :3], want[..., :3], rtol=2e-6, atol=0) and (got[..., 3] == 1).all()
+    for ow, oh in ((100, 50), (128, 32), (512, 256)):
+        with pytest.raises(ValueError):
+            O.hdr_downsize(img, ow, oh)

@@ -8,6 +8,7 @@ VQHIP_ERR_INVALID_ARG = -1
 VQHIP_ERR_HIP = -2
 VQHIP_ERR_UNSUPPORTED = -3
 VQHIP_ERR_NO_DEVICE = -4
+VQHIP_ERR_RCCL = -5
 
 FMT_RGBA32F, FMT_RGBA16F, FMT_RGBA8_UNORM, FMT_RG16F, FMT_RG32F = 0, 1, 2, 3, 4
 FMT_BPP = {FMT_RGBA32F: 16, FMT_RGBA16F: 8, FMT_RGBA8_UNORM: 4, FMT_RG16F: 4, FMT_RG32F: 8}

@@ -66,6 +66,7 @@ def load_library():
         "vqhip_skydome": (i32, [vp, vp, vp, i32, i32, C.POINTER(abi.SkydomeParams), C.POINTER(abi.Interpolants), vp, i32, i32, i32, i32]),
         "vqhip_hdr_parse_header": (i32, [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]),
         "vqhip_hdr_decode_rgba32f": (i32, [vp, vp, C.c_char_p, sz, vp, i32, i32]),
+        "vqhip_hdr_downsize_rgba32f": (i32, [vp, vp, vp, i32, i32, vp, i32, i32]),
         "vqhip_fsr_easu_con": (None, [C.POINTER(C.c_uint32), f32, f32, f32, f32, f32, f32]),
         "vqhip_fsr_rcas_con": (None, [C.POINTER(C.c_uint32), f32]),
         "vqhip_fsr_easu": (i32, [vp, vp, vp, i32, i32, i32, C.POINTER(C.c_uint32), vp, i32, i32, i32]),
@@ -95,7 +96,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
-    "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f",
+    "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f", "vqhip_hdr_downsize_rgba32f",
     "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections",
     "vqhip_rowtile", "vqhip_comm_unique_id", "vqhip_comm_create", "vqhip_comm_adopt", "vqhip_comm_destroy", "vqhip_exchange_blur_halos",
     "vqhip_composite_tiles",
@@ -425,6 +426,13 @@ class Context:
         w, h, _ = hdr_parse_header(data)
         out = torch.empty((h, w, 4), dtype=torch.float32, device=self.device)
         self._ck(self.lib.vqhip_hdr_decode_rgba32f(self._h, self._stream(stream), data, len(data), _ptr(out), w, h))
+        return out
+
+    def hdr_downsize(self, img, out_w, out_h, stream=None):
+        """Image::CreateResizedImage as the HDRI fallback uses it (EnvironmentMap.cpp:167): integer ratios only (k x k mean), else VQHipError(-3)."""
+        _check_img(img, FMT_RGBA32F, "img")
+        out = torch.empty((out_h, out_w, 4), dtype=torch.float32, device=self.device)
+        self._ck(self.lib.vqhip_hdr_downsize_rgba32f(self._h, self._stream(stream), _ptr(img), img.shape[1], img.shape[0], _ptr(out), out_w, out_h))
         return out
 
     # ---- skydome (Skydome.hlsl:39-56, SceneRendering.cpp:1822-1850; SURVEY.md §8f.2) -------------------------

@@ -521,6 +521,21 @@ int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, siz
 static uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 
 // FsrEasuCon, ffx_fsr1.h:156-203, as called on the CPU by FFSR1_EASU::UpdateEASUConstantBlock (PostProcess.cpp:47-79)
+int vqhip_hdr_downsize_rgba32f(vqhip_ctx* ctx, void* stream, const void* in, int width, int height, void* out, int out_width, int out_height) {
+    vqk::Range range_("DownsizeHDRI");
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "hdr_downsize: ctx is NULL");
+    if (!in || !out || width <= 0 || height <= 0 || out_width <= 0 || out_height <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "hdr_downsize: bad argument");
+    if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "hdr_downsize: in-place is not supported");
+    const int k = width / out_width;
+    if (k < 1 || out_width * k != width || out_height * k != height)
+        return fail(ctx, VQHIP_ERR_UNSUPPORTED, "hdr_downsize: only integer ratios, the same in x and y, are implemented (the engine's 8k/4k/2k/1k table); "
+                                                "general resampling (stb_image_resize, absent from the reference tree) is not");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (k == 1) { HIP_TRY(ctx, hipMemcpyAsync(out, in, (size_t)width * height * 16, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return VQHIP_OK; }
+    hipError_t e = launch_downsize_box((hipStream_t)stream, in, out, width, height, k);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "downsize launch");
+}
+
 void vqhip_fsr_easu_con(uint32_t con[16], float inVpW, float inVpH, float inSzW, float inSzH, float outW, float outH) {
     const float rOutW = 1.0f / outW, rOutH = 1.0f / outH, rInW = 1.0f / inSzW, rInH = 1.0f / inSzH;
     con[0] = fbits(inVpW * rOutW);                 con[1] = fbits(inVpH * rOutH);

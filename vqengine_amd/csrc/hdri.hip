@@ -125,6 +125,25 @@ __global__ __launch_bounds__(256) void k_rgbe_to_rgba32f(const uint32_t* __restr
     }
 }
 
+// HDRI downsize by an integer factor k in both directions (8k -> 4k / 2k / 1k: k = 2, 4, 8): every output texel is the mean of its k x k
+// block. One lane per output texel; the block is summed row by row, left to right (a fixed fp32 order the oracle repeats), then scaled
+// by 1/(k*k) (a power of two for the engine's resolutions: exact). Alpha := 1. HBM-bound: 16 B * k*k in, 16 B out per texel.
+__global__ __launch_bounds__(256) void k_downsize_box(const float4* __restrict__ src, float4* __restrict__ dst, int sw, int dw, int dh, int k, float inv) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+    for (int j = 0; j < k; ++j) {
+        const float4* row = src + (size_t)(y * k + j) * sw + (size_t)x * k;
+        for (int i = 0; i < k; ++i) { const float4 t = row[i]; ax = ax + t.x; ay = ay + t.y; az = az + t.z; }
+    }
+    dst[(size_t)y * dw + x] = make_float4(ax * inv, ay * inv, az * inv, 1.0f);
+}
+hipError_t launch_downsize_box(hipStream_t s, const void* src, void* dst, int sw, int sh, int k) {
+    const int dw = sw / k, dh = sh / k;
+    hipLaunchKernelGGL(k_downsize_box, dim3((dw + 255) / 256, dh), dim3(256), 0, s, (const float4*)src, (float4*)dst, sw, dw, dh, k, 1.0f / (float)(k * k));
+    return hipGetLastError();
+}
+
 hipError_t launch_rgbe_to_rgba32f(hipStream_t s, const void* rgbe, void* out, size_t n) {
     const size_t blocks = (n + 255) / 256;
     hipLaunchKernelGGL(k_rgbe_to_rgba32f, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, (const uint32_t*)rgbe, (float4*)out, n);
