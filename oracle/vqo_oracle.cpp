@@ -503,6 +503,11 @@ void vqo_cube_edge_neighbor(int f, int i, int j, int N, int* out3) { cube_edge_n
 void vqo_sample_cube_rgba16f(const uint16_t* cube, int N, const float* dir, float* out4) {
     f4 c = sample_cube_rgba16f(cube, N, { dir[0], dir[1], dir[2] }); out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = c.w;
 }
+void vqo_sample_2d_rg16f_clamp(const uint16_t* tex, int W, int H, float u, float v, float* out2) { f2 r = sample_2d_rg16f_clamp(tex, W, H, u, v); out2[0] = r.x; out2[1] = r.y; }
+void vqo_sample_material_tex(const vqhip_texture2d* t, const float* uv, const float* ddx, const float* ddy, float bias, float* out4) {
+    f4 c = sample_material_tex(*t, { uv[0], uv[1] }, { ddx[0], ddx[1] }, { ddy[0], ddy[1] }, bias); out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = c.w;
+}
+float vqo_fetch_r8_point_wrap(const uint8_t* tex, int W, int H, float u, float v) { return fetch_r8_point_wrap(tex, W, H, u, v); }
 void vqo_direction_to_equirect_uv(const float* d, float* uv) { f2 r = DirectionToEquirectUV({ d[0], d[1], d[2] }); uv[0] = r.x; uv[1] = r.y; }
 void vqo_sample_equirect_lod(const float* chain, int w0, int h0, int nMips, float u, float v, float lod, float* out4) {
     f4 c = sample_equirect_lod(chain, w0, h0, nMips, u, v, lod); out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = c.w;

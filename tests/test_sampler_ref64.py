@@ -1,0 +1,142 @@
+"""oracle/vqo_sampling.h (the statement of D3D's texture-filtering rules shared by the oracle, the HIP kernels and — through
+oracle/ref_src/ref_hooks.cpp — the reference's HLSL when it runs on the CPU) against the INDEPENDENT float64 statement tests/ref64_sampling.py.
+Bound per sample: the two agree to binary32 rounding (1e-5 of the largest tap) unless the oracle's binary32 texel coordinate falls on the other
+side of a 1/512 boundary of the 8-bit fraction; then they differ by at most ONE fraction step = (1/256) x (max - min of the taps involved).
+The fraction of such samples is asserted small (< 1 %). Directions / coordinates are chosen to hit face edges, corners, seams, texel centres
+and borders, the LOD clamps and the WRAP seam."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import oracle_lib as O
+from tests import ref64_sampling as R
+from vqengine_amd import abi
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = O.load()
+    vp, f32, i32 = C.c_void_p, C.c_float, C.c_int
+    lib.vqo_sample_cube_rgba16f.argtypes = [vp, i32, vp, vp]
+    lib.vqo_sample_equirect_lod.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp]
+    lib.vqo_sample_2d_rg16f_clamp.argtypes = [vp, i32, i32, f32, f32, vp]
+    lib.vqo_sample_material_tex.argtypes = [vp, vp, vp, vp, f32, vp]
+    lib.vqo_fetch_r8_point_wrap.argtypes = [vp, i32, i32, f32, f32]
+    lib.vqo_fetch_r8_point_wrap.restype = f32
+    return lib
+
+
+def _check(got, want, taps, stats):
+    taps = np.stack(taps)
+    scale = max(float(np.abs(taps).max()), 1e-30)
+    err = float(np.abs(np.asarray(got, np.float64) - want).max())
+    span = float((taps.max(0) - taps.min(0)).max())
+    if err <= 1e-5 * scale:
+        stats[0] += 1
+    else:
+        assert err <= span / 256.0 * 1.001 + 1e-5 * scale, (err, span, scale)          # exactly one 8-bit fraction step apart
+        stats[1] += 1
+
+
+def _directions(rng, N):
+    d = [rng.normal(size=3) for _ in range(1500)]
+    for f in range(6):                                               # texel centres, texel borders, face edges and corners of every face
+        F, U, Rr = R._basis(f)
+        for u in (-1.0, -1 + 1.0 / N, -1 + 2.0 / N, -0.3, 0.0, 0.5 / N, 1 - 1.0 / N, 1 - 1e-4, 1.0):
+            for v in (-1.0, -1 + 1.0 / N, 0.0, 0.37, 1 - 1.0 / N, 1 - 1e-5, 1.0):
+                d.append(F + u * Rr + v * U)
+    d += [np.array(c, np.float64) for c in ((1, 1, 1), (1, -1, 1), (-1, 1, -1), (1, 1, 0), (0, -1, 1), (1, 0, 0), (0, 0, -1), (1, 1, 0.999), (0.999, 1, 1))]
+    return [np.asarray(v, np.float32) for v in d]
+
+
+@pytest.mark.parametrize("N", [4, 16, 128])
+def test_seamless_cube_bilinear(lib, N):
+    rng = np.random.default_rng(N)
+    cube = (rng.random((6, N, N, 4)) * rng.choice([0.1, 1.0, 50.0], (6, N, N, 1))).astype(np.float16)
+    c64 = cube.astype(np.float64)
+    stats = [0, 0]
+    out = np.zeros(4, np.float32)
+    for d in _directions(rng, N):
+        lib.vqo_sample_cube_rgba16f(cube.ctypes.data, N, d.ctypes.data, out.ctypes.data)
+        want, taps = R.sample_cube(c64, d.astype(np.float64))
+        _check(out, want, taps, stats)
+    assert stats[1] <= 0.01 * sum(stats), stats
+
+
+def test_equirect_trilinear_wrap_and_lod_clamp(lib):
+    rng = np.random.default_rng(7)
+    w0, h0 = 64, 32
+    lv0 = (rng.random((h0, w0, 4)) * 30).astype(np.float32)
+    chain, n = O.mip_chain(lv0)
+    levels, off = [], 0
+    for l in range(n):
+        w, h = max(1, w0 >> l), max(1, h0 >> l)
+        levels.append(chain[off:off + w * h].reshape(h, w, 4).astype(np.float64))
+        off += w * h
+    stats = [0, 0]
+    out = np.zeros(4, np.float32)
+    uvs = [(rng.uniform(-1.5, 2.5), rng.uniform(-0.5, 1.5)) for _ in range(1200)] + [(0.0, 0.5), (1.0, 0.5), (0.5 / w0, 0.5 / h0), (1 - 0.5 / w0, 1.0), (0.999999, 0.0)]
+    lods = [0.0, 0.5, 1.0, 2.25, 3.999, float(n - 1), float(n + 3), -2.0, float("nan"), 1.0 / 256, 0.998]
+    for k, (u, v) in enumerate(uvs):
+        lod = lods[k % len(lods)]
+        lib.vqo_sample_equirect_lod(chain.ctypes.data, w0, h0, n, np.float32(u), np.float32(v), np.float32(lod), out.ctypes.data)
+        want, taps = R.sample_chain(levels, np.float32(u), np.float32(v), float(np.float32(lod)), "wrap")
+        _check(out, want, taps, stats)
+    assert stats[1] <= 0.01 * sum(stats), stats
+
+
+def test_lut_bilinear_clamp(lib):
+    rng = np.random.default_rng(9)
+    S = 32
+    lut = rng.random((S, S, 2)).astype(np.float16)
+    stats = [0, 0]
+    out = np.zeros(2, np.float32)
+    pts = [(rng.uniform(-0.1, 1.1), rng.uniform(-0.1, 1.1)) for _ in range(1500)] + [(0, 0), (1, 1), (0.5 / S, 1 - 0.5 / S), (1.0, 0.0), (0.25, 0.75)]
+    for u, v in pts:
+        lib.vqo_sample_2d_rg16f_clamp(lut.ctypes.data, S, S, np.float32(u), np.float32(v), out.ctypes.data)
+        want, taps = R.sample_2d(lut.astype(np.float64), np.float32(u), np.float32(v), "clamp")
+        _check(out, want, taps, stats)
+    assert stats[1] <= 0.01 * sum(stats), stats
+
+
+def test_material_sample_lod_from_derivatives(lib):
+    """Texture2D.Sample / SampleBias of an RGBA8 mip chain: LOD = log2 of the longer derivative in texel units (+ bias), clamped, trilinear.
+    The LOD goes through the contract's polynomial log2 (<= 2.1 ulp) — one extra fraction step of the LOD is inside the same bound."""
+    rng = np.random.default_rng(11)
+    W, H = 64, 16
+    lv0 = rng.integers(0, 256, (H, W, 4), dtype=np.uint8)
+    chain, n = O.mip_chain_rgba8(lv0)
+    levels, off = [], 0
+    for l in range(n):
+        w, h = max(1, W >> l), max(1, H >> l)
+        levels.append(chain[off:off + w * h].reshape(h, w, 4).astype(np.float64) / 255.0)
+        off += w * h
+    t = abi.Texture2D(chain.ctypes.data, W, H, n, 0)
+    stats = [0, 0]
+    out = np.zeros(4, np.float32)
+    for k in range(1500):
+        uv = np.array([rng.uniform(-2, 3), rng.uniform(-2, 3)], np.float32)
+        s = 10 ** rng.uniform(-4, 0)
+        ddx = (np.array([rng.normal(), rng.normal()]) * s).astype(np.float32)
+        ddy = (np.array([rng.normal(), rng.normal()]) * s).astype(np.float32) if k % 7 else np.zeros(2, np.float32)
+        bias = float(rng.choice([0.0, -0.5, 0.75, 1.0]))
+        lib.vqo_sample_material_tex(C.byref(t), uv.ctypes.data, ddx.ctypes.data, ddy.ctypes.data, bias, out.ctypes.data)
+        lod = R.lod_from_derivatives(ddx, ddy, W, H, bias)
+        want, taps = R.sample_chain(levels, uv[0], uv[1], lod, "wrap")
+        _check(out, want, taps, stats)
+    assert stats[1] <= 0.02 * sum(stats), stats
+
+
+def test_ssao_point_fetch_on_texel_borders(lib):
+    """texScreenSpaceAO.Sample(PointSampler, (pixel + 1) / dims) (ForwardLighting.hlsl:280-281): the coordinate sits exactly on a texel
+    border; with the 8-bit snap both statements pick texel x+1 (wrapping at the right / bottom edge) for every pixel of odd-sized images."""
+    rng = np.random.default_rng(13)
+    for W, H in ((7, 5), (48, 27), (1920, 4), (3, 1080)):
+        img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        for y in range(H):
+            for x in range(0, W, max(1, W // 97)):
+                u, v = np.float32((np.float32(x) + np.float32(1.0)) / np.float32(W)), np.float32((np.float32(y) + np.float32(1.0)) / np.float32(H))
+                got = lib.vqo_fetch_r8_point_wrap(img.ctypes.data, W, H, u, v)
+                assert got == np.float32(R.point_wrap(img, u, v)) * np.float32(1.0 / 255.0) or abs(got - float(R.point_wrap(img, u, v)) / 255.0) < 1e-7
+                assert R.point_wrap(img, u, v) == img[(y + 1) % H, (x + 1) % W]
