@@ -19,12 +19,32 @@
 #include <vector>
 #include "vqhip.h"
 
+// The interface the adaptors derive from:
+//   * inside the engine: define VQHIP_ENGINE_RENDERPASS_H to the include path of the engine's own RenderPass.h (e.g.
+//     -DVQHIP_ENGINE_RENDERPASS_H='"Renderer/Rendering/RenderPass/RenderPass.h"'). The adaptors then derive from the ENGINE'S ::IRenderPass,
+//     implement its CollectPSOCreationParameters() (RenderPass.h:58) as "no PSOs: kernels are compiled ahead of time", and can be stored
+//     in VQRenderer::mRenderPasses (std::vector<std::shared_ptr<IRenderPass>>, Renderer.h:403) next to the other passes;
+//   * stand-alone (tests, tools): the stand-in interface below with the same five virtuals.
+// tests/cpp/test_passes_engine.cpp compiles the first form against a stand-in of the engine header (tests/cpp/mock_engine/).
+#ifdef VQHIP_ENGINE_RENDERPASS_H
+#include VQHIP_ENGINE_RENDERPASS_H
 namespace vqhip {
-
+using IRenderPassResourceCollection = ::IRenderPassResourceCollection;      // RenderPass.h:27
+using IRenderPassDrawParameters = ::IRenderPassDrawParameters;              // RenderPass.h:29
+class IRenderPass : public ::IRenderPass {                                  // RenderPass.h:44-59
+public:
+    std::vector<FPSOCreationTaskParameters> CollectPSOCreationParameters() override { return {}; }   // :58 — nothing to compile at load time
+    int LastStatus() const { return mStatus; }      // the reference asserts/logs; here the last vqhip_status is kept
+protected:
+    int mStatus = VQHIP_OK;
+};
+} // namespace vqhip
+#else
+namespace vqhip {
 struct IRenderPassResourceCollection {};            // RenderPass.h:27
 struct IRenderPassDrawParameters {};                // RenderPass.h:29
 
-class IRenderPass {                                 // RenderPass.h:44-59 (CollectPSOCreationParameters has no analogue: kernels are AOT)
+class IRenderPass {                                 // RenderPass.h:44-59 (CollectPSOCreationParameters only exists in the engine build above)
 public:
     virtual ~IRenderPass() = default;
     virtual bool Initialize() = 0;
@@ -36,6 +56,10 @@ public:
 protected:
     int mStatus = VQHIP_OK;
 };
+} // namespace vqhip
+#endif
+
+namespace vqhip {
 
 class RenderPassBase : public IRenderPass {         // RenderPass.h:65-89: holds the renderer; here the vqhip context
 protected:
@@ -120,6 +144,16 @@ public:
         VQ_TonemapperParams TonemapperParams = { VQ_COLOR_SPACE_REC_709, VQ_DISPLAY_CURVE_SRGB, 200.0f, 1 };   // FTonemapper defaults, PostProcess.h:84-91
         bool bEnableGaussianBlur = false;                        // FPostProcessParameters::bEnableGaussianBlur (PostProcess.h:166); compiled out in the reference (:2526)
         bool bHDR = false;                                       // selects the RGBA16F tonemapper target
+        // Row-tiled multi-GPU frame (no reference analogue): this pass was sized for ONE ROW TILE of the frame
+        // (vqhip_rowtile) and pSceneColor is that tile. With pComm set the pass exchanges the 10 X-blurred halo rows with the tiles
+        // above / below before the Y blur, and afterwards composites the finished tiles into pCompositeFrame on CompositeRoot
+        // (VQHIP_ALL_RANKS: on every rank). pCompositeFrame: FrameHeight x Width texels of the output format, or nullptr on ranks that
+        // do not receive the frame.
+        vqhip_comm* pComm = nullptr;
+        int World = 1, Rank = 0;                                 // the communicator's size and this process's rank in it
+        int FrameHeight = 0;
+        int CompositeRoot = 0;
+        void* pCompositeFrame = nullptr;
     };
     explicit HipPostProcessPass(vqhip_ctx* Ctx) : RenderPassBase(Ctx) {}
     ~HipPostProcessPass() override { OnDestroyWindowSizeDependentResources(); }
@@ -130,8 +164,11 @@ public:
         mWidth = Width; mHeight = Height;
         const size_t px = (size_t)Width * Height;
         mBlurIntermediate = Alloc(px * 8); mBlurOutput = Alloc(px * 8); mTonemapperOut = Alloc(px * 8);
+        mHaloTop = Alloc((size_t)VQHIP_HALO_ROWS * Width * 8); mHaloBottom = Alloc((size_t)VQHIP_HALO_ROWS * Width * 8);   // row-tiled mode only
     }
-    void OnDestroyWindowSizeDependentResources() override { Free(mBlurIntermediate); Free(mBlurOutput); Free(mTonemapperOut); mWidth = mHeight = 0; }
+    void OnDestroyWindowSizeDependentResources() override {
+        Free(mBlurIntermediate); Free(mBlurOutput); Free(mTonemapperOut); Free(mHaloTop); Free(mHaloBottom); mWidth = mHeight = 0;
+    }
     void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) override {
         const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
         if (!p || !p->pSceneColor || !mTonemapperOut) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
@@ -144,21 +181,34 @@ public:
             const VQ_BlurParams bp = { (int32_t)mWidth, (int32_t)mHeight };                                      // FBlurParams, PostProcess.h:92-96
             mStatus = vqhip_gaussian_blur_x(mCtx, p->Stream, p->pSceneColor, mBlurIntermediate, &bp, VQHIP_FMT_RGBA16F);
             if (mStatus != VQHIP_OK) return;
-            if (!p->bHDR) {
-                mStatus = vqhip_gaussian_blur_y_tonemap(mCtx, p->Stream, mBlurIntermediate, mTonemapperOut, nullptr, nullptr, 0, &bp, &p->TonemapperParams,
-                                                        VQHIP_FMT_RGBA16F, mOutFormat);
-                return;
+            const void* top = nullptr; const void* bottom = nullptr; int haloRows = 0;
+            if (p->pComm) {                                      // exchange 1: the 10 boundary rows of the X-blurred tile (RCCL send/recv on p->Stream)
+                mStatus = vqhip_exchange_blur_halos(p->pComm, p->Stream, mBlurIntermediate, (int)mWidth, (int)mHeight, (int)mWidth, VQHIP_FMT_RGBA16F, mHaloTop, mHaloBottom);
+                if (mStatus != VQHIP_OK) return;
+                int row0 = 0, rows = 0;
+                mStatus = vqhip_rowtile(p->FrameHeight, p->World, p->Rank, &row0, &rows);
+                if (mStatus == VQHIP_OK && rows != (int)mHeight) mStatus = VQHIP_ERR_INVALID_ARG;             // the pass must have been sized for this tile
+                if (mStatus != VQHIP_OK) return;
+                top = p->Rank > 0 ? mHaloTop : nullptr; bottom = p->Rank < p->World - 1 ? mHaloBottom : nullptr; haloRows = (top || bottom) ? VQHIP_HALO_ROWS : 0;
             }
-            mStatus = vqhip_gaussian_blur_y(mCtx, p->Stream, mBlurIntermediate, mBlurOutput, nullptr, nullptr, 0, &bp, VQHIP_FMT_RGBA16F);
-            if (mStatus != VQHIP_OK) return;
-            mStatus = vqhip_tonemap(mCtx, p->Stream, mBlurOutput, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
-            return;
+            if (!p->bHDR) {
+                mStatus = vqhip_gaussian_blur_y_tonemap(mCtx, p->Stream, mBlurIntermediate, mTonemapperOut, top, bottom, haloRows, &bp, &p->TonemapperParams,
+                                                        VQHIP_FMT_RGBA16F, mOutFormat);
+            } else {
+                mStatus = vqhip_gaussian_blur_y(mCtx, p->Stream, mBlurIntermediate, mBlurOutput, top, bottom, haloRows, &bp, VQHIP_FMT_RGBA16F);
+                if (mStatus != VQHIP_OK) return;
+                mStatus = vqhip_tonemap(mCtx, p->Stream, mBlurOutput, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
+            }
+        } else {
+            mStatus = vqhip_tonemap(mCtx, p->Stream, p->pSceneColor, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
         }
-        mStatus = vqhip_tonemap(mCtx, p->Stream, p->pSceneColor, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
+        if (mStatus == VQHIP_OK && p->pComm)                     // exchange 2: the finished tiles -> the frame on the presenting rank
+            mStatus = vqhip_composite_tiles(p->pComm, p->Stream, mTonemapperOut, (int)mWidth, p->FrameHeight, mOutFormat, p->CompositeRoot, p->pCompositeFrame);
     }
     void* GetOutput() const { return mTonemapperOut; }
     vqhip_format GetOutputFormat() const { return mOutFormat; }
 private:
+    void* mHaloTop = nullptr; void* mHaloBottom = nullptr;
     void* mBlurIntermediate = nullptr; void* mBlurOutput = nullptr; void* mTonemapperOut = nullptr;
     vqhip_format mOutFormat = VQHIP_FMT_RGBA8_UNORM;
     unsigned mWidth = 0, mHeight = 0;

@@ -85,6 +85,23 @@ int main(int argc, char** argv) {
         if (hipStreamSynchronize(stream) != hipSuccess) return 3;
         writeDev(dir + "/scene_ip_rgba16f.bin", lighting.GetSceneColor(), (size_t)W * H * 8);
     }
+    // --- row-tiled mode of the post pass through the real RCCL: a world of one rank (the box has one GPU). No halos, the composite of the
+    // single tile is the tile: the frame must equal the SDR image written above.
+    if (argc > 6 && std::string(argv[6]) == "rccl") {
+        char id[VQHIP_COMM_ID_BYTES];
+        vqhip_comm* comm = nullptr;
+        if (vqhip_comm_unique_id(id) != VQHIP_OK || vqhip_comm_create(id, 1, 0, &comm) != VQHIP_OK) { fprintf(stderr, "comm: %s\n", vqhip_last_error(nullptr)); return 6; }
+        void* frame = nullptr;
+        if (hipMalloc(&frame, (size_t)W * H * 4) != hipSuccess) return 3;
+        pd.pComm = comm; pd.World = 1; pd.Rank = 0; pd.FrameHeight = H; pd.CompositeRoot = 0; pd.pCompositeFrame = frame;
+        post.RecordCommands(&pd);
+        CHECK(post);
+        if (hipStreamSynchronize(stream) != hipSuccess) return 3;
+        writeDev(dir + "/frame_rgba8.bin", frame, (size_t)W * H * 4);
+        pd.pComm = nullptr;
+        vqhip_comm_destroy(comm);
+        (void)hipFree(frame);
+    }
     // error behaviour: RecordCommands without parameters reports, never crashes
     lighting.RecordCommands(nullptr);
     if (lighting.LastStatus() != VQHIP_ERR_INVALID_ARG) return 5;

@@ -38,7 +38,7 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
         mats[i].data = d
         mats[i].data.textureConfig = 0.0
     (tmp_path / "materials.bin").write_bytes(bytes(mats))
-    r = subprocess.run([EXE, str(tmp_path), str(W), str(H), str(EW), str(EH)], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([EXE, str(tmp_path), str(W), str(H), str(EW), str(EH), "rccl"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     diff = np.fromfile(tmp_path / "diffuse_blurred.bin", np.float16).reshape(6, 8, 8, 4)
     n_bad, idx = O.bits_equal(diff, pre["diffuse_blurred"])
@@ -58,3 +58,13 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
     sdr = O.tonemap(O.gaussian_blur(scene, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
     got = np.fromfile(tmp_path / "sdr_rgba8.bin", np.uint8).reshape(H, W, 4)
     assert np.array_equal(got, sdr)
+    # the post pass in row-tiled mode over a world of one rank (real RCCL): its composite frame is the same image
+    assert np.array_equal(np.fromfile(tmp_path / "frame_rgba8.bin", np.uint8).reshape(H, W, 4), sdr)
+
+
+def test_adaptors_derive_from_the_engine_interface():
+    """include/vqhip_passes.hpp with VQHIP_ENGINE_RENDERPASS_H defined (tests/cpp/test_passes_engine.cpp against tests/cpp/mock_engine/): the
+    adaptors are ::IRenderPass objects that VQRenderer::mRenderPasses can hold. Host-only program; run here because it links libvqhip.so."""
+    exe = os.path.join(os.path.dirname(EXE), "test_passes_engine")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "engine-interface passes OK" in r.stdout, r.stdout + r.stderr
