@@ -58,8 +58,10 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
     sdr = O.tonemap(O.gaussian_blur(scene, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
     got = np.fromfile(tmp_path / "sdr_rgba8.bin", np.uint8).reshape(H, W, 4)
     assert np.array_equal(got, sdr)
-    # the post pass in row-tiled mode over a world of one rank (real RCCL): its composite frame is the same image
-    assert np.array_equal(np.fromfile(tmp_path / "frame_rgba8.bin", np.uint8).reshape(H, W, 4), sdr)
+    # the post pass in row-tiled mode over a world of one rank (real RCCL), run on the scene colour of the §8f.1 path (the last one rendered):
+    # its composite frame is the post chain of that image
+    sdr_ip = O.tonemap(O.gaussian_blur(scene_ip, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
+    assert np.array_equal(np.fromfile(tmp_path / "frame_rgba8.bin", np.uint8).reshape(H, W, 4), sdr_ip)
 
 
 def test_adaptors_derive_from_the_engine_interface():
