@@ -359,6 +359,15 @@ VQHIP_API int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const 
 VQHIP_API int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
         const VQ_TonemapperParams* params, vqhip_format inFmt, vqhip_format outFmt);
 
+/* Replaces the blur + tonemapper part of VQRenderer::RenderPostProcess as ONE call (SceneRendering.cpp:2579-2656: "BlurCS" { CSMain_X, CSMain_Y }
+ * when bEnableGaussianBlur, then "TonemapperCS"): sceneColor -> out. BlurIntermediate lives in a scratch buffer of the context; for the
+ * reference's formats (RGBA16F scene colour, RGBA8 SDR target) and a display curve that does not mix channels (sRGB, LINEAR, ST2084 on Rec.2020
+ * content) the Y pass and the tonemapper are one kernel and BlurOutput never exists. Identical bits to vqhip_gaussian_blur_x -> _y ->
+ * vqhip_tonemap (the intermediate roundings to the blur format are reproduced). enableGaussianBlur == 0: the tonemapper alone.
+ * VQHIP_POST_ONE_KERNEL=1 in the environment selects an experimental single-kernel form (X-blurred rows in LDS): same bits, measured slower. */
+VQHIP_API int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, void* out, int width, int height,
+        const VQ_TonemapperParams* tonemapParams, int enableGaussianBlur, vqhip_format inFmt, vqhip_format outFmt);
+
 /* Replaces VQRenderer::ComputeBRDFIntegrationLUT (Renderer.cpp:871-909) == CubemapConvolution.hlsl:
  * CSMain_BRDFIntegration :225-240. Reference values: size 1024, samples 2048, RG16F. */
 VQHIP_API int vqhip_brdf_lut(vqhip_ctx* ctx, void* stream, void* outRG, int size, int samples, vqhip_format fmt);

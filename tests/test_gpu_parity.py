@@ -357,6 +357,32 @@ def test_forward_cfg3_full_frame_with_ibl(ctx):
 # ---------------------------------------------------------------------------------------------------
 # post chain
 # ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2160, 3840), (97, 301), (64, 64), (33, 1000), (540, 257), (1440, 2560), (32, 64), (31, 700)])
+@pytest.mark.parametrize("one_kernel", ["0", "1"])
+def test_post_process_one_call_equals_three_dispatches(ctx, shape, one_kernel, monkeypatch):
+    """vqhip_post_process against the oracle's three passes, bit for bit, in both of its forms: the default (blur X into the context's scratch,
+    then blur Y + tonemap) and the experimental single kernel (VQHIP_POST_ONE_KERNEL=1, k_post_fused: X blur -> LDS ring -> Y blur -> tonemap
+    table): 4K, sizes that are no multiple of the 256-column strips / 8-row steps / segment height, images smaller than the single kernel
+    accepts, negative and NaN inputs (the half of the table that is not in LDS)."""
+    monkeypatch.setenv("VQHIP_POST_ONE_KERNEL", one_kernel)
+    h, w = shape
+    img = synth.hdr_image(w, h, seed=h * 7 + w).astype(np.float16)
+    img[h // 3, w // 2, 0] = np.float16(-3.5)          # negative / NaN colours reach the half of the table that is not in LDS
+    img[h // 2, w // 3, 1] = np.float16(np.nan)
+    img[0, 0, 2] = np.float16(-0.0)
+    want = O.tonemap(O.gaussian_blur(img, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
+    got = ctx.post_process(dev(img), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
+    assert_bits(got, want, f"post_process {shape}")
+    if h <= 100:
+        for p in (abi.TonemapperParams(0, abi.DISPLAY_CURVE_SRGB, 200.0, 0), abi.TonemapperParams(1, abi.DISPLAY_CURVE_ST2084, 200.0, 1),
+                  abi.TonemapperParams(0, abi.DISPLAY_CURVE_ST2084, 200.0, 1), abi.TonemapperParams(0, abi.DISPLAY_CURVE_LINEAR, 200.0, 1)):
+            want = O.tonemap(O.gaussian_blur(img, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, params=p)
+            assert_bits(ctx.post_process(dev(img), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, params=p), want, f"post_process {shape} curve {p.OutputDisplayCurveEnum}")
+        want16 = O.tonemap(O.gaussian_blur(img, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA16F)
+        assert_bits(ctx.post_process(dev(img), abi.FMT_RGBA16F, abi.FMT_RGBA16F), want16, "post_process HDR target (three dispatches)")
+        assert_bits(ctx.post_process(dev(img), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, blur=False), O.tonemap(img, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM), "no blur")
+
+
 @pytest.mark.parametrize("rows", [270, 135, 27])
 def test_blur_y_halo_at_the_end_of_an_allocation(ctx, rows):
     """Tile heights that are no multiple of the 16-row groups of the Y kernels (270 = 2160/8, 135): the register window of the last

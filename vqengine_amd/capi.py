@@ -46,6 +46,7 @@ def load_library():
         "vqhip_gaussian_blur_y": (i32, [vp, vp, vp, vp, vp, vp, i32, C.POINTER(abi.BlurParams), i32]),
         "vqhip_tonemap": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.TonemapperParams), i32, i32]),
         "vqhip_gaussian_blur_y_tonemap": (i32, [vp, vp, vp, vp, vp, vp, i32, C.POINTER(abi.BlurParams), C.POINTER(abi.TonemapperParams), i32, i32]),
+        "vqhip_post_process": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.TonemapperParams), i32, i32, i32]),
         "vqhip_brdf_lut": (i32, [vp, vp, vp, i32, i32, i32]),
         "vqhip_mip_level_count": (i32, [i32, i32]),
         "vqhip_mip_chain_bytes": (sz, [i32, i32, i32]),
@@ -92,7 +93,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "vqhip_abi_version", "vqhip_create", "vqhip_destroy", "vqhip_last_error", "vqhip_forward_lighting",
-    "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_gaussian_blur_y_tonemap", "vqhip_tonemap", "vqhip_brdf_lut",
+    "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_gaussian_blur_y_tonemap", "vqhip_tonemap", "vqhip_post_process", "vqhip_brdf_lut",
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
@@ -318,6 +319,17 @@ class Context:
         p = abi.BlurParams(w, h)
         self._ck(self.lib.vqhip_gaussian_blur_y_tonemap(self._h, self._stream(stream), _ptr(src), _ptr(out), _ptr(halo_top), _ptr(halo_bottom), rows,
                                                          C.byref(p), C.byref(params), fmt, out_fmt))
+        return out
+
+    def post_process(self, src, in_fmt, out_fmt=FMT_RGBA8_UNORM, params=None, blur=True, out=None, stream=None):
+        """RenderPostProcess's blur + tonemapper as one call (one kernel for RGBA16F -> RGBA8 and a per-channel curve); same bits as
+        gaussian_blur_x -> gaussian_blur_y -> tonemap."""
+        _check_img(src, in_fmt, "src")
+        h, w = src.shape[0], src.shape[1]
+        out = out if out is not None else empty_image(h, w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out", (h, w))
+        params = params if params is not None else abi.TonemapperParams.default()
+        self._ck(self.lib.vqhip_post_process(self._h, self._stream(stream), _ptr(src), _ptr(out), w, h, C.byref(params), int(bool(blur)), in_fmt, out_fmt))
         return out
 
     def tonemap(self, src, in_fmt, out_fmt=FMT_RGBA8_UNORM, params=None, out=None, stream=None):

@@ -345,6 +345,36 @@ int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int w
     return slot >= 0 ? releaseTonemapLut(ctx, (hipStream_t)stream, slot) : VQHIP_OK;
 }
 
+int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, void* out, int width, int height,
+                       const VQ_TonemapperParams* tm, int enableGaussianBlur, vqhip_format inFmt, vqhip_format outFmt) {
+    vqk::Range range_("RenderPostProcess");
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "post_process: ctx is NULL");
+    if (!sceneColor || !out || !tm || width <= 0 || height <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "post_process: bad argument");
+    if (!isImageFmt(inFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "post_process: inFmt must be RGBA32F or RGBA16F");
+    if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "post_process: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
+    if (sceneColor == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "post_process: in-place is not supported");
+    if (!enableGaussianBlur) return vqhip_tonemap(ctx, stream, sceneColor, out, width, height, tm, inFmt, outFmt);
+    hipStream_t st = (hipStream_t)stream;
+    const char* one = std::getenv("VQHIP_POST_ONE_KERNEL");
+    if (one && one[0] == '1' && post_chain_fusable(*tm, inFmt, outFmt, width, height)) {   // experimental single kernel (post.hip:k_post_fused): measured slower, opt-in
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int slot = -1;
+        const int rc = acquireTonemapLut(ctx, st, *tm, outFmt, &slot);
+        if (rc) return rc;
+        const hipError_t e = launch_post_fused(st, sceneColor, out, width, height, ctx->lut[slot].table);
+        if (e != hipSuccess) return failHip(ctx, e, "post chain launch");
+        return releaseTonemapLut(ctx, st, slot);
+    }
+    // blur X into a BlurIntermediate held in the context's scratch buffer, then blur Y + tonemap in one kernel (or two: HDR / RGBA32F targets)
+    const size_t bpp = inFmt == VQHIP_FMT_RGBA32F ? 16 : 8;
+    const int rc0 = ensureScratch(ctx, (size_t)width * height * bpp);
+    if (rc0) return rc0;
+    const VQ_BlurParams bp = { width, height };
+    int rc = vqhip_gaussian_blur_x(ctx, stream, sceneColor, ctx->scratch, &bp, inFmt);
+    if (rc) return rc;
+    return vqhip_gaussian_blur_y_tonemap(ctx, stream, ctx->scratch, out, nullptr, nullptr, 0, &bp, tm, inFmt, outFmt);
+}
+
 int vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode) {
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "set_fresnel_pow: ctx is NULL");
     if (mode != VQHIP_FRESNEL_POW_PRODUCT && mode != VQHIP_FRESNEL_POW_EXP2_LOG2) return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_fresnel_pow: unknown mode");

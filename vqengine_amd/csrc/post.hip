@@ -360,9 +360,150 @@ __global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restri
     }
 }
 
+
+// ---- the whole post chain in ONE kernel: CSMain_X -> CSMain_Y -> Tonemapper (RGBA16F scene colour in, RGBA8 out) -----------------------
+// EXPERIMENTAL, opt-in (VQHIP_POST_ONE_KERNEL=1): bit-identical to the dispatches but SLOWER at 4K — 100 us against 58 us for blur X + fused
+// blur Y/tonemap (profiles/r2e_post_chain.md: the row-major ring makes the Y pass 72 strided ds_read_b32 per lane, 8 waves per CU cannot hide
+// it, and the kernel issues ~250 VALU per pixel against a floor of 126 mads). Kept as the measured starting point of DESIGN.md §10.
+// BlurIntermediate and BlurOutput never exist in HBM: 8 B read (+ halo re-reads) and 4 B written per pixel instead of 8+8, 8+4.
+// A persistent 512-lane workgroup owns a column strip of TW = 256 outputs and walks down a segment of rows, RI = 8 input rows per step:
+//   1. the 8 x 276 raw pixels of the step (prefetched into registers one step ahead) are converted ONCE to fp32 and staged in LDS as
+//      three planes (R, G, B): lane (row r, t) reads its 24-pixel window as 6 aligned ds_read_b128 per channel — consecutive lanes read
+//      consecutive float4s, no bank conflicts — filters 4 consecutive outputs, rounds them to fp16 exactly like the store to
+//      BlurIntermediate and writes the rounded values (as fp32: the Y pass then needs no converts) into a 28-row ring of X-blurred rows;
+//   2. lane (column c, group g) streams the 24 ring rows under its 4 output rows through 12 accumulators (each output still sums its 21
+//      taps in the HLSL's order, one mad per tap), rounds to fp16 like the store to BlurOutput and looks the 16 bits up in the tonemap
+//      table — the 32 KB half of it that covers non-negative inputs lives in LDS, negative / NaN-signed inputs read the table in memory.
+// Rows / columns outside the image are clamped when the raw pixels are loaded (CSMain_X :143, CSMain_Y :178), which commutes with the
+// row-wise X pass. Outputs lag the input by 20 rows; two barriers per step. Identical bits to the three dispatches.
+// LDS: 32 KB table + 8 x 3 x 280 fp32 raw + 28 x 3 x 256 fp32 ring = 145 KB: one workgroup (8 waves) per CU.
+namespace pf {
+constexpr int TW = 256, RI = 8, RING = 28, NPX = TW + 2 * R, NPXP = (NPX + 3) & ~3;
+constexpr int LUT_BYTES = 32768;
+constexpr int RAW_FLOATS = RI * 3 * NPXP, RING_FLOATS = RING * 3 * TW;
+constexpr int LDS_BYTES = LUT_BYTES + (RAW_FLOATS + RING_FLOATS) * 4;
+}
+__global__ __launch_bounds__(512) void k_post_fused(const h4* __restrict__ in, uint32_t* __restrict__ out, int W, int H, const uint8_t* __restrict__ table,
+                                                    int strips, int segRows, int nWG) {
+    using namespace pf;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    uint8_t* lut = lds;
+    float* raw = (float*)(lds + LUT_BYTES);                 // [RI][3][NPXP]
+    float* ring = raw + RAW_FLOATS;                         // [RING][3][TW]
+    const int tid = threadIdx.x;
+    for (int i = tid * 16; i < LUT_BYTES; i += 512 * 16) *(uint4*)(lut + i) = *(const uint4*)(table + i);
+    const float w0 = 0.224716f, w1 = 0.191756f, w2 = 0.119146f, w3 = 0.053897f, w4 = 0.017746f, w5 = 0.004252f, w6 = 0.000741f, w7 = 0.000094f,
+                w8 = 0.000009f, w9 = 0.000001f, w10 = 0.0f;                                      // KERNEL_WEIGHTS, GaussianBlur.hlsl:109-111
+    const float wt[21] = { w10, w9, w8, w7, w6, w5, w4, w3, w2, w1, w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10 };   // offset -10 .. +10
+
+    for (int wg = blockIdx.x; wg < nWG; wg += gridDim.x) {
+        const int seg = wg / strips, strip = wg - seg * strips;
+        const int x0 = strip * TW, y0 = seg * segRows;
+        const int rows = min(segRows, H - y0);
+        const int nIter = (rows + 2 * R + RI - 1) / RI;
+        h4 pre[5];
+        auto fetch = [&](int it) {                          // raw rows j = it*RI .. +7 of the segment: image row y0 - 10 + j, columns x0 - 10 + p
+            #pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int e = tid + 512 * k;                // element of the RI x NPX block
+                if (e < RI * NPX) {
+                    const int r = e / NPX, p = e - r * NPX;
+                    const int y = min(max(y0 - R + it * RI + r, 0), H - 1), x = min(max(x0 - R + p, 0), W - 1);
+                    pre[k] = in[(size_t)y * W + x];
+                }
+            }
+        };
+        fetch(0);
+        for (int it = 0; it < nIter; ++it) {
+            // 1a. stage the prefetched raw pixels as fp32 planes
+            #pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int e = tid + 512 * k;
+                if (e < RI * NPX) {
+                    const int r = e / NPX, p = e - r * NPX;
+                    float* dst = raw + (r * 3) * NPXP + p;
+                    dst[0] = (float)pre[k].x; dst[NPXP] = (float)pre[k].y; dst[2 * NPXP] = (float)pre[k].z;
+                }
+            }
+            __syncthreads();                                // A: raw visible; the Y pass of the previous step is done with the ring rows X now overwrites
+            if (it + 1 < nIter) fetch(it + 1);
+            // 1b. X pass: lane (r, t) -> outputs 4t .. 4t+3 of raw row r -> ring row (it*RI + r) % RING
+            {
+                const int r = tid >> 6, t = tid & 63;
+                const int slot = (it * RI + r) % RING;
+                #pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float4* src = (const float4*)(raw + (r * 3 + ch) * NPXP) + t;
+                    float v[24];
+                    #pragma unroll
+                    for (int g = 0; g < 6; ++g) { const float4 q = src[g]; v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w; }
+                    float o[4];
+                    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float acc = 0.0f;
+                        #pragma unroll
+                        for (int k = 0; k < 21; ++k) acc = fma_(v[j + k], wt[k], acc);
+                        o[j] = (float)to_f16(acc);          // == the RGBA16F store to BlurIntermediate
+                    }
+                    *((float4*)(ring + (slot * 3 + ch) * TW) + t) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+            __syncthreads();                                // B: the new ring rows are visible
+            // 2. Y pass + tonemap: lane (c, g) -> output rows ob .. ob+3 of column c, ob = it*RI - 20 + 4g
+            {
+                const int c = tid & 255, g = tid >> 8;
+                const int ob = it * RI - 2 * R + 4 * g;
+                const int x = x0 + c;
+                if (ob + 3 >= 0 && ob < rows && x < W) {
+                    float ax[4] = { 0, 0, 0, 0 }, ay[4] = { 0, 0, 0, 0 }, az[4] = { 0, 0, 0, 0 };
+                    int slot = (ob + RING * 4) % RING;      // ring row of X-blurred row j = ob (ob >= -20)
+                    #pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        const float* px = ring + (slot * 3) * TW + c;
+                        const float vx = px[0], vy = px[TW], vz = px[2 * TW];
+                        #pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            const int k = i - o;            // tap index of output o for window row i
+                            if (k >= 0 && k <= 20) { ax[o] = fma_(vx, wt[k], ax[o]); ay[o] = fma_(vy, wt[k], ay[o]); az[o] = fma_(vz, wt[k], az[o]); }
+                        }
+                        slot = slot + 1 == RING ? 0 : slot + 1;
+                    }
+                    #pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        const int oy = ob + o;
+                        if (oy < 0 || oy >= rows) continue;
+                        const uint32_t hx = float_to_half_bits(ax[o]), hy = float_to_half_bits(ay[o]), hz = float_to_half_bits(az[o]);   // == the BlurOutput store
+                        const uint32_t tx = hx < 0x8000u ? lut[hx] : table[hx], ty = hy < 0x8000u ? lut[hy] : table[hy], tz = hz < 0x8000u ? lut[hz] : table[hz];
+                        out[(size_t)(y0 + oy) * W + x] = tx | (ty << 8) | (tz << 16) | (255u << 24);     // alpha 1 -> 255
+                    }
+                }
+            }
+        }
+        __syncthreads();                                    // the next work item of this workgroup reuses raw / ring
+    }
+}
+
 } // namespace
 
 namespace vqk {
+
+// CSMain_X + CSMain_Y + Tonemapper as ONE kernel (k_post_fused) when the table path applies; `table` = the tonemap table of (p, RGBA8).
+bool post_chain_fusable(const VQ_TonemapperParams& p, int inFmt, int outFmt, int W, int H) {
+    return blur_y_tonemap_uses_lut(p, inFmt, outFmt, (size_t)W * H) && W >= 64 && H >= 32;
+}
+hipError_t launch_post_fused(hipStream_t s, const void* in, void* out, int W, int H, const void* table) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_post_fused, hipFuncAttributeMaxDynamicSharedMemorySize, pf::LDS_BYTES);   // > 64 KB opt-in, per device
+    if (e != hipSuccess) return e;
+    const int strips = (W + pf::TW - 1) / pf::TW;
+    int nseg = (256 + strips - 1) / strips;                  // about one work item per CU
+    if (nseg > (H + 31) / 32) nseg = (H + 31) / 32;          // segments of at least 32 rows: each re-reads 20 halo rows
+    if (nseg < 1) nseg = 1;
+    const int segRows = (H + nseg - 1) / nseg;
+    nseg = (H + segRows - 1) / segRows;
+    const int nWG = strips * nseg;
+    hipLaunchKernelGGL(k_post_fused, dim3(nWG < 256 ? nWG : 256), dim3(512), pf::LDS_BYTES, s, (const h4*)in, (uint32_t*)out, W, H, (const uint8_t*)table, strips, segRows, nWG);
+    return hipGetLastError();
+}
 
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt) {
 #ifndef VQ_BLUR_X4
