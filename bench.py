@@ -227,6 +227,28 @@ def main():
         dist.broadcast_object_list(ids, src=0)               # control plane: 2 x 128 bytes
         comm_halo = capi.Comm(ids[0], world, rank)
         comm_comp = capi.Comm(ids[1], world, rank)
+        # wiring check before anything is timed: every rank sends rows that name their sender and their row, so a transfer that lands in the
+        # wrong place, comes from the wrong neighbour or does not arrive at all is a loud failure here instead of a wrong frame later
+        chk_rows = tiling.RowTiling(64, 16 * world + (world // 2), world, rank)          # uneven tiles on purpose
+        t_x = torch.empty((chk_rows.tile_rows, 64, 4), dtype=torch.float16, device=ctx.device)
+        t_x[:] = (torch.arange(chk_rows.row0, chk_rows.row1, device=ctx.device, dtype=torch.float32) + 1000.0 * rank).to(torch.float16)[:, None, None]
+        h_t = torch.zeros((capi.HALO_ROWS, 64, 4), dtype=torch.float16, device=ctx.device) if rank > 0 else None
+        h_b = torch.zeros((capi.HALO_ROWS, 64, 4), dtype=torch.float16, device=ctx.device) if rank < world - 1 else None
+        comm_halo.exchange_blur_halos(t_x, abi.FMT_RGBA16F, h_t, h_b, stream=C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream))
+        t_c = torch.full((chk_rows.tile_rows, 64, 4), rank + 1, dtype=torch.uint8, device=ctx.device)
+        f_c = torch.zeros((chk_rows.frame_height, 64, 4), dtype=torch.uint8, device=ctx.device)
+        comm_comp.composite_tiles(t_c, abi.FMT_RGBA8_UNORM, chk_rows.frame_height, capi.ALL_RANKS, f_c, stream=C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream))
+        torch.cuda.synchronize()
+        if h_t is not None:
+            want = (torch.arange(chk_rows.row0 - capi.HALO_ROWS, chk_rows.row0, device=ctx.device, dtype=torch.float32) + 1000.0 * (rank - 1)).to(torch.float16)
+            assert torch.equal(h_t[:, 0, 0], want), f"rank {rank}: top halo rows are not the last 10 rows of rank {rank - 1}"
+        if h_b is not None:
+            want = (torch.arange(chk_rows.row1, chk_rows.row1 + capi.HALO_ROWS, device=ctx.device, dtype=torch.float32) + 1000.0 * (rank + 1)).to(torch.float16)
+            assert torch.equal(h_b[:, 0, 0], want), f"rank {rank}: bottom halo rows are not the first 10 rows of rank {rank + 1}"
+        for k in range(world):
+            r0, n = capi.rowtile(chk_rows.frame_height, world, k)
+            assert bool((f_c[r0:r0 + n] == k + 1).all()), f"rank {rank}: rows of rank {k} are wrong in the composited frame"
+        del t_x, h_t, h_b, t_c, f_c
 
     F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
     scene = [capi.empty_image(rows, W, F16, ctx.device) for _ in range(2)]
