@@ -94,7 +94,7 @@ VQD float4 blend_taps(const Taps4& q, const LevelTaps& k) {
     r.x = fma_(k.w11, c11.x, fma_(k.w01, c01.x, fma_(k.w10, c10.x, k.w00 * c00.x)));
     r.y = fma_(k.w11, c11.y, fma_(k.w01, c01.y, fma_(k.w10, c10.y, k.w00 * c00.y)));
     r.z = fma_(k.w11, c11.z, fma_(k.w01, c01.z, fma_(k.w10, c10.z, k.w00 * c00.z)));
-    r.w = 0.0f;                                                      // alpha is read by no consumer in PSMain (ENABLE_ALPHA_MASK off): not filtered
+    r.w = fma_(k.w11, c11.w, fma_(k.w01, c01.w, fma_(k.w10, c10.w, k.w00 * c00.w)));     // alpha: read by the ENABLE_ALPHA_MASK discard test (:237-240)
     return r;
 }
 

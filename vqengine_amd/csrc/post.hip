@@ -123,8 +123,7 @@ __global__ __launch_bounds__(256) void k_blur_x4p(const void* __restrict__ in, v
             float wx[24], wy[24], wz[24];
             #pragma unroll
             for (int k = 0; k < 24; ++k) {
-                const int p = 4 * t + k;
-                const float4 s = load_px<FMT>(tile, (size_t)(p + (p >> 2)));
+                const float4 s = load_px<FMT>(tile, (size_t)(5 * t + k + (k >> 2)));     // slot of pixel 4t + k: constant offsets from one address
                 wx[k] = s.x; wy[k] = s.y; wz[k] = s.z;
             }
             #pragma unroll
@@ -329,19 +328,22 @@ __global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restri
     __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
     for (int i = threadIdx.x * 16; i < 65536; i += 512 * 16) *(uint4*)(lds + i) = *(const uint4*)((const unsigned char*)table + i);
     __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave index as an SGPR: the row logic of the window becomes scalar code
     for (int tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
         const int ty = tile / tilesX, tx = tile - ty * tilesX;
         const int x = tx * 64 + (threadIdx.x & 63);
-        const int yBase = (ty * 8 + (threadIdx.x >> 6)) * ROWS;
+        const int yBase = (ty * 8 + wv) * ROWS;
         if (x >= W || yBase >= H) continue;
         float wx[ROWS + 2 * R], wy[ROWS + 2 * R], wz[ROWS + 2 * R];
         #pragma unroll
         for (int i = 0; i < ROWS + 2 * R; ++i) {
             int sy = yBase - R + i;
             float4 s;
-            if (sy < 0 && haloTop)              s = load_px<1>(haloTop, (size_t)(haloRows + max(sy, -haloRows)) * W + x);      // never outside the halo buffer
-            else if (sy > H - 1 && haloBottom)  s = load_px<1>(haloBottom, (size_t)min(sy - H, haloRows - 1) * W + x);
-            else { sy = min(max(sy, 0), H - 1); s = load_px<1>(in, (size_t)sy * W + x); }      // clamp :178
+            const h4* rowp;                                           // wave-uniform row source: image / halo / clamp (GaussianBlur.hlsl:178); never outside the halo buffers
+            if (sy < 0 && haloTop)              rowp = (const h4*)haloTop + (size_t)(haloRows + max(sy, -haloRows)) * W;
+            else if (sy > H - 1 && haloBottom)  rowp = (const h4*)haloBottom + (size_t)min(sy - H, haloRows - 1) * W;
+            else                                rowp = (const h4*)in + (size_t)min(max(sy, 0), H - 1) * W;
+            s = load_px<1>(rowp, (size_t)x);
             wx[i] = s.x; wy[i] = s.y; wz[i] = s.z;
         }
         #pragma unroll
