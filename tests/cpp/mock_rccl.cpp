@@ -109,7 +109,7 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommInitRank(ncclComm_t*
     close(fd);
     if (p == MAP_FAILED) return 2;
     MockComm* c = new MockComm{ (Shared*)p, world, rank, {} };
-    std::strncpy(c->name, id.internal, sizeof(c->name) - 1);
+    std::memcpy(c->name, id.internal, sizeof(c->name) - 1);      // the name written by ncclGetUniqueId is < 40 characters
     c->sh->arrived.fetch_add(1);
     while (c->sh->arrived.load() < world) sched_yield();    // collective, like the real one
     if (rank == 0) shm_unlink(c->name);                     // every rank has it mapped: the name can go
