@@ -527,10 +527,13 @@ def test_hip_path_reproduces_golden_fixtures(ctx):
     assert_bits(ctx.tonemap(bl, abi.FMT_RGBA16F, abi.FMT_RGBA16F, abi.TonemapperParams(0, abi.DISPLAY_CURVE_ST2084, 200.0, 1)), fx["pq_rgba16f"], "golden pq")
 
 
-def test_forward_fuzz_adversarial_inputs(ctx, env_small):
+@pytest.mark.parametrize("huge_ranges", [True, False])
+def test_forward_fuzz_adversarial_inputs(ctx, env_small, huge_ranges):
     """Fuzz: G-buffer fields drawn from random BIT PATTERNS (all exponents, denormals, infs, NaNs) mixed with normal
     values, lights at degenerate distances (0, 1e-25, 1e25). Exercises the slow (IEEE) fall-backs of the proven-range
-    fast reciprocals in add_point_light and every NaN/inf propagation path; must still match the oracle bit-for-bit."""
+    fast reciprocals in add_point_light and every NaN/inf propagation path; must still match the oracle bit-for-bit.
+    huge_ranges: ranges beyond 2^30 switch the whole light set to the IEEE loop (FrameConstants::pointFastOK); without them the
+    fast loop runs and single pixels are redone (validity minimum below 2^-40, roughness outside [0.04, 1])."""
     rng = np.random.default_rng(77)
     W, H = 1024, 12
     gb = synth.gbuffer(W, H, seed=0xF022)
@@ -542,8 +545,9 @@ def test_forward_fuzz_adversarial_inputs(ctx, env_small):
     pts = synth.point_lights(10, seed=0xF022)
     pts[1].position.set(gb[0][3, 100, :3]); pts[1].range = 1e9                     # D == 0 for one pixel
     pts[2].position.set(gb[0][5, 200, :3] + np.float32(1e-25)); pts[2].range = 1e9 # D^2 below 2^-60
-    pts[3].position.set((1e25, 1e25, -1e25)); pts[3].range = 3.0e38                # D^2 overflows
-    pts[4].position.set((1e12, 0, 0)); pts[4].range = 3.0e38                       # D^2 = 1e24 > 2^60
+    big = 3.0e38 if huge_ranges else 1.0e9
+    pts[3].position.set((1e25, 1e25, -1e25)); pts[3].range = big                   # D^2 overflows
+    pts[4].position.set((1e12, 0, 0)); pts[4].range = big                          # D^2 = 1e24 > 2^60
     pts[5].brightness = float("inf")
     pts[6].color.set((float("nan"), 1.0, -1.0))
     pts[7].range = float("nan")

@@ -42,6 +42,7 @@ struct Pixel {
 };
 
 VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
+VQD float min3abs_acc(float m, float a, float b) { return __builtin_fminf(__builtin_fminf(m, __builtin_fabsf(a)), __builtin_fabsf(b)); }   // m >= 0
 VQD float min3abs(f3 v) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)); }   // one v_min3_f32 with |.| modifiers
 
 VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
@@ -140,19 +141,22 @@ VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op va
 }
 
 // Hot-loop form: I = CalculatePointLightIllumination(..., acc = I). All reciprocals / square roots use the unchecked
-// fast sequences (RcpTrust); their validity is PROVEN from three range tests instead of being checked per operation:
+// fast sequences (RcpTrust); their validity is PROVEN from range tests instead of being checked per operation, and the tests are
+// folded into ONE comparison per pixel after the loop (vmin, below):
 //   pixel  : roughness in [0.04,1]  (px.fastOK)  =>  k in [1/8,1/2], 1-k in [1/2,7/8], a2 in [2.5e-6,1], hence
 //              gL = fma(NL,1-k,k)+1e-4 in [0.125, 1.4]   (NL = max(0,.) <= 1+eps, NaN -> 0)
 //              pi t^2 in [1.9e-11, pi] (t = fma(nh2, a2-1, 1) in [a2 - 2^-25, 1], nh2 saturated)
 //              denom = max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
 //              => the merged reciprocal's operand (pi t^2 * gL) * denom in [2.4e-16, 17.6]: operand and result normal
-//   light  : every component of Lw-P has magnitude >= 2^-40 (one v_min3) and dd = |Lw-P|^2 <= 2^60 (false for NaN / inf operands too)
+//   light  : every component of Lw-P has magnitude >= 2^-40 and dd = |Lw-P|^2 < rangeSq <= 2^60 (the host checks the thresholds of the whole
+//            light set: FrameConstants::pointFastOK; a NaN / inf dd fails the cull)
 //            => dd in [2^-80, 2^60], D in [2^-40, 2^30]: sqrt, 1/D normal ((1/D)^2 is a plain product), quotients d/D free of underflow
-//   light  : every component of Wo+Wi has magnitude >= 2^-40 (one v_min3; Wo, Wi finite => no NaN) => hh = |Wo+Wi|^2 in [2^-80, ~4]
+//   light  : every component of Wo+Wi has magnitude >= 2^-40 (Wo, Wi finite => no NaN) => hh = |Wo+Wi|^2 in [2^-80, ~4]
 //   => the corrected quotients d/D, Hs/|Hs| (fdiv_rcp: exhaustively equal to IEEE division when nothing underflows) are the IEEE
-//      quotients; a zero or tiny component (a light exactly above the pixel on one axis) takes the IEEE path for that light
+//      quotients; a zero or tiny component (a light exactly above the pixel on one axis) sends the pixel to the IEEE loop
 // all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
-// degenerate geometry, roughness outside [0,1]) redoes that light with IEEE operations; results are identical bits.
+// degenerate geometry, roughness outside [0.04,1], a range beyond 2^30) redoes the pixel's point-light loop with IEEE operations
+// (k_forward_lighting); where both are valid the two give identical bits, so the redo changes only what was invalid.
 struct RcpTrust {
     // roughness >= 0.04 (px.fastOK) => a2 >= 2.5e-6, t = fma(nh2, a2-1, 1) >= a2 - 2^-25 >= 2.5e-6 for nh2 in [0,1]
     // => pi t^2 >= 1.9e-11 > EPSILON (1e-12): the GGX early-out never fires on this path
@@ -161,26 +165,26 @@ struct RcpTrust {
     VQD float sqrt(float x) const { return sqrt_newton(x); }
     VQD float div(float a, float b, float r) const { return fdiv_rcp(a, b, r); }
 };
-VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I) {
-    const f3 Iprev = I;
+// `vmin` collects the smallest |component| of Lw-P and Wo+Wi over the lights that passed the range cull (three v_min3 with |.| modifiers);
+// the caller compares it with 2^-40 ONCE after the loop and, when the test fails, redoes the pixel's whole point-light loop with IEEE
+// operations (k_forward_lighting) — the accumulator needs no copy per light and the loop carries no validity masks.
+// dd <= 2^60 follows from dd < rangeSq <= 2^60 (FrameConstants::pointFastOK, host); a NaN / inf dd fails the cull like the reference's D < range.
+VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I, float& vmin) {
     const f3 lpos = mk3(l.px, l.py, l.pz), cb = mk3(l.cbx, l.cby, l.cbz);
     const f3 d = sub(lpos, px.P);
     const float dd = dot_lit(d, d);                          // as written: D decides the range cull
-    bool ok = px.fastOK & (dd <= 0x1p60f) & (min3abs(d) >= 0x1p-40f);
     if (dd < l.rangeSq) {                                    // == (length(Lw - P) < l.range), exactly (host-made threshold): culled lights
         RcpTrust rc;                                         // need no square root; wave-coherent (execz skip)
         const float D = sqrt_newton(dd);
         const float rD = rc(D);
         const f3 Wi = mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P)
         const f3 Hs = add(px.Wo, Wi);
-        const bool okH = min3abs(Hs) >= 0x1p-40f;
-        ok = ok & okH;
+        vmin = min3abs_acc(min3abs_acc(min3abs_acc(vmin, d.x, d.y), d.z, Hs.x), Hs.y, Hs.z);
         const float NdotL = saturate(dot(px.Nraw, Wi));
         const float w = (rD * rD) * NdotL;
         const f3 b = brdf_t(px, Wi, rc);
         I = lit(I, b, cb, w);
     }
-    if (__builtin_expect(!ok, 0)) { RcpIEEE ieee; I = point_light_t(px, lpos, l.range, cb, Iprev, ieee); }
 }
 
 // SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333 (no range cull)
@@ -313,23 +317,22 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     // the host into 32-byte records {position, range, color*brightness}
     const vqk::DevPointLight* pts = (const vqk::DevPointLight*)(fc + 1);
     const int nP = fc->numPointAll;
-#ifndef VQ_LIGHT_PREFETCH
-#define VQ_LIGHT_PREFETCH 0      // A/B (same box, scripts/bench_variants.sh): prefetching the next record 1.034 ms vs 1.022 ms without: off
-#endif
-#if VQ_LIGHT_PREFETCH
-    // software-pipelined scalar loads: the record of light p+1 is requested before light p is evaluated (6 waves per SIMD
-    // already hide the scalar-cache latency, so this only adds SGPR moves)
-    if (nP > 0) {
-        vqk::DevPointLight cur = pts[0];
-        for (int p = 0; p < nP; ++p) {
-            const vqk::DevPointLight nxt = pts[p + 1 < nP ? p + 1 : p];
-            add_point_light(px, cur, I);
-            cur = nxt;
-        }
+    // Fast loop: unchecked reciprocal / sqrt sequences whose validity is established once per pixel (vmin, see add_point_light). The rare
+    // pixel that fails (roughness outside [0.04, 1], a light exactly above the pixel on an axis, a range beyond 2^30, NaN inputs) is redone
+    // from the accumulator's value before the loop with IEEE operations; where both are valid the two paths agree bit for bit.
+    // (A software-pipelined prefetch of the next 32-byte record was measured and is not used: 1.034 ms vs 1.022 ms, profiles/r2c_shade_variants.md.)
+    const f3 I0 = I;
+    const bool fast = px.fastOK & (fc->pointFastOK != 0);
+    float vmin = 0.0f;
+    if (fast) {
+        vmin = __builtin_inff();
+        for (int p = 0; p < nP; ++p) add_point_light(px, pts[p], I, vmin);
     }
-#else
-    for (int p = 0; p < nP; ++p) add_point_light(px, pts[p], I);
-#endif
+    if (__builtin_expect(!(vmin >= 0x1p-40f), 0)) {
+        I = I0;
+        RcpIEEE ieee;
+        for (int p = 0; p < nP; ++p) I = point_light_t(px, mk3(pts[p].px, pts[p].py, pts[p].pz), pts[p].range, mk3(pts[p].cbx, pts[p].cby, pts[p].cbz), I, ieee);
+    }
     const VQ_SceneLighting& L = fc->perFrame.Lights;
     const int nS = L.numSpotLights;
     for (int s = 0; s < nS; ++s) I = spot_light(px, L.spot_lights[s], I);                     // :314-317

@@ -29,6 +29,7 @@ struct alignas(16) FrameConstants {
     int32_t                hasEnv;
     int32_t                numPointAll;    // numPointLights + numExtraPoint
     int32_t                pow5ExpLog;     // vqhip_set_fresnel_pow: 0 = product (default), 1 = exp2(5*log2 x)
+    int32_t                pointFastOK;    // every point light's rangeSq <= 2^60 (or never lit): precondition of the unchecked light loop (shade.hip)
     float                  hdriSin, hdriCos;   // vqd::sincos_(-fHDRIOffsetInRadians): frame-uniform, evaluated once on the host by the
                                                // very same routine (IEEE ops only, so host and device agree bit for bit)
     // DevPointLight pts[numPointAll] follows
