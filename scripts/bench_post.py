@@ -17,7 +17,7 @@ from vqengine_amd import abi, capi, synth  # noqa: E402
 F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
 
 
-def timed(fn, reps=200, spin=300):
+def timed(fn, reps=int(os.environ.get("VQ_POST_REPS", "200")), spin=int(os.environ.get("VQ_POST_SPIN", "300"))):
     for _ in range(spin):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -45,6 +45,20 @@ def main():
 
     def one():
         ctx.post_process(img, F16, R8, out=sdr)
+    def x_only():
+        ctx.gaussian_blur_x(img, F16, out=xb)
+
+    def ytm_only():
+        ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=sdr)
+
+    def copy16():                                            # the box's copy rate on the X pass's bytes (8 B/px in, 8 B/px out)
+        yb.copy_(img)
+    if os.environ.get("VQ_POST_PARTS") == "1":
+        for name, fn, bpp in (("copy 8+8 B/px", copy16, 16), ("blur X alone", x_only, 16), ("blur Y + tonemap alone", ytm_only, 12)):
+            ms = timed(fn)
+            print(json.dumps({"variant": name, "us": round(ms * 1e3, 2), "GBps_algorithmic": round(px * bpp / ms / 1e6, 1), "frac_of_8TBps": round(px * bpp / ms / 1e6 / 8000, 4)}), flush=True)
+    if os.environ.get("VQ_POST_PARTS_ONLY") == "1":
+        return
     ref = None
     for name, fn, bpp in (("split", split, 44), ("fused-y", fused_y, 28), ("one", one, 12)):
         ms = timed(fn)
