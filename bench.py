@@ -347,6 +347,25 @@ def main():
         step(args.steps + i + (args.steps & 1), evd[i])
     drain()
     barrier()
+    # 3b. the post kernels on their own: 20 back-to-back launches of each between two events, on the frame's own buffers (no event, no other
+    #     kernel in between). In the frame loop each of them follows a kernel that has just filled the caches with other data, and the
+    #     per-stage events above sit inside the intervals they measure; both figures are reported.
+    iso = None
+    if args.post == "fused":
+        iso = {}
+        for name, fn in (("blur_x", lambda: ctx.gaussian_blur_x(scene[0], F16, out=xblur)),
+                         ("blur_y_tonemap", lambda: ctx.gaussian_blur_y_tonemap(xblur, F16, R8, out=sdr[0], halo_top=halo_top, halo_bottom=halo_bottom))):
+            for _ in range(5):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s_main)
+            for _ in range(20):
+                fn()
+            e1.record(s_main)
+            e1.synchronize()
+            iso[name] = e0.elapsed_time(e1) / 20 * 1e-3
+        drain()
+        barrier()
     # 4. frame latency: one step at a time, nothing in flight before or after it (the throughput figure pipelines the composite)
     lat = []
     for i in range(5):
@@ -425,7 +444,14 @@ def main():
                           {"blur_x_ms": round(t_blur * 1e3, 4), "blur_x_GBps": round(px_tile * 16 / t_blur / 1e9, 1),
                            "blur_y_tonemap_ms": round(t_tm * 1e3, 4), "blur_y_tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1),
                            "post_chain_ms": round((t_blur + t_tm) * 1e3, 4), "post_chain_GBps": round(px_tile * 28 / (t_blur + t_tm) / 1e9, 1),
-                           "post_chain_frac_of_hbm_peak": round(px_tile * 28 / (t_blur + t_tm) / 1e9 / HBM_PEAK_GBPS, 4)}),
+                           "post_chain_frac_of_hbm_peak": round(px_tile * 28 / (t_blur + t_tm) / 1e9 / HBM_PEAK_GBPS, 4),
+                           "isolated": {"blur_x_ms": round(iso["blur_x"] * 1e3, 4), "blur_x_GBps": round(px_tile * 16 / iso["blur_x"] / 1e9, 1),
+                                        "blur_x_frac_of_hbm_peak": round(px_tile * 16 / iso["blur_x"] / 1e9 / HBM_PEAK_GBPS, 4),
+                                        "blur_y_tonemap_ms": round(iso["blur_y_tonemap"] * 1e3, 4),
+                                        "blur_y_tonemap_GBps": round(px_tile * 12 / iso["blur_y_tonemap"] / 1e9, 1),
+                                        "blur_y_tonemap_frac_of_hbm_peak": round(px_tile * 12 / iso["blur_y_tonemap"] / 1e9 / HBM_PEAK_GBPS, 4),
+                                        "note": "20 back-to-back launches of the one kernel between two events; the figures above are taken inside the frame "
+                                                "loop with an event record between the stages"}}),
                        **({"blur_x_includes": "halo exchange"} if world > 1 else {})},
             "frame_latency_ms": round(frame_latency * 1e3, 4),
             "cold_start": {"steps": COLD_STEPS, "ms_per_step": round(dt_cold / COLD_STEPS * 1e3, 4), "value": round(px_frame * COLD_STEPS / dt_cold / 1e6, 2),
