@@ -402,9 +402,12 @@ def test_blur_y_halo_at_the_end_of_an_allocation(ctx, rows):
     assert_bits(hdr, O.tonemap(full[10:10 + rows], abi.FMT_RGBA16F, abi.FMT_RGBA16F), "fused blur Y + tonemap, LDS-tile kernel")
 
 
+@pytest.mark.parametrize("x_wgs", [None, "3", "2048"])             # the X pass's forms: one workgroup per segment (default) / persistent, pipelined
 @pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
-@pytest.mark.parametrize("shape", [(97, 301), (1, 5), (64, 64), (40, 1)])
-def test_blur(ctx, fmt, shape):
+@pytest.mark.parametrize("shape", [(97, 301), (1, 5), (64, 64), (40, 1), (7, 2051)])
+def test_blur(ctx, fmt, shape, x_wgs, monkeypatch):
+    if x_wgs is not None:
+        monkeypatch.setenv("VQHIP_BLUR_X_WGS", x_wgs)
     h, w = shape
     img = synth.hdr_image(w, h).astype(O._NP[fmt][0])
     x_o = O.blur_pass(img, fmt, 0)

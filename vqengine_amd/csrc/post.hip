@@ -45,6 +45,17 @@ __global__ __launch_bounds__(256) void k_blur_x(const void* __restrict__ in, voi
     store_px<FMT>(out, row + x, make_float4(ax, ay, az, 1.0f));
 }
 
+// two adjacent pixels with ONE 16-byte store (RGBA16F; idx even) / two float4 stores
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+template <int FMT> VQD void store_px2(void* base, size_t idx, float4 a, float4 b) {
+    if (FMT == 1) {
+        h8 v;
+        v[0] = to_f16(a.x); v[1] = to_f16(a.y); v[2] = to_f16(a.z); v[3] = to_f16(a.w);
+        v[4] = to_f16(b.x); v[5] = to_f16(b.y); v[6] = to_f16(b.z); v[7] = to_f16(b.w);
+        *(h8*)((h4*)base + idx) = v;
+    } else { store_px<FMT>(base, idx, a); store_px<FMT>(base, idx + 1, b); }
+}
+
 // X pass, 4 consecutive pixels per lane: a 256-lane workgroup covers a 1024-pixel row segment whose 1044 input pixels
 // are staged once in LDS in the storage format; each lane reads a 24-pixel register window (6 LDS reads per output
 // instead of 21). One padding pixel after every 4 puts lane i's window element k at 5i + k + k/4: the stride-5-pixel
@@ -72,9 +83,9 @@ __global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, vo
         const float4 s = load_px<FMT>(tile, (size_t)(p + (p >> 2)));
         wx[k] = s.x; wy[k] = s.y; wz[k] = s.z;
     }
+    float4 res[4];
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (xb + j >= W) break;
         float ax = 0.0f, ay = 0.0f, az = 0.0f;
         #pragma unroll
         for (int it = 0; it < 21; ++it) {
@@ -82,19 +93,15 @@ __global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, vo
             const float w = kW[off < 0 ? -off : off];
             ax = fma_(wx[j + it], w, ax); ay = fma_(wy[j + it], w, ay); az = fma_(wz[j + it], w, az);
         }
-        store_px<FMT>(out, row + xb + j, make_float4(ax, ay, az, 1.0f));
+        res[j] = make_float4(ax, ay, az, 1.0f);
     }
-}
-
-// two adjacent pixels with ONE 16-byte store (RGBA16F; idx even) / two float4 stores
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-template <int FMT> VQD void store_px2(void* base, size_t idx, float4 a, float4 b) {
-    if (FMT == 1) {
-        h8 v;
-        v[0] = to_f16(a.x); v[1] = to_f16(a.y); v[2] = to_f16(a.z); v[3] = to_f16(a.w);
-        v[4] = to_f16(b.x); v[5] = to_f16(b.y); v[6] = to_f16(b.z); v[7] = to_f16(b.w);
-        *(h8*)((h4*)base + idx) = v;
-    } else { store_px<FMT>(base, idx, a); store_px<FMT>(base, idx + 1, b); }
+    if (xb + 3 < W && ((row + xb) & 1) == 0) {               // the lane's 4 pixels are 32 contiguous bytes (RGBA16F): two 16-byte stores
+        #pragma unroll
+        for (int j = 0; j < 4; j += 2) store_px2<FMT>(out, row + xb + j, res[j], res[j + 1]);
+    } else {
+        #pragma unroll
+        for (int j = 0; j < 4; ++j) if (xb + j < W) store_px<FMT>(out, row + xb + j, res[j]);
+    }
 }
 
 // Same arithmetic as k_blur_x4, software-pipelined: a persistent workgroup walks over 1024-pixel row segments and issues the
@@ -525,30 +532,26 @@ hipError_t launch_post_fused(hipStream_t s, const void* in, void* out, int W, in
     return hipGetLastError();
 }
 
+// Which form of the X pass runs is chosen for the FRAME, not for the kernel alone (profiles/r2k_frame_loop.md): the software-pipelined persistent
+// form is the fastest kernel in isolation (25.9 us at 4K with 1 024 workgroups, 27.3 with 2 048), but with many workgroups in flight on real image
+// data it makes the chip throttle, and the shade kernel that follows it runs 2-13 % slower. VQHIP_BLUR_X_WGS overrides the default for tuning:
+// 0 = one workgroup per 1024-pixel segment (k_blur_x4), n > 0 = n persistent workgroups (k_blur_x4p).
+static int blur_x_workgroups() {                              // read per launch (a getenv is ~0.1 us): tests switch the form inside one process
+    const char* e = std::getenv("VQHIP_BLUR_X_WGS");
+    return e ? std::atoi(e) : 0;
+}
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt) {
-#ifndef VQ_BLUR_X4
-#define VQ_BLUR_X4 1
-#endif
-#ifndef VQ_BLUR_XP
-#define VQ_BLUR_XP 1
-#endif
-#ifndef VQ_BLUR_XP_WGS
-#define VQ_BLUR_XP_WGS 2048      // persistent workgroups (A/B at 4K, blur X+Y in the chain: non-persistent 65.1 us, 512: 64.1, 1024: 62.3, 2048: 61.2)
-#endif
-#if VQ_BLUR_XP
     const int segsPerRow = (W + 1023) / 1024, nSeg = segsPerRow * H;
-    const int wgs = nSeg < VQ_BLUR_XP_WGS ? nSeg : VQ_BLUR_XP_WGS;
-    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4p<0>), dim3(wgs), dim3(256), 0, s, in, out, W, H, segsPerRow, nSeg);
-    else                          hipLaunchKernelGGL((k_blur_x4p<1>), dim3(wgs), dim3(256), 0, s, in, out, W, H, segsPerRow, nSeg);
-#elif VQ_BLUR_X4
-    dim3 grid((W + 1023) / 1024, H);
-    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4<0>), grid, dim3(256), 0, s, in, out, W, H);
-    else                          hipLaunchKernelGGL((k_blur_x4<1>), grid, dim3(256), 0, s, in, out, W, H);
-#else
-    dim3 grid((W + 255) / 256, H);
-    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x<0>), grid, dim3(256), 0, s, in, out, W, H);
-    else                          hipLaunchKernelGGL((k_blur_x<1>), grid, dim3(256), 0, s, in, out, W, H);
-#endif
+    const int want = blur_x_workgroups();
+    if (want > 0) {
+        const int wgs = nSeg < want ? nSeg : want;
+        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4p<0>), dim3(wgs), dim3(256), 0, s, in, out, W, H, segsPerRow, nSeg);
+        else                          hipLaunchKernelGGL((k_blur_x4p<1>), dim3(wgs), dim3(256), 0, s, in, out, W, H, segsPerRow, nSeg);
+    } else {
+        dim3 grid(segsPerRow, H);
+        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4<0>), grid, dim3(256), 0, s, in, out, W, H);
+        else                          hipLaunchKernelGGL((k_blur_x4<1>), grid, dim3(256), 0, s, in, out, W, H);
+    }
     return hipGetLastError();
 }
 
