@@ -48,7 +48,7 @@ SPINUP_STEPS = int(os.environ.get("VQ_BENCH_SPINUP", "200"))     # untimed stead
 COLD_STEPS = 20                 # the first steps after the idle set-up phase, timed on their own ("cold_start")
 VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
-PMC_SOURCES = ["vqengine_amd/csrc/shade.hip", "vqengine_amd/csrc/vq_devmath.h", "vqengine_amd/csrc/vq_sampling.h"]
+PMC_SOURCES = ["vqengine_amd/csrc/shade.hip", "vqengine_amd/csrc/vq_devmath.h", "vqengine_amd/csrc/vq_sampling.h", "vqengine_amd/csrc/Makefile"]
 
 
 def kernel_source_hash():

@@ -34,6 +34,8 @@ def gpu_ms(fn, reps=20, warm=5):
 
 
 def cpu_s(fn):
+    if os.environ.get("VQ_STAGES_NO_CPU") == "1":            # GPU-only A/B runs (scripts/bench_variants-style comparisons)
+        return 0
     t0 = time.perf_counter(); fn(); return time.perf_counter() - t0
 
 
