@@ -19,32 +19,6 @@ namespace {
 __device__ const float kW[11] = { 0.224716f, 0.191756f, 0.119146f, 0.053897f, 0.017746f, 0.004252f, 0.000741f, 0.000094f, 0.000009f, 0.000001f, 0.0f };
 constexpr int R = 10;    // KERNEL_RANGE_MINUS1
 
-template <int FMT>
-__global__ __launch_bounds__(256) void k_blur_x(const void* __restrict__ in, void* __restrict__ out, int W, int H) {
-    __shared__ float4 tile[256 + 2 * R];
-    const int y = blockIdx.y;
-    const int x0 = blockIdx.x * 256;
-    const int t = threadIdx.x;
-    const size_t row = (size_t)y * W;
-    for (int i = t; i < 256 + 2 * R; i += 256) {
-        int sx = x0 - R + i;
-        sx = min(max(sx, 0), W - 1);                        // clamp(sampleCoord.x, 0, iImageSize.x - 1) :143
-        tile[i] = load_px<FMT>(in, row + sx);
-    }
-    __syncthreads();
-    const int x = x0 + t;
-    if (x >= W) return;                                     // early out :129
-    float ax = 0.0f, ay = 0.0f, az = 0.0f;
-    #pragma unroll
-    for (int it = 0; it < 21; ++it) {
-        const int off = it - R;
-        const float w = kW[off < 0 ? -off : off];
-        const float4 s = tile[t + it];
-        ax = fma_(s.x, w, ax); ay = fma_(s.y, w, ay); az = fma_(s.z, w, az);
-    }
-    store_px<FMT>(out, row + x, make_float4(ax, ay, az, 1.0f));
-}
-
 // two adjacent pixels with ONE 16-byte store (RGBA16F; idx even) / two float4 stores
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 template <int FMT> VQD void store_px2(void* base, size_t idx, float4 a, float4 b) {
