@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY"; do
   i=$((i+1)); rm -rf gpurun_out/pmc_util_$i
-  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmc_util_$i -- python bench.py --no-cpu-baseline --steps 10 --warmup 3 > /dev/null 2>gpurun_out/pmc_util_$i.err
+  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmc_util_$i -- python bench.py --no-cpu-baseline --no-second-mode --steps 10 --warmup 3 > /dev/null 2>gpurun_out/pmc_util_$i.err
   echo "group $i rc=$? : $grp"
 done
 python - <<PY
@@ -16,4 +16,12 @@ for f in glob.glob("gpurun_out/pmc_util_*/*/*counter_collection.csv"):
             vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in sorted(vals):
     print(f"{k:24s} median {st.median(vals[k]):16.0f}  (n={len(vals[k])})")
+durs = []
+for f in glob.glob("gpurun_out/pmc_util_1/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "k_forward_lighting" in r["Kernel_Name"]:
+            durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+if durs and vals.get("SQ_BUSY_CYCLES"):
+    d = st.median(durs)
+    print(f"kernel duration median {d / 1e3:.1f} us; SQ_BUSY_CYCLES / 32 SQ instances / duration = {st.median(vals['SQ_BUSY_CYCLES']) / 32 / d:.3f} GHz")
 PY
