@@ -43,3 +43,30 @@ def test_cfg5_strong_scaling_flow_matches_the_untiled_frame():
     d = _run(3, ["--config", "cfg5"])
     assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["frame_height"] == 4320 and d["config"]["tile_rows"] == 1440
     assert d["config"]["lights"] == 256 and d["verify"]["mismatching_bytes"] == 0, d["verify"]
+
+
+def test_single_gpu_line_carries_the_contract_fields():
+    """`python bench.py` (N = 1, defaults shortened): one JSON line with the driver's contract fields, the roofline and cpu_baseline objects,
+    counter constants that belong to the current kernel sources, and the self-audit extras (engine lowering, cold start, isolated post kernels)."""
+    env = dict(os.environ, VQ_BENCH_SPINUP="30")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout"
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "stages", "engine_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "Mpix/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert isinstance(r["traffic"], int) and r["traffic"] > 597196800 // 2
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpix/s" and c["sample"]
+    assert d["pmc_constants"]["stale"] is False
+    assert d["engine_lowering"]["fresnel_pow"] == "exp2_log2" and 0 < d["engine_lowering"]["value"] < 1.05 * d["value"]
+    iso = d["stages"]["isolated"]
+    assert 0 < iso["blur_x_ms"] < 0.2 and 0 < iso["blur_y_tonemap_ms"] < 0.2
+    assert d["stages"]["shade_ms"] < d["ms_per_step"]
