@@ -167,8 +167,8 @@ def cpu_reference_source(cfg, env_np, pf, extra, pv, frame_h, target_s=6.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)       # a step is ~1.1 ms: 50 + 10 keep the clocks ramped, the run stays setup-dominated
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)      # a step is ~1 ms: 0.2 s of timed GPU work; the run stays dominated by set-up and the CPU baselines
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--post", choices=["fused", "split"], default="fused",
