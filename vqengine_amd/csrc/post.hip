@@ -516,7 +516,8 @@ static int blur_x_workgroups() {                              // read per launch
 }
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt) {
     const int segsPerRow = (W + 1023) / 1024, nSeg = segsPerRow * H;
-    const int want = blur_x_workgroups();
+    int want = blur_x_workgroups();
+    if (want <= 0 && H > 65535) want = 1024;               // grid.y is limited to 65 535: taller images take the persistent form
     if (want > 0) {
         const int wgs = nSeg < want ? nSeg : want;
         if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4p<0>), dim3(wgs), dim3(256), 0, s, in, out, W, H, segsPerRow, nSeg);
