@@ -13,6 +13,7 @@
  *   - return value: VQHIP_OK (0) or a negative vqhip_status; vqhip_last_error() gives the text.
  *     (The reference returns void and asserts/logs: e.g. EnvironmentMapRendering.cpp:139, Renderer.cpp:871.)
  *   - images are dense row-major, `row_pitch_px` pixels between rows where stated, otherwise == width.
+ *     An image (or row tile) has at most 65 535 rows: several kernels map rows to grid.y; taller inputs fail with VQHIP_ERR_HIP.
  *
  * Struct layouts are byte-for-byte those of Shaders/LightingConstantBufferData.h (namespace
  * VQ_SHADER_DATA); the static asserts below pin the offsets derived in SURVEY.md §8(b).
