@@ -595,7 +595,9 @@ hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const
                                  const VQ_TonemapperParams& p, int fmt, int outFmt, const void* lutTable) {
     if (lutTable && blur_y_tonemap_uses_lut(p, fmt, outFmt, (size_t)W * H)) {
         const int tilesX = (W + 63) / 64, tilesY = (H + 127) / 128, nTiles = tilesX * tilesY;
-        hipLaunchKernelGGL((k_blur_y_tonemap_lut<16>), dim3(nTiles < 512 ? nTiles : 512), dim3(512), 0, s, in, out, haloTop, haloBottom, haloRows, W, H,
+        int wgs = 512;                                        // two 64 KB tables per CU
+        if (const char* e = std::getenv("VQHIP_BLUR_Y_WGS")) { const int v = std::atoi(e); if (v > 0) wgs = v; }     // tuning knob, like VQHIP_BLUR_X_WGS
+        hipLaunchKernelGGL((k_blur_y_tonemap_lut<16>), dim3(nTiles < wgs ? nTiles : wgs), dim3(512), 0, s, in, out, haloTop, haloBottom, haloRows, W, H,
                            lutTable, tilesX, nTiles);
         return hipGetLastError();
     }
