@@ -8,10 +8,18 @@ A "step" is one pass of the hot path over one synthetic frame (tile) that is alr
     blur Y + tonemap (Reinhard + sRGB OETF)           -> RGBA8_UNORM             [vqhip_gaussian_blur_y_tonemap]
     (N > 1) composite of the RGBA8 tiles on rank 0                               [vqhip_composite_tiles, RCCL send/recv]
 
---config cfg3 (default; BASELINE config 3, the configuration the metric is quoted on): 3840x2160 tile per GPU, 64 point lights + the
-    full-size cfg4 IBL. N > 1 is WEAK scaling: the frame is 3840 x (2160*N), one 4K tile per GPU.
---config cfg5 (BASELINE config 5): ONE 7680x4320 frame, 256 point lights (100 in the cbuffer + 156 through the extension array),
-    row-tiled over the N GPUs (4320/N rows each): STRONG scaling. At N = 1 the whole 2.1 GB G-buffer is shaded by one GPU.
+The HEADLINE (`metric`, `value`, `ms_per_step`, `roofline`) is --config cfg3, BASELINE config 3, the configuration the metric is quoted on:
+a 3840x2160 tile per GPU, 64 point lights + the full-size cfg4 IBL; N > 1 is WEAK scaling (frame 3840 x 2160*N). K timed steps, exactly.
+
+Every invocation (N = 1 included) ALSO times, outside the headline's timed region and reported as extra objects of the same JSON line:
+  cfg5_strong    BASELINE config 5, the configuration the ">= 6x at 8 GPUs" target is defined on: ONE 7680x4320 frame, 256 point lights
+                 (100 cbuffer + 156 extension), 4320/N rows per GPU — STRONG scaling; with shade / halo / composite / latency figures
+  (N = 1 only)
+  cfg2           BASELINE config 2: 1920x1080, 16 point lights, shade kernel (the size where HBM is the roof that matters)
+  ibl_load       BASELINE config 4: the load-time IBL stages (min-filter mip chain, diffuse irradiance, specular prefilter, BRDF LUT), timed
+  coherent_scene the cfg3 frame on surface-coherent content (synth.gbuffer_rows_coherent) instead of white noise — never the headline
+  tile_curve     per-tile step time of the cfg5 frame at 4320/N rows, N = 1, 2, 4, 8, on this one GPU + a labelled MODELLED speed-up
+--config cfg5 makes cfg5 the headline instead (then `scaling` is "strong"); --no-extras skips everything but the headline.
 
 Every byte that crosses GPUs goes through the C ABI (include/vqhip.h, vqengine_amd/csrc/mgpu.hip); torch.distributed is the control
 plane only (communicator-id broadcast, barriers, the max-over-ranks reduction of the wall time).
@@ -34,10 +42,13 @@ sys.path.insert(0, ROOT)
 from vqengine_amd import abi, capi, synth, tiling  # noqa: E402
 
 CONFIGS = {
-    "cfg3": dict(width=3840, height=2160, lights=64, env=True, seed=0x6400, scaling="weak",
+    "cfg2": dict(width=1920, height=1080, lights=16, env=False, seed=0xC0FFEE, light_seed=0x1600, scaling="weak",
+                 metric="Mpixels/s forward-PBR @1080p,16 lights (BASELINE cfg2)",
+                 workload="BASELINE cfg2: 1920x1080 float4 G-buffer, 16 point lights, no IBL -> RGBA16F"),
+    "cfg3": dict(width=3840, height=2160, lights=64, env=True, seed=0x6400, light_seed=0x6400, scaling="weak",
                  metric="Mpixels/s forward-PBR @4K,64 lights",
                  workload="BASELINE cfg3: 3840x2160 float4 G-buffer tile per GPU, 64 point lights + IBL sample -> RGBA16F, 21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8"),
-    "cfg5": dict(width=7680, height=4320, lights=256, env=False, seed=0x2560, scaling="strong",
+    "cfg5": dict(width=7680, height=4320, lights=256, env=False, seed=0x2560, light_seed=0x2560, scaling="strong",
                  metric="Mpixels/s forward-PBR @8K,256 lights (BASELINE cfg5, one frame row-tiled over the GPUs)",
                  workload="BASELINE cfg5: ONE 7680x4320 float4 G-buffer, 256 point lights (100 cbuffer + 156 extension) -> RGBA16F, 21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8"),
 }
@@ -47,8 +58,11 @@ SHADE_BYTES_PER_PX = 64 + 8     # 4 float4 G-buffer planes in + RGBA16F out (DES
 SPINUP_STEPS = int(os.environ.get("VQ_BENCH_SPINUP", "200"))     # untimed steady-state spin-up before the W warm-up steps (~0.25 s of GPU work)
 COLD_STEPS = 20                 # the first steps after the idle set-up phase, timed on their own ("cold_start")
 VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip)
+XGMI_LINK_GBPS = 153.0          # per direct GPU-GPU link, peak; the tile-curve model also quotes half of it
+WATCHDOG_S = float(os.environ.get("VQ_BENCH_WATCHDOG_S", "30"))
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
 PMC_SOURCES = ["vqengine_amd/csrc/shade.hip", "vqengine_amd/csrc/vq_devmath.h", "vqengine_amd/csrc/vq_sampling.h", "vqengine_amd/csrc/Makefile"]
+F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
 
 
 def kernel_source_hash():
@@ -76,22 +90,41 @@ def load_pmc_constants(config, fresnel_pow):
     return entry, dict(meta, stale=False)
 
 
-def build_ibl(ctx):
+def _ev():
+    return torch.cuda.Event(enable_timing=True)
+
+
+def build_ibl(ctx, timings=None):
     """Load-time inputs (outside the timed region): BASELINE config 4 — 2048^2 equirect -> min-filter mips ->
-    diffuse 64^2 (step 0.010) + blur + 7-mip specular 128^2, and the 1024^2 x 2048 BRDF LUT."""
+    diffuse 64^2 (step 0.010) + blur + 7-mip specular 128^2, and the 1024^2 x 2048 BRDF LUT. With `timings` (a dict) each stage is
+    bracketed by HIP events on the stream it runs on and, after the product call, re-run on its own for a per-stage figure."""
     eq = torch.from_numpy(synth.equirect(2048, 2048)).cuda()
+    e = [_ev() for _ in range(4)]
+    e[0].record()
     chain, n = ctx.mip_chain(eq)
+    e[1].record()
     pre = ctx.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_WAVE64)
+    e[2].record()
     lut = ctx.brdf_lut(1024, 2048, abi.FMT_RG16F)
+    e[3].record()
     torch.cuda.synchronize()
+    if timings is not None:
+        timings.update(mip_chain_ms=round(e[0].elapsed_time(e[1]), 4), prefilter_ms=round(e[1].elapsed_time(e[2]), 4), brdf_lut_ms=round(e[2].elapsed_time(e[3]), 4))
+        for name, fn in (("conv_diffuse_ms", lambda: ctx.conv_diffuse(chain, 2048, 2048, n, 64, 0.010, abi.CONV_WAVE64, abi.FMT_RGBA16F)),
+                         ("conv_specular_ms", lambda: ctx.conv_specular(chain, 2048, 2048, n, 128, abi.CONV_WAVE64, abi.FMT_RGBA16F)),
+                         ("brdf_lut_warm_ms", lambda: ctx.brdf_lut(1024, 2048, abi.FMT_RG16F))):
+            a, b = _ev(), _ev()
+            a.record(); fn(); b.record(); b.synchronize()
+            timings[name] = round(a.elapsed_time(b), 4)
     return pre, lut
 
 
-def upload_tile(cfg, frame_h, row0, row1):
+def upload_tile(cfg, frame_h, row0, row1, coherent=False):
     W = cfg["width"]
+    gen = synth.gbuffer_rows_coherent if coherent else synth.gbuffer_rows
     gb = [torch.empty((row1 - row0, W, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
     for r in range(row0, row1, 240):
-        part = synth.gbuffer_rows(W, frame_h, r, min(r + 240, row1), seed=cfg["seed"])
+        part = gen(W, frame_h, r, min(r + 240, row1), seed=cfg["seed"])
         for k in range(4):
             gb[k][r - row0:r - row0 + part[k].shape[0]].copy_(torch.from_numpy(part[k]))
     return gb
@@ -164,175 +197,344 @@ def cpu_reference_source(cfg, env_np, pf, extra, pv, frame_h, target_s=6.0):
                       f"oracle/ref_src/hlsl_shim.h, 1 thread, {k} bands of {W}x{rows_per} rows of the same frame ({W * rows / 1e6:.2f} Mpix); {t:.1f} s"}
 
 
+class Dist:
+    """Control plane: world / rank, the barrier + synchronize bracket, max-over-ranks reductions, and CPU-side agreement (gloo) that keeps
+    working when a GPU stream does not progress."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus and self.world > 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}")
+        # VQ_BENCH_SHARE_GPU=1 (debug aid for single-GPU boxes): every rank uses the visible GPUs round-robin, the control plane runs over
+        # gloo and the C ABI's RCCL calls are served by tests/cpp/libmock_rccl.so (shared memory), so that the N > 1 control flow — tiles,
+        # halo exchange, double-buffered composite, drain — can be exercised on real kernels without N GPUs. Never set by the driver.
+        self.share = os.environ.get("VQ_BENCH_SHARE_GPU") == "1"
+        self.device_ordinal = local_rank % torch.cuda.device_count() if self.share else local_rank
+        torch.cuda.set_device(self.device_ordinal)
+        self.cpu_group = None
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.share:
+                os.environ["VQHIP_RCCL_LIBRARY"] = os.path.join(ROOT, "tests", "cpp", "libmock_rccl.so")
+                dist.init_process_group("gloo")
+                self.cpu_group = dist.group.WORLD
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.device_ordinal))
+                self.cpu_group = dist.new_group(backend="gloo")
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.cpu_group)
+        return float(t.item())
+
+    def all_true(self, flag):
+        if self.world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.cpu_group)
+        return bool(t.item())
+
+    def share_ids(self, n):
+        ids = [capi.comm_unique_id() for _ in range(n)] if self.rank == 0 else [None] * n
+        dist.broadcast_object_list(ids, src=0, group=self.cpu_group)          # control plane: n x 128 bytes
+        return ids
+
+
+class Comms:
+    """The communicators of the data path (C ABI) and how the composite overlaps the next frame.
+       one-comm : ONE communicator; the halo exchange runs on the main stream, the composite on a second stream. Every rank issues the
+                  operations of the communicator in the same host order (composite n, halo n+1, composite n+1, ...), RCCL orders them on
+                  the device, and composite n has the whole shading of frame n+1 to finish in before halo n+1 needs the communicator.
+       two-comms: round 2's form — a second communicator for the composite, nothing orders the two on the device.
+       off      : one communicator, one stream order: the composite sits on the critical path.
+    --composite-overlap auto = one-comm under a watchdog: the wiring check and the first overlapped steps must complete within
+    VQ_BENCH_WATCHDOG_S seconds on every rank, else every rank aborts its communicator (ncclCommAbort), builds a new one and runs `off`."""
+
+    def __init__(self, d, mode):
+        self.d, self.requested = d, mode
+        self.mode = "one-comm" if mode in ("auto", "on") else mode
+        self.fallback = None
+        self.halo = self.comp = None
+        if d.world > 1:
+            self._create()
+
+    def _create(self):
+        d = self.d
+        ids = d.share_ids(2 if self.mode == "two-comms" else 1)
+        self.halo = capi.Comm(ids[0], d.world, d.rank)
+        self.comp = capi.Comm(ids[1], d.world, d.rank) if self.mode == "two-comms" else self.halo
+
+    @property
+    def overlap(self):
+        return self.d.world > 1 and self.mode != "off"
+
+    def fall_back(self, why):
+        for c in {id(self.halo): self.halo, id(self.comp): self.comp}.values():
+            c.abort()
+        torch.cuda.synchronize()
+        self.fallback, self.mode = why, "off"
+        self._create()
+
+    def close(self):
+        for c in {id(self.halo): self.halo, id(self.comp): self.comp}.values():
+            if c is not None:
+                c.close()
+
+    def info(self):
+        if self.halo is None:
+            return {"nranks_seen": 1, "note": "N = 1: no communicator is created, RCCL is not loaded"}
+        q = self.halo.query()
+        return {"version": q["version"], "nranks_seen": q["nranks_seen"], "rank_seen": q["rank_seen"], "library_path": q["library_path"],
+                "communicators": 2 if self.mode == "two-comms" else 1, "composite_overlap_mode": self.mode, "requested": self.requested,
+                "fallback": self.fallback, "note": "read back from the communicator (ncclGetVersion / ncclCommCount / ncclCommUserRank, dladdr of ncclSend); version 0 = the "
+                                                   "shared-memory test stand-in"}
+
+
+class Pipeline:
+    """One workload resident on this rank's GPU: the G-buffer tile, the intermediate images, and `step(i)` = one pass of the hot path."""
+
+    def __init__(self, ctx, d, comms, cfg, args, env=None, max_env_lod=0, coherent=False, composite_root=0, rows_limit=None):
+        self.ctx, self.d, self.comms, self.cfg, self.args, self.env = ctx, d, comms, cfg, args, env
+        W, world = cfg["width"], d.world
+        self.W = W
+        self.frame_h = cfg["height"] * world if cfg["scaling"] == "weak" else cfg["height"]
+        self.tl = tiling.RowTiling(W, self.frame_h, world, d.rank)
+        self.rows = self.tl.tile_rows if rows_limit is None else rows_limit
+        self.pf, self.extra = synth.per_frame(points=synth.point_lights(cfg["lights"], seed=cfg["light_seed"]), hdri_offset=0.3 if env is not None else 0.0)
+        self.pv = synth.per_view(W, self.frame_h, max_env_lod=max_env_lod)
+        self.gb = upload_tile(cfg, self.frame_h, self.tl.row0, self.tl.row0 + self.rows, coherent)
+        dev = ctx.device
+        self.scene = [capi.empty_image(self.rows, W, F16, dev) for _ in range(2)]
+        self.xblur = capi.empty_image(self.rows, W, F16, dev)
+        self.yblur = capi.empty_image(self.rows, W, F16, dev) if args.post == "split" else None
+        self.sdr = [capi.empty_image(self.rows, W, R8, dev) for _ in range(2)]
+        self.root = composite_root
+        need_frame = world > 1 and (self.root == capi.ALL_RANKS or d.rank == 0)
+        self.frame = [torch.empty((self.frame_h, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)] if need_frame else [None, None]
+        self.halo_top = capi.empty_image(capi.HALO_ROWS, W, F16, dev) if world > 1 and d.rank > 0 else None
+        self.halo_bottom = capi.empty_image(capi.HALO_ROWS, W, F16, dev) if world > 1 and d.rank < world - 1 else None
+        self.s_main = torch.cuda.current_stream(dev)
+        self.s_comp = torch.cuda.Stream(dev) if world > 1 else self.s_main       # used only while comms.overlap
+        self.e_post = [torch.cuda.Event(), torch.cuda.Event()]
+        self.e_comp = [None, None]
+
+    def free(self):
+        self.gb = self.scene = self.sdr = self.frame = self.xblur = self.yblur = None
+        torch.cuda.empty_cache()
+
+    def step(self, i, ev=None):
+        """ev: dict of events to record: t0, shade (end of the shade kernel), x (end of the X pass), halo (end of the halo exchange),
+        post (end of the last post kernel) on the main stream; comp0 / comp1 around the composite on the stream it runs on."""
+        ctx, world, overlap = self.ctx, self.d.world, self.comms.overlap
+        s_main = self.s_main
+        s_comp = self.s_comp if overlap else s_main
+        b = i & 1
+        rec = (lambda k, s=s_main: ev[k].record(s)) if ev else (lambda k, s=None: None)
+        if overlap and self.e_comp[b] is not None:   # sdr[b] / frame[b] were last touched by the composite of step i-2
+            s_main.wait_event(self.e_comp[b])
+        if ev and "t0" in ev:
+            rec("t0")
+        ctx.forward_lighting(self.gb, self.pf, self.pv, out=self.scene[b], out_fmt=F16, extra_point=self.extra, env=self.env)
+        if ev and "shade" in ev:
+            rec("shade")
+        ctx.gaussian_blur_x(self.scene[b], F16, out=self.xblur)
+        if ev and "x" in ev:
+            rec("x")
+        if world > 1:
+            self.comms.halo.exchange_blur_halos(self.xblur, F16, self.halo_top, self.halo_bottom, stream=C.c_void_p(s_main.cuda_stream))
+        if ev and "halo" in ev:
+            rec("halo")
+        if self.args.post == "fused":
+            # CSMain_Y + Tonemapper in one kernel: bit-identical to the two dispatches, BlurOutput never touches HBM
+            ctx.gaussian_blur_y_tonemap(self.xblur, F16, R8, out=self.sdr[b], halo_top=self.halo_top, halo_bottom=self.halo_bottom)
+        else:
+            ctx.gaussian_blur_y(self.xblur, F16, out=self.yblur, halo_top=self.halo_top, halo_bottom=self.halo_bottom)
+            if ev and "y" in ev:
+                rec("y")
+            ctx.tonemap(self.yblur, F16, R8, out=self.sdr[b])
+        if ev and "post" in ev:
+            rec("post")
+        if world > 1:
+            if overlap:
+                self.e_post[b].record(s_main)
+                s_comp.wait_event(self.e_post[b])
+            if ev and "comp0" in ev:
+                rec("comp0", s_comp)
+            self.comms.comp.composite_tiles(self.sdr[b], R8, self.frame_h, self.root, self.frame[b], stream=C.c_void_p(s_comp.cuda_stream))
+            if ev and "comp1" in ev:
+                rec("comp1", s_comp)
+            if overlap:
+                self.e_comp[b] = torch.cuda.Event()
+                self.e_comp[b].record(s_comp)
+
+    def drain(self):
+        if self.comms.overlap:
+            self.s_main.wait_stream(self.s_comp)
+
+    def timed(self, n_steps, evs=None, first=0):
+        self.d.barrier()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            self.step(first + i, evs[i] if evs else None)
+        self.drain()
+        self.d.barrier()
+        return self.d.max_over_ranks(time.perf_counter() - t0)
+
+    def latency(self, n=5):
+        """one step at a time, nothing in flight before or after it (the throughput figure pipelines the composite)"""
+        lat = []
+        for i in range(n):
+            self.d.barrier()
+            t0 = time.perf_counter()
+            self.step(i)
+            self.drain()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        return self.d.max_over_ranks(float(np.median(lat)))
+
+    def completes_within(self, n_steps, seconds):
+        """Watchdog: enqueue n_steps and poll (no blocking call) until both streams have drained or `seconds` have passed."""
+        for i in range(n_steps):
+            self.step(i)
+        marks = [torch.cuda.Event(), torch.cuda.Event()]
+        marks[0].record(self.s_main); marks[1].record(self.s_comp)
+        deadline = time.perf_counter() + seconds
+        while not (marks[0].query() and marks[1].query()):
+            if time.perf_counter() > deadline:
+                return False
+            time.sleep(0.005)
+        return os.environ.get("VQ_BENCH_FAKE_OVERLAP_TIMEOUT") != "1"      # test hook: exercise the fall-back path on a healthy box
+
+
+def wiring_check(d, comms, ctx):
+    """Before anything is timed: every rank sends rows that name their sender and their row, so a transfer that lands in the wrong place,
+    comes from the wrong neighbour or does not arrive at all is a loud failure here instead of a wrong frame later."""
+    world, rank = d.world, d.rank
+    chk = tiling.RowTiling(64, 16 * world + (world // 2), world, rank)          # uneven tiles on purpose
+    stream = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
+    t_x = torch.empty((chk.tile_rows, 64, 4), dtype=torch.float16, device=ctx.device)
+    t_x[:] = (torch.arange(chk.row0, chk.row1, device=ctx.device, dtype=torch.float32) + 1000.0 * rank).to(torch.float16)[:, None, None]
+    h_t = torch.zeros((capi.HALO_ROWS, 64, 4), dtype=torch.float16, device=ctx.device) if rank > 0 else None
+    h_b = torch.zeros((capi.HALO_ROWS, 64, 4), dtype=torch.float16, device=ctx.device) if rank < world - 1 else None
+    comms.halo.exchange_blur_halos(t_x, F16, h_t, h_b, stream=stream)
+    t_c = torch.full((chk.tile_rows, 64, 4), rank + 1, dtype=torch.uint8, device=ctx.device)
+    f_c = torch.zeros((chk.frame_height, 64, 4), dtype=torch.uint8, device=ctx.device)
+    comms.comp.composite_tiles(t_c, R8, chk.frame_height, capi.ALL_RANKS, f_c, stream=stream)
+    torch.cuda.synchronize()
+    if h_t is not None:
+        want = (torch.arange(chk.row0 - capi.HALO_ROWS, chk.row0, device=ctx.device, dtype=torch.float32) + 1000.0 * (rank - 1)).to(torch.float16)
+        assert torch.equal(h_t[:, 0, 0], want), f"rank {rank}: top halo rows are not the last 10 rows of rank {rank - 1}"
+    if h_b is not None:
+        want = (torch.arange(chk.row1, chk.row1 + capi.HALO_ROWS, device=ctx.device, dtype=torch.float32) + 1000.0 * (rank + 1)).to(torch.float16)
+        assert torch.equal(h_b[:, 0, 0], want), f"rank {rank}: bottom halo rows are not the first 10 rows of rank {rank + 1}"
+    for k in range(world):
+        r0, n = capi.rowtile(chk.frame_height, world, k)
+        assert bool((f_c[r0:r0 + n] == k + 1).all()), f"rank {rank}: rows of rank {k} are wrong in the composited frame"
+    q = comms.halo.query()
+    assert q["nranks_seen"] in (world, -1) and q["rank_seen"] in (rank, -1), f"rank {rank}: the communicator reports {q}"
+
+
+def mean_ms(evs, a, b):
+    return float(np.mean([e[a].elapsed_time(e[b]) for e in evs]))
+
+
+def measure_strong(pipe, steps, warmup):
+    """A shorter protocol for the extra objects: warm-up, K timed steps (barrier + synchronize bracket, max over ranks), a detail pass with
+    per-stage events, the frame latency."""
+    for i in range(warmup):
+        pipe.step(i)
+    pipe.drain()
+    keys = ["t0", "shade", "x", "halo", "post"] + (["comp0", "comp1"] if pipe.d.world > 1 else [])
+    dt = pipe.timed(steps)
+    evd = [{k: _ev() for k in keys} for _ in range(min(steps, 6))]
+    for i in range(len(evd)):
+        pipe.step(steps + i + (steps & 1), evd[i])
+    pipe.drain()
+    pipe.d.barrier()
+    px = pipe.W * pipe.frame_h
+    out = {"value": round(px * steps / dt / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+           "frame": [pipe.W, pipe.frame_h], "tile_rows": pipe.rows, "lights": pipe.cfg["lights"], "scaling": pipe.cfg["scaling"],
+           "shade_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "t0", "shade")), 4),
+           "blur_x_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "shade", "x")), 4),
+           "halo_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "x", "halo")), 4) if pipe.d.world > 1 else 0.0,
+           "blur_y_tonemap_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "halo", "post")), 4),
+           "composite_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "comp0", "comp1")), 4) if pipe.d.world > 1 else 0.0,
+           "composite_overlapped": pipe.comms.overlap,
+           "frame_latency_ms": round(pipe.latency() * 1e3, 4),
+           "note": "max over ranks of each rank's mean; halo_ms includes waiting for the slower neighbour's X pass; composite_ms is measured on the "
+                   "stream the composite runs on and overlaps the next frame's shading when composite_overlapped"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)      # a step is ~1 ms: 0.2 s of timed GPU work; the run stays dominated by set-up and the CPU baselines
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg3")
+    ap.add_argument("--config", choices=["cfg3", "cfg5"], default="cfg3", help="the HEADLINE workload (the other BASELINE configs are reported as extra objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip cfg5_strong / cfg2 / ibl_load / coherent_scene / tile_curve")
     ap.add_argument("--post", choices=["fused", "split"], default="fused",
                     help="post chain after the X blur: Y blur and tonemapper as two dispatches (split) or one kernel (fused); identical bits")
     ap.add_argument("--composite", choices=["root", "all"], default="root",
                     help="final composite of the RGBA8 tiles: on rank 0 only (the presenting GPU; it receives over its N-1 direct xGMI links) or on every rank")
-    ap.add_argument("--composite-overlap", choices=["on", "off"], default="on",
-                    help="on: the composite of frame n runs on a second stream / second communicator and overlaps the shading of frame n+1 (drained "
-                         "inside the timed region); off: everything in one stream order")
+    ap.add_argument("--composite-overlap", choices=["auto", "on", "off", "two-comms"], default="auto",
+                    help="auto / on: ONE communicator, the composite of frame n on a second stream so that it overlaps the shading of frame n+1 (drained inside "
+                         "the timed region); auto adds a watchdog that falls back to `off` (one stream order) if the first steps do not complete; "
+                         "two-comms: round 2's form with a second communicator for the composite")
     ap.add_argument("--fresnel-pow", choices=["product", "exp2_log2"], default="product",
                     help="pow(1 - cos, 5) of the Fresnel terms: the product x*((x*x)*(x*x)) (default, contract v4) or exp2(5*log2 x), the engine's own "
                          "DXC lowering (vqhip_set_fresnel_pow; DESIGN.md 3.2). The other mode is timed too and reported as `engine_lowering`.")
     ap.add_argument("--no-second-mode", action="store_true", help="skip the timing of the other Fresnel-pow mode")
+    ap.add_argument("--content", choices=["noise", "coherent"], default="noise",
+                    help="noise: the BASELINE workload (white-noise G-buffer, SURVEY.md 8d). coherent: the same frame size on surface-coherent content; the line is "
+                         "then NOT the headline (metric and data say so) — used to collect counters for `coherent_scene` (scripts/pmc_refresh.sh)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    # VQ_BENCH_SHARE_GPU=1 (debug aid for single-GPU boxes): every rank uses the visible GPUs round-robin, the control plane runs over
-    # gloo and the C ABI's RCCL calls are served by tests/cpp/libmock_rccl.so (shared memory), so that the N > 1 control flow — tiles,
-    # halo exchange, double-buffered composite, drain — can be exercised on real kernels without N GPUs. Never set by the driver.
-    share = os.environ.get("VQ_BENCH_SHARE_GPU") == "1"
-    device_ordinal = local_rank % torch.cuda.device_count() if share else local_rank
-    torch.cuda.set_device(device_ordinal)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share:
-            os.environ["VQHIP_RCCL_LIBRARY"] = os.path.join(ROOT, "tests", "cpp", "libmock_rccl.so")
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device_ordinal))
-    ctx = capi.Context(device_ordinal)
+    d = Dist(args)
+    world, rank = d.world, d.rank
+    ctx = capi.Context(d.device_ordinal)
     ctx.set_fresnel_pow(args.fresnel_pow == "exp2_log2")
-
-    W, L = cfg["width"], cfg["lights"]
-    frame_h = cfg["height"] * world if cfg["scaling"] == "weak" else cfg["height"]
-    tl = tiling.RowTiling(W, frame_h, world, rank)
-    rows = tl.tile_rows
-    env = pre = lut = None
-    if cfg["env"]:
-        pre, lut = build_ibl(ctx)
-        env = capi.make_envmap(pre["diffuse_blurred"], pre["specular"], 128, pre["spec_mips"], lut)
-    pf, extra = synth.per_frame(points=synth.point_lights(L, seed=cfg["seed"]), hdri_offset=0.3 if cfg["env"] else 0.0)
-    pv = synth.per_view(W, frame_h, max_env_lod=pre["spec_mips"] if pre else 0)
-    gb = upload_tile(cfg, frame_h, tl.row0, tl.row1)
-
-    # communicators of the data path (C ABI): one for the halo exchange (critical path, main stream), one for the composite
-    comm_halo = comm_comp = None
+    comms = Comms(d, args.composite_overlap)
     if world > 1:
-        ids = [capi.comm_unique_id(), capi.comm_unique_id()] if rank == 0 else [None, None]
-        dist.broadcast_object_list(ids, src=0)               # control plane: 2 x 128 bytes
-        comm_halo = capi.Comm(ids[0], world, rank)
-        comm_comp = capi.Comm(ids[1], world, rank)
-        # wiring check before anything is timed: every rank sends rows that name their sender and their row, so a transfer that lands in the
-        # wrong place, comes from the wrong neighbour or does not arrive at all is a loud failure here instead of a wrong frame later
-        chk_rows = tiling.RowTiling(64, 16 * world + (world // 2), world, rank)          # uneven tiles on purpose
-        t_x = torch.empty((chk_rows.tile_rows, 64, 4), dtype=torch.float16, device=ctx.device)
-        t_x[:] = (torch.arange(chk_rows.row0, chk_rows.row1, device=ctx.device, dtype=torch.float32) + 1000.0 * rank).to(torch.float16)[:, None, None]
-        h_t = torch.zeros((capi.HALO_ROWS, 64, 4), dtype=torch.float16, device=ctx.device) if rank > 0 else None
-        h_b = torch.zeros((capi.HALO_ROWS, 64, 4), dtype=torch.float16, device=ctx.device) if rank < world - 1 else None
-        comm_halo.exchange_blur_halos(t_x, abi.FMT_RGBA16F, h_t, h_b, stream=C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream))
-        t_c = torch.full((chk_rows.tile_rows, 64, 4), rank + 1, dtype=torch.uint8, device=ctx.device)
-        f_c = torch.zeros((chk_rows.frame_height, 64, 4), dtype=torch.uint8, device=ctx.device)
-        comm_comp.composite_tiles(t_c, abi.FMT_RGBA8_UNORM, chk_rows.frame_height, capi.ALL_RANKS, f_c, stream=C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream))
-        torch.cuda.synchronize()
-        if h_t is not None:
-            want = (torch.arange(chk_rows.row0 - capi.HALO_ROWS, chk_rows.row0, device=ctx.device, dtype=torch.float32) + 1000.0 * (rank - 1)).to(torch.float16)
-            assert torch.equal(h_t[:, 0, 0], want), f"rank {rank}: top halo rows are not the last 10 rows of rank {rank - 1}"
-        if h_b is not None:
-            want = (torch.arange(chk_rows.row1, chk_rows.row1 + capi.HALO_ROWS, device=ctx.device, dtype=torch.float32) + 1000.0 * (rank + 1)).to(torch.float16)
-            assert torch.equal(h_b[:, 0, 0], want), f"rank {rank}: bottom halo rows are not the first 10 rows of rank {rank + 1}"
-        for k in range(world):
-            r0, n = capi.rowtile(chk_rows.frame_height, world, k)
-            assert bool((f_c[r0:r0 + n] == k + 1).all()), f"rank {rank}: rows of rank {k} are wrong in the composited frame"
-        del t_x, h_t, h_b, t_c, f_c
+        wiring_check(d, comms, ctx)
 
-    F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
-    scene = [capi.empty_image(rows, W, F16, ctx.device) for _ in range(2)]
-    xblur = capi.empty_image(rows, W, F16, ctx.device)
-    yblur = capi.empty_image(rows, W, F16, ctx.device) if args.post == "split" else None
-    sdr = [capi.empty_image(rows, W, R8, ctx.device) for _ in range(2)]
+    ibl_t = {}
+    pre, lut = build_ibl(ctx, ibl_t if (world == 1 and not args.no_extras) else None)     # cfg4: the headline's IBL inputs (cfg3) — and, timed, `ibl_load`
+    env = capi.make_envmap(pre["diffuse_blurred"], pre["specular"], 128, pre["spec_mips"], lut)
     root = 0 if args.composite == "root" else capi.ALL_RANKS
-    need_frame = world > 1 and (root == capi.ALL_RANKS or rank == 0)
-    frame = [torch.empty((frame_h, W, 4), dtype=torch.uint8, device=ctx.device) for _ in range(2)] if need_frame else [None, None]
-    halo_top = capi.empty_image(capi.HALO_ROWS, W, F16, ctx.device) if world > 1 and rank > 0 else None
-    halo_bottom = capi.empty_image(capi.HALO_ROWS, W, F16, ctx.device) if world > 1 and rank < world - 1 else None
-    overlap = world > 1 and args.composite_overlap == "on"
-    s_main = torch.cuda.current_stream(ctx.device)
-    s_comp = torch.cuda.Stream(ctx.device) if overlap else s_main
-    h_main, h_comp = C.c_void_p(s_main.cuda_stream), C.c_void_p(s_comp.cuda_stream)
-    e_post = [torch.cuda.Event(), torch.cuda.Event()]
-    e_comp = [None, None]
+    pipe = Pipeline(ctx, d, comms, cfg, args, env=env if cfg["env"] else None, max_env_lod=pre["spec_mips"] if cfg["env"] else 0, composite_root=root,
+                    coherent=args.content == "coherent")
+    W, L, rows, frame_h = cfg["width"], cfg["lights"], pipe.rows, pipe.frame_h
 
-    def step(i, ev=None):
-        b = i & 1
-        if overlap and e_comp[b] is not None:        # sdr[b] / frame[b] were last touched by the composite of step i-2
-            s_main.wait_event(e_comp[b])
-        if ev:
-            ev[0].record(s_main)
-        ctx.forward_lighting(gb, pf, pv, out=scene[b], out_fmt=F16, extra_point=extra, env=env)
-        if ev:
-            ev[1].record(s_main)
-        if ev and len(ev) == 5:
-            ev[4].record(s_main)
-        ctx.gaussian_blur_x(scene[b], F16, out=xblur)
-        if world > 1:
-            comm_halo.exchange_blur_halos(xblur, F16, halo_top, halo_bottom, stream=h_main)
-        if args.post == "fused":
-            # CSMain_Y + Tonemapper in one kernel (register-window Y pass whose store goes through the 64 KB tonemap table in
-            # LDS): bit-identical to the two dispatches, BlurOutput never touches HBM. ev[2] then closes the X pass (+ halo exchange).
-            if ev and len(ev) == 5:
-                ev[2].record(s_main)
-            ctx.gaussian_blur_y_tonemap(xblur, F16, R8, out=sdr[b], halo_top=halo_top, halo_bottom=halo_bottom)
-        else:
-            ctx.gaussian_blur_y(xblur, F16, out=yblur, halo_top=halo_top, halo_bottom=halo_bottom)
-            if ev and len(ev) == 5:
-                ev[2].record(s_main)
-            ctx.tonemap(yblur, F16, R8, out=sdr[b])
-        if ev and len(ev) >= 4:
-            ev[3].record(s_main)
-        if world > 1:
-            if overlap:
-                e_post[b].record(s_main)
-                s_comp.wait_event(e_post[b])
-            comm_comp.composite_tiles(sdr[b], R8, frame_h, root, frame[b], stream=h_comp)
-            if overlap:
-                e_comp[b] = torch.cuda.Event()
-                e_comp[b].record(s_comp)
-
-    def drain():
-        if overlap:
-            s_main.wait_stream(s_comp)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(n_steps, evs=None, first=0):
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(n_steps):
-            step(first + i, evs[i] if evs else None)
-        drain()
-        barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=ctx.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+    if world > 1 and args.composite_overlap == "auto":
+        ok = pipe.completes_within(3, WATCHDOG_S)
+        if not d.all_true(ok):
+            if rank == 0:
+                print(f"bench.py: the overlapped composite did not complete within {WATCHDOG_S:.0f} s on every rank: falling back to one stream order", file=sys.stderr)
+            comms.fall_back(f"first 3 overlapped steps did not complete within {WATCHDOG_S:.0f} s on every rank")
+            pipe.e_comp = [None, None]
+            wiring_check(d, comms, ctx)
+    overlap = comms.overlap
 
     # 1. cold start: the very first steps after the idle set-up phase, timed on their own (the chip has not ramped its clocks yet)
-    dt_cold = timed(COLD_STEPS)
+    dt_cold = pipe.timed(COLD_STEPS)
     # 2. untimed spin-up: the chip needs ~0.2-0.3 s of sustained load to reach its steady-state clocks, so a fixed number of extra
     #    untimed steps precedes the W warm-up steps whatever W is. The timed region is still exactly K steps.
     for i in range(max(0, SPINUP_STEPS - COLD_STEPS)):
-        step(i)
-    drain()
+        pipe.step(i)
+    pipe.drain()
     # 2b. the post kernels on their own, after the spin-up and before the warm-up: 20 back-to-back launches of each between two events, on the
     #     frame's own buffers (no event, no other kernel in between). In the frame loop each of them follows a kernel that has just filled the
     #     caches with other data, and the per-stage events sit inside the intervals they measure; both figures are reported. (Taken here rather
@@ -341,52 +543,42 @@ def main():
     iso = None
     if args.post == "fused":
         iso = {}
-        for name, fn in (("blur_x", lambda: ctx.gaussian_blur_x(scene[0], F16, out=xblur)),
-                         ("blur_y_tonemap", lambda: ctx.gaussian_blur_y_tonemap(xblur, F16, R8, out=sdr[0], halo_top=halo_top, halo_bottom=halo_bottom))):
+        for name, fn in (("blur_x", lambda: ctx.gaussian_blur_x(pipe.scene[0], F16, out=pipe.xblur)),
+                         ("blur_y_tonemap", lambda: ctx.gaussian_blur_y_tonemap(pipe.xblur, F16, R8, out=pipe.sdr[0], halo_top=pipe.halo_top, halo_bottom=pipe.halo_bottom))):
             for _ in range(5):
                 fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(s_main)
+            e0, e1 = _ev(), _ev()
+            e0.record(pipe.s_main)
             for _ in range(20):
                 fn()
-            e1.record(s_main)
+            e1.record(pipe.s_main)
             e1.synchronize()
             iso[name] = e0.elapsed_time(e1) / 20 * 1e-3
-        drain()
-        barrier()
+        pipe.drain()
+        d.barrier()
     for i in range(args.warmup):
-        step(i)
-    drain()
+        pipe.step(i)
+    pipe.drain()
     # 3. timed region: only the dominant kernel is bracketed by HIP events (2 records per step); the per-stage timings of the
     #    HBM-bound post kernels are taken in a separate, untimed pass afterwards so their instrumentation does not sit in `value`
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
-    dt = timed(args.steps, evs)
+    evs = [{"t0": _ev(), "shade": _ev()} for _ in range(args.steps)]
+    dt = pipe.timed(args.steps, evs)
 
     n_detail = min(args.steps, 10)
-    evd = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n_detail)]
+    keys = ["t0", "shade", "x", "halo", "post"] + (["y"] if args.post == "split" else []) + (["comp0", "comp1"] if world > 1 else [])
+    evd = [{k: _ev() for k in keys} for _ in range(n_detail)]
     for i in range(n_detail):
-        step(args.steps + i + (args.steps & 1), evd[i])
-    drain()
-    barrier()
-    # the chain as a whole, without an event between its kernels: [1] after shade ... [3] after the last post kernel
-    evc = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_detail)]
+        pipe.step(args.steps + i + (args.steps & 1), evd[i])
+    pipe.drain()
+    d.barrier()
+    # the chain as a whole, without an event between its kernels: `shade` after the shade kernel ... `post` after the last post kernel
+    evc = [{"shade": _ev(), "post": _ev()} for _ in range(n_detail)]
     for i in range(n_detail):
-        step(args.steps + i + (args.steps & 1), evc[i])
-    drain()
-    barrier()
-    # 4. frame latency: one step at a time, nothing in flight before or after it (the throughput figure pipelines the composite)
-    lat = []
-    for i in range(5):
-        barrier()
-        t0 = time.perf_counter()
-        step(i)
-        drain()
-        torch.cuda.synchronize()
-        lat.append(time.perf_counter() - t0)
-    lat_t = torch.tensor([float(np.median(lat))], dtype=torch.float64, device=ctx.device)
-    if world > 1:
-        dist.all_reduce(lat_t, op=dist.ReduceOp.MAX)
-    frame_latency = float(lat_t.item())
+        pipe.step(args.steps + i + (args.steps & 1), evc[i])
+    pipe.drain()
+    d.barrier()
+    # 4. frame latency: one step at a time, nothing in flight before or after it
+    frame_latency = pipe.latency()
 
     verify = None
     if world > 1 and os.environ.get("VQ_BENCH_VERIFY") == "1":
@@ -396,11 +588,11 @@ def main():
         last = 4 & 1
         if rank == 0:
             gb_full = upload_tile(cfg, frame_h, 0, frame_h)
-            sc = ctx.forward_lighting(gb_full, pf, pv, out_fmt=F16, extra_point=extra, env=env)
+            sc = ctx.forward_lighting(gb_full, pipe.pf, pipe.pv, out_fmt=F16, extra_point=pipe.extra, env=pipe.env)
             xb = ctx.gaussian_blur_x(sc, F16)
             want = ctx.gaussian_blur_y_tonemap(xb, F16, R8)
             torch.cuda.synchronize()
-            verify = {"mismatching_bytes": int((want != frame[last]).sum().item()), "frame": [W, frame_h]}
+            verify = {"mismatching_bytes": int((want != pipe.frame[last]).sum().item()), "frame": [W, frame_h]}
             del gb_full, sc, xb, want
         dist.barrier()
 
@@ -410,43 +602,66 @@ def main():
         other = "exp2_log2" if args.fresnel_pow == "product" else "product"
         ctx.set_fresnel_pow(other == "exp2_log2")
         for i in range(20):
-            step(i)
-        drain()
-        evs2 = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(args.steps)]
-        dt2 = timed(args.steps, evs2)
+            pipe.step(i)
+        pipe.drain()
+        evs2 = [{"t0": _ev(), "shade": _ev()} for _ in range(args.steps)]
+        dt2 = pipe.timed(args.steps, evs2)
         ctx.set_fresnel_pow(args.fresnel_pow == "exp2_log2")
         second = {"fresnel_pow": other, "value": round(W * frame_h * args.steps / dt2 / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
-                  "shade_ms": round(float(np.mean([e[0].elapsed_time(e[1]) for e in evs2])), 4)}
+                  "shade_ms": round(mean_ms(evs2, "t0", "shade"), 4)}
+
+    # 6. the other BASELINE configs, outside the headline's timed region (every rank takes part in the distributed ones)
+    extras = {}
+    pf_head, extra_head, pv_head = pipe.pf, pipe.extra, pipe.pv
+    if not args.no_extras:
+        x_steps = max(4, min(args.steps, 20))
+        if args.config != "cfg5":
+            pipe.free()
+            p5 = Pipeline(ctx, d, comms, CONFIGS["cfg5"], args, composite_root=root)
+            extras["cfg5_strong"] = measure_strong(p5, x_steps, 3)
+            extras["cfg5_strong"]["workload"] = CONFIGS["cfg5"]["workload"] + f"; {p5.rows} of 4320 rows on each of {world} GPU(s)"
+            if world == 1:
+                extras["tile_curve"] = tile_curve(ctx, d, comms, args, p5, extras["cfg5_strong"])
+            p5.free()
+        if world == 1:
+            extras["cfg2"] = shade_only(ctx, d, comms, args, CONFIGS["cfg2"], None, 0)
+            extras["ibl_load"] = ibl_load_report(ibl_t)
+            if args.config == "cfg3":
+                extras["coherent_scene"] = coherent_scene(ctx, d, comms, args, cfg, env, pre["spec_mips"])
 
     if rank == 0:
         px_tile, px_frame = W * rows, W * frame_h
-        t_shade = float(np.mean([e[0].elapsed_time(e[1]) for e in evs])) * 1e-3
-        t_blur = float(np.mean([e[4].elapsed_time(e[2]) for e in evd])) * 1e-3
-        t_tm = float(np.mean([e[2].elapsed_time(e[3]) for e in evd])) * 1e-3
-        t_chain = float(np.mean([e[1].elapsed_time(e[3]) for e in evc])) * 1e-3
+        t_shade = mean_ms(evs, "t0", "shade") * 1e-3
+        if args.post == "split":
+            t_blur, t_tm = mean_ms(evd, "shade", "y") * 1e-3, mean_ms(evd, "y", "post") * 1e-3
+        else:
+            t_blur, t_tm = mean_ms(evd, "shade", "halo") * 1e-3, mean_ms(evd, "halo", "post") * 1e-3
+        t_chain = mean_ms(evc, "shade", "post") * 1e-3
         ach = SHADE_BYTES_PER_PX * px_tile / t_shade / 1e9
         flops_px = 170 * L + 160
-        pmc, pmc_meta = load_pmc_constants(args.config, args.fresnel_pow)
+        pmc, pmc_meta = load_pmc_constants(args.config + ("_coherent" if args.content == "coherent" else ""), args.fresnel_pow)
         if pmc_meta.get("stale"):
             print(f"bench.py: PMC constants not used: {pmc_meta.get('why')}", file=sys.stderr)
         out = {
-            "metric": cfg["metric"], "value": round(px_frame * args.steps / dt / 1e6, 2), "unit": "Mpix/s",
+            "metric": cfg["metric"] + (" [NOT the BASELINE workload: surface-coherent content]" if args.content == "coherent" else ""),
+            "value": round(px_frame * args.steps / dt / 1e6, 2), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": cfg["scaling"], "vs_baseline": None, "dtype": "f32", "data": "synthetic" if args.content == "noise" else "synthetic-coherent",
             "config": {"workload": cfg["workload"] + ("" if world == 1 else f"; frame {W}x{frame_h} row-tiled {rows} rows per GPU, RCCL p2p halo exchange + composite on "
                                                        f"{'rank 0' if root == 0 else 'every rank'} through the C ABI"),
                        "name": args.config, "width": W, "frame_height": frame_h, "tile_rows": rows, "lights": L, "parallelism": f"rows{world}",
                        "composite_overlap": overlap, "untimed_spinup_steps": SPINUP_STEPS, "fresnel_pow": args.fresnel_pow,
                        "post": "blur X, then blur Y + tonemap in one kernel (identical bits to three dispatches)" if args.post == "fused" else "blur X, blur Y, tonemap"},
-            "roofline": {"bound": "hbm", "kernel": f"k_forward_lighting<{'env' if env is not None else 'noenv'},nocasters,RGBA16F>", "achieved": round(ach, 2),
+            "roofline": {"bound": "hbm", "kernel": f"k_forward_lighting<{'env' if cfg['env'] else 'noenv'},nocasters,RGBA16F>", "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
                          "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "traffic_unit": "bytes/launch",
                          "traffic_source": "rocprofv3 PMC, separate passes, 2*FETCH_SIZE + WRITE_SIZE (profiles/pmc_constants.json); algorithmic = %d" % (SHADE_BYTES_PER_PX * px_tile),
                          "bytes_per_px": SHADE_BYTES_PER_PX, "ms": round(t_shade * 1e3, 4),
-                         "note": f"{L}-light shading is VALU-bound by construction (SURVEY.md 8d): see valu / valu_issue"},
+                         "note": f"{L}-light shading is VALU-bound by construction (SURVEY.md 8d): see valu / valu_issue; the HBM-bound kernels are under stages and cfg2"},
             "valu": {"achieved_tflops_model": round(flops_px * px_tile / t_shade / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
                      "frac": round(flops_px * px_tile / t_shade / 1e12 / VALU_PEAK_TFLOPS, 4), "flops_per_px_model": flops_px},
             "pmc_constants": pmc_meta,
+            "rccl": comms.info(),
             "stages": {"shade_Mpix_s": round(px_tile / t_shade / 1e6, 1), "shade_ms": round(t_shade * 1e3, 4),
                        **({"blur_xy_ms": round(t_blur * 1e3, 4), "blur_xy_GBps": round(px_tile * 32 / t_blur / 1e9, 1),
                            "tonemap_ms": round(t_tm * 1e3, 4), "tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1)} if args.post == "split" else
@@ -463,7 +678,7 @@ def main():
                                         "blur_y_tonemap_frac_of_hbm_peak": round(px_tile * 12 / iso["blur_y_tonemap"] / 1e9 / HBM_PEAK_GBPS, 4),
                                         "note": "20 back-to-back launches of the one kernel between two events, after the spin-up and before the warm-up steps; "
                                                 "the figures above are taken inside the frame loop with an event record between the stages"}}),
-                       **({"blur_x_includes": "halo exchange"} if world > 1 else {})},
+                       **({"blur_x_includes": "halo exchange", "composite_ms": round(mean_ms(evd, "comp0", "comp1"), 4)} if world > 1 else {})},
             "frame_latency_ms": round(frame_latency * 1e3, 4),
             "cold_start": {"steps": COLD_STEPS, "ms_per_step": round(dt_cold / COLD_STEPS * 1e3, 4), "value": round(px_frame * COLD_STEPS / dt_cold / 1e6, 2),
                            "note": "the first steps after the idle set-up phase, before the clocks ramp; `value` is the steady-state figure"},
@@ -481,14 +696,20 @@ def main():
             out["engine_lowering" if second["fresnel_pow"] == "exp2_log2" else "product_lowering"] = second
         if verify is not None:
             out["verify"] = verify
+        out.update(extras)
+        if "coherent_scene" in out:
+            cc = load_pmc_constants("cfg3_coherent", args.fresnel_pow)[0]
+            if cc:
+                out["coherent_scene"].update(traffic=cc.get("hbm_bytes_per_launch"), valu_instr_per_wave=cc["valu_instr_per_wave"],
+                                             traffic_ratio_to_algorithmic=round(cc["hbm_bytes_per_launch"] / (SHADE_BYTES_PER_PX * px_tile), 3) if cc.get("hbm_bytes_per_launch") else None)
         if world == 1 and not args.no_cpu_baseline:
-            env_np = (pre["diffuse_blurred"].cpu().numpy(), pre["specular"].cpu().numpy(), 128, pre["spec_mips"], lut.cpu().numpy()) if pre else None
+            env_np = (pre["diffuse_blurred"].cpu().numpy(), pre["specular"].cpu().numpy(), 128, pre["spec_mips"], lut.cpu().numpy()) if cfg["env"] else None
             if args.fresnel_pow == "exp2_log2":
                 from tests import oracle_lib as _O
                 _O.load().vqo_set_fresnel_pow(1)             # keeps the cpu_baseline leg on the same arithmetic
-            out["cpu_baseline"] = cpu_baseline(cfg, env_np, pf, extra, pv, frame_h)
+            out["cpu_baseline"] = cpu_baseline(cfg, env_np, pf_head, extra_head, pv_head, frame_h)
             try:                                             # optional second baseline: only where oracle/_ref exists
-                ref_line = cpu_reference_source(cfg, env_np, pf, extra, pv, frame_h)
+                ref_line = cpu_reference_source(cfg, env_np, pf_head, extra_head, pv_head, frame_h)
                 if ref_line is not None:
                     out["cpu_reference_source"] = ref_line
             except Exception as e:                           # never let the optional leg break the bench line
@@ -496,10 +717,94 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
-        comm_halo.close()
-        comm_comp.close()
+        comms.close()
         dist.destroy_process_group()
     ctx.close()
+
+
+# ---- the extra objects ------------------------------------------------------------------------------------------------------------------
+def _time_loop(fn, n, spin):
+    for i in range(spin):
+        fn(i)
+    a, b = _ev(), _ev()
+    a.record()
+    for i in range(n):
+        fn(i)
+    b.record(); b.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def shade_only(ctx, d, comms, args, cfg, env, max_env_lod, coherent=False):
+    """The shade kernel of `cfg` alone (N = 1): back-to-back launches between two events after a spin-up, with both roofs."""
+    p = Pipeline(ctx, d, comms, cfg, args, env=env, max_env_lod=max_env_lod, coherent=coherent)
+    out_img = p.scene[0]
+    ms = _time_loop(lambda i: ctx.forward_lighting(p.gb, p.pf, p.pv, out=out_img, out_fmt=F16, extra_point=p.extra, env=p.env), 60, 120)
+    px, L = p.W * p.rows, cfg["lights"]
+    res = {"workload": cfg["workload"] + (" [surface-coherent content]" if coherent else ""), "shade_ms": round(ms, 4), "shade_Mpix_s": round(px / ms / 1e3, 1),
+           "hbm_GBps": round(SHADE_BYTES_PER_PX * px / ms / 1e6, 1), "hbm_frac": round(SHADE_BYTES_PER_PX * px / ms / 1e6 / HBM_PEAK_GBPS, 4),
+           "valu_frac_model": round((170 * L + 160) * px / ms / 1e9 / VALU_PEAK_TFLOPS, 4), "bytes_per_px": SHADE_BYTES_PER_PX, "flops_per_px_model": 170 * L + 160,
+           "note": "shade kernel only, 60 back-to-back launches after a 120-launch spin-up"}
+    if coherent:
+        r = p.gb[1][..., 3]
+        res["slow_path_pixel_fraction_round2"] = round(float((r < 0.04).float().mean().item()), 4)
+    p.free()
+    return res
+
+
+def coherent_scene(ctx, d, comms, args, cfg, env, spec_mips):
+    """The headline frame on surface-coherent content (terrain normals, material regions, 12 % polished regions): what real frames cost. The
+    white-noise frame of the headline never takes the wave-uniform skip of back-facing lights and has no pixel below roughness 0.04."""
+    res = shade_only(ctx, d, comms, args, cfg, env, spec_mips, coherent=True)
+    res["note"] = ("the cfg3 shade kernel on synth.gbuffer_rows_coherent; slow_path_pixel_fraction_round2 = pixels with roughness < 0.04, which round 2 sent "
+                   "through the IEEE light loop wave by wave; now whole waves choose the EPSILON-select / back-facing-skip forms (shade.hip)")
+    return res
+
+
+def ibl_load_report(t):
+    """BASELINE config 4 as the engine runs it at load time (EnvironmentMapRendering.cpp:139-486, Renderer.cpp:871-909), with the flop models
+    of SURVEY.md 8d: diffuse 6x64^2 texels x 99 382 taps x ~60 flop, specular 67 M taps x ~80, LUT 1024^2 x 2048 samples x ~80."""
+    model = {"conv_diffuse_ms": 6 * 64 * 64 * 99382 * 60.0, "conv_specular_ms": 67.1e6 * 80.0, "brdf_lut_warm_ms": 1024 * 1024 * 2048 * 80.0}
+    out = dict(t)
+    out["total_ms"] = round(t["mip_chain_ms"] + t["prefilter_ms"] + t["brdf_lut_ms"], 4)
+    for k, fl in model.items():
+        out[k.replace("_ms", "_valu_frac_model")] = round(fl / (t[k] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)
+    out["mip_chain_hbm_frac"] = round((2048 * 2048 * 16 * 5.0 / 3.0) / (t["mip_chain_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)   # each level read once, written once
+    out["workload"] = "BASELINE cfg4: 2048^2 RGBA32F equirect -> 12-level min-filter chain, diffuse irradiance 6x64^2 at step 0.010 (99 382 taps/texel) + blur, 7-mip GGX specular 128^2, BRDF LUT 1024^2 x 2048"
+    out["note"] = ("mip_chain / prefilter (diffuse + face blur + specular) / brdf_lut are the product calls as build_ibl() issues them, first use of each kernel "
+                   "(code load and cold clocks included); conv_diffuse / conv_specular / brdf_lut_warm are a second run of the stage on its own")
+    return out
+
+
+def tile_curve(ctx, d, comms, args, p5, strong):
+    """One GPU can say how the cfg5 tile step shrinks with the tile: step time for the top 4320/N rows, N = 1, 2, 4, 8 (same frame, same lights).
+    The speed-up line is a MODEL, labelled as such: tile step + halo bytes / link + (composite bytes into the root over its N-1 links when it
+    is not overlapped). It bounds compute efficiency and tail effects; RCCL latency and launch skew are not in it."""
+    W, H = p5.W, p5.frame_h
+    res = {"frame": [W, H], "lights": p5.cfg["lights"], "tiles": [], "t1_ms": None,
+           "model": "speedup(N) = t_step(4320 rows) / (t_step(4320/N rows) + halo + composite_if_not_overlapped); halo = 2 x 10 rows x 7680 px x 8 B over one link, "
+                    "composite = (N-1)/N x 132.7 MB into the root over N-1 links; link = 153 GB/s peak (76 GB/s in the conservative column). MODELLED, not measured."}
+    t1 = None
+    for n in (1, 2, 4, 8):
+        rows = H // n
+        gb = [g[:rows] for g in p5.gb]
+        sc, xb, sd = p5.scene[0][:rows], p5.xblur[:rows], p5.sdr[0][:rows]
+
+        def step(i):
+            ctx.forward_lighting(gb, p5.pf, p5.pv, out=sc, out_fmt=F16, extra_point=p5.extra)
+            ctx.gaussian_blur_x(sc, F16, out=xb)
+            ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=sd)
+        ms = _time_loop(step, 8 * n if n < 8 else 40, 3 * n)
+        t1 = t1 or ms
+        halo_b, comp_b = 2 * 10 * W * 8, (n - 1) / n * W * H * 4
+        row = {"gpus_modelled": n, "tile_rows": rows, "workgroups_shade": ((W + 255) // 256) * rows, "step_ms": round(ms, 4), "compute_speedup": round(t1 / ms, 3)}
+        for tag, bw in (("peak_link", XGMI_LINK_GBPS), ("half_link", XGMI_LINK_GBPS / 2)):
+            halo_ms = 0.0 if n == 1 else halo_b / bw / 1e6
+            comp_ms = 0.0 if n == 1 else comp_b / (bw * (n - 1)) / 1e6
+            row[f"modelled_speedup_overlapped_{tag}"] = round(t1 / (ms + halo_ms), 3)
+            row[f"modelled_speedup_serial_{tag}"] = round(t1 / (ms + halo_ms + comp_ms), 3)
+        res["tiles"].append(row)
+    res["t1_ms"] = round(t1, 4)
+    return res
 
 
 if __name__ == "__main__":

@@ -544,9 +544,24 @@ VQHIP_API int  vqhip_comm_unique_id(void* id128);
 VQHIP_API int  vqhip_comm_create(const void* id128, int world, int rank, vqhip_comm** out_comm);
 VQHIP_API int  vqhip_comm_adopt(void* nccl_comm, int world, int rank, vqhip_comm** out_comm);
 VQHIP_API void vqhip_comm_destroy(vqhip_comm* comm);
+/* ncclCommAbort: ends the transfers in flight on the communicator (a watchdog's way out of an exchange that does not complete) and frees
+ * it like vqhip_comm_destroy; collective in effect — every rank must abort and build a new communicator before it exchanges again. */
+VQHIP_API int  vqhip_comm_abort(vqhip_comm* comm);
+/* What the communicator itself reports (read back from RCCL, not from the arguments of vqhip_comm_create): size and rank as RCCL sees
+ * them (ncclCommCount / ncclCommUserRank), the library's version (ncclGetVersion; 0 = the test stand-in) and the path it was loaded from. */
+typedef struct vqhip_comm_info {
+    int32_t world, rank;                 /* as given to vqhip_comm_create / vqhip_comm_adopt */
+    int32_t nranks_seen, rank_seen;      /* as RCCL reports them; -1 when the library lacks the query */
+    int32_t rccl_version;                /* ncclGetVersion: e.g. 22105; -1 when unavailable */
+    int32_t reserved;
+    char    library_path[232];           /* dladdr of ncclSend */
+} vqhip_comm_info;
+VQHIP_API int  vqhip_comm_query(const vqhip_comm* comm, vqhip_comm_info* out_info);
 /* Exchange 1. xblur_tile: this rank's X-blurred tile (tile_rows x width, row_pitch_px pixels per row, fmt RGBA16F | RGBA32F).
  * Sends its first 10 rows to rank-1 and its last 10 rows to rank+1 and receives theirs into halo_top / halo_bottom (dense
- * 10 x width buffers, the layout vqhip_gaussian_blur_y takes; ignored — may be NULL — at the frame's top / bottom edge). */
+ * 10 x width buffers, the layout vqhip_gaussian_blur_y takes; ignored — may be NULL — at the frame's top / bottom edge).
+ * ONE message per neighbour and direction whatever the pitch: rows of a pitched tile are first packed into a dense staging block
+ * owned by the communicator (hipMemcpy2DAsync on `stream`), so both sides always post one send and one receive of 10*width pixels. */
 VQHIP_API int  vqhip_exchange_blur_halos(vqhip_comm* comm, void* stream, const void* xblur_tile, int width, int tile_rows,
         int row_pitch_px, vqhip_format fmt, void* halo_top, void* halo_bottom);
 /* Exchange 2. tile: this rank's finished tile (dense rows, fmt e.g. RGBA8_UNORM). root >= 0: only that rank receives the

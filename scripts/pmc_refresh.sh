@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 export VQ_BENCH_SPINUP=20
 run() {   # tag, counters, bench args
   rm -rf gpurun_out/pmc/$1
-  timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d gpurun_out/pmc/$1 -- python bench.py --no-cpu-baseline --no-second-mode --steps 6 --warmup 2 $3 > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d gpurun_out/pmc/$1 -- python bench.py --no-cpu-baseline --no-second-mode --no-extras --steps 6 --warmup 2 $3 > /dev/null 2>&1
   echo "pass $1 rc=$?"
 }
 run cfg3_product_valu  "SQ_INSTS_VALU SQ_WAVES" "--config cfg3"
@@ -18,6 +18,9 @@ run cfg3_product_fetch "FETCH_SIZE"             "--config cfg3"
 run cfg3_product_write "WRITE_SIZE"             "--config cfg3"
 run cfg3_exp2_valu     "SQ_INSTS_VALU SQ_WAVES" "--config cfg3 --fresnel-pow exp2_log2"
 run cfg3_exp2_trans    "SQ_INSTS_VALU_TRANS"    "--config cfg3 --fresnel-pow exp2_log2"
+run cfg3c_product_valu  "SQ_INSTS_VALU SQ_WAVES" "--config cfg3 --content coherent"
+run cfg3c_product_fetch "FETCH_SIZE"             "--config cfg3 --content coherent"
+run cfg3c_product_write "WRITE_SIZE"             "--config cfg3 --content coherent"
 run cfg5_product_valu  "SQ_INSTS_VALU SQ_WAVES" "--config cfg5"
 run cfg5_product_trans "SQ_INSTS_VALU_TRANS"    "--config cfg5"
 run cfg5_product_fetch "FETCH_SIZE"             "--config cfg5"
@@ -35,7 +38,7 @@ def med(tag, counter):
 out = {"kernel_sources_sha256": bench.kernel_source_hash(), "measured_at_commit": os.environ.get("VQ_COMMIT", "unknown"),
        "profile": "scripts/pmc_refresh.sh: rocprofv3 --pmc <counter> --kernel-trace, one pass per counter group, medians over the shade launches of bench.py --steps 6",
        "sources": bench.PMC_SOURCES}
-for key, tag in (("cfg3/product", "cfg3_product"), ("cfg3/exp2_log2", "cfg3_exp2"), ("cfg5/product", "cfg5_product")):
+for key, tag in (("cfg3/product", "cfg3_product"), ("cfg3/exp2_log2", "cfg3_exp2"), ("cfg3_coherent/product", "cfg3c_product"), ("cfg5/product", "cfg5_product")):
     valu, waves = med(tag + "_valu", "SQ_INSTS_VALU"), med(tag + "_valu", "SQ_WAVES")
     if not valu or not waves:
         print("no VALU counters for", key); continue
@@ -44,7 +47,7 @@ for key, tag in (("cfg3/product", "cfg3_product"), ("cfg3/exp2_log2", "cfg3_exp2
     if tr:
         e["quarter_rate_instr_per_wave"] = round(tr / waves, 1)
     else:   # the counter is not exposed on this pool: ISA count instead — 5 v_rsq/v_rcp per executed light (2 sqrt seeds, 3 reciprocals), ~12 per pixel
-        lights = bench.CONFIGS[key.split("/")[0]]["lights"]
+        lights = bench.CONFIGS[key.split("/")[0].split("_")[0]]["lights"]
         e["quarter_rate_instr_per_wave"] = round(5 * lights * 0.82 + 12)
         e["quarter_rate_source"] = "estimate: ISA count (5 per executed light + 12) x 0.82 wave-level executed-light fraction; SQ_INSTS_VALU_TRANS is not available"
     f, w = med(tag + "_fetch", "FETCH_SIZE"), med(tag + "_write", "WRITE_SIZE")

@@ -7,7 +7,8 @@
 //   * a GPU is visible: buffers are DEVICE memory; the stream is drained, bytes move with hipMemcpy(Default) through the mailbox
 //     (tests/test_gpu_bench_flow.py: N ranks sharing one GPU)
 // Semantics kept from RCCL: sends / receives between GroupStart and GroupEnd are posted together and progress concurrently (no ordering
-// deadlock), messages between one ordered pair of ranks match in posting order.
+// deadlock), messages between one ordered pair of ranks match ONE TO ONE in posting order and a send whose byte count differs from the
+// receive it meets ABORTS the process (real RCCL hangs or corrupts there: ten row-sized sends against one ten-row receive must not pass).
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
@@ -30,7 +31,7 @@ typedef struct { char internal[128]; } ncclUniqueId;
 namespace {
 constexpr int kMaxRanks = 8;
 constexpr size_t kSlotBytes = 4u << 20;                    // one in-flight chunk per ordered pair
-struct Mailbox { std::atomic<uint64_t> produced, consumed; std::atomic<uint64_t> bytes; char pad[40]; };
+struct Mailbox { std::atomic<uint64_t> produced, consumed; std::atomic<uint64_t> bytes; std::atomic<uint64_t> total; char pad[32]; };
 struct Shared { std::atomic<int> arrived; char pad[60]; Mailbox box[kMaxRanks][kMaxRanks]; };   // payload slots follow
 size_t sharedBytes() { return sizeof(Shared) + (size_t)kMaxRanks * kMaxRanks * kSlotBytes; }
 char* slot(Shared* s, int src, int dst) { return (char*)(s + 1) + ((size_t)src * kMaxRanks + dst) * kSlotBytes; }
@@ -57,12 +58,18 @@ bool progress(MockComm* c, Op& op) {
         if (m.produced.load(std::memory_order_acquire) != m.consumed.load(std::memory_order_acquire)) return false;     // slot still full
         const size_t n = std::min(kSlotBytes, op.bytes - op.done);
         copyIn(slot(c->sh, src, dst), op.buf + op.done, n);
+        if (op.done == 0) m.total.store(op.bytes, std::memory_order_relaxed);       // size of the whole message, checked by the receive it meets
         m.bytes.store(n, std::memory_order_relaxed);
         m.produced.fetch_add(1, std::memory_order_release);
         op.done += n;
     } else {
         if (m.produced.load(std::memory_order_acquire) == m.consumed.load(std::memory_order_acquire)) return false;     // nothing there yet
         const size_t n = m.bytes.load(std::memory_order_relaxed);
+        if (op.done == 0 && m.total.load(std::memory_order_relaxed) != op.bytes) {
+            std::fprintf(stderr, "mock_rccl: rank %d posted a receive of %zu bytes from rank %d, the matching send has %llu bytes (RCCL requires equal counts)\n",
+                         c->rank, op.bytes, op.peer, (unsigned long long)m.total.load());
+            std::abort();
+        }
         if (n > op.bytes - op.done) { std::fprintf(stderr, "mock_rccl: message larger than the posted receive\n"); std::abort(); }
         copyIn(op.buf + op.done, slot(c->sh, src, dst), n);
         m.consumed.fetch_add(1, std::memory_order_release);
@@ -117,6 +124,10 @@ __attribute__((visibility("default"))) ncclResult_t ncclCommInitRank(ncclComm_t*
     return 0;
 }
 __attribute__((visibility("default"))) ncclResult_t ncclCommDestroy(ncclComm_t c) { if (c) { munmap(c->sh, sharedBytes()); delete c; } return 0; }
+__attribute__((visibility("default"))) ncclResult_t ncclCommAbort(ncclComm_t c) { if (c) { munmap(c->sh, sharedBytes()); delete c; } return 0; }
+__attribute__((visibility("default"))) ncclResult_t ncclGetVersion(int* v) { *v = 0; return 0; }          // 0 = this stand-in
+__attribute__((visibility("default"))) ncclResult_t ncclCommCount(const ncclComm_t c, int* n) { *n = c->world; return 0; }
+__attribute__((visibility("default"))) ncclResult_t ncclCommUserRank(const ncclComm_t c, int* r) { *r = c->rank; return 0; }
 __attribute__((visibility("default"))) ncclResult_t ncclGroupStart() { ++g_depth; return 0; }
 __attribute__((visibility("default"))) ncclResult_t ncclGroupEnd() { if (--g_depth == 0) runGroup(); return 0; }
 __attribute__((visibility("default"))) ncclResult_t ncclSend(const void* buf, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st) {

@@ -21,8 +21,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(ranks, extra_args):
-    env = dict(os.environ, VQ_BENCH_SHARE_GPU="1", VQ_BENCH_VERIFY="1", VQ_BENCH_SPINUP="4", MASTER_ADDR="127.0.0.1")
+def _run(ranks, extra_args, **more_env):
+    env = dict(os.environ, VQ_BENCH_SHARE_GPU="1", VQ_BENCH_VERIFY="1", VQ_BENCH_SPINUP="4", MASTER_ADDR="127.0.0.1", **more_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "4", "--warmup", "1",
            "--no-cpu-baseline", "--no-second-mode"] + extra_args
@@ -31,18 +31,51 @@ def _run(ranks, extra_args):
     return json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
 
 
-@pytest.mark.parametrize("ranks,composite,overlap", [(2, "root", "on"), (2, "all", "off"), (3, "root", "on")])
-def test_cfg3_weak_scaling_flow_matches_the_untiled_frame(ranks, composite, overlap):
-    """3 ranks: the middle tile exchanges halos with both neighbours."""
-    d = _run(ranks, ["--config", "cfg3", "--composite", composite, "--composite-overlap", overlap])
+def _check_rccl(d, ranks, mode):
+    r = d["rccl"]                                            # read back from the communicator (vqhip_comm_query), the stand-in reports version 0
+    assert r["nranks_seen"] == ranks and r["rank_seen"] == 0 and r["version"] == 0 and r["library_path"].endswith("libmock_rccl.so"), r
+    assert r["composite_overlap_mode"] == mode, r
+
+
+@pytest.mark.parametrize("ranks,composite,overlap,mode", [(2, "root", "auto", "one-comm"), (2, "all", "off", "off"), (3, "root", "on", "one-comm"),
+                                                          (2, "root", "two-comms", "two-comms")])
+def test_cfg3_weak_scaling_flow_matches_the_untiled_frame(ranks, composite, overlap, mode):
+    """3 ranks: the middle tile exchanges halos with both neighbours. Headline only (--no-extras)."""
+    d = _run(ranks, ["--config", "cfg3", "--composite", composite, "--composite-overlap", overlap, "--no-extras"])
     assert d["n_gpus"] == ranks and d["scaling"] == "weak" and d["config"]["frame_height"] == 2160 * ranks
     assert d["verify"]["mismatching_bytes"] == 0, d["verify"]
+    _check_rccl(d, ranks, mode)
+    assert "cfg5_strong" not in d
+
+
+def test_every_run_also_times_cfg5_strong_scaling():
+    """The standard invocation at N = 3: the cfg3 headline (weak) AND the cfg5 strong-scaling object the >= 6x target is defined on
+    (one 7680x4320 frame, 256 lights, 1440 rows per rank), with its stage figures and the communicator's own report."""
+    d = _run(3, [])
+    assert d["config"]["name"] == "cfg3" and d["scaling"] == "weak" and d["verify"]["mismatching_bytes"] == 0
+    c = d["cfg5_strong"]
+    assert c["frame"] == [7680, 4320] and c["tile_rows"] == 1440 and c["lights"] == 256 and c["scaling"] == "strong"
+    for k in ("value", "ms_per_step", "shade_ms", "halo_ms", "composite_ms", "frame_latency_ms", "blur_x_ms", "blur_y_tonemap_ms"):
+        assert c[k] > 0, (k, c)
+    assert abs(c["value"] - 7680 * 4320 / (c["ms_per_step"] * 1e-3) / 1e6) < 0.01 * c["value"]
+    assert c["shade_ms"] < c["ms_per_step"] and c["composite_overlapped"] is True
+    _check_rccl(d, 3, "one-comm")
+    for k in ("cfg2", "ibl_load", "coherent_scene", "tile_curve"):      # single-GPU objects
+        assert k not in d
 
 
 def test_cfg5_strong_scaling_flow_matches_the_untiled_frame():
-    d = _run(3, ["--config", "cfg5"])
+    d = _run(3, ["--config", "cfg5", "--no-extras"])
     assert d["n_gpus"] == 3 and d["scaling"] == "strong" and d["config"]["frame_height"] == 4320 and d["config"]["tile_rows"] == 1440
     assert d["config"]["lights"] == 256 and d["verify"]["mismatching_bytes"] == 0, d["verify"]
+
+
+def test_overlap_watchdog_falls_back_to_one_stream_order():
+    """--composite-overlap auto: when the first overlapped steps do not complete in time (forced here), every rank aborts its communicator,
+    builds a new one and runs the composite in stream order; the frame is still the untiled one."""
+    d = _run(2, ["--config", "cfg3", "--no-extras"], VQ_BENCH_FAKE_OVERLAP_TIMEOUT="1")
+    assert d["verify"]["mismatching_bytes"] == 0, d["verify"]
+    assert d["config"]["composite_overlap"] is False and d["rccl"]["composite_overlap_mode"] == "off" and d["rccl"]["fallback"], d["rccl"]
 
 
 def test_single_gpu_line_carries_the_contract_fields():
@@ -55,7 +88,8 @@ def test_single_gpu_line_carries_the_contract_fields():
     assert len(lines) == 1, "bench.py must print exactly one line on stdout"
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline", "stages", "engine_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants"):
+              "roofline", "cpu_baseline", "stages", "engine_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants", "rccl",
+              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "Mpix/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
@@ -70,3 +104,17 @@ def test_single_gpu_line_carries_the_contract_fields():
     iso = d["stages"]["isolated"]
     assert 0 < iso["blur_x_ms"] < 0.2 and 0 < iso["blur_y_tonemap_ms"] < 0.2
     assert d["stages"]["shade_ms"] < d["ms_per_step"]
+    # the other BASELINE configs ride in the same line
+    c5 = d["cfg5_strong"]
+    assert c5["frame"] == [7680, 4320] and c5["tile_rows"] == 4320 and c5["lights"] == 256 and 0 < c5["shade_ms"] < c5["ms_per_step"] and c5["halo_ms"] == 0
+    c2 = d["cfg2"]
+    assert 0 < c2["shade_ms"] < 1.0 and 0 < c2["hbm_frac"] < 1 and 0 < c2["valu_frac_model"] < 1
+    ib = d["ibl_load"]
+    for k in ("mip_chain_ms", "prefilter_ms", "brdf_lut_ms", "conv_diffuse_ms", "conv_specular_ms", "brdf_lut_warm_ms", "total_ms", "conv_diffuse_valu_frac_model"):
+        assert ib[k] > 0, k
+    co = d["coherent_scene"]
+    assert 0 < co["shade_ms"] < 5 and 0.05 < co["slow_path_pixel_fraction_round2"] < 0.3
+    tc = d["tile_curve"]["tiles"]
+    assert [t["tile_rows"] for t in tc] == [4320, 2160, 1080, 540] and all(t["step_ms"] > 0 for t in tc)
+    assert tc[3]["compute_speedup"] > 4 and tc[3]["modelled_speedup_serial_half_link"] <= tc[3]["modelled_speedup_overlapped_peak_link"] <= tc[3]["compute_speedup"]
+    assert d["rccl"]["nranks_seen"] == 1

@@ -1,0 +1,171 @@
+"""GPU parity of the round-3 kernel forms, each bit-exact against the CPU oracle through the C ABI:
+  * shade: the wave-uniform forms of the point-light loop (GGX EPSILON early-out as a select for roughness < 0.04, the skip of lights
+    behind the surface of a whole wave) on the surface-coherent frame, on polished-metal fuzz, on adversarial inputs and on -0 accumulators;
+  * post: every form of the fused Y blur + tonemap kernel (compact 8 KB tonemap table, 16-byte stores) and of the table tonemapper."""
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle_lib as O
+from tests.test_gpu_parity import _envs, assert_bits, dev, env_small  # noqa: F401  (env_small is a fixture)
+from vqengine_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+Y_FORMS = ["lut64", "c8", "c8s", "c8sw5", "c12s", "c16", "c16s"]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# shade
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+def test_forward_coherent_frame(ctx, env_small, fmt):
+    """The surface-coherent frame (height-field normals, material regions, 12 % polished regions with roughness 0..0.03): whole waves take
+    the skip form and the EPSILON-select form of the light loop. 64 lights + IBL, 2 spots, directional; ragged width."""
+    W, H = 1100, 136
+    gb = synth.gbuffer(W, H, seed=0x6400, coherent=True)
+    assert (gb[1][..., 3] < 0.04).mean() > 0.03 and (gb[1][..., 3] == 0.0).any()
+    pf, _ = synth.per_frame(points=synth.point_lights(64, seed=0x6400), spots=synth.spot_lights(2), directional=synth.directional_light(), hdri_offset=0.3)
+    env_o, env_g = _envs(env_small)
+    pv = synth.per_view(W, H, max_env_lod=env_small["pre_o"]["spec_mips"])
+    ref = O.forward_lighting(gb, pf, pv, fmt, env=env_o)
+    got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=fmt, env=env_g)
+    assert_bits(got, ref, f"coherent frame fmt={fmt}")
+    # the other Fresnel lowering never takes the skip form (exp2(5 log2 x) is NaN for x < 0): still bit-exact
+    ctx.set_fresnel_pow(True); O.load().vqo_set_fresnel_pow(1)
+    try:
+        with np.errstate(all="ignore"):
+            ref = O.forward_lighting(gb, pf, pv, fmt, env=env_o)
+        assert_bits(ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=fmt, env=env_g), ref, "coherent frame, exp2/log2 Fresnel")
+    finally:
+        ctx.set_fresnel_pow(False); O.load().vqo_set_fresnel_pow(0)
+
+
+def test_forward_coherent_cfg3_and_cfg5_bands(ctx):
+    """Bands of the coherent variants of the BASELINE frames at full width: cfg3 (64 lights + the full-size cfg4 IBL) and cfg5 (256 lights)."""
+    from tests import ref_cases
+    g = ref_cases.cfg4_env()
+    keep = []
+    env_g, env_o = ref_cases.dev_env(g, keep), ref_cases.host_env(g)
+    W, H = 3840, 2160
+    pf, _ = synth.per_frame(points=synth.point_lights(64, seed=0x6400), hdri_offset=0.3)
+    pv = synth.per_view(W, H, max_env_lod=g["spec_mips"])
+    for r0 in (64, 1500):
+        gb = synth.gbuffer_rows_coherent(W, H, r0, r0 + 24, seed=0x6400)
+        got = ctx.forward_lighting([dev(x) for x in gb], pf, pv, out_fmt=abi.FMT_RGBA16F, env=env_g)
+        assert_bits(got, O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F, env=env_o), f"coherent cfg3 rows {r0}")
+    W5, H5 = 7680, 4320
+    pf5, extra = synth.per_frame(points=synth.point_lights(256, seed=0x2560))
+    pv5 = synth.per_view(W5, H5)
+    gb = synth.gbuffer_rows_coherent(W5, H5, 2000, 2008, seed=0x2560)
+    got = ctx.forward_lighting([dev(x) for x in gb], pf5, pv5, out_fmt=abi.FMT_RGBA16F, extra_point=extra)
+    assert_bits(got, O.forward_lighting(gb, pf5, pv5, abi.FMT_RGBA16F, extra_point=extra), "coherent cfg5 band")
+
+
+@pytest.mark.parametrize("base", ["noise", "coherent"])
+def test_forward_polished_metal_fuzz(ctx, env_small, base):
+    """roughness in [0, 0.04): the GGX EPSILON early-out range (BRDF.hlsl:76). Whole frames of it, single pixels of it inside rough waves,
+    roughness exactly 0 with the half vector on the normal (pi t^2 == 0), denormal roughness, and lights placed on the mirror direction."""
+    rng = np.random.default_rng(31)
+    W, H = 640, 24
+    gb = synth.gbuffer(W, H, seed=0xABCD, coherent=(base == "coherent"))
+    r = gb[1][..., 3]
+    r[:8] = rng.choice(np.array([0.0, 1e-30, 1e-3, 0.01, 0.02, 0.0399999, 0.039, 0.04], np.float32), r[:8].shape)   # whole waves polished
+    sel = rng.random(r[8:16].shape) < 0.02                                                                           # a few lanes per wave
+    r[8:16] = np.where(sel, rng.choice(np.array([0.0, 0.005, 0.03], np.float32), sel.shape), r[8:16])
+    gb[2][:8, :, 3] = 1.0
+    pts = synth.point_lights(24, seed=0xABCD)
+    cam = np.array([0.0, 10.0, -60.0], np.float32)
+    # lights exactly on the mirror direction of a few polished pixels: NdotH == 1, t == 1 - nh2 == 0
+    for k, (y, x) in enumerate(((1, 17), (2, 300), (5, 511), (9, 77))):
+        P, N = gb[0][y, x, :3], gb[1][y, x, :3] / np.linalg.norm(gb[1][y, x, :3])
+        V = (cam - P) / np.linalg.norm(cam - P)
+        Rm = 2.0 * np.dot(N, V) * N - V
+        pts[k].position.set((P + np.float32(7.0) * Rm).astype(np.float32)); pts[k].range = 500.0
+    pf, _ = synth.per_frame(points=pts, hdri_offset=0.3)
+    env_o, env_g = _envs(env_small)
+    pv = synth.per_view(W, H, max_env_lod=env_small["pre_o"]["spec_mips"])
+    for env_pair in ((None, None), (env_o, env_g)):
+        ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F, env=env_pair[0])
+        got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F, env=env_pair[1])
+        assert_bits(got, ref, f"polished fuzz base={base}")
+    assert np.isfinite(ref[..., :3]).all()
+
+
+def test_forward_skip_keeps_signed_zero_and_nonfinite(ctx):
+    """The back-facing-light skip must be invisible: accumulators that hold -0 / +0 (no ambient, no emissive, albedo -0), non-finite albedo,
+    infinite light colours and NaN normals inside otherwise coherent waves, all lights below the surface."""
+    W, H = 512, 8
+    gb = synth.gbuffer(W, H, seed=0x5EED, coherent=True)
+    gb[0][..., 3] = 0.0                                       # ao = 0: I starts at albedo*0 + emissive*intensity
+    gb[3][...] = 0.0
+    gb[2][0, :, :3] = -0.0                                    # -0*0 + 0*0 = +0 ; with emissive -0: -0 + -0 = -0
+    gb[3][1, :, :3] = -0.0; gb[3][1, :, 3] = 1.0; gb[2][1, :, :3] = -0.0
+    gb[2][2, ::5, 0] = np.inf; gb[2][2, 1::5, 1] = np.nan     # non-finite BRDF in some lanes
+    gb[1][3, ::9, :3] = np.nan
+    gb[1][4, ::64, :3] *= -1.0                                # one lane per wave faces the other way
+    pts = synth.point_lights(12, seed=0x5EED)
+    for i in range(12):                                       # every light well below the terrain
+        p = pts[i].position
+        pts[i].position.set((p.x, -40.0 - i, p.z)); pts[i].range = 500.0
+    for variant in range(3):
+        if variant == 1:
+            pts[3].color.set((float("inf"), 1.0, 1.0))         # pointSkipOK = 0
+        if variant == 2:
+            pts[3].color.set((1.0, 1.0, 1.0)); pts[5].position.set((0.0, 40.0, 0.0))   # one light above: mixed skipping
+        pf, _ = synth.per_frame(points=pts, ambient=0.0)
+        pv = synth.per_view(W, H)
+        with np.errstate(all="ignore"):
+            ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F)
+        got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F)
+        assert_bits(got, ref, f"signed zero / non-finite, variant {variant}")
+    assert (ref[..., :3] == 0).any()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# post
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("form", Y_FORMS)
+@pytest.mark.parametrize("shape", [(300, 256), (1080, 1920), (97, 701), (70, 1000), (513, 130)])
+def test_blur_y_tonemap_forms(ctx, form, shape, monkeypatch):
+    """Every form of the fused Y blur + tonemap kernel (VQHIP_BLUR_Y_FORM) == oracle: whole images, odd widths (no 16-byte stores), heights
+    that are no multiple of the tile, and a row tile with halos."""
+    monkeypatch.setenv("VQHIP_BLUR_Y_FORM", form)
+    h, w = shape
+    F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
+    img = synth.hdr_image(w, h, scale=30.0)
+    img[::7, ::5, :3] = 0.0
+    img[3::11, 2::13, 0] = 7e4                                # overflows to inf in fp16
+    x = O.blur_pass(img.astype(np.float16), F16, 0)
+    xg = dev(x)
+    for p in (abi.TonemapperParams.default(), abi.TonemapperParams(abi.COLOR_SPACE_REC_2020, abi.DISPLAY_CURVE_ST2084, 300.0, 1),
+              abi.TonemapperParams(0, abi.DISPLAY_CURVE_SRGB, 200.0, 0)):
+        with np.errstate(all="ignore"):
+            ref = O.tonemap(O.blur_pass(x, F16, 1), F16, R8, p)
+        assert_bits(ctx.gaussian_blur_y_tonemap(xg, F16, R8, params=p), ref, f"form {form} {shape}")
+    if h > 600:
+        t0, t1 = h // 3, h // 3 + 257
+        got = ctx.gaussian_blur_y_tonemap(xg[t0:t1].contiguous(), F16, R8, halo_top=xg[t0 - 10:t0].contiguous(), halo_bottom=xg[t1:t1 + 10].contiguous())
+        with np.errstate(all="ignore"):
+            ref = O.tonemap(O.blur_pass(x, F16, 1), F16, R8)
+        assert_bits(got, ref[t0:t1], f"form {form} tile with halos")
+
+
+@pytest.mark.parametrize("form", ["compact", "lut64"])
+def test_tonemap_compact_table(ctx, form, monkeypatch):
+    """The compact (2 048-entry) tonemap table == the oracle for EVERY half bit pattern, every per-channel curve, through the standalone
+    tonemapper (k_tonemap_c) and through the fused Y kernel (constant columns: the blur of a constant is the constant wherever the 21 mads
+    reproduce it)."""
+    monkeypatch.setenv("VQHIP_TONEMAP_FORM", form)
+    allh = np.arange(65536, dtype=np.uint16).view(np.float16)
+    rng = np.random.default_rng(9)
+    img = np.empty((259, 257, 4), np.float16)                 # 66 563 px: no multiple of 4
+    for c in range(4):
+        img[..., c] = np.concatenate([rng.permutation(allh), rng.choice(allh, img.shape[0] * img.shape[1] - 65536)]).reshape(img.shape[:2])
+    g = dev(img)
+    for p in (abi.TonemapperParams(0, abi.DISPLAY_CURVE_SRGB, 200.0, 1), abi.TonemapperParams(1, abi.DISPLAY_CURVE_SRGB, 200.0, 0),
+              abi.TonemapperParams(1, abi.DISPLAY_CURVE_ST2084, 450.0, 1), abi.TonemapperParams(1, abi.DISPLAY_CURVE_ST2084, 10000.0, 1),
+              abi.TonemapperParams(0, abi.DISPLAY_CURVE_LINEAR, 200.0, 1)):
+        with np.errstate(all="ignore"):
+            ref = O.tonemap(img, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, p)
+        assert_bits(ctx.tonemap(g, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, params=p), ref, f"{form} curve={p.OutputDisplayCurveEnum} cs={p.ContentColorSpaceEnum}")

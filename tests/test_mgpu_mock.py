@@ -38,12 +38,14 @@ def _worker(rank, world, H, root, pitch_pad, conn, q):
             uid = conn.recv()
         fr = tiling.RowTiledFrame(uid, W, H, world, rank)
         tl = fr.tiling
+        info = fr.comm.query()                               # read back from the communicator, not from the arguments
+        assert (info["nranks_seen"], info["rank_seen"], info["version"]) == (world, rank, 0) and info["library_path"].endswith("libmock_rccl.so"), info
         gb = synth.gbuffer_rows(W, H, tl.row0, tl.row1, seed=0xD157)
         pf, _ = synth.per_frame(points=synth.point_lights(12, seed=0xD157))
         scene = O.forward_lighting(gb, pf, synth.per_view(W, H), abi.FMT_RGBA16F)
         x = O.blur_pass(scene, abi.FMT_RGBA16F, 0)
         top, bottom = np.full((10, W, 4), 7, np.float16), np.full((10, W, 4), 7, np.float16)
-        if pitch_pad:                                        # a tile whose rows are pitch_pad pixels apart: one message per row
+        if pitch_pad:                                        # a tile whose rows are pitch_pad pixels apart: packed into ONE dense message per neighbour
             xp = np.zeros((tl.tile_rows, W + pitch_pad, 4), np.float16)
             xp[:, :W] = x
             rc = fr.comm.lib.vqhip_exchange_blur_halos(fr.comm._h, None, xp.ctypes.data, W, tl.tile_rows, W + pitch_pad, abi.FMT_RGBA16F,
@@ -103,3 +105,36 @@ def test_rowtile_partition_and_errors():
         capi.rowtile(79, 8, 0)                               # 9-row tiles: shorter than the halo
     with pytest.raises(capi.VQHipError):
         capi.rowtile(100, 4, 4)
+
+
+def _mismatched(rank, conn):
+    """ten 1-row sends against one 10-row receive: what a per-row send of a pitched tile would do to a neighbour with a dense halo buffer"""
+    import ctypes as C
+    os.environ["VQHIP_RCCL_LIBRARY"] = MOCK
+    from vqengine_amd import capi
+    uid = capi.comm_unique_id() if rank == 0 else conn.recv()
+    if rank == 0:
+        conn.send(uid)
+    comm = capi.Comm(uid, 2, rank)
+    mock = C.CDLL(MOCK)
+    buf = np.zeros(10 * 64, np.uint8)
+    mock.ncclSend.argtypes = mock.ncclRecv.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    h = C.cast(comm._h, C.POINTER(C.c_void_p))[0]            # vqhip_comm::comm is the first member
+    if rank == 0:
+        for y in range(10):
+            mock.ncclSend(buf.ctypes.data + 64 * y, 64, 1, 1, h, None)
+    else:
+        mock.ncclRecv(buf.ctypes.data, 640, 1, 0, h, None)
+
+
+def test_mock_rccl_refuses_mismatched_message_sizes():
+    """The stand-in enforces RCCL's matching rule (equal counts, one send per receive): the receiver of a mismatched message aborts."""
+    ctx = mp.get_context("spawn")
+    a, b = ctx.Pipe()
+    procs = [ctx.Process(target=_mismatched, args=(0, a)), ctx.Process(target=_mismatched, args=(1, b))]
+    for p in procs:
+        p.start()
+    procs[1].join(60)
+    assert procs[1].exitcode not in (0, None), "the mismatched receive must abort"
+    procs[0].kill()
+    procs[0].join(10)

@@ -112,6 +112,11 @@ class GBuffer(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32), ("row_pitch_px", C.c_int32)]
 
 
+class CommInfo(C.Structure):    # vqhip_comm_info
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("nranks_seen", C.c_int32), ("rank_seen", C.c_int32),
+                ("rccl_version", C.c_int32), ("reserved", C.c_int32), ("library_path", C.c_char * 232)]
+
+
 class EnvMapOut(C.Structure):
     _fields_ = [("diffuse_unblurred", C.c_void_p), ("diffuse_blurred", C.c_void_p), ("blur_tmp", C.c_void_p),
                 ("specular", C.c_void_p)]

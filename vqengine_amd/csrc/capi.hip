@@ -262,15 +262,17 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
     // pack the non-shadowing point lights for the hot loop: cbuffer array first, then the extension array, in index order
     DevPointLight* pts = (DevPointLight*)(fc + 1);
     const int nPts = L.numPointLights + numExtraPoint;
-    int32_t pointFastOK = 1;
+    int32_t pointFastOK = 1, pointSkipOK = 1;
     for (int i = 0; i < nPts; ++i) {
         const VQ_PointLight& l = i < L.numPointLights ? L.point_lights[i] : extraPoint[i - L.numPointLights];
         pts[i].px = l.position.x; pts[i].py = l.position.y; pts[i].pz = l.position.z; pts[i].range = l.range;
         pts[i].cbx = l.color.x * l.brightness; pts[i].cby = l.color.y * l.brightness; pts[i].cbz = l.color.z * l.brightness;   // l.color * l.brightness (Lighting.hlsl:317)
         pts[i].rangeSq = rangeCullThreshold(l.range);
         if (pts[i].rangeSq > 0x1p60f) pointFastOK = 0;                           // false for a NaN threshold (never lit)
+        if (!(std::isfinite(pts[i].cbx) && std::isfinite(pts[i].cby) && std::isfinite(pts[i].cbz))) pointSkipOK = 0;
     }
     fc->pointFastOK = pointFastOK;
+    fc->pointSkipOK = pointSkipOK;
     fc->numPointAll = nPts;
     rc = commitSlot(ctx, slot, sizeof(FrameConstants) + (size_t)nPts * sizeof(DevPointLight), st);
     if (rc) return rc;

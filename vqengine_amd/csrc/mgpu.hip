@@ -30,11 +30,15 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int*) = nullptr;               // optional queries (vqhip_comm_query)
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     std::string error;
 };
 
@@ -62,6 +66,10 @@ Rccl& rccl() {
         r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
         r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.CommAbort = (decltype(r.CommAbort))dlsym(r.lib, "ncclCommAbort");
+        r.GetVersion = (decltype(r.GetVersion))dlsym(r.lib, "ncclGetVersion");
+        r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+        r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
         r.hostBuffers = dlsym(r.lib, "vqmock_rccl_host_buffers") != nullptr && ((int (*)())dlsym(r.lib, "vqmock_rccl_host_buffers"))() != 0;
         if (!ok) { dlclose(r.lib); r.lib = nullptr; }
     });
@@ -86,19 +94,34 @@ struct vqhip_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
     bool owned = false;
+    // dense staging block for the boundary rows of a PITCHED tile (2 x 10 rows): the message structure must not depend on the local pitch —
+    // RCCL matches sends and receives one to one, in posting order, with equal counts, and the neighbour always posts ONE receive per halo
+    char* stage = nullptr; size_t stageBytes = 0;
+    hipEvent_t stageFree = nullptr; bool stageUsed = false;  // recorded after the sends that read the block: the next pack waits for it
 };
 
 namespace {
 
-// rows [r0, r0+n) of an image whose rows are `pitchB` bytes apart and `rowB` bytes long: one message when dense, one per row otherwise
-int sendRows(Rccl& r, vqhip_comm* c, hipStream_t st, const char* base, int r0, int n, size_t rowB, size_t pitchB, int peer) {
-    if (rowB == pitchB) { RCCL_TRY(r.Send(base + (size_t)r0 * pitchB, (size_t)n * rowB, ncclUint8, peer, c->comm, st)); return VQHIP_OK; }
-    for (int y = 0; y < n; ++y) RCCL_TRY(r.Send(base + (size_t)(r0 + y) * pitchB, rowB, ncclUint8, peer, c->comm, st));
-    return VQHIP_OK;
+// a dense [n][rowB] block at c->stage + offset holding rows [r0, r0+n) of a tile whose rows are pitchB bytes apart
+int packRows(Rccl& r, vqhip_comm* c, hipStream_t st, const char* base, int r0, int n, size_t rowB, size_t pitchB, size_t offset) {
+    if (r.hostBuffers) { for (int y = 0; y < n; ++y) std::memcpy(c->stage + offset + (size_t)y * rowB, base + (size_t)(r0 + y) * pitchB, rowB); return VQHIP_OK; }
+    const hipError_t e = hipMemcpy2DAsync(c->stage + offset, rowB, base + (size_t)r0 * pitchB, pitchB, rowB, (size_t)n, hipMemcpyDeviceToDevice, st);
+    return e == hipSuccess ? VQHIP_OK : vqk::fail_global(VQHIP_ERR_HIP, std::string("vqhip_exchange_blur_halos: hipMemcpy2DAsync: ") + hipGetErrorString(e));
 }
-int recvRows(Rccl& r, vqhip_comm* c, hipStream_t st, char* base, int r0, int n, size_t rowB, size_t pitchB, int peer) {
-    if (rowB == pitchB) { RCCL_TRY(r.Recv(base + (size_t)r0 * pitchB, (size_t)n * rowB, ncclUint8, peer, c->comm, st)); return VQHIP_OK; }
-    for (int y = 0; y < n; ++y) RCCL_TRY(r.Recv(base + (size_t)(r0 + y) * pitchB, rowB, ncclUint8, peer, c->comm, st));
+int ensureStage(Rccl& r, vqhip_comm* c, hipStream_t st, size_t bytes) {
+    if (c->stageUsed && !r.hostBuffers) {                   // the previous exchange's sends may still be reading the block (possibly on another stream)
+        const hipError_t e = hipStreamWaitEvent(st, c->stageFree, 0);
+        if (e != hipSuccess) return vqk::fail_global(VQHIP_ERR_HIP, std::string("vqhip_exchange_blur_halos: hipStreamWaitEvent: ") + hipGetErrorString(e));
+    }
+    if (c->stageBytes >= bytes) return VQHIP_OK;
+    if (r.hostBuffers) { std::free(c->stage); c->stage = (char*)std::malloc(bytes); if (!c->stage) return vqk::fail_global(VQHIP_ERR_HIP, "staging allocation failed"); }
+    else {
+        if (c->stage) { (void)hipEventSynchronize(c->stageFree); (void)hipFree(c->stage); c->stage = nullptr; }
+        hipError_t e = hipMalloc((void**)&c->stage, bytes);
+        if (e == hipSuccess && !c->stageFree) e = hipEventCreateWithFlags(&c->stageFree, hipEventDisableTiming);
+        if (e != hipSuccess) return vqk::fail_global(VQHIP_ERR_HIP, std::string("vqhip_exchange_blur_halos: staging allocation: ") + hipGetErrorString(e));
+    }
+    c->stageBytes = bytes;
     return VQHIP_OK;
 }
 
@@ -155,7 +178,18 @@ int vqhip_comm_adopt(void* nccl_comm, int world, int rank, vqhip_comm** out) {
 void vqhip_comm_destroy(vqhip_comm* c) {
     if (!c) return;
     if (c->owned && c->comm && rccl().CommDestroy) rccl().CommDestroy(c->comm);
+    if (c->stage) { if (rccl().hostBuffers) std::free(c->stage); else { if (c->stageFree) (void)hipEventSynchronize(c->stageFree); (void)hipFree(c->stage); } }
+    if (c->stageFree) (void)hipEventDestroy(c->stageFree);
     delete c;
+}
+
+int vqhip_comm_abort(vqhip_comm* c) {
+    if (!c) return vqk::fail_global(VQHIP_ERR_INVALID_ARG, "vqhip_comm_abort: comm is NULL");
+    Rccl& r = rccl();
+    ncclResult_t e = ncclSuccess;
+    if (c->owned && c->comm) { e = r.CommAbort ? r.CommAbort(c->comm) : (r.CommDestroy ? r.CommDestroy(c->comm) : ncclSuccess); c->comm = nullptr; }
+    vqhip_comm_destroy(c);                                  // the staging block and its event (c->comm is gone: no second destroy)
+    return e == ncclSuccess ? VQHIP_OK : failRccl("ncclCommAbort", e);
 }
 
 int vqhip_exchange_blur_halos(vqhip_comm* c, void* stream, const void* xblur_tile, int width, int tile_rows, int row_pitch_px,
@@ -171,16 +205,33 @@ int vqhip_exchange_blur_halos(vqhip_comm* c, void* stream, const void* xblur_til
     hipStream_t st = (hipStream_t)stream;
     const size_t bpp = bytesPerPixel(fmt), rowB = (size_t)width * bpp, pitchB = (size_t)row_pitch_px * bpp;
     const char* src = (const char*)xblur_tile;
+    // my first 10 rows are the bottom halo of the tile above, my last 10 rows the top halo of the tile below; halo buffers are dense.
+    // One send and one receive of 10 dense rows per neighbour: a pitched tile's rows are packed first.
+    const size_t haloB = (size_t)VQHIP_HALO_ROWS * rowB;
+    const char* sendUp = src;
+    const char* sendDown = src + (size_t)(tile_rows - VQHIP_HALO_ROWS) * pitchB;
+    const bool pitched = rowB != pitchB;
+    if (pitched) {
+        int rc = ensureStage(r, c, st, 2 * haloB);
+        if (rc == VQHIP_OK && up)   rc = packRows(r, c, st, src, 0, VQHIP_HALO_ROWS, rowB, pitchB, 0);
+        if (rc == VQHIP_OK && down) rc = packRows(r, c, st, src, tile_rows - VQHIP_HALO_ROWS, VQHIP_HALO_ROWS, rowB, pitchB, haloB);
+        if (rc != VQHIP_OK) return rc;
+        sendUp = c->stage; sendDown = c->stage + haloB;
+    }
     RCCL_TRY(r.GroupStart());
-    int rc = VQHIP_OK;
-    // my first 10 rows are the bottom halo of the tile above, my last 10 rows the top halo of the tile below; halo buffers are dense
-    if (up)   { rc = sendRows(r, c, st, src, 0, VQHIP_HALO_ROWS, rowB, pitchB, c->rank - 1);
-                if (rc == VQHIP_OK) rc = recvRows(r, c, st, (char*)halo_top, 0, VQHIP_HALO_ROWS, rowB, rowB, c->rank - 1); }
-    if (down && rc == VQHIP_OK) { rc = sendRows(r, c, st, src, tile_rows - VQHIP_HALO_ROWS, VQHIP_HALO_ROWS, rowB, pitchB, c->rank + 1);
-                if (rc == VQHIP_OK) rc = recvRows(r, c, st, (char*)halo_bottom, 0, VQHIP_HALO_ROWS, rowB, rowB, c->rank + 1); }
-    const ncclResult_t e = r.GroupEnd();
-    if (rc != VQHIP_OK) return rc;
-    if (e != ncclSuccess) return failRccl("ncclGroupEnd", e);
+    ncclResult_t e = ncclSuccess;
+    if (up)                      { e = r.Send(sendUp, haloB, ncclUint8, c->rank - 1, c->comm, st);
+                                   if (e == ncclSuccess) e = r.Recv(halo_top, haloB, ncclUint8, c->rank - 1, c->comm, st); }
+    if (down && e == ncclSuccess) { e = r.Send(sendDown, haloB, ncclUint8, c->rank + 1, c->comm, st);
+                                   if (e == ncclSuccess) e = r.Recv(halo_bottom, haloB, ncclUint8, c->rank + 1, c->comm, st); }
+    const ncclResult_t eg = r.GroupEnd();
+    if (e != ncclSuccess) return failRccl("ncclSend / ncclRecv (blur halos)", e);
+    if (eg != ncclSuccess) return failRccl("ncclGroupEnd", eg);
+    if (pitched && !r.hostBuffers) {
+        const hipError_t he = hipEventRecord(c->stageFree, st);
+        if (he != hipSuccess) return vqk::fail_global(VQHIP_ERR_HIP, std::string("vqhip_exchange_blur_halos: hipEventRecord: ") + hipGetErrorString(he));
+        c->stageUsed = true;
+    }
     return VQHIP_OK;
 }
 
@@ -208,17 +259,32 @@ int vqhip_composite_tiles(vqhip_comm* c, void* stream, const void* tile, int wid
     }
     if (c->world == 1) return VQHIP_OK;
     RCCL_TRY(r.GroupStart());
-    int rc = VQHIP_OK;
-    for (int k = 0; k < c->world && rc == VQHIP_OK; ++k) {
+    ncclResult_t e = ncclSuccess;
+    for (int k = 0; k < c->world && e == ncclSuccess; ++k) {
         if (k == c->rank) continue;
-        if (root == VQHIP_ALL_RANKS || root == k)          // k receives my tile
-            rc = sendRows(r, c, st, (const char*)tile, 0, rows[c->rank], rowB, rowB, k);
-        if (rc == VQHIP_OK && receiver)                     // I receive k's tile straight into its place in the frame
-            rc = recvRows(r, c, st, (char*)frame, row0[k], rows[k], rowB, rowB, k);
+        if (root == VQHIP_ALL_RANKS || root == k)          // k receives my tile: one message
+            e = r.Send(tile, (size_t)rows[c->rank] * rowB, ncclUint8, k, c->comm, st);
+        if (e == ncclSuccess && receiver)                   // I receive k's tile straight into its place in the frame
+            e = r.Recv((char*)frame + (size_t)row0[k] * rowB, (size_t)rows[k] * rowB, ncclUint8, k, c->comm, st);
     }
-    const ncclResult_t e = r.GroupEnd();
-    if (rc != VQHIP_OK) return rc;
-    if (e != ncclSuccess) return failRccl("ncclGroupEnd", e);
+    const ncclResult_t eg = r.GroupEnd();
+    if (e != ncclSuccess) return failRccl("ncclSend / ncclRecv (composite)", e);
+    if (eg != ncclSuccess) return failRccl("ncclGroupEnd", eg);
+    return VQHIP_OK;
+}
+
+int vqhip_comm_query(const vqhip_comm* c, vqhip_comm_info* out) {
+    if (!c || !out) return vqk::fail_global(VQHIP_ERR_INVALID_ARG, "vqhip_comm_query: NULL argument");
+    Rccl& r = rccl();
+    std::memset(out, 0, sizeof(*out));
+    out->world = c->world; out->rank = c->rank;
+    out->nranks_seen = out->rank_seen = out->rccl_version = -1;
+    int v = 0;
+    if (r.GetVersion && r.GetVersion(&v) == ncclSuccess) out->rccl_version = v;
+    if (r.CommCount && c->comm && r.CommCount(c->comm, &v) == ncclSuccess) out->nranks_seen = v;
+    if (r.CommUserRank && c->comm && r.CommUserRank(c->comm, &v) == ncclSuccess) out->rank_seen = v;
+    Dl_info di;
+    if (r.Send && dladdr((void*)r.Send, &di) && di.dli_fname) std::snprintf(out->library_path, sizeof(out->library_path), "%s", di.dli_fname);
     return VQHIP_OK;
 }
 

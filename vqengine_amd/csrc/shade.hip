@@ -38,7 +38,8 @@ struct Pixel {
     bool p5ExpLog;                        // wave-uniform: Fresnel pow as exp2(5*log2 x) instead of the product (vqhip_set_fresnel_pow). Kept a RUN-TIME
                                           // flag on purpose: with the mode as a template parameter (no branch in the light loop) the same arithmetic ran
                                           // 9 % slower on the same box (profiles/r2c_shade_variants.md) — the scheduler's choice for the longer block
-    bool fastOK;                          // roughness in [0,1]: precondition of the unchecked fast reciprocals (add_point_light)
+    bool fastOK;                          // roughness in [0,1] and a finite Wo: precondition of the unchecked fast reciprocals (add_point_light)
+    bool skipOK;                          // finite F0 / kA and a normal close to the wave's first one: this lane may take part in the back-facing-light skip
 };
 
 VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
@@ -71,9 +72,13 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.a2 = a * a;
     px.a2m1 = px.a2 - 1.0f;
     px.a2G1V = px.a2 * px.G1V;
-    // preconditions of the unchecked fast path of add_point_light that depend on the pixel only: roughness in [0.04, 1] (below 0.04 the GGX
-    // EPSILON early-out may fire) and a finite Wo (with a finite Wi it makes Wo + Wi free of NaN, which the min3 test there cannot see)
-    px.fastOK = (px.roughness >= 0.04f) & (px.roughness <= 1.0f) & (dot_lit(px.Wo, px.Wo) <= 4.0f);      // the comparison is false for a NaN component
+    // preconditions of the unchecked fast path of add_point_light that depend on the pixel only: roughness in [0, 1] (below 0.04 the GGX
+    // EPSILON early-out may fire: such a wave takes the loop form that keeps the early-out as a select, RcpTrustEps) and a finite Wo (with a
+    // finite Wi it makes Wo + Wi free of NaN, which the min3 test there cannot see)
+    px.fastOK = (px.roughness >= 0.0f) & (px.roughness <= 1.0f) & (dot_lit(px.Wo, px.Wo) <= 4.0f);       // the comparison is false for a NaN component
+    // the skip of back-facing lights (add_point_light<.., true>) needs a finite BRDF whatever the light: finite F0 (hence 1 - F0) and kA
+    px.skipOK = ((__builtin_fabsf(px.F0.x) + __builtin_fabsf(px.F0.y) + __builtin_fabsf(px.F0.z)) +
+                 (__builtin_fabsf(px.kA.x) + __builtin_fabsf(px.kA.y) + __builtin_fabsf(px.kA.z))) < __builtin_inff();
 }
 
 // BRDF(s, Wi, V), BRDF.hlsl:163-194. As written: H = normalize(Wo + Wi) (IEEE quotients through rc.div), NdotH, nh2*(a2-1)+1.
@@ -143,9 +148,10 @@ VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op va
 // Hot-loop form: I = CalculatePointLightIllumination(..., acc = I). All reciprocals / square roots use the unchecked
 // fast sequences (RcpTrust); their validity is PROVEN from range tests instead of being checked per operation, and the tests are
 // folded into ONE comparison per pixel after the loop (vmin, below):
-//   pixel  : roughness in [0.04,1]  (px.fastOK)  =>  k in [1/8,1/2], 1-k in [1/2,7/8], a2 in [2.5e-6,1], hence
+//   pixel  : roughness in [0.04,1]  (px.fastOK + the wave-uniform `eps` test of k_forward_lighting)  =>  k in [1/8,1/2], 1-k in [1/2,7/8],
+//              a2 in [2.5e-6,1], hence
 //              gL = fma(NL,1-k,k)+1e-4 in [0.125, 1.4]   (NL = max(0,.) <= 1+eps, NaN -> 0)
-//              pi t^2 in [1.9e-11, pi] (t = fma(nh2, a2-1, 1) in [a2 - 2^-25, 1], nh2 saturated)
+//              pi t^2 in [1.9e-11, pi] (t = nh2*(a2-1) + 1, product and sum each rounded — contract v5 — in [a2 - 2^-24, 1], nh2 saturated)
 //              denom = max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
 //              => the merged reciprocal's operand (pi t^2 * gL) * denom in [2.4e-16, 17.6]: operand and result normal
 //   light  : every component of Lw-P has magnitude >= 2^-40 and dd = |Lw-P|^2 < rangeSq <= 2^60 (the host checks the thresholds of the whole
@@ -155,36 +161,57 @@ VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op va
 //   => the corrected quotients d/D, Hs/|Hs| (fdiv_rcp: exhaustively equal to IEEE division when nothing underflows) are the IEEE
 //      quotients; a zero or tiny component (a light exactly above the pixel on one axis) sends the pixel to the IEEE loop
 // all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
-// degenerate geometry, roughness outside [0.04,1], a range beyond 2^30) redoes the pixel's point-light loop with IEEE operations
+// degenerate geometry, roughness outside [0,1], a range beyond 2^30) redoes the pixel's point-light loop with IEEE operations
 // (k_forward_lighting); where both are valid the two give identical bits, so the redo changes only what was invalid.
 struct RcpTrust {
-    // roughness >= 0.04 (px.fastOK) => a2 >= 2.5e-6, t = fma(nh2, a2-1, 1) >= a2 - 2^-25 >= 2.5e-6 for nh2 in [0,1]
-    // => pi t^2 >= 1.9e-11 > EPSILON (1e-12): the GGX early-out never fires on this path
+    // roughness >= 0.04 (every lane of the wave: `eps` in k_forward_lighting) => a2 >= 2.56e-6, t = RN(RN(nh2*(a2-1)) + 1) >= a2 - 2^-24 >= 2.5e-6
+    // for nh2 in [0,1] => pi t^2 >= 1.9e-11 > EPSILON (1e-12): the GGX early-out never fires on this path
     static constexpr bool kGgxDenomAboveEps = true;
     VQD float operator()(float b) const { return rcp_newton(b); }
     VQD float sqrt(float x) const { return sqrt_newton(x); }
     VQD float div(float a, float b, float r) const { return fdiv_rcp(a, b, r); }
 };
+// The same fast sequences for a wave that holds a pixel of roughness < 0.04 (polished metal, a2 down to 0): there pi t^2 can fall below EPSILON
+// and `if (denom < EPSILON) return 1` (BRDF.hlsl:76) must stay — as a select, like the IEEE form. The reciprocal's operand is then
+// gL * denom in [1.25e-5, 5.6] on the early-out branch and (pi t^2 * gL) * denom >= 1e-12 * 0.125 * 1e-4 otherwise: still normal, so the
+// validity proof above carries over with roughness in [0, 1] (k in [1/8, 1/2] as before). Where the early-out cannot fire the select form
+// and RcpTrust give identical bits, so which of the two a wave runs is a pure speed choice (+3 VALU per light).
+struct RcpTrustEps : RcpTrust { static constexpr bool kGgxDenomAboveEps = false; };
 // `vmin` collects the smallest |component| of Lw-P and Wo+Wi over the lights that passed the range cull (three v_min3 with |.| modifiers);
 // the caller compares it with 2^-40 ONCE after the loop and, when the test fails, redoes the pixel's whole point-light loop with IEEE
 // operations (k_forward_lighting) — the accumulator needs no copy per light and the loop carries no validity masks.
 // dd <= 2^60 follows from dd < rangeSq <= 2^60 (FrameConstants::pointFastOK, host); a NaN / inf dd fails the cull like the reference's D < range.
-VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I, float& vmin) {
+// SKIP (wave-uniform choice of the caller): a light that faces away from every lane that passed the cull — NdotL = saturate(dot(N, Wi)) = +0 —
+// adds b * (cb * +0) = +-0 to the accumulator when b and cb are finite, which changes nothing unless the accumulator holds a zero (the sign of
+// -0 + +0). `izmin` = min |component| of I is kept per lane; when no lane has NdotL > 0 or a zero in I the BRDF (~70 of the ~108 VALU of a
+// light) is skipped for the wave. Finite b: px.skipOK (finite F0, kA) and the proven ranges above; finite cb: FrameConstants::pointSkipOK;
+// the product form of the Fresnel power only (exp2(5 log2 x) is NaN for the x = -6e-8 that a dot product rounding above 1 yields).
+// On surface-coherent content about half the lights are behind the surface of a whole wave; white-noise normals never take this form.
+template <class RC, bool SKIP>
+VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I, float& vmin, float& izmin) {
     const f3 lpos = mk3(l.px, l.py, l.pz), cb = mk3(l.cbx, l.cby, l.cbz);
     const f3 d = sub(lpos, px.P);
     const float dd = dot_lit(d, d);                          // as written: D decides the range cull
     if (dd < l.rangeSq) {                                    // == (length(Lw - P) < l.range), exactly (host-made threshold): culled lights
-        RcpTrust rc;                                         // need no square root; wave-coherent (execz skip)
+        RC rc;                                               // need no square root; wave-coherent (execz skip)
         const float D = sqrt_newton(dd);
         const float rD = rc(D);
         const f3 Wi = mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P)
         const f3 Hs = add(px.Wo, Wi);
         vmin = min3abs_acc(min3abs_acc(min3abs_acc(vmin, d.x, d.y), d.z, Hs.x), Hs.y, Hs.z);
-        const float NdotL = saturate(dot(px.Nraw, Wi));
+        const float dNL = dot(px.Nraw, Wi);
+        if (SKIP) { if (__builtin_amdgcn_ballot_w64((dNL > 0.0f) | !(izmin > 0.0f)) == 0) return; }
+        const float NdotL = saturate(dNL);
         const float w = (rD * rD) * NdotL;
         const f3 b = brdf_t(px, Wi, rc);
         I = lit(I, b, cb, w);
+        if (SKIP) izmin = min3abs(I);
     }
+}
+template <class RC, bool SKIP>
+VQD void point_light_loop(const Pixel& px, const vqk::DevPointLight* pts, int nP, f3& I, float& vmin) {
+    float izmin = SKIP ? min3abs(I) : 0.0f;
+    for (int p = 0; p < nP; ++p) add_point_light<RC, SKIP>(px, pts[p], I, vmin, izmin);
 }
 
 // SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333 (no range cull)
@@ -318,7 +345,7 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     const vqk::DevPointLight* pts = (const vqk::DevPointLight*)(fc + 1);
     const int nP = fc->numPointAll;
     // Fast loop: unchecked reciprocal / sqrt sequences whose validity is established once per pixel (vmin, see add_point_light). The rare
-    // pixel that fails (roughness outside [0.04, 1], a light exactly above the pixel on an axis, a range beyond 2^30, NaN inputs) is redone
+    // pixel that fails (roughness outside [0, 1], a light exactly above the pixel on an axis, a range beyond 2^30, NaN inputs) is redone
     // from the accumulator's value before the loop with IEEE operations; where both are valid the two paths agree bit for bit.
     // (A software-pipelined prefetch of the next 32-byte record was measured and is not used: 1.034 ms vs 1.022 ms, profiles/r2c_shade_variants.md.)
     const f3 I0 = I;
@@ -326,7 +353,18 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     float vmin = 0.0f;
     if (fast) {
         vmin = __builtin_inff();
-        for (int p = 0; p < nP; ++p) add_point_light(px, pts[p], I, vmin);
+        // wave-uniform choice among four forms of the same loop (identical bits wherever more than one applies):
+        //   eps  : some lane has roughness < 0.04 -> the GGX EPSILON early-out stays in, as a select (RcpTrustEps)
+        //   skip : every lane has a finite BRDF and a normal within 60 degrees of the first lane's (a surface, not noise) -> lights behind
+        //          the surface of the whole wave cost the cull, the normalize and one dot product instead of the BRDF
+        const bool eps = __builtin_amdgcn_ballot_w64(px.roughness < 0.04f) != 0;
+        const f3 n0 = mk3(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, px.Nraw.x))),
+                          __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, px.Nraw.y))),
+                          __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, px.Nraw.z))));
+        const bool laneSkipOK = px.skipOK & (dot(px.Nraw, n0) > 0.5f);
+        const bool skip = (fc->pointSkipOK != 0) & !px.p5ExpLog & (__builtin_amdgcn_ballot_w64(!laneSkipOK) == 0);
+        if (skip) { if (eps) point_light_loop<RcpTrustEps, true>(px, pts, nP, I, vmin); else point_light_loop<RcpTrust, true>(px, pts, nP, I, vmin); }
+        else      { if (eps) point_light_loop<RcpTrustEps, false>(px, pts, nP, I, vmin); else point_light_loop<RcpTrust, false>(px, pts, nP, I, vmin); }
     }
     if (__builtin_expect(!(vmin >= 0x1p-40f), 0)) {
         I = I0;

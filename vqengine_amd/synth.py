@@ -55,8 +55,67 @@ def gbuffer_rows(width, frame_height, row0, row1, seed=0xC0FFEE):
     return planes
 
 
-def gbuffer(width, height, seed=0xC0FFEE):
-    return gbuffer_rows(width, height, 0, height, seed)
+def gbuffer(width, height, seed=0xC0FFEE, coherent=False):
+    return (gbuffer_rows_coherent if coherent else gbuffer_rows)(width, height, 0, height, seed)
+
+
+def _hash01(a, b, c):
+    """Integer hash of (a, b, c) -> float32 in [0,1): material parameters of a region, independent of how the frame is cut into rows."""
+    h = (np.asarray(a, np.uint64) * np.uint64(0x9E3779B1) + np.asarray(b, np.uint64) * np.uint64(0x85EBCA77) + np.uint64(c) * np.uint64(0xC2B2AE3D)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15); h = (h * np.uint64(0x2C1B3C6D)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(12); h = (h * np.uint64(0x297A2D39)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(15)
+    return (h >> np.uint64(8)).astype(np.float32) / np.float32(1 << 24)
+
+
+def gbuffer_rows_coherent(width, frame_height, row0, row1, seed=0xC0FFEE):
+    """A SURFACE-COHERENT frame, next to the white-noise one of gbuffer_rows (which stays the BASELINE workload): what the engine's rasteriser
+    hands to PSMain on real content. Rolling terrain over [-50,50]^2 seen from above (P on a smooth height field, N = the field's analytic normal
+    with a fine normal-map ripple, NOT renormalised), materials in 96 x 64-pixel regions: per-region albedo / metalness / roughness with a
+    little per-pixel grain, 12 % of the regions POLISHED (roughness 0, 0.01, 0.02 or 0.03: the GGX EPSILON early-out range, shade.hip), 3 % emissive.
+    Any row range can be produced on its own (row-tiled ranks agree with the untiled frame)."""
+    planes = [np.empty((row1 - row0, width, 4), np.float32) for _ in range(4)]
+    c0, c1 = row0 // ROW_CHUNK, (row1 + ROW_CHUNK - 1) // ROW_CHUNK
+    cols = np.arange(width, dtype=np.float32)
+    X = (-50.0 + 100.0 * (cols + 0.5) / width)[None, :].astype(np.float32)
+    for ch in range(c0, c1):
+        r = _chunk_rng(seed ^ 0x5EED, ch)
+        n = ROW_CHUNK
+        rows = np.arange(ch * ROW_CHUNK, ch * ROW_CHUNK + n)
+        u = r.random((n, width, 6), dtype=np.float32)
+        Z = (-50.0 + 100.0 * (rows.astype(np.float32) + 0.5) / frame_height)[:, None].astype(np.float32)
+        g = [np.empty((n, width, 4), np.float32) for _ in range(4)]
+        # height field and its gradient
+        hgt = 3.0 * np.sin(0.11 * X) * np.cos(0.07 * Z) + 1.2 * np.sin(0.31 * X + 0.23 * Z) + 0.4 * np.cos(0.9 * Z)
+        dhx = 3.0 * 0.11 * np.cos(0.11 * X) * np.cos(0.07 * Z) + 1.2 * 0.31 * np.cos(0.31 * X + 0.23 * Z)
+        dhz = -3.0 * 0.07 * np.sin(0.11 * X) * np.sin(0.07 * Z) + 1.2 * 0.23 * np.cos(0.31 * X + 0.23 * Z) - 0.4 * 0.9 * np.sin(0.9 * Z)
+        # fine ripple (a tiling normal map) on top of the geometric normal
+        dhx = dhx + 0.15 * np.sin(5.3 * X) * np.cos(4.1 * Z)
+        dhz = dhz + 0.15 * np.cos(4.7 * X) * np.sin(5.9 * Z)
+        inv = (1.0 / np.sqrt(dhx * dhx + dhz * dhz + 1.0)).astype(np.float32)
+        g[0][..., 0] = np.broadcast_to(X, (n, width)); g[0][..., 1] = hgt; g[0][..., 2] = np.broadcast_to(Z, (n, width))
+        g[0][..., 3] = 0.055 * (0.55 + 0.45 * np.cos(0.5 * X) * np.sin(0.4 * Z) ** 2)
+        g[1][..., 0] = -dhx * inv; g[1][..., 1] = inv; g[1][..., 2] = -dhz * inv
+        # material regions
+        bx = (np.arange(width) // 96)[None, :] + np.zeros((n, 1), np.int64)
+        by = (rows // 64)[:, None] + np.zeros((1, width), np.int64)
+        hk = lambda c: _hash01(bx, by, c + (int(seed) & 0xFFFF) * 16)      # noqa: E731
+        kind = hk(0)
+        rough = np.where(kind < 0.12, np.floor(hk(1) * 4.0) * 0.01, 0.05 + 0.95 * hk(1)).astype(np.float32)
+        rough = np.where(kind < 0.12, rough, np.clip(rough + 0.02 * (u[..., 0] - 0.5), 0.05, 1.0)).astype(np.float32)
+        g[1][..., 3] = rough
+        metal = np.where(kind < 0.12, 1.0, np.where(hk(2) < 0.5, 0.0, np.where(hk(2) < 0.7, 1.0, hk(3)))).astype(np.float32)
+        for c in range(3):
+            g[2][..., c] = np.clip(0.1 + 0.85 * hk(4 + c) + 0.06 * (u[..., 1 + c] - 0.5), 0.0, 1.0)
+        g[2][..., 3] = metal
+        em = hk(7) > 0.97
+        for c in range(3):
+            g[3][..., c] = np.where(em, hk(8 + c), 0.0)
+        g[3][..., 3] = np.where(em, 1.0 + 4.0 * hk(11), 0.0)
+        lo, hi = max(row0, ch * ROW_CHUNK), min(row1, (ch + 1) * ROW_CHUNK)
+        for k in range(4):
+            planes[k][lo - row0:hi - row0] = g[k][lo - ch * ROW_CHUNK:hi - ch * ROW_CHUNK].astype(np.float32)
+    return planes
 
 
 def point_lights(n, seed=0x1600):
