@@ -16,6 +16,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#ifdef VQ_SHIM_DXC
+#include "../vqo_math.h"      // the contract's exp2_ / log2_ for the DXC reading of pow
+#endif
 
 namespace hlsl {
 
@@ -269,7 +272,11 @@ inline float trunc(float x) { return truncf(x); }
 inline float clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 inline float abs(float x) { return fabsf(x); }
 inline float sqrt(float x) { return sqrtf(x); }
+#ifdef VQ_SHIM_DXC
+inline float rsqrt(float x) { return (float)(1.0 / std::sqrt((double)x)); }   // DXIL Rsqrt, correctly rounded (one rounding, not 1/RN(sqrt))
+#else
 inline float rsqrt(float x) { return 1.0f / sqrtf(x); }
+#endif
 inline float rcp(float x) { return 1.0f / x; }
 inline float sin(float x) { return sinf(x); }
 inline float cos(float x) { return cosf(x); }
@@ -283,7 +290,11 @@ inline float exp(float x) { return expf(x); }
 inline float log(float x) { return logf(x); }
 inline float floor(float x) { return floorf(x); }
 inline float frac(float x) { return x - floorf(x); }
+#ifdef VQ_SHIM_DXC
+inline float pow(float x, float y) { return vqo::exp2_(y * vqo::log2_(x)); }    // DXIL Exp(y * Log(x)) with the contract's exp2 / log2 (vqo_math.h) in place of libm's
+#else
 inline float pow(float x, float y) { return exp2f(y * log2f(x)); }          // DXC: pow -> exp2(y * log2(x))
+#endif
 inline float lerp(float a, float b, float t) { return a + t * (b - a); }
 inline float step(float e, float x) { return x >= e ? 1.0f : 0.0f; }
 inline float sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
@@ -298,6 +309,18 @@ inline int asint(uint u) { return (int)u; }
 uint f32tof16(float f);          // RNE, defined by the harness that needs it (vqo::f32_to_f16)
 float f16tof32(uint h);
 
+// The two READINGS of the intrinsics whose lowering the HLSL does not fix:
+//   literal (default): dot = products and sums rounded one by one, left to right; normalize(v) = v / length(v) (IEEE quotients)
+//   VQ_SHIM_DXC      : what DXC's HLOperationLower emits — DXIL Dot2/3/4 evaluated as an FMA chain fma(az,bz, fma(ay,by, ax*bx)) (how GPU
+//                      back ends expand the intrinsic), normalize(v) = v * rsqrt(dot(v,v)) (TranslateNormalize: Dot -> Rsqrt -> FMul) with a
+//                      correctly rounded rsqrt, pow = exp2(y * log2 x) with the contract's exp2 / log2; SURVEY.md §8c's list
+#ifdef VQ_SHIM_DXC
+#define VQ_SHIM_DOT_STEP(x, y, s) __builtin_fmaf((x), (y), (s))
+#define VQ_SHIM_NORMALIZE(a) ((a) * rsqrt(dot((a), (a))))
+#else
+#define VQ_SHIM_DOT_STEP(x, y, s) ((s) + (x) * (y))
+#define VQ_SHIM_NORMALIZE(a) ((a) / length(a))
+#endif
 #define VQ_HLSL_MAP1(V, N, FN) inline V FN(const V& a) { V r; for (int i = 0; i < N; ++i) r.d[i] = FN(a.d[i]); return r; }
 #define VQ_HLSL_MAP2(V, N, FN) inline V FN(const V& a, const V& b) { V r; for (int i = 0; i < N; ++i) r.d[i] = FN(a.d[i], b.d[i]); return r; }
 #define VQ_HLSL_VEC(V, N)                                                                                            \
@@ -312,9 +335,9 @@ float f16tof32(uint h);
     inline V clamp(const V& a, const V& lo, const V& hi) { V r; for (int i = 0; i < N; ++i) r.d[i] = clamp(a.d[i], lo.d[i], hi.d[i]); return r; } \
     inline V lerp(const V& a, const V& b, float t) { V r; for (int i = 0; i < N; ++i) r.d[i] = lerp(a.d[i], b.d[i], t); return r; } \
     inline V lerp(const V& a, const V& b, const V& t) { V r; for (int i = 0; i < N; ++i) r.d[i] = lerp(a.d[i], b.d[i], t.d[i]); return r; } \
-    inline float dot(const V& a, const V& b) { float s = a.d[0] * b.d[0]; for (int i = 1; i < N; ++i) s = s + a.d[i] * b.d[i]; return s; } \
+    inline float dot(const V& a, const V& b) { float s = a.d[0] * b.d[0]; for (int i = 1; i < N; ++i) s = VQ_SHIM_DOT_STEP(a.d[i], b.d[i], s); return s; } \
     inline float length(const V& a) { return sqrtf(dot(a, a)); }                                                           \
-    inline V normalize(const V& a) { return a / length(a); }                                                               \
+    inline V normalize(const V& a) { return VQ_SHIM_NORMALIZE(a); }                                                        \
     inline V reflect(const V& i, const V& n) { return i - 2.0f * dot(n, i) * n; }
 VQ_HLSL_VEC(float2, 2)
 VQ_HLSL_VEC(float3, 3)

@@ -17,7 +17,24 @@ def key16(x):
     return np.where(u & 0x8000, -(u & 0x7fff), u)
 
 
+def three_way():
+    """--reading dxc: product arithmetic (the oracle; the HIP kernels are bit-identical to it) vs the LITERAL reading of the reference's
+    HLSL vs its DXC reading (hlsl_shim.h VQ_SHIM_DXC) on the bands of the BASELINE frames, in RGBA16F ulps of the scene colour."""
+    lit = np.load(os.path.join(ROOT, "tests", "golden", "ref_outputs.npz"))
+    dxc = np.load(os.path.join(ROOT, "tests", "golden", "ref_outputs_dxc.npz"))
+    print("| band | pair | channels | max ulps | differing | > 1 ulp | > 4 ulps |\n|---|---|---|---|---|---|---|")
+    for tag, (build, _, oracle_scene) in ref_cases.DXC_SCENES.items():
+        o = oracle_scene(build())
+        for a, b, name in ((o, lit[tag + "/scene"], "product vs literal"), (o, dxc[tag + "/scene"], "product vs dxc"), (lit[tag + "/scene"], dxc[tag + "/scene"], "literal vs dxc")):
+            fin = np.isfinite(np.asarray(a, np.float32).astype(np.float16)) & np.isfinite(np.asarray(b, np.float32).astype(np.float16))
+            d = np.abs(key16(a) - key16(b))[fin]
+            print(f"| {tag} | {name} | {d.size} | {int(d.max())} | {np.mean(d > 0) * 100:.4f} % | {np.mean(d > 1) * 100:.4f} % | {np.mean(d > 4) * 100:.4f} % |")
+
+
 def main():
+    if "--reading" in sys.argv:
+        assert sys.argv[sys.argv.index("--reading") + 1] == "dxc"
+        return three_way()
     fx = np.load(os.path.join(ROOT, "tests", "golden", "ref_outputs.npz"))
     pat = sys.argv[1] if len(sys.argv) > 1 else ""
     for c in ref_cases.CASES:

@@ -31,6 +31,18 @@ def main():
     path = os.path.join(ROOT, "tests", "golden", "ref_outputs.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes")
+    # the SECOND reading of the reference's intrinsics (hlsl_shim.h VQ_SHIM_DXC) on the BASELINE-shape bands: scene colour, RGBA16F
+    assert ref_lib.available("shaders_dxc") and ref_lib.available("shaders_dxc_l256")
+    dxc = {}
+    for tag, (build, ref_dxc, _) in ref_cases.DXC_SCENES.items():
+        inp = build()
+        with np.errstate(over="ignore"):
+            dxc[tag + "/scene"] = np.asarray(ref_dxc(inp)).astype(np.float16)
+        dxc[tag + "/scene/inputs"] = np.frombuffer(ref_cases.checksum(inp).encode(), np.uint8)
+        print(f"dxc reading {tag:28s} {dxc[tag + '/scene'].shape}")
+    path = os.path.join(ROOT, "tests", "golden", "ref_outputs_dxc.npz")
+    np.savez_compressed(path, **dxc)
+    print(path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":

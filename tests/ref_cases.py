@@ -629,6 +629,9 @@ def dev_shadow_dims(s, keep):
     return abi.ShadowMaps(d.data_ptr(), s["dims"][0], sp.data_ptr(), s["dims"][1], p.data_ptr(), s["dims"][2])
 
 
+DXC_SCENES = {}
+
+
 def _band_cases(tag, width, frame_h, row0, rows, n_lights, seed, use_env, post, fractions, default_scene=False):
     """Adds `<tag>/scene` (RGBA16F scene colour) and, with post, `<tag>/blur` (RGBA16F after CSMain_X, CSMain_Y) and `<tag>/sdr` (RGBA8)."""
     def build():
@@ -646,9 +649,9 @@ def _band_cases(tag, width, frame_h, row0, rows, n_lights, seed, use_env, post, 
     def shadow_host(i):
         return host_shadow_dims(i["shadow"]) if i["shadow"] is not None else None
 
-    def ref_chain(i):
+    def ref_chain(i, reading="literal"):
         from tests import ref_lib as R
-        scene = R.forward_from_gbuffer(i["gb_raw"], i["pf"], i["pv"], env=host_env(i["env"]), shadow=shadow_host(i), extra=i["extra"])
+        scene = R.forward_from_gbuffer(i["gb_raw"], i["pf"], i["pv"], env=host_env(i["env"]), shadow=shadow_host(i), extra=i["extra"], reading=reading)
         assert (scene[..., 3] == i["gb"][1][..., 3]).all()          # o.color.a = Surface.roughness, ForwardLighting.hlsl:380
         out = {"scene": scene}
         if post:
@@ -682,6 +685,8 @@ def _band_cases(tag, width, frame_h, row0, rows, n_lights, seed, use_env, post, 
             out["sdr"] = sdr.cpu().numpy()
             assert (out["blur"][..., 3] == 1).all() and (out["sdr"][..., 3] == 255).all()
         return out
+    # the SECOND reading of the reference's intrinsics (oracle/ref_src/hlsl_shim.h VQ_SHIM_DXC) on the same band: scene colour only
+    DXC_SCENES[tag] = (build, lambda i: ref_chain(i, "dxc")["scene"][..., :3], lambda i: _memo((tag, "oracle"), lambda: oracle_chain(i))["scene"][..., :3])
     stages = [("scene", ("ulp16", 1, fractions[0]))]
     if post:                              # post == "sdr": the (large) blur intermediate is checked through the final RGBA8 image only
         stages += ([] if post == "sdr" else [("blur", ("ulp16", 1, fractions[1]))]) + [("sdr", ("u8", 1, fractions[2]))]

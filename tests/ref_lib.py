@@ -30,7 +30,7 @@ def load(name="shaders"):
             lib.vqref_fsr_rcas_con.argtypes = [vp, f32]
             lib.vqref_half_bits.argtypes = [f32]
             lib.vqref_half_bits.restype = u32
-        elif name == "shaders_l256":
+        elif name in ("shaders_l256", "shaders_dxc_l256"):
             lib.vqref_forward_from_gbuffer.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
         elif name == "shaders_am":
             lib.vqref_forward_psmain.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
@@ -74,15 +74,17 @@ def fsr_rcas_con(stops):
     return con
 
 
-def forward_from_gbuffer(gb, per_frame, per_view, env=None, shadow=None, extra=None):
+def forward_from_gbuffer(gb, per_frame, per_view, env=None, shadow=None, extra=None, reading="literal"):
     """PSMain per G-buffer pixel. `extra` (point lights beyond the cbuffer's 100, BASELINE cfg5) needs the build whose cap is raised
-    to 256 (libvqref_shaders_l256.so, oracle/Makefile)."""
+    to 256 (libvqref_shaders_l256.so, oracle/Makefile). reading: "literal" (the intrinsics as the HLSL is written: the reading the product
+    follows) or "dxc" (libvqref_shaders_dxc*.so: dot as an FMA chain, normalize = v * rsqrt(dot), contract pow — hlsl_shim.h VQ_SHIM_DXC)."""
     gb = [np.ascontiguousarray(g, np.float32) for g in gb]
     h, w = gb[0].shape[:2]
     out = np.empty((h, w, 4), np.float32)
     g = abi.GBuffer(gb[0].ctypes.data, gb[1].ctypes.data, gb[2].ctypes.data, gb[3].ctypes.data, w, h, w)
     n_extra = len(extra) if extra is not None else 0
-    lib = load("shaders_l256") if n_extra else load()
+    base = "shaders" if reading == "literal" else "shaders_dxc"
+    lib = load(base + "_l256") if n_extra else load(base)
     rc = lib.vqref_forward_from_gbuffer(C.byref(g), C.byref(per_frame), C.byref(per_view), extra if n_extra else None, n_extra,
                                         _ref(env), _ref(shadow), out.ctypes.data)
     assert rc == 0, rc
