@@ -46,7 +46,7 @@ def main():
             d = np.abs(got.astype(np.int32) - (ref if ref.dtype == np.uint8 else ref_cases.to_unorm8(ref)).astype(np.int32))
         else:
             d = np.abs(key16(got) - key16(ref))
-        print(f"{c.name:36s} n={d.size:7d} max={int(d.max()):4d} frac>0={np.mean(d > 0):.5f} frac>1={np.mean(d > 1):.5f}")
+        print(f"{c.name:36s} n={d.size:7d} max={int(d.max()):4d} frac>0={np.mean(d > 0):.5f} frac>1={np.mean(d > 1):.6f} count>1={int((d > 1).sum())}")
 
 
 if __name__ == "__main__":

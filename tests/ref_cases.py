@@ -77,6 +77,10 @@ def check(name, got, ref, tol):
         d = ulp16_distance(got, ref)
         assert d.max() <= tol[1] and np.mean(d != 0) <= tol[2], (name, int(d.max()), float(np.mean(d != 0)))
         return
+    if tol[0] == "ulp16tail":                   # ("ulp16tail", 1, max fraction differing, tail max ulps, max fraction above 1 ulp): <= 1 ulp but for a THIN, BOUNDED tail
+        d = ulp16_distance(got, ref)
+        assert d.max() <= tol[3] and np.mean(d != 0) <= tol[2] and np.mean(d > tol[1]) <= tol[4], (name, int(d.max()), float(np.mean(d != 0)), float(np.mean(d > tol[1])))
+        return
     if tol[0] == "u8":
         r8 = ref if ref.dtype == np.uint8 else to_unorm8(ref)
         d = np.abs(got.astype(np.int32) - r8.astype(np.int32))
@@ -708,5 +712,143 @@ _band_cases("cfg2_band_1920x32", 1920, 1080, 512, 32, 16, 0x1600, False, False, 
 _band_cases("cfg5_band_7680x16", 7680, 4320, 2152, 16, 256, 0x2560, False, False, (5e-4,))         # measured 1.1e-4
 # cfg1 substitute: 1280x720, the Default scene's lights (directional + 2 spot casters, PCF)
 _band_cases("cfg1_default_1280x16", 1280, 720, 352, 16, 0, 0xC0FFEE, False, True, (5e-4, 1e-3, 2e-4), default_scene=True)   # measured 5e-5, 1.6e-4, 2e-5
+
+# ---- PCF at the ENGINE'S shadow-map sizes: 2048^2 directional, 5 x 1024^2 spot, 5 x 6 x 1024^2 point (SceneRendering.cpp:439-441),
+# the maximum caster counts (5 / 5 / 1, LightingConstantBufferData.h:42-44): different wrap / addressing magnitudes than the 64 / 32 / 16 toy maps
+def shadow_scene_engine_sizes():
+    rng = np.random.default_rng(0x5AD0)
+    pf, _ = synth.per_frame(points=synth.point_lights(3), directional=synth.directional_light(shadowing=1))
+    L = pf.Lights
+    spots = synth.spot_lights(5, seed=77)
+    L.numSpotCasters = 5
+    for i in range(5):
+        L.spot_casters[i] = spots[i]
+    pc = synth.point_lights(5, seed=99)
+    L.numPointCasters = 5
+    for i in range(5):
+        pc[i].depthBias = 5e-5
+        pc[i].range = float(np.float32(120.0 + 30.0 * i))
+        L.point_casters[i] = pc[i]
+
+    def mat(scale, tz, shear):
+        m = abi.matrix()
+        m.m[0][0] = scale; m.m[2][1] = scale; m.m[2][0] = shear; m.m[1][2] = -0.02; m.m[3][2] = tz; m.m[3][3] = 1.0
+        return m
+    L.shadowViewDirectional = mat(1 / 60.0, 0.5, 0.001)
+    for i in range(5):
+        L.shadowViews[i] = mat(1 / (45.0 + 6.0 * i), 0.45 + 0.02 * i, 0.002 * i)
+
+    def depth(shape, lo, hi, fx, fy):       # structured occluders: smooth ridges + grain, a lit half (depth 1) with a wavy border
+        h, w = shape[-2:]
+        yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+        base = lo + (hi - lo) * (0.5 + 0.5 * np.sin(xx * fx) * np.cos(yy * fy))
+        out = np.empty(shape, np.float32)
+        for idx in np.ndindex(*shape[:-2]):
+            k = 1.0 + 0.13 * sum(idx)
+            out[idx] = base * np.float32(k % 1.0 * 0.2 + 0.9) + rng.random((h, w), dtype=np.float32) * 0.02
+            out[idx][xx > w * 0.5 + 0.1 * w * np.sin(yy * 0.01 * k)] = 1.0
+        return out
+    dmap = depth((2048, 2048), 0.4, 0.6, 0.011, 0.017)
+    smap = depth((5, 1024, 1024), 0.35, 0.65, 0.02, 0.013)
+    pmap = depth((5, 6, 1024, 1024), 0.05, 0.55, 0.015, 0.019)
+    pf.f2DirectionalLightShadowMapDimensions = abi.float2(2048.0, 2048.0)
+    pf.f2SpotLightShadowMapDimensions = abi.float2(1024.0, 1024.0)
+    pf.f2PointLightShadowMapDimensions = abi.float2(1024.0, 1024.0)
+    return pf, {"dir": dmap, "spot": smap, "point": pmap, "dims": (2048, 1024, 1024)}
+
+
+def _pcf_engine_case():
+    W, H = 192, 48
+
+    def build():
+        gb_raw, gb = unit_normal_gbuffer(W, H, 0x9CF)
+        pf, sh = shadow_scene_engine_sizes()
+        return {"gb": gb, "gb_raw": gb_raw, "pf": pf, "pv": synth.per_view(W, H), "shadow": sh}
+
+    def ref(i):
+        from tests import ref_lib as R
+        return R.forward_from_gbuffer(i["gb_raw"], i["pf"], i["pv"], shadow=host_shadow_dims(i["shadow"]))[..., :3]
+
+    def oracle(i):
+        return O.forward_lighting(i["gb"], i["pf"], i["pv"], F16, shadow=host_shadow_dims(i["shadow"]))[..., :3]
+
+    def product(ctx, i):
+        keep = []
+        return ctx.forward_lighting([_dev(g) for g in i["gb"]], i["pf"], i["pv"], out_fmt=F16, shadow=dev_shadow_dims(i["shadow"], keep)).cpu().numpy()[..., :3]
+    return Case("forward_casters_pcf_engine_sizes", build, ref, oracle, product, ("ulp16", 1, 0.002), store="f16")
+
+
+CASES.append(_pcf_engine_case())
+
+# ---- BASELINE cfg4 at FULL SIZE against the reference's own HLSL: the load-time passes on the bench's 2048^2 equirect ----
+_CFG4_IN = {}
+
+
+def _cfg4_inputs():
+    if not _CFG4_IN:
+        eq = synth.equirect(2048, 2048)
+        chain, n = O.mip_chain(eq)
+        _CFG4_IN.update(chain=chain, n=n)
+    return dict(_CFG4_IN)
+
+
+def _cfg4_full_cases():
+    runs = [(k * (6 * 64 * 64 // 64) + (k * 37) % 368, 16) for k in range(64)]          # 64 runs of 16 texels spread over the six 64^2 faces: 1 024 texels
+    lut_rows = sorted(set([0, 1, 2, 3, 5, 8, 13, 21, 34, 55, 63, 64, 65, 89, 144, 233, 377, 511, 512, 610, 777, 987, 1000, 1022, 1023] + list(range(40, 1024, 25))))[:64]
+    mips = abi.specular_mip_count(128)
+
+    def build():
+        i = _cfg4_inputs()
+        i.update(runs=np.array(runs, np.int32), lut_rows=np.array(lut_rows, np.int32))
+        return i
+
+    def ref_spec(i):
+        from tests import ref_lib as R
+        return np.concatenate([R.conv_specular_mip(i["chain"], 2048, 2048, i["n"], 128 >> m, float(np.float32(m) / np.float32(mips - 1)), m).reshape(-1, 4)
+                               for m in range(mips)])[:, :3]
+
+    def pick(full):                       # [6,64,64,C] -> the 1 024 chosen texels
+        flat = np.asarray(full).reshape(-1, full.shape[-1])
+        return np.concatenate([flat[t0:t0 + n] for t0, n in runs])[:, :3]
+
+    def ref_diff(i):
+        from tests import ref_lib as R
+        out = np.zeros((6 * 64 * 64, 4), np.float32)
+        for t0, n in runs:
+            out[t0:t0 + n] = R.conv_diffuse(i["chain"], 2048, 2048, i["n"], 64, t0=t0, t1=t0 + n).reshape(-1, 4)[t0:t0 + n]
+        return pick(out.reshape(6, 64, 64, 4))
+
+    def oracle_diff(i, order):
+        out = np.zeros((6 * 64 * 64, 4), np.float16)
+        for t0, n in runs:
+            out[t0:t0 + n] = O.conv_diffuse(i["chain"], 2048, 2048, i["n"], 64, 0.010, order, F16, t0=t0, t1=t0 + n).reshape(-1, 4)[t0:t0 + n]
+        return pick(out.reshape(6, 64, 64, 4))
+
+    def ref_lut(i):
+        from tests import ref_lib as R
+        xs = np.arange(1024, dtype=np.int32)
+        return np.stack([R.brdf_lut_texels(xs, np.full_like(xs, y)) for y in lut_rows])
+    # Measured (scripts/ulp_report.py cfg4_): the full 128^2 x 7-mip cube — 393 192 channels — is within 1 RGBA16F ulp of the reference's HLSL except
+    # 26 channels (6.6e-5) in mips 0-2 next to the 2.6e4-radiance suns, max 7 ulps: one tap whose equirect uv lands an ulp to the other side of a
+    # 1/256 filter-fraction boundary (the contract's polynomial atan2 / asin / log2 vs libm's: both inside D3D's tolerance) moves a
+    # 512-tap mean by up to 0.7 % there. The 16^2 toy case (conv_specular_16) never showed it. Diffuse, 1 024 texels at 99 382 taps: sequential
+    # order max 1 ulp (0.2 % of channels); the product's default 64-lane order max 2 ulps (17.6 % differing, 0.1 % above 1): a different summation
+    # order of the same taps.
+    for order, tag, ts, td in ((abi.CONV_SEQUENTIAL, "", ("ulp16tail", 1, 0.005, 8, 2e-4), ("ulp16", 1, 0.02)),
+                               (abi.CONV_WAVE64, "_wave64", ("ulp16tail", 1, 0.05, 8, 2e-4), ("ulp16tail", 1, 0.3, 2, 5e-3))):
+        CASES.append(Case("cfg4_specular_128x7_full" + tag, build, ref_spec,
+                          lambda i, order=order: O.conv_specular(i["chain"], 2048, 2048, i["n"], 128, order, F16)[0][:, :3],
+                          lambda ctx, i, order=order: ctx.conv_specular(_dev(i["chain"]), 2048, 2048, i["n"], 128, order, F16)[0].cpu().numpy()[:, :3],
+                          ts, store="f16"))
+        CASES.append(Case("cfg4_diffuse_1024_texels" + tag, build, ref_diff, lambda i, order=order: oracle_diff(i, order),
+                          lambda ctx, i, order=order: pick(ctx.conv_diffuse(_dev(i["chain"]), 2048, 2048, i["n"], 64, 0.010, order, F16).cpu().numpy()),
+                          td, store="f16"))
+    CASES.append(Case("cfg4_brdf_lut_64_rows", build, ref_lut,
+                      lambda i: np.stack([O.brdf_lut(1024, 2048, abi.FMT_RG16F, rows=(int(y), int(y) + 1))[0] for y in lut_rows]),
+                      lambda ctx, i: ctx.brdf_lut(1024, 2048, abi.FMT_RG16F).cpu().numpy()[np.array(lut_rows)],
+                      ("ulp16", 1, 0.01), store="f16"))
+
+
+_cfg4_full_cases()
 
 BY_NAME = {c.name: c for c in CASES}
