@@ -427,6 +427,19 @@ VQHIP_API int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream,
         const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
         float fAmbientLightingFactor, const vqhip_ssao* ssao, const vqhip_gbuffer* out);
 
+/* PSMain as the engine runs it (Shaders/ForwardLighting.hlsl:226-380; the lit draws of VQRenderer::RenderSceneColor,
+ * SceneRendering.cpp:1619-1760): vqhip_gbuffer_from_materials and vqhip_forward_lighting in ONE kernel. The 64-byte G-buffer record of a
+ * pixel never leaves registers (128 B/pixel of HBM traffic less than the two calls); the result is bit-identical to the two calls with
+ * fAmbientLightingFactor = perFrame->fAmbientLightingFactor (the same cbuffer field PSMain reads, :247). Pixels without geometry and
+ * discarded fragments shade the all-zero record exactly like the two calls do — composite the sky over them with vqhip_skydome
+ * (alpha-masked discards are marked -1 in in->ip2.w as by vqhip_gbuffer_from_materials). Arguments: as the two calls. */
+VQHIP_API int vqhip_forward_lighting_from_materials(vqhip_ctx* ctx, void* stream,
+        const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials, const vqhip_ssao* ssao,
+        const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+        const VQ_PointLight* extraPoint, int numExtraPoint,
+        const vqhip_envmap* env, const vqhip_shadowmaps* sm,
+        void* out, int out_row_pitch_px, vqhip_format outFmt);
+
 /* Replaces VQ_DXGI_UTILS::MipImage's 4-byte branch (DXGIUtils.cpp:264-285) as driven by
  * TextureManager::GenerateMips: each channel = (sum of the 2x2 block) / 4, integer division.
  * Same buffer convention as vqhip_mip_chain_min_rgba32f with 4-byte texels; w0, h0 powers of two. */

@@ -83,3 +83,17 @@ def test_product_does_not_reference_the_oracle():
     assert not bad, bad
     out = subprocess.run(["ldd", capi.lib_path()], capture_output=True, text=True).stdout
     assert "vqoracle" not in out
+
+
+def test_context_guard_is_declared_for_every_ctx_entry_point():
+    """Every entry point that takes a vqhip_ctx marks the context busy for the duration of the call (CtxGuard, capi.hip): a second thread
+    entering the same context is refused instead of corrupting the constant ring. Source-level check (the behaviour needs a GPU:
+    tests/test_gpu_round3.py::test_context_refuses_a_second_thread)."""
+    import re
+    src = open(os.path.join(ROOT, "vqengine_amd", "csrc", "capi.hip")).read()
+    entries = re.findall(r"\n(?:int|size_t) (vqhip_[a-z0-9_]+)\(vqhip_ctx\* ctx", src)
+    assert len(entries) >= 24
+    for name in entries:
+        body = src[src.index(f" {name}(vqhip_ctx* ctx"):]
+        body = body[:body.index("\n}\n")]
+        assert "CTX_GUARD(ctx" in body, name

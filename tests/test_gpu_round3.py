@@ -169,3 +169,113 @@ def test_tonemap_compact_table(ctx, form, monkeypatch):
         with np.errstate(all="ignore"):
             ref = O.tonemap(img, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, p)
         assert_bits(ctx.tonemap(g, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, params=p), ref, f"{form} curve={p.OutputDisplayCurveEnum} cs={p.ContentColorSpaceEnum}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# PSMain in one kernel: vqhip_forward_lighting_from_materials == vqhip_gbuffer_from_materials -> vqhip_forward_lighting == oracle chain
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,with_ssao,lights", [((640, 360), True, "env"), ((333, 127), False, "points"), ((130, 3), True, "casters"), ((1, 1), False, "points"),
+                                                     ((2, 257), True, "env")])
+def test_forward_lighting_from_materials_equals_the_two_calls(ctx, env_small, shape, with_ssao, lights):
+    from tests import ref_cases
+    from tests.test_gpu_gbuffer import build_materials
+    W, H = shape
+    n_mat = 6
+    ip = synth.interpolants(W, H, n_mat)
+    datas, host_chains, hmats, dmats, keep = build_materials(ctx, n_mat)
+    ssao = synth.ssao_image(W, H) if with_ssao else None
+    env_o = env_g = sh_o = sh_g = None
+    pv = synth.per_view(W, H)
+    if lights == "env":
+        pf, extra = synth.per_frame(points=synth.point_lights(24, seed=3), spots=synth.spot_lights(2), directional=synth.directional_light(), hdri_offset=0.3, ambient=0.055)
+        env_o, env_g = _envs(env_small)
+        pv = synth.per_view(W, H, max_env_lod=env_small["pre_o"]["spec_mips"])
+    elif lights == "casters":
+        pf, sh = ref_cases.shadow_scene()
+        sh_o = ref_cases.host_shadow(sh)
+        sh_g = ref_cases.dev_shadow(sh, keep)
+        extra = None
+    else:
+        pf, extra = synth.per_frame(points=synth.point_lights(130, seed=9), ambient=0.02)       # 100 in the cbuffer + 30 through the extension array
+    ipd = [dev(p) for p in ip]
+    for fmt in (abi.FMT_RGBA16F, abi.FMT_RGBA32F):
+        fused = ctx.forward_lighting_from_materials([t.clone() for t in ipd], dmats, pf, pv, ssao=dev(ssao) if with_ssao else None, out_fmt=fmt,
+                                                    extra_point=extra, env=env_g, shadow=sh_g)
+        gb = ctx.gbuffer_from_materials([t.clone() for t in ipd], dmats, pf.fAmbientLightingFactor, dev(ssao) if with_ssao else None)
+        two = ctx.forward_lighting(gb, pf, pv, out_fmt=fmt, extra_point=extra, env=env_g, shadow=sh_g)
+        assert torch.equal(fused.view(torch.int16 if fmt == abi.FMT_RGBA16F else torch.int32), two.view(torch.int16 if fmt == abi.FMT_RGBA16F else torch.int32)), \
+            f"fused != two calls, fmt {fmt}"
+        with np.errstate(all="ignore"):
+            ref = O.forward_lighting(O.gbuffer_from_materials(ip, hmats, pf.fAmbientLightingFactor, ssao), pf, pv, fmt, extra_point=extra, env=env_o, shadow=sh_o)
+        assert_bits(fused, ref, f"fused PSMain vs oracle chain {shape} {lights} fmt {fmt}")
+
+
+def test_forward_lighting_from_materials_alpha_mask_and_errors(ctx):
+    import ctypes as C
+    W, H = 256, 64
+    ip = synth.interpolants(W, H, 4)
+    datas, texsets = synth.material_set(4, max_dim=64)
+    dmats, keep = (abi.MaterialDesc * 4)(), []
+    for k, (d, ts) in enumerate(zip(datas, texsets)):
+        d.uvScaleOffset = abi.float4(0.02 * (k + 1), 0.015 * (k + 2), d.uvScaleOffset.z, d.uvScaleOffset.w)      # magnified: low LODs, whole texels transparent
+        if "texDiffuse" in ts:
+            ts["texDiffuse"][: 48 if ts["texDiffuse"].shape[0] >= 64 else ts["texDiffuse"].shape[0] // 2, :, 3] = 0
+        dmats[k].data = d
+        for slot, img in ts.items():
+            chain_g, nm = ctx.mip_chain_rgba8(dev(img))
+            keep.append(chain_g)
+            setattr(dmats[k], slot, abi.Texture2D(chain_g.data_ptr(), img.shape[1], img.shape[0], nm, 0))
+        dmats[k].texDiffuse.reserved = abi.MATERIAL_ALPHA_MASKED
+    pf, _ = synth.per_frame(points=synth.point_lights(8))
+    pv = synth.per_view(W, H)
+    ipa, ipb = [dev(p) for p in ip], [dev(p) for p in ip]
+    fused = ctx.forward_lighting_from_materials(ipa, dmats, pf, pv, out_fmt=abi.FMT_RGBA16F)
+    gb = ctx.gbuffer_from_materials(ipb, dmats, pf.fAmbientLightingFactor, None)
+    two = ctx.forward_lighting(gb, pf, pv, out_fmt=abi.FMT_RGBA16F)
+    assert torch.equal(fused.view(torch.int16), two.view(torch.int16))
+    assert torch.equal(ipa[2].view(torch.int32), ipb[2].view(torch.int32))                   # the same fragments were discarded (index -> -1)
+    assert int((ipa[2].view(torch.int32)[..., 3] != dev(ip[2]).view(torch.int32)[..., 3]).sum().item()) > 0
+    lib, st = ctx.lib, C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    inter = abi.Interpolants(ipa[0].data_ptr(), ipa[1].data_ptr(), ipa[2].data_ptr(), W, H, W)
+    out = torch.empty((H, W, 4), dtype=torch.float16, device="cuda")
+    call = lambda inter_=inter, n=4, pf_=pf, out_=out, pitch=W, fmt=abi.FMT_RGBA16F: lib.vqhip_forward_lighting_from_materials(      # noqa: E731
+        ctx._h, st, C.byref(inter_) if inter_ is not None else None, dmats, n, None, C.byref(pf_) if pf_ is not None else None, C.byref(pv), None, 0, None, None,
+        C.c_void_p(out_.data_ptr()) if out_ is not None else None, pitch, fmt)
+    assert call() == 0
+    assert call(inter_=None) == abi.VQHIP_ERR_INVALID_ARG and call(pf_=None) == abi.VQHIP_ERR_INVALID_ARG and call(out_=None) == abi.VQHIP_ERR_INVALID_ARG
+    assert call(pitch=W - 1) == abi.VQHIP_ERR_INVALID_ARG and call(n=lib.vqhip_max_materials() + 1) == abi.VQHIP_ERR_INVALID_ARG
+    assert call(fmt=abi.FMT_RGBA8_UNORM) == abi.VQHIP_ERR_UNSUPPORTED
+
+
+def test_context_refuses_a_second_thread(ctx):
+    """One thread at a time per vqhip_ctx: a second thread that enters the same context while a call is in progress gets
+    VQHIP_ERR_INVALID_ARG ("in use on another thread") instead of racing on the constant ring; the context stays usable afterwards."""
+    import threading
+    from vqengine_amd import capi
+    W, H = 64, 8
+    gb = [dev(g) for g in synth.gbuffer(W, H)]
+    pf, _ = synth.per_frame(points=synth.point_lights(100))
+    pv = synth.per_view(W, H)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    refused, other = [0, 0], []
+
+    def work(k):
+        out = capi.empty_image(H, W, abi.FMT_RGBA16F, ctx.device)
+        for _ in range(3000):
+            try:
+                ctx.forward_lighting(gb, pf, pv, out=out, out_fmt=abi.FMT_RGBA16F, stream=streams[k])
+            except capi.VQHipError as e:
+                if "another thread" in str(e):
+                    refused[k] += 1
+                else:
+                    other.append(str(e))
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not other, other[:3]
+    assert refused[0] + refused[1] > 0, "two threads hammered one context for 3000 calls each and never met"
+    ref = O.forward_lighting(synth.gbuffer(W, H), pf, pv, abi.FMT_RGBA16F)
+    assert_bits(ctx.forward_lighting(gb, pf, pv, out_fmt=abi.FMT_RGBA16F), ref, "context after the collision")

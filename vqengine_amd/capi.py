@@ -60,6 +60,9 @@ def load_library():
         "vqhip_max_materials": (i32, []),
         "vqhip_gbuffer_from_materials": (i32, [vp, vp, C.POINTER(abi.Interpolants), C.POINTER(abi.MaterialDesc), i32, f32,
                                                C.POINTER(abi.SSAO), C.POINTER(abi.GBuffer)]),
+        "vqhip_forward_lighting_from_materials": (i32, [vp, vp, C.POINTER(abi.Interpolants), C.POINTER(abi.MaterialDesc), i32, C.POINTER(abi.SSAO),
+                                                        C.POINTER(abi.PerFrameData), C.POINTER(abi.PerViewLightingData), vp, i32,
+                                                        C.POINTER(abi.EnvMap), C.POINTER(abi.ShadowMaps), vp, i32, i32]),
         "vqhip_mip_chain_bytes_rgba8": (sz, [i32, i32, i32]),
         "vqhip_mip_chain_box_rgba8": (i32, [vp, vp, vp, i32, i32, i32]),
         "vqhip_set_fresnel_pow": (i32, [vp, i32]),
@@ -98,7 +101,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_gaussian_blur_y_tonemap", "vqhip_tonemap", "vqhip_post_process", "vqhip_brdf_lut",
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
-    "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
+    "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_forward_lighting_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
     "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f", "vqhip_hdr_downsize_rgba32f",
     "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections",
     "vqhip_rowtile", "vqhip_comm_unique_id", "vqhip_comm_create", "vqhip_comm_adopt", "vqhip_comm_destroy", "vqhip_comm_query", "vqhip_comm_abort", "vqhip_exchange_blur_halos",
@@ -407,6 +410,32 @@ class Context:
         n = len(materials) if materials is not None else 0
         self._ck(self.lib.vqhip_gbuffer_from_materials(self._h, self._stream(stream), C.byref(inter), materials if n else None, n,
                                                        float(ambient), C.byref(s) if s is not None else None, C.byref(gbuf)))
+        return out
+
+    def forward_lighting_from_materials(self, ip, materials, per_frame, per_view, ssao=None, out=None, out_fmt=FMT_RGBA16F, extra_point=None,
+                                        env=None, shadow=None, stream=None):
+        """PSMain in one kernel: gbuffer_from_materials(ip, materials, per_frame.fAmbientLightingFactor, ssao) + forward_lighting, the G-buffer
+        record never leaving registers. Same bits as the two calls."""
+        for i, t in enumerate(ip):
+            _check_img(t, FMT_RGBA32F, f"ip{i}")
+        h, w = ip[0].shape[0], ip[0].shape[1]
+        if out is None:
+            out = empty_image(h, w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out", (h, w))
+        inter = abi.Interpolants(ip[0].data_ptr(), ip[1].data_ptr(), ip[2].data_ptr(), w, h, w)
+        s = None
+        if ssao is not None:
+            if not (ssao.is_cuda and ssao.is_contiguous() and ssao.dtype == torch.uint8 and ssao.dim() == 2):
+                raise ValueError("ssao: expected contiguous cuda uint8 [H,W]")
+            s = abi.SSAO(ssao.data_ptr(), ssao.shape[1], ssao.shape[0])
+        n = len(materials) if materials is not None else 0
+        n_extra, extra_ptr = 0, C.c_void_p(None)
+        if extra_point is not None and len(extra_point):
+            n_extra, extra_ptr = len(extra_point), C.cast(extra_point, C.c_void_p)
+        self._ck(self.lib.vqhip_forward_lighting_from_materials(
+            self._h, self._stream(stream), C.byref(inter), materials if n else None, n, C.byref(s) if s is not None else None,
+            C.byref(per_frame), C.byref(per_view), extra_ptr, n_extra, C.byref(env) if env is not None else None,
+            C.byref(shadow) if shadow is not None else None, _ptr(out), out.shape[1], out_fmt))
         return out
 
     # ---- FSR 1.0 (SceneRendering.cpp:2695-2784; SURVEY.md §8f.4) -----------------------------------------------

@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 #include "vq_internal.h"
 #include "vq_devmath.h"      // vqd::sincos_ is __host__ __device__: frame-uniform trigonometry is evaluated here, once
@@ -28,11 +30,16 @@ struct vqhip_ctx {
     void* scratch = nullptr; size_t scratchBytes = 0;
     int pow5ExpLog = 0;            // vqhip_set_fresnel_pow
     // 65536-entry tonemap tables (post.hip:k_tonemap_lut), cached per (TonemapperParams, output format): the table is built once
-    // per parameter set instead of once per frame, and two streams of one context can no longer race on a shared scratch table.
+    // per parameter set instead of once per frame. Streams that HIT a cached table only wait for the event of its build. A table is replaced
+    // only when a fifth parameter set shows up: the least recently used one goes (a hit counts as a use), and because its readers may sit on
+    // any number of streams the replacement waits for the whole device once (hipDeviceSynchronize) instead of tracking one event per reader.
     static constexpr int kLuts = 4;
     struct TonemapLut { void* table = nullptr; VQ_TonemapperParams key{}; int outFmt = -1; bool valid = false;
-                        hipEvent_t built = nullptr, lastUse = nullptr; bool used = false; } lut[kLuts];
-    int nextLut = 0;
+                        hipEvent_t built = nullptr; bool used = false; uint64_t lastUseTick = 0; } lut[kLuts];
+    uint64_t lutTick = 0;
+    // one thread at a time per context: entry points detect a second thread inside the same context and refuse it
+    std::atomic<int> busyDepth{0};
+    std::thread::id busyThread;
     std::string lastError;
 };
 
@@ -83,34 +90,51 @@ int ensureScratch(vqhip_ctx* ctx, size_t bytes) {
 }
 
 // The tonemap table of (p, outFmt), ready to be read by work enqueued on `st` after this call: a cached table makes `st` wait for the
-// event of its build (it may have happened on another stream); a miss rebuilds the least recently claimed slot on `st`, after the
-// last reader of the table that is being replaced. The caller records the slot's lastUse event once its kernel is enqueued.
+// event of its build (it may have happened on another stream); a miss rebuilds the LEAST RECENTLY USED slot on `st` — after a device-wide
+// wait when that table has ever been read (its readers may be on other streams).
 int acquireTonemapLut(vqhip_ctx* ctx, hipStream_t st, const VQ_TonemapperParams& p, int outFmt, int* slotOut) {
+    int victim = 0;
     for (int i = 0; i < vqhip_ctx::kLuts; ++i) {
         auto& L = ctx->lut[i];
         if (L.valid && L.outFmt == outFmt && std::memcmp(&L.key, &p, sizeof(p)) == 0) {
             HIP_TRY(ctx, hipStreamWaitEvent(st, L.built, 0));
+            L.lastUseTick = ++ctx->lutTick;
+            L.used = true;
             *slotOut = i;
             return VQHIP_OK;
         }
+        if (!L.valid) { if (ctx->lut[victim].valid) victim = i; }
+        else if (ctx->lut[victim].valid && L.lastUseTick < ctx->lut[victim].lastUseTick) victim = i;
     }
-    const int i = ctx->nextLut;
-    ctx->nextLut = (i + 1) % vqhip_ctx::kLuts;
-    auto& L = ctx->lut[i];
-    if (L.used) HIP_TRY(ctx, hipStreamWaitEvent(st, L.lastUse, 0));
+    auto& L = ctx->lut[victim];
+    if (L.valid && L.used) HIP_TRY(ctx, hipDeviceSynchronize());
     L.valid = false;
     hipError_t e = launch_tonemap_lut_build(st, L.table, p, outFmt);
     if (e != hipSuccess) return failHip(ctx, e, "tonemap table build launch");
     HIP_TRY(ctx, hipEventRecord(L.built, st));
-    L.key = p; L.outFmt = outFmt; L.valid = true; L.used = false;
-    *slotOut = i;
+    L.key = p; L.outFmt = outFmt; L.valid = true; L.used = true; L.lastUseTick = ++ctx->lutTick;
+    *slotOut = victim;
     return VQHIP_OK;
 }
-int releaseTonemapLut(vqhip_ctx* ctx, hipStream_t st, int slot) {
-    HIP_TRY(ctx, hipEventRecord(ctx->lut[slot].lastUse, st));
-    ctx->lut[slot].used = true;
-    return VQHIP_OK;
-}
+int releaseTonemapLut(vqhip_ctx*, hipStream_t, int) { return VQHIP_OK; }
+
+// RAII marker of "this thread is inside an entry point of ctx". A second THREAD entering the same context while one is inside is refused
+// (VQHIP_ERR_INVALID_ARG) instead of corrupting the constant ring / table cache; nested calls of the same thread (vqhip_post_process ->
+// vqhip_gaussian_blur_x) pass. The context may migrate between threads, it just cannot be shared at the same time.
+struct CtxGuard {
+    vqhip_ctx* c; bool ok;
+    explicit CtxGuard(vqhip_ctx* ctx) : c(ctx), ok(true) {
+        if (!c) return;
+        const std::thread::id me = std::this_thread::get_id();
+        int d = c->busyDepth.load(std::memory_order_acquire);
+        if (d > 0 && c->busyThread == me) { c->busyDepth.store(d + 1, std::memory_order_release); return; }
+        int expected = 0;
+        if (!c->busyDepth.compare_exchange_strong(expected, 1, std::memory_order_acq_rel)) { ok = false; c = nullptr; return; }
+        c->busyThread = me;
+    }
+    ~CtxGuard() { if (c) c->busyDepth.fetch_sub(1, std::memory_order_acq_rel); }
+};
+#define CTX_GUARD(ctx, who) CtxGuard guard_(ctx); if (!guard_.ok) return fail(nullptr, VQHIP_ERR_INVALID_ARG, std::string(who) + ": the context is in use on another thread (one thread at a time per vqhip_ctx)")
 
 int mipDim(int d0, int l) { int d = d0 >> l; return d < 1 ? 1 : d; }
 
@@ -184,8 +208,7 @@ int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
         return rc;
     }
     for (int i = 0; i < vqhip_ctx::kLuts; ++i)
-        if ((e = hipMalloc(&ctx->lut[i].table, 131072)) != hipSuccess || (e = hipEventCreateWithFlags(&ctx->lut[i].built, hipEventDisableTiming)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&ctx->lut[i].lastUse, hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "vqhip_create: tonemap tables"); vqhip_destroy(ctx); return rc; }
+        if ((e = hipMalloc(&ctx->lut[i].table, 131072)) != hipSuccess || (e = hipEventCreateWithFlags(&ctx->lut[i].built, hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "vqhip_create: tonemap tables"); vqhip_destroy(ctx); return rc; }
     for (int i = 0; i < vqhip_ctx::kSlots; ++i)
         if ((e = hipEventCreateWithFlags(&ctx->slotEvent[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->copyEvent[i], hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "hipEventCreate"); vqhip_destroy(ctx); return rc; }
@@ -206,47 +229,41 @@ void vqhip_destroy(vqhip_ctx* ctx) {
     for (int i = 0; i < vqhip_ctx::kLuts; ++i) {
         if (ctx->lut[i].table) (void)hipFree(ctx->lut[i].table);
         if (ctx->lut[i].built) (void)hipEventDestroy(ctx->lut[i].built);
-        if (ctx->lut[i].lastUse) (void)hipEventDestroy(ctx->lut[i].lastUse);
     }
     delete ctx;
 }
 
-int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb,
-        const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
-        const VQ_PointLight* extraPoint, int numExtraPoint,
-        const vqhip_envmap* env, const vqhip_shadowmaps* sm,
-        void* out, int out_row_pitch_px, vqhip_format outFmt) {
-    vqk::Range range_("RenderSceneColor");
-    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "forward_lighting: ctx is NULL");
-    if (!gb || !perFrame || !perView || !out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: NULL argument");
-    if (!gb->gb0 || !gb->gb1 || !gb->gb2 || !gb->gb3) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: NULL G-buffer plane");
-    if (gb->width <= 0 || gb->height <= 0 || gb->row_pitch_px < gb->width || out_row_pitch_px < gb->width)
-        return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: bad dimensions / pitch");
-    if (!isImageFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "forward_lighting: outFmt must be RGBA32F or RGBA16F");
+// validation of the lighting half shared by vqhip_forward_lighting and vqhip_forward_lighting_from_materials; *casters = shadow casters present
+static int validateLighting(vqhip_ctx* ctx, const char* who, const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+                            const VQ_PointLight* extraPoint, int numExtraPoint, const vqhip_envmap* env, const vqhip_shadowmaps* sm, vqhip_format outFmt, bool* casters) {
+    const std::string w(who);
+    if (!perFrame || !perView) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": NULL argument");
+    if (!isImageFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, w + ": outFmt must be RGBA32F or RGBA16F");
     const VQ_SceneLighting& L = perFrame->Lights;
     if (L.numPointLights < 0 || L.numPointLights > VQ_NUM_LIGHTS__POINT || L.numSpotLights < 0 || L.numSpotLights > VQ_NUM_LIGHTS__SPOT ||
         L.numPointCasters < 0 || L.numPointCasters > VQ_NUM_SHADOWING_LIGHTS__POINT || L.numSpotCasters < 0 || L.numSpotCasters > VQ_NUM_SHADOWING_LIGHTS__SPOT)
-        return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: light count exceeds the cbuffer array (LightingConstantBufferData.h:39-44)");
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": light count exceeds the cbuffer array (LightingConstantBufferData.h:39-44)");
     if (numExtraPoint < 0 || numExtraPoint > kMaxExtraPointLights || (numExtraPoint > 0 && !extraPoint))
-        return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: bad extraPoint / numExtraPoint");
-    const bool casters = L.numPointCasters > 0 || L.numSpotCasters > 0 || (L.directional.enabled && L.directional.shadowing);
-    if (casters) {
-        if (!sm) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: shadow casters present but sm is NULL");
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": bad extraPoint / numExtraPoint");
+    *casters = L.numPointCasters > 0 || L.numSpotCasters > 0 || (L.directional.enabled && L.directional.shadowing);
+    if (*casters) {
+        if (!sm) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": shadow casters present but sm is NULL");
         if ((L.numPointCasters > 0 && (!sm->point || sm->point_dim <= 0)) || (L.numSpotCasters > 0 && (!sm->spot || sm->spot_dim <= 0)) ||
             (L.directional.enabled && L.directional.shadowing && (!sm->directional || sm->dir_dim <= 0)))
-            return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: missing shadow map for a caster");
+            return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": missing shadow map for a caster");
     }
     if (env) {
-        if (!env->diffuse_cube || env->diffuse_res <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: env->diffuse_cube missing");
+        if (!env->diffuse_cube || env->diffuse_res <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": env->diffuse_cube missing");
         if (!perView->EnvironmentMapDiffuseOnlyIllumination &&
             (!env->specular_cube || env->spec_res0 <= 0 || env->spec_mips <= 0 || (env->spec_res0 >> (env->spec_mips - 1)) < 1 || !env->brdf_lut || env->lut_size <= 0))
-            return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: env specular cube / BRDF LUT missing");
+            return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": env specular cube / BRDF LUT missing");
     }
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;
-    int slot;
-    int rc = acquireSlot(ctx, &slot);
-    if (rc) return rc;
+    return VQHIP_OK;
+}
+// the lighting pass's constant block (cbuffers b0 / b1 + descriptors + the packed point-light records) into a ring slot; returns its byte size
+static size_t fillFrameConstants(vqhip_ctx* ctx, int slot, const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+                                 const VQ_PointLight* extraPoint, int numExtraPoint, const vqhip_envmap* env, const vqhip_shadowmaps* sm) {
+    const VQ_SceneLighting& L = perFrame->Lights;
     FrameConstants* fc = (FrameConstants*)(ctx->hostRing + (size_t)slot * kConstSlotBytes);
     std::memset(fc, 0, sizeof(FrameConstants));
     fc->perFrame = *perFrame;
@@ -274,7 +291,31 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
     fc->pointFastOK = pointFastOK;
     fc->pointSkipOK = pointSkipOK;
     fc->numPointAll = nPts;
-    rc = commitSlot(ctx, slot, sizeof(FrameConstants) + (size_t)nPts * sizeof(DevPointLight), st);
+    return sizeof(FrameConstants) + (size_t)nPts * sizeof(DevPointLight);
+}
+
+int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb,
+        const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+        const VQ_PointLight* extraPoint, int numExtraPoint,
+        const vqhip_envmap* env, const vqhip_shadowmaps* sm,
+        void* out, int out_row_pitch_px, vqhip_format outFmt) {
+    vqk::Range range_("RenderSceneColor");
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "forward_lighting: ctx is NULL");
+    CTX_GUARD(ctx, "forward_lighting");
+    if (!gb || !perFrame || !perView || !out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: NULL argument");
+    if (!gb->gb0 || !gb->gb1 || !gb->gb2 || !gb->gb3) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: NULL G-buffer plane");
+    if (gb->width <= 0 || gb->height <= 0 || gb->row_pitch_px < gb->width || out_row_pitch_px < gb->width)
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting: bad dimensions / pitch");
+    bool casters = false;
+    int rc = validateLighting(ctx, "forward_lighting", perFrame, perView, extraPoint, numExtraPoint, env, sm, outFmt, &casters);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int slot;
+    rc = acquireSlot(ctx, &slot);
+    if (rc) return rc;
+    const size_t bytes = fillFrameConstants(ctx, slot, perFrame, perView, extraPoint, numExtraPoint, env, sm);
+    rc = commitSlot(ctx, slot, bytes, st);
     if (rc) return rc;
     ShadeArgs a;
     a.gb0 = (const float4*)gb->gb0; a.gb1 = (const float4*)gb->gb1; a.gb2 = (const float4*)gb->gb2; a.gb3 = (const float4*)gb->gb3;
@@ -289,6 +330,7 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
 int vqhip_gaussian_blur_x(vqhip_ctx* ctx, void* stream, const void* in, void* out, const VQ_BlurParams* p, vqhip_format fmt) {
     vqk::Range range_("BlurX");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur_x: ctx is NULL");
+    CTX_GUARD(ctx, "gaussian_blur_x");
     if (!in || !out || !p || p->iImageSizeX <= 0 || p->iImageSizeY <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_x: bad argument");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_x: fmt must be RGBA32F or RGBA16F");
     if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_x: in-place blur is not supported");
@@ -301,6 +343,7 @@ int vqhip_gaussian_blur_y(vqhip_ctx* ctx, void* stream, const void* in, void* ou
                           const VQ_BlurParams* p, vqhip_format fmt) {
     vqk::Range range_("BlurY");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y: ctx is NULL");
+    CTX_GUARD(ctx, "gaussian_blur_y");
     if (!in || !out || !p || p->iImageSizeX <= 0 || p->iImageSizeY <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y: bad argument");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_y: fmt must be RGBA32F or RGBA16F");
     if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y: in-place blur is not supported");
@@ -314,6 +357,7 @@ int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const void* in, 
                                   const VQ_BlurParams* p, const VQ_TonemapperParams* tm, vqhip_format blurFmt, vqhip_format outFmt) {
     vqk::Range range_("BlurY+TonemapperCS");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: ctx is NULL");
+    CTX_GUARD(ctx, "gaussian_blur_y_tonemap");
     if (!in || !out || !p || !tm || p->iImageSizeX <= 0 || p->iImageSizeY <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_y_tonemap: bad argument");
     if (!isImageFmt(blurFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_y_tonemap: blurFmt must be RGBA32F or RGBA16F");
     if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_y_tonemap: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
@@ -329,6 +373,8 @@ int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const void* in, 
 }
 
 int vqhip_gaussian_blur(vqhip_ctx* ctx, void* stream, const void* in, void* tmp, void* out, const VQ_BlurParams* p, vqhip_format fmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gaussian_blur: ctx is NULL");
+    CTX_GUARD(ctx, "gaussian_blur");
     if (!tmp) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur: tmp is NULL");
     int rc = vqhip_gaussian_blur_x(ctx, stream, in, tmp, p, fmt);
     if (rc) return rc;
@@ -339,6 +385,7 @@ int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int w
                   const VQ_TonemapperParams* p, vqhip_format inFmt, vqhip_format outFmt) {
     vqk::Range range_("TonemapperCS");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "tonemap: ctx is NULL");
+    CTX_GUARD(ctx, "tonemap");
     if (!in || !out || !p || width <= 0 || height <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "tonemap: bad argument");
     if (!isImageFmt(inFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "tonemap: inFmt must be RGBA32F or RGBA16F");
     if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "tonemap: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
@@ -354,6 +401,7 @@ int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, voi
                        const VQ_TonemapperParams* tm, int enableGaussianBlur, vqhip_format inFmt, vqhip_format outFmt) {
     vqk::Range range_("RenderPostProcess");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "post_process: ctx is NULL");
+    CTX_GUARD(ctx, "post_process");
     if (!sceneColor || !out || !tm || width <= 0 || height <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "post_process: bad argument");
     if (!isImageFmt(inFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "post_process: inFmt must be RGBA32F or RGBA16F");
     if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "post_process: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
@@ -382,6 +430,7 @@ int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, voi
 
 int vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode) {
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "set_fresnel_pow: ctx is NULL");
+    CTX_GUARD(ctx, "set_fresnel_pow");
     if (mode != VQHIP_FRESNEL_POW_PRODUCT && mode != VQHIP_FRESNEL_POW_EXP2_LOG2) return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_fresnel_pow: unknown mode");
     ctx->pow5ExpLog = mode == VQHIP_FRESNEL_POW_EXP2_LOG2 ? 1 : 0;
     return VQHIP_OK;
@@ -390,6 +439,7 @@ int vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode) {
 int vqhip_brdf_lut(vqhip_ctx* ctx, void* stream, void* outRG, int size, int samples, vqhip_format fmt) {
     vqk::Range range_("CreateBRDFIntegralLUT");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "brdf_lut: ctx is NULL");
+    CTX_GUARD(ctx, "brdf_lut");
     if (!outRG || size <= 0 || samples <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "brdf_lut: bad argument");
     if (fmt != VQHIP_FMT_RG16F && fmt != VQHIP_FMT_RG32F) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "brdf_lut: fmt must be RG16F or RG32F");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -408,6 +458,7 @@ size_t vqhip_mip_chain_bytes(int w0, int h0, int nMips) { return vqhip_mip_level
 int vqhip_mip_chain_min_rgba32f(vqhip_ctx* ctx, void* stream, void* mips, int w0, int h0, int nMips) {
     vqk::Range range_("GenerateMips");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "mip_chain: ctx is NULL");
+    CTX_GUARD(ctx, "mip_chain");
     if (!mips || w0 <= 0 || h0 <= 0 || nMips <= 0 || nMips > vqhip_mip_level_count(w0, h0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "mip_chain: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     for (int l = 1; l < nMips; ++l) {
@@ -425,6 +476,7 @@ size_t vqhip_mip_chain_bytes_rgba8(int w0, int h0, int nMips) { return vqhip_mip
 int vqhip_mip_chain_box_rgba8(vqhip_ctx* ctx, void* stream, void* mips, int w0, int h0, int nMips) {
     vqk::Range range_("GenerateMips");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "mip_chain_box_rgba8: ctx is NULL");
+    CTX_GUARD(ctx, "mip_chain_box_rgba8");
     if (!mips || w0 <= 0 || h0 <= 0 || nMips <= 0 || nMips > vqhip_mip_level_count(w0, h0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "mip_chain_box_rgba8: bad argument");
     if ((w0 & (w0 - 1)) || (h0 & (h0 - 1))) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "mip_chain_box_rgba8: w0 and h0 must be powers of two");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -443,38 +495,52 @@ static bool badTexture(const vqhip_texture2d& t) {
     return t.texels && (t.width <= 0 || t.height <= 0 || t.mips <= 0 || t.mips > vqhip_mip_level_count(t.width, t.height));
 }
 
-int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
-                                 float fAmbientLightingFactor, const vqhip_ssao* ssao, const vqhip_gbuffer* out) {
-    vqk::Range range_("Geometry");                       // :1723 (surface assembly half of the lit draws)
-    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: ctx is NULL");
-    if (!in || !out || !in->ip0 || !in->ip1 || !in->ip2 || !out->gb0 || !out->gb1 || !out->gb2 || !out->gb3)
-        return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: NULL plane");
-    if (in->width <= 0 || in->height <= 0 || in->row_pitch_px < in->width || out->width != in->width || out->height != in->height || out->row_pitch_px < in->width)
-        return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: bad dimensions / pitch");
-    if ((uint64_t)in->row_pitch_px * in->height * 16u >= (1ull << 32) || (uint64_t)out->row_pitch_px * out->height * 16u >= (1ull << 32) ||
-        in->row_pitch_px >= (1 << 24) || out->row_pitch_px >= (1 << 24) || in->height >= (1 << 24))
-        return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gbuffer_from_materials: a plane must be smaller than 4 GiB (32-bit offsets in the kernel)");
+static int validateProducer(vqhip_ctx* ctx, const char* who, const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials, const vqhip_ssao* ssao) {
+    const std::string w(who);
+    if (!in || !in->ip0 || !in->ip1 || !in->ip2) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": NULL plane");
+    if (in->width <= 0 || in->height <= 0 || in->row_pitch_px < in->width) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": bad dimensions / pitch");
+    if ((uint64_t)in->row_pitch_px * in->height * 16u >= (1ull << 32) || in->row_pitch_px >= (1 << 24) || in->height >= (1 << 24))
+        return fail(ctx, VQHIP_ERR_UNSUPPORTED, w + ": a plane must be smaller than 4 GiB (32-bit offsets in the kernel)");
     if (numMaterials < 0 || numMaterials > kMaxMaterials || (numMaterials > 0 && !materials))
-        return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: bad materials / numMaterials (see vqhip_max_materials)");
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": bad materials / numMaterials (see vqhip_max_materials)");
     for (int i = 0; i < numMaterials; ++i) {
         const vqhip_material& m = materials[i];
         if (badTexture(m.texDiffuse) || badTexture(m.texNormals) || badTexture(m.texEmissive) || badTexture(m.texMetalness) ||
             badTexture(m.texRoughness) || badTexture(m.texOcclRoughMetal) || badTexture(m.texLocalAO))
-            return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: material " + std::to_string(i) + " has a texture with bad dimensions / mip count");
+            return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": material " + std::to_string(i) + " has a texture with bad dimensions / mip count");
     }
-    if (ssao && ssao->texels && (ssao->width <= 0 || ssao->height <= 0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: bad ssao dimensions");
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;
-    int slot;
-    int rc = acquireSlot(ctx, &slot);
-    if (rc) return rc;
+    if (ssao && ssao->texels && (ssao->width <= 0 || ssao->height <= 0)) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": bad ssao dimensions");
+    return VQHIP_OK;
+}
+static size_t fillGbufConstants(vqhip_ctx* ctx, int slot, const vqhip_material* materials, int numMaterials, float ambient, const vqhip_ssao* ssao) {
     GbufConstants* gc = (GbufConstants*)(ctx->hostRing + (size_t)slot * kConstSlotBytes);
     std::memset(gc, 0, offsetof(GbufConstants, mats));
-    gc->ambient = fAmbientLightingFactor;
+    gc->ambient = ambient;
     gc->numMaterials = numMaterials;
     if (ssao && ssao->texels) gc->ssao = *ssao;
     if (numMaterials > 0) std::memcpy(gc->mats, materials, (size_t)numMaterials * sizeof(vqhip_material));
-    rc = commitSlot(ctx, slot, offsetof(GbufConstants, mats) + (size_t)numMaterials * sizeof(vqhip_material), st);
+    return offsetof(GbufConstants, mats) + (size_t)numMaterials * sizeof(vqhip_material);
+}
+
+int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
+                                 float fAmbientLightingFactor, const vqhip_ssao* ssao, const vqhip_gbuffer* out) {
+    vqk::Range range_("Geometry");                       // :1723 (surface assembly half of the lit draws)
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: ctx is NULL");
+    CTX_GUARD(ctx, "gbuffer_from_materials");
+    if (!out || !out->gb0 || !out->gb1 || !out->gb2 || !out->gb3) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: NULL plane");
+    int rc = validateProducer(ctx, "gbuffer_from_materials", in, materials, numMaterials, ssao);
+    if (rc) return rc;
+    if (out->width != in->width || out->height != in->height || out->row_pitch_px < in->width)
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "gbuffer_from_materials: bad dimensions / pitch");
+    if ((uint64_t)out->row_pitch_px * out->height * 16u >= (1ull << 32) || out->row_pitch_px >= (1 << 24))
+        return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gbuffer_from_materials: a plane must be smaller than 4 GiB (32-bit offsets in the kernel)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int slot;
+    rc = acquireSlot(ctx, &slot);
+    if (rc) return rc;
+    const size_t bytes = fillGbufConstants(ctx, slot, materials, numMaterials, fAmbientLightingFactor, ssao);
+    rc = commitSlot(ctx, slot, bytes, st);
     if (rc) return rc;
     GbufArgs a;
     a.ip0 = (const float4*)in->ip0; a.ip1 = (const float4*)in->ip1; a.ip2 = (const float4*)in->ip2;
@@ -486,11 +552,47 @@ int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_inter
     return releaseSlot(ctx, slot, st);
 }
 
+// PSMain as the engine runs it (ForwardLighting.hlsl:226-380, the lit draws of RenderSceneColor, SceneRendering.cpp:1619-1760): interpolants +
+// materials in, scene colour out, one kernel — the G-buffer record stays in registers. Two ring slots: the producer's constants and the lighting's.
+int vqhip_forward_lighting_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
+        const vqhip_ssao* ssao, const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+        const VQ_PointLight* extraPoint, int numExtraPoint, const vqhip_envmap* env, const vqhip_shadowmaps* sm,
+        void* out, int out_row_pitch_px, vqhip_format outFmt) {
+    vqk::Range range_("RenderSceneColor");
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "forward_lighting_from_materials: ctx is NULL");
+    CTX_GUARD(ctx, "forward_lighting_from_materials");
+    if (!out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting_from_materials: out is NULL");
+    int rc = validateProducer(ctx, "forward_lighting_from_materials", in, materials, numMaterials, ssao);
+    if (rc) return rc;
+    if (out_row_pitch_px < in->width) return fail(ctx, VQHIP_ERR_INVALID_ARG, "forward_lighting_from_materials: bad output pitch");
+    bool casters = false;
+    rc = validateLighting(ctx, "forward_lighting_from_materials", perFrame, perView, extraPoint, numExtraPoint, env, sm, outFmt, &casters);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int slotG, slotF;
+    if ((rc = acquireSlot(ctx, &slotG)) != VQHIP_OK || (rc = acquireSlot(ctx, &slotF)) != VQHIP_OK) return rc;
+    const size_t bytesG = fillGbufConstants(ctx, slotG, materials, numMaterials, perFrame->fAmbientLightingFactor, ssao);     // cbPerFrame.fAmbientLightingFactor, :247
+    const size_t bytesF = fillFrameConstants(ctx, slotF, perFrame, perView, extraPoint, numExtraPoint, env, sm);
+    if ((rc = commitSlot(ctx, slotG, bytesG, st)) != VQHIP_OK || (rc = commitSlot(ctx, slotF, bytesF, st)) != VQHIP_OK) return rc;
+    GbufArgs a;
+    a.ip0 = (const float4*)in->ip0; a.ip1 = (const float4*)in->ip1; a.ip2 = (const float4*)in->ip2;
+    a.gb0 = a.gb1 = a.gb2 = a.gb3 = nullptr;
+    a.gc = (const GbufConstants*)(ctx->devRing + (size_t)slotG * kConstSlotBytes);
+    a.width = in->width; a.height = in->height; a.pitch = in->row_pitch_px; a.outPitch = 0;
+    hipError_t e = launch_forward_from_materials(st, a, (const FrameConstants*)(ctx->devRing + (size_t)slotF * kConstSlotBytes), env != nullptr, casters,
+                                                 out, out_row_pitch_px, outFmt);
+    if (e != hipSuccess) return failHip(ctx, e, "forward_lighting_from_materials launch");
+    if ((rc = releaseSlot(ctx, slotG, st)) != VQHIP_OK) return rc;
+    return releaseSlot(ctx, slotF, st);
+}
+
 // ---- skydome ------------------------------------------------------------------------
 int vqhip_skydome(vqhip_ctx* ctx, void* stream, const void* equirect_level0, int w0, int h0, const VQ_SkydomeParams* params,
                   const vqhip_interpolants* coverage, void* color, int width, int height, int row_pitch_px, vqhip_format fmt) {
     vqk::Range range_("EnvironmentMap");                 // SceneRendering.cpp:1824
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "skydome: ctx is NULL");
+    CTX_GUARD(ctx, "skydome");
     if (!equirect_level0 || !params || !color || w0 <= 0 || h0 <= 0 || width <= 0 || height <= 0 || row_pitch_px < width)
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "skydome: bad argument");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "skydome: fmt must be RGBA32F or RGBA16F");
@@ -507,6 +609,7 @@ int vqhip_unlit_composite(vqhip_ctx* ctx, void* stream, const vqhip_interpolants
                           void* color, int width, int height, int row_pitch_px, vqhip_format fmt) {
     vqk::Range range_("Lights");                         // :1790
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "unlit_composite: ctx is NULL");
+    CTX_GUARD(ctx, "unlit_composite");
     if (!coverage || !coverage->ip2 || !color || width <= 0 || height <= 0 || row_pitch_px < width || numColors < 0 || (numColors > 0 && !colors))
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "unlit_composite: bad argument");
     if (numColors > VQHIP_MAX_UNLIT_COLORS) return fail(ctx, VQHIP_ERR_INVALID_ARG, "unlit_composite: more than VQHIP_MAX_UNLIT_COLORS gizmos");
@@ -534,6 +637,7 @@ int vqhip_hdr_parse_header(const void* file, size_t bytes, int* width, int* heig
 int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, size_t bytes, void* out_rgba32f, int width, int height) {
     vqk::Range range_("LoadHDRI");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "hdr_decode: ctx is NULL");
+    CTX_GUARD(ctx, "hdr_decode");
     if (!file || !out_rgba32f) return fail(ctx, VQHIP_ERR_INVALID_ARG, "hdr_decode: NULL argument");
     const char* err = nullptr; int w = 0, h = 0; size_t off = 0;
     if (hdr_parse_header((const uint8_t*)file, bytes, &w, &h, &off, &err)) return fail(ctx, VQHIP_ERR_INVALID_ARG, err);
@@ -559,6 +663,7 @@ static uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 int vqhip_hdr_downsize_rgba32f(vqhip_ctx* ctx, void* stream, const void* in, int width, int height, void* out, int out_width, int out_height) {
     vqk::Range range_("DownsizeHDRI");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "hdr_downsize: ctx is NULL");
+    CTX_GUARD(ctx, "hdr_downsize");
     if (!in || !out || width <= 0 || height <= 0 || out_width <= 0 || out_height <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "hdr_downsize: bad argument");
     if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "hdr_downsize: in-place is not supported");
     const int k = width / out_width;
@@ -598,6 +703,7 @@ int vqhip_fsr_easu(vqhip_ctx* ctx, void* stream, const void* in, int inW, int in
                    void* out, int outW, int outH, vqhip_format outFmt) {
     vqk::Range range_("FSR-EASU CS");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "fsr_easu: ctx is NULL");
+    CTX_GUARD(ctx, "fsr_easu");
     if (!in || !out || !con || inW <= 0 || inH <= 0 || outW <= 0 || outH <= 0 || inW >= (1 << 24) || outW >= (1 << 24))
         return fail(ctx, VQHIP_ERR_INVALID_ARG, "fsr_easu: bad argument");
     if (!isColorFmt(inFmt) || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "fsr_easu: formats must be RGBA8_UNORM, RGBA16F or RGBA32F");
@@ -611,6 +717,7 @@ int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void* out, int 
                    vqhip_format inFmt, vqhip_format outFmt) {
     vqk::Range range_("FSR-RCAS CS");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "fsr_rcas: ctx is NULL");
+    CTX_GUARD(ctx, "fsr_rcas");
     if (!in || !out || !con || width <= 0 || height <= 0 || width >= (1 << 24)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "fsr_rcas: bad argument");
     if (!isColorFmt(inFmt) || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "fsr_rcas: formats must be RGBA8_UNORM, RGBA16F or RGBA32F");
     if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "fsr_rcas: in-place is not supported");
@@ -623,6 +730,7 @@ int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int
                     vqhip_format inFmt, vqhip_format outFmt) {
     vqk::Range range_("RenderPostProcess_DebugViz");      // :2543
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "visualize: ctx is NULL");
+    CTX_GUARD(ctx, "visualize");
     if (!in || !out || !params || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "visualize: bad argument");
     if (!isColorFmt(inFmt) || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "visualize: formats must be RGBA8_UNORM, RGBA16F or RGBA32F");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -633,6 +741,7 @@ int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int
 int vqhip_apply_reflections(vqhip_ctx* ctx, void* stream, const void* reflectionRadiance, void* sceneColor, int width, int height, vqhip_format fmt) {
     vqk::Range range_("CompositeReflections");            // :2374
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "apply_reflections: ctx is NULL");
+    CTX_GUARD(ctx, "apply_reflections");
     if (!reflectionRadiance || !sceneColor || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "apply_reflections: bad argument");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "apply_reflections: fmt must be RGBA32F or RGBA16F");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -659,6 +768,7 @@ int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, 
     vqk::Range range_("DiffuseIrradianceCubemap");
     int rc = checkChain(ctx, equirect_mips, w0, h0, nMips, "conv_diffuse");
     if (rc) return rc;
+    CTX_GUARD(ctx, "conv_diffuse");
     if (!outCube || diffuseRes <= 0 || !(step > 0.0f)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_diffuse: bad argument");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_diffuse: fmt must be RGBA32F or RGBA16F");
     if (order != VQHIP_CONV_SEQUENTIAL && order != VQHIP_CONV_WAVE64) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_diffuse: bad order");
@@ -688,6 +798,7 @@ int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equirect_mips,
     vqk::Range range_("SpecularIrradianceCubemap");
     int rc = checkChain(ctx, equirect_mips, w0, h0, nMips, "conv_specular");
     if (rc) return rc;
+    CTX_GUARD(ctx, "conv_specular");
     const int MIPS = vqhip_specular_mip_count(specRes0);
     if (!outCubeMips || specRes0 < 4 || (specRes0 & (specRes0 - 1)) || MIPS < 2) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_specular: specRes0 must be a power of two >= 4");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_specular: fmt must be RGBA32F or RGBA16F");
@@ -708,6 +819,7 @@ int vqhip_envmap_prefilter(vqhip_ctx* ctx, void* stream, const void* equirect_mi
                            int diffuseRes, float diffuseStep, int specRes0, vqhip_conv_order order, const vqhip_envmap_out* out) {
     vqk::Range range_("RenderEnvironmentMapCubeFaces");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "envmap_prefilter: ctx is NULL");
+    CTX_GUARD(ctx, "envmap_prefilter");
     if (!out || !out->diffuse_blurred || !out->blur_tmp || !out->specular) return fail(ctx, VQHIP_ERR_INVALID_ARG, "envmap_prefilter: missing output buffer");
     void* diff = out->diffuse_unblurred;
     const size_t faceBytes = (size_t)diffuseRes * diffuseRes * 8;

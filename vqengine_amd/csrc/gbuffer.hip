@@ -24,9 +24,12 @@
 // materials stream at the HBM roof; with all seven maps bound the kernel is bound by VALU + L1 gathers.
 //
 // Arithmetic/sampling contract: DESIGN.md "G-buffer producer".
-#include "vq_internal.h"
-#include "vq_sampling.h"
+#include "vq_shade.h"          // vq_internal.h, vq_devmath.h, vq_sampling.h + the lighting body of the fused kernel
 
+#include <cstdlib>
+#ifndef VQ_PSMAIN_WAVES_DEFAULT
+#define VQ_PSMAIN_WAVES_DEFAULT 5      // measured at 4K, 12 materials + 64 lights + IBL (profiles/r3e_psmain.jsonl): 4 / 5 / 6 waves -> 1.532 / 1.529 / 1.552 ms
+#endif
 namespace vqk {
 using namespace vqd;
 
@@ -148,12 +151,13 @@ struct MaterialSampler {
     }
 };
 
-__global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
+// The G-buffer record of pixel (x, y) — the state of PSMain at ForwardLighting.hlsl:284-293 — for the lane's pixel of the wave's 32x2 strip;
+// all-zero for a pixel without geometry or a discarded fragment. Every lane of the wave must call it (quad swaps, ballots).
+struct Record { float4 g0, g1, g2, g3; };
+VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane) {
     const GbufConstants* __restrict__ gc = a.gc;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = (blockIdx.x * 4 + wave) * 32 + ((lane >> 2) << 1) + (lane & 1);
-    const int y = blockIdx.y * 2 + ((lane >> 1) & 1);
-    const bool inside = (x < a.width) & (y < a.height);
+    Record rec;
+    rec.g0 = rec.g1 = rec.g2 = rec.g3 = make_float4(0, 0, 0, 0);
     const uint32_t o = (__umul24(y, a.pitch) + (uint32_t)x) << 4;      // 32-bit byte offsets: planes are < 4 GB (checked by the C ABI)
 
     float4 i0 = make_float4(0, 0, 0, 0), i1 = i0, i2 = i0;
@@ -167,11 +171,7 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
     const float hu = __shfl_xor(i0.w, 1), hv = __shfl_xor(i1.w, 1); const int hidx = __shfl_xor(idx, 1);
     const float vu = __shfl_xor(i0.w, 2), vv = __shfl_xor(i1.w, 2); const int vidx = __shfl_xor(idx, 2);
 
-    const uint32_t q = (__umul24(y, a.outPitch) + (uint32_t)x) << 4;
-    if (inside && idx < 0) {                                          // no geometry: all-zero record
-        const float4 z = make_float4(0, 0, 0, 0);
-        *(float4*)((char*)a.gb0 + q) = z; *(float4*)((char*)a.gb1 + q) = z; *(float4*)((char*)a.gb2 + q) = z; *(float4*)((char*)a.gb3 + q) = z;
-    }
+    // idx < 0 (no geometry): the record stays all-zero
 
     bool todo = idx >= 0;
     for (;;) {
@@ -221,9 +221,7 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
             // the fragment is gone: zero record, and the pixel's index in the coverage plane becomes "no geometry" (quad partners keep the
             // index they read before, like the helper lanes of a discarded fragment keep serving derivatives)
             if ((mt.texDiffuse.reserved & VQHIP_MATERIAL_ALPHA_MASKED) && has_bit(TEX_CFG, 0) && AlbedoAlpha.w < 0.01f) {
-                const float4 z = make_float4(0, 0, 0, 0);
-                *(float4*)((char*)a.gb0 + q) = z; *(float4*)((char*)a.gb1 + q) = z; *(float4*)((char*)a.gb2 + q) = z; *(float4*)((char*)a.gb3 + q) = z;
-                ((float*)((char*)a.ip2 + o))[3] = __int_as_float(-1);
+                ((float*)((char*)a.ip2 + o))[3] = __int_as_float(-1);            // the record stays all-zero
                 todo = false;
                 continue;
             }
@@ -261,18 +259,69 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
                 ty = ty >= gc->ssao.height ? ty - gc->ssao.height : ty;
                 ao *= (float)((const uint8_t*)gc->ssao.texels)[(uint32_t)ty * (uint32_t)gc->ssao.width + (uint32_t)tx] * 0.0039215688593685627f;
             }
-            *(float4*)((char*)a.gb0 + q) = make_float4(i0.x, i0.y, i0.z, ao);                                  // :284
-            *(float4*)((char*)a.gb1 + q) = make_float4(SurfN.x, SurfN.y, SurfN.z, roughness);
-            *(float4*)((char*)a.gb2 + q) = make_float4(diffuseColor.x, diffuseColor.y, diffuseColor.z, metalness);
-            *(float4*)((char*)a.gb3 + q) = make_float4(emissiveColor.x, emissiveColor.y, emissiveColor.z, m.emissiveIntensity);   // :251
+            rec.g0 = make_float4(i0.x, i0.y, i0.z, ao);                                  // :284
+            rec.g1 = make_float4(SurfN.x, SurfN.y, SurfN.z, roughness);
+            rec.g2 = make_float4(diffuseColor.x, diffuseColor.y, diffuseColor.z, metalness);
+            rec.g3 = make_float4(emissiveColor.x, emissiveColor.y, emissiveColor.z, m.emissiveIntensity);   // :251
             todo = false;
         }
     }
+    return rec;
 }
+
+// lane -> pixel of the wave's 32x2 strip, quad-major (lanes 4q..4q+3 = the 2x2 pixel quad q)
+VQD void strip_pixel(int& x, int& y, int& lane) {
+    lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    x = (blockIdx.x * 4 + wave) * 32 + ((lane >> 2) << 1) + (lane & 1);
+    y = blockIdx.y * 2 + ((lane >> 1) & 1);
+}
+
+__global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
+    int x, y, lane;
+    strip_pixel(x, y, lane);
+    const bool inside = (x < a.width) & (y < a.height);
+    const Record r = produce_record(a, x, y, inside, lane);
+    if (!inside) return;
+    const uint32_t q = (__umul24(y, a.outPitch) + (uint32_t)x) << 4;
+    *(float4*)((char*)a.gb0 + q) = r.g0; *(float4*)((char*)a.gb1 + q) = r.g1; *(float4*)((char*)a.gb2 + q) = r.g2; *(float4*)((char*)a.gb3 + q) = r.g3;
+}
+
+// PSMain as the engine has it (ForwardLighting.hlsl:226-380): the producer and the lighting body (vq_shade.h) in ONE kernel — the 64-byte record
+// stays in registers instead of making a 128 B/pixel round trip through HBM. Bit-identical to vqhip_gbuffer_from_materials followed by
+// vqhip_forward_lighting (the record is the same fp32 values either way; pixels without geometry shade the all-zero record like the two calls do).
+template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_forward_from_materials(GbufArgs a, const FrameConstants* fc, void* out, int outPitch) {
+    int x, y, lane;
+    strip_pixel(x, y, lane);
+    const bool inside = (x < a.width) & (y < a.height);
+    const Record r = produce_record(a, x, y, inside, lane);
+    if (!inside) return;
+    const float4 c = shade_pixel<HAS_ENV, HAS_CASTERS>(r.g0, r.g1, r.g2, r.g3, fc);
+    store_px<OUTFMT>(out, (size_t)y * outPitch + x, c);
+}
+
 
 hipError_t launch_gbuffer_from_materials(hipStream_t s, const GbufArgs& a) {
     dim3 grid((a.width + 127) / 128, (a.height + 1) / 2);
     hipLaunchKernelGGL(k_gbuffer_from_materials, grid, dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt) {
+    dim3 grid((a.width + 127) / 128, (a.height + 1) / 2);
+    // register budget of the fused kernel: the producer half peaks at ~120 VGPRs (4 waves per SIMD), the lighting half needs 67; VQHIP_PSMAIN_WAVES = 5 / 6
+    // caps the kernel at 96 / 80 VGPRs (the producer half then spills a little, the 64-light loop runs at higher occupancy)
+    const char* we = std::getenv("VQHIP_PSMAIN_WAVES");          // read per launch (~0.1 us): tests and benches switch the form inside one process
+    const int wv = we ? std::atoi(we) : VQ_PSMAIN_WAVES_DEFAULT;
+#define FFM(E, C, F) do { if (wv >= 6) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 6>), grid, dim3(256), 0, s, a, fc, out, outPitch); \
+                          else if (wv == 5) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 5>), grid, dim3(256), 0, s, a, fc, out, outPitch); \
+                          else hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 4>), grid, dim3(256), 0, s, a, fc, out, outPitch); } while (0)
+#define FFM2(E, C) do { if (outFmt == VQHIP_FMT_RGBA32F) FFM(E, C, 0); else FFM(E, C, 1); } while (0)
+    if (hasEnv) { if (hasCasters) FFM2(true, true); else FFM2(true, false); }
+    else        { if (hasCasters) FFM2(false, true); else FFM2(false, false); }
+#undef FFM2
+#undef FFM
     return hipGetLastError();
 }
 

@@ -1,325 +1,8 @@
-// shade.hip — forward-PBR lighting kernel for gfx950: ForwardLighting.hlsl:PSMain :289-380 evaluated per
-// G-buffer pixel. One lane per pixel, 256-lane workgroups, float4 SoA plane
-// loads (16 B/lane, fully coalesced), light records read through the scalar cache (wave-uniform index),
-// every light-invariant term hoisted to per-pixel setup.
-//
-// Arithmetic follows the contract in DESIGN.md §3 (intrinsic lowering: vq_devmath.h). Contract v5: everything evaluated once per
-// pixel, and per light the chain into the GGX denominator and the range cull (Lw - P, its length, Wi, H, dot(N,H), nh2*(a2-1)+1), is
-// the HLSL AS WRITTEN (products / sums rounded one by one, IEEE quotients: the *_lit functions) — one ulp there is tens of RGBA16F
-// ulps of a highlight pixel. The insensitive rest of the light loop keeps the regrouped trees of contract v2-v4 (scalar factors of
-// vector products gathered, a*b+c as one mad, the three divisions of D*G/denom merged into one reciprocal, 1/(D*D) = (1/D)^2):
-//   Shaders/BRDF.hlsl:65-79,82-97,118-121,132-136,152-161,163-207
-//   Shaders/Lighting.hlsl:29-32,57-73,110-174,177-272,308-395
-//   Shaders/ForwardLighting.hlsl:284-380
-#include "vq_internal.h"
-#include "vq_devmath.h"
-#include "vq_sampling.h"
-
-using namespace vqd;
+// shade.hip — forward-PBR lighting kernel for gfx950: ForwardLighting.hlsl:PSMain :289-380 evaluated per G-buffer pixel (SURVEY.md §8a rows
+// A1-A7). One lane per pixel, 256-lane workgroups, float4 SoA plane loads (16 B/lane, fully coalesced); the per-pixel body is vq_shade.h.
+#include "vq_shade.h"
 
 namespace {
-
-constexpr float PI_      = 3.14159265359f;    // ShadingMath.hlsl:25
-constexpr float EPSILON_ = 0.000000000001f;   // BRDF.hlsl:21
-
-#ifndef VQ_SHADE_WAVES
-#define VQ_SHADE_WAVES 1
-#endif
-
-// Per-pixel state: BRDF_Surface (BRDF.hlsl:50-58) + everything in BRDF() that does not depend on the light.
-struct Pixel {
-    f3 P, V, Wo, Nraw, Nn, albedo, F0, omF0, kA;
-    float roughness, metalness, omm;      // omm = 1 - metalness
-    float NdotV4;                         // 4 * saturate(dot(N, Wo))
-    float G1V;                            // Geometry_Smiths_SchlickGGX(N, Wo, roughness)
-    float k, omk;                         // k = (roughness+1)^2/8, omk = 1-k
-    float a2, a2m1;                       // GGX alpha^2, alpha^2 - 1
-    float a2G1V;                          // a2 * G1V: the light-independent part of the merged D*G numerator
-    bool p5ExpLog;                        // wave-uniform: Fresnel pow as exp2(5*log2 x) instead of the product (vqhip_set_fresnel_pow). Kept a RUN-TIME
-                                          // flag on purpose: with the mode as a template parameter (no branch in the light loop) the same arithmetic ran
-                                          // 9 % slower on the same box (profiles/r2c_shade_variants.md) — the scheduler's choice for the longer block
-    bool fastOK;                          // roughness in [0,1] and a finite Wo: precondition of the unchecked fast reciprocals (add_point_light)
-    bool skipOK;                          // finite F0 / kA and a normal close to the wave's first one: this lane may take part in the back-facing-light skip
-};
-
-VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
-VQD float min3abs_acc(float m, float a, float b) { return __builtin_fminf(__builtin_fminf(m, __builtin_fabsf(a)), __builtin_fabsf(b)); }   // m >= 0
-VQD float min3abs(f3 v) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)); }   // one v_min3_f32 with |.| modifiers
-
-VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
-    px.P = mk3(g0.x, g0.y, g0.z);
-    px.Nraw = mk3(g1.x, g1.y, g1.z);
-    px.roughness = g1.w;
-    px.albedo = mk3(g2.x, g2.y, g2.z);
-    px.metalness = g2.w;
-    // once per pixel: as written (contract v5)
-    px.V = normalize_lit(sub(cam, px.P));                    // ForwardLighting.hlsl:285
-    px.Wo = normalize_lit(px.V);                             // BRDF.hlsl:166
-    px.Nn = normalize_lit(px.Nraw);                          // :167
-    px.F0 = mk3(lerp_lit(0.04f, px.albedo.x, px.metalness), lerp_lit(0.04f, px.albedo.y, px.metalness), lerp_lit(0.04f, px.albedo.z, px.metalness));   // :178
-    px.omF0 = mk3(1.0f - px.F0.x, 1.0f - px.F0.y, 1.0f - px.F0.z);
-    px.omm = 1.0f - px.metalness;
-    const float invPI = rcp(PI_);
-    px.kA = mk3((px.omm * px.albedo.x) * invPI, (px.omm * px.albedo.y) * invPI, (px.omm * px.albedo.z) * invPI);     // (1-metal)*albedo/PI
-    const float NdotV = saturate(dot_lit(px.Nn, px.Wo));     // :171
-    px.NdotV4 = 4.0f * NdotV;
-    const float rp1 = px.roughness + 1.0f;                   // Geometry_Smiths_SchlickGGX :92-96
-    px.k = (rp1 * rp1) * 0.125f;                             // / 8.0f: exact either way
-    px.omk = 1.0f - px.k;
-    const float NV = max_(0.0f, dot_lit(px.Nn, px.Wo));
-    px.G1V = fdiv_(NV, (NV * px.omk + px.k) + 0.0001f);
-    const float a = px.roughness * px.roughness;             // NormalDistributionGGX :74-75
-    px.a2 = a * a;
-    px.a2m1 = px.a2 - 1.0f;
-    px.a2G1V = px.a2 * px.G1V;
-    // preconditions of the unchecked fast path of add_point_light that depend on the pixel only: roughness in [0, 1] (below 0.04 the GGX
-    // EPSILON early-out may fire: such a wave takes the loop form that keeps the early-out as a select, RcpTrustEps) and a finite Wo (with a
-    // finite Wi it makes Wo + Wi free of NaN, which the min3 test there cannot see)
-    px.fastOK = (px.roughness >= 0.0f) & (px.roughness <= 1.0f) & (dot_lit(px.Wo, px.Wo) <= 4.0f);       // the comparison is false for a NaN component
-    // the skip of back-facing lights (add_point_light<.., true>) needs a finite BRDF whatever the light: finite F0 (hence 1 - F0) and kA
-    px.skipOK = ((__builtin_fabsf(px.F0.x) + __builtin_fabsf(px.F0.y) + __builtin_fabsf(px.F0.z)) +
-                 (__builtin_fabsf(px.kA.x) + __builtin_fabsf(px.kA.y) + __builtin_fabsf(px.kA.z))) < __builtin_inff();
-}
-
-// BRDF(s, Wi, V), BRDF.hlsl:163-194. As written: H = normalize(Wo + Wi) (IEEE quotients through rc.div), NdotH, nh2*(a2-1)+1.
-// Regrouped (contract v2-v4): fma(F, sG - kA, kA) with sG = (D*G)*rcp(denom) and the per-pixel kA = ((1-metal)*albedo)*rcp(PI).
-// `rc` is the reciprocal / sqrt / quotient policy (vq_devmath.h).
-template <class R>
-VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
-    const f3 Hs = add(px.Wo, Wi);
-    const float Hl = rc.sqrt(dot_lit(Hs, Hs));               // length(Wo + Wi)
-    const float rH = rc(Hl);
-    const f3 H = mk3(rc.div(Hs.x, Hl, rH), rc.div(Hs.y, Hl, rH), rc.div(Hs.z, Hl, rH));     // :168
-    const float NdotH = saturate(dot_lit(px.Nn, H));         // :169
-    const float dNL = dot(px.Nn, Wi);
-    const float NdotL = saturate(dNL);
-    // Fresnel_Schlick(H, V, F0) :132-136
-    const float x5 = 1.0f - max_(0.0f, dot(H, px.V));
-    const float p5 = px.p5ExpLog ? pow5_explog(x5) : pow5(x5);   // default: x*((x*x)*(x*x)), FXC's mul-only pattern (contract v4)
-    const f3 F = mk3(fma_(px.omF0.x, p5, px.F0.x), fma_(px.omF0.y, p5, px.F0.y), fma_(px.omF0.z, p5, px.F0.z));
-    // D*G/denom with the three divisions merged into one (contract v3):
-    //   D = a2/(PI t^2) (NormalDistributionGGX :65-79; 1 when PI t^2 < EPSILON), G = G1V * NL/(NL(1-k)+k+1e-4) (Geometry_Smith :118-121)
-    //   sG = ((a2*G1V) * NL) * rcp((PI t^2 * gL) * denom)      [ (G1V*NL) * rcp(gL*denom) on the EPSILON branch ]
-    const float NL = max_(0.0f, dNL);
-    const float gL = fma_(NL, px.omk, px.k) + 0.0001f;
-    const float nh2 = NdotH * NdotH;
-    const float t = nh2 * px.a2m1 + 1.0f;                    // :77 as written: the product is rounded before the sum
-    const float dd = PI_ * (t * t);
-    const float den = max_(px.NdotV4 * NdotL, 0.0001f);
-    float sG;
-    if constexpr (R::kGgxDenomAboveEps) {
-        sG = (px.a2G1V * NL) * rc((dd * gL) * den);          // `if (denom < EPSILON) return 1` (:76) cannot trigger: proven below (RcpTrust)
-    } else {
-        const bool eps = dd < EPSILON_;
-        const float num = (eps ? px.G1V : px.a2G1V) * NL;
-        const float d3 = eps ? gL * den : (dd * gL) * den;
-        sG = num * rc(d3);
-    }
-    // Id + Is = (1-F)*kA + F*sG regrouped as kA + F*(sG - kA) (contract v3)
-    return mk3(fma_(F.x, sG - px.kA.x, px.kA.x), fma_(F.y, sG - px.kA.y, px.kA.y), fma_(F.z, sG - px.kA.z, px.kA.z));
-}
-
-// acc + b * (cb * w): cb = l.color * l.brightness, w = attenuation [* cone] * NdotL (one mad per channel)
-VQD f3 lit(f3 acc, f3 b, f3 cb, float w) { return mk3(fma_(b.x, cb.x * w, acc.x), fma_(b.y, cb.y * w, acc.y), fma_(b.z, cb.z * w, acc.z)); }
-VQD f3 light_cb(const VQ_float3& color, float brightness) { return mk3(color.x * brightness, color.y * brightness, color.z * brightness); }
-
-// CalculatePointLightIllumination, Lighting.hlsl:308-322 (general form, shadow casters)
-template <class R>
-VQD f3 point_light_t(const Pixel& px, f3 lpos, float range, f3 cb, f3 acc, R& rc) {
-    const f3 d = sub(lpos, px.P);
-    const float D = rc.sqrt(dot_lit(d, d));                  // length(Lw - P) as written; normalize() shares the sqrt
-    if (D < range) {
-        const float rD = rc(D);                              // one reciprocal for the quotients of normalize(Lw - P) and for AttenuationBRDF :29-32
-        const f3 Wi = mk3(rc.div(d.x, D, rD), rc.div(d.y, D, rD), rc.div(d.z, D, rD));
-        const float NdotL = saturate(dot(px.Nraw, Wi));
-        const float w = (rD * rD) * NdotL;                   // 1/(D*D) as (1/D)*(1/D) (contract v3)
-        return lit(acc, brdf_t(px, Wi, rc), cb, w);
-    }
-    return acc;
-}
-VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op validity flag; used for the <= 5 casters
-    const f3 zero = mk3(0.0f, 0.0f, 0.0f), cb = light_cb(l.color, l.brightness);
-    RcpFast fast;
-    f3 r = point_light_t(px, ld3(l.position), l.range, cb, zero, fast);
-    if (__builtin_expect(!fast.ok, 0)) { RcpIEEE ieee; r = point_light_t(px, ld3(l.position), l.range, cb, zero, ieee); }
-    return r;
-}
-
-// Hot-loop form: I = CalculatePointLightIllumination(..., acc = I). All reciprocals / square roots use the unchecked
-// fast sequences (RcpTrust); their validity is PROVEN from range tests instead of being checked per operation, and the tests are
-// folded into ONE comparison per pixel after the loop (vmin, below):
-//   pixel  : roughness in [0.04,1]  (px.fastOK + the wave-uniform `eps` test of k_forward_lighting)  =>  k in [1/8,1/2], 1-k in [1/2,7/8],
-//              a2 in [2.5e-6,1], hence
-//              gL = fma(NL,1-k,k)+1e-4 in [0.125, 1.4]   (NL = max(0,.) <= 1+eps, NaN -> 0)
-//              pi t^2 in [1.9e-11, pi] (t = nh2*(a2-1) + 1, product and sum each rounded — contract v5 — in [a2 - 2^-24, 1], nh2 saturated)
-//              denom = max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
-//              => the merged reciprocal's operand (pi t^2 * gL) * denom in [2.4e-16, 17.6]: operand and result normal
-//   light  : every component of Lw-P has magnitude >= 2^-40 and dd = |Lw-P|^2 < rangeSq <= 2^60 (the host checks the thresholds of the whole
-//            light set: FrameConstants::pointFastOK; a NaN / inf dd fails the cull)
-//            => dd in [2^-80, 2^60], D in [2^-40, 2^30]: sqrt, 1/D normal ((1/D)^2 is a plain product), quotients d/D free of underflow
-//   light  : every component of Wo+Wi has magnitude >= 2^-40 (Wo, Wi finite => no NaN) => hh = |Wo+Wi|^2 in [2^-80, ~4]
-//   => the corrected quotients d/D, Hs/|Hs| (fdiv_rcp: exhaustively equal to IEEE division when nothing underflows) are the IEEE
-//      quotients; a zero or tiny component (a light exactly above the pixel on one axis) sends the pixel to the IEEE loop
-// all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
-// degenerate geometry, roughness outside [0,1], a range beyond 2^30) redoes the pixel's point-light loop with IEEE operations
-// (k_forward_lighting); where both are valid the two give identical bits, so the redo changes only what was invalid.
-struct RcpTrust {
-    // roughness >= 0.04 (every lane of the wave: `eps` in k_forward_lighting) => a2 >= 2.56e-6, t = RN(RN(nh2*(a2-1)) + 1) >= a2 - 2^-24 >= 2.5e-6
-    // for nh2 in [0,1] => pi t^2 >= 1.9e-11 > EPSILON (1e-12): the GGX early-out never fires on this path
-    static constexpr bool kGgxDenomAboveEps = true;
-    VQD float operator()(float b) const { return rcp_newton(b); }
-    VQD float sqrt(float x) const { return sqrt_newton(x); }
-    VQD float div(float a, float b, float r) const { return fdiv_rcp(a, b, r); }
-};
-// The same fast sequences for a wave that holds a pixel of roughness < 0.04 (polished metal, a2 down to 0): there pi t^2 can fall below EPSILON
-// and `if (denom < EPSILON) return 1` (BRDF.hlsl:76) must stay — as a select, like the IEEE form. The reciprocal's operand is then
-// gL * denom in [1.25e-5, 5.6] on the early-out branch and (pi t^2 * gL) * denom >= 1e-12 * 0.125 * 1e-4 otherwise: still normal, so the
-// validity proof above carries over with roughness in [0, 1] (k in [1/8, 1/2] as before). Where the early-out cannot fire the select form
-// and RcpTrust give identical bits, so which of the two a wave runs is a pure speed choice (+3 VALU per light).
-struct RcpTrustEps : RcpTrust { static constexpr bool kGgxDenomAboveEps = false; };
-// `vmin` collects the smallest |component| of Lw-P and Wo+Wi over the lights that passed the range cull (three v_min3 with |.| modifiers);
-// the caller compares it with 2^-40 ONCE after the loop and, when the test fails, redoes the pixel's whole point-light loop with IEEE
-// operations (k_forward_lighting) — the accumulator needs no copy per light and the loop carries no validity masks.
-// dd <= 2^60 follows from dd < rangeSq <= 2^60 (FrameConstants::pointFastOK, host); a NaN / inf dd fails the cull like the reference's D < range.
-// SKIP (wave-uniform choice of the caller): a light that faces away from every lane that passed the cull — NdotL = saturate(dot(N, Wi)) = +0 —
-// adds b * (cb * +0) = +-0 to the accumulator when b and cb are finite, which changes nothing unless the accumulator holds a zero (the sign of
-// -0 + +0). `izmin` = min |component| of I is kept per lane; when no lane has NdotL > 0 or a zero in I the BRDF (~70 of the ~108 VALU of a
-// light) is skipped for the wave. Finite b: px.skipOK (finite F0, kA) and the proven ranges above; finite cb: FrameConstants::pointSkipOK;
-// the product form of the Fresnel power only (exp2(5 log2 x) is NaN for the x = -6e-8 that a dot product rounding above 1 yields).
-// On surface-coherent content about half the lights are behind the surface of a whole wave; white-noise normals never take this form.
-template <class RC, bool SKIP>
-VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I, float& vmin, float& izmin) {
-    const f3 lpos = mk3(l.px, l.py, l.pz), cb = mk3(l.cbx, l.cby, l.cbz);
-    const f3 d = sub(lpos, px.P);
-    const float dd = dot_lit(d, d);                          // as written: D decides the range cull
-    if (dd < l.rangeSq) {                                    // == (length(Lw - P) < l.range), exactly (host-made threshold): culled lights
-        RC rc;                                               // need no square root; wave-coherent (execz skip)
-        const float D = sqrt_newton(dd);
-        const float rD = rc(D);
-        const f3 Wi = mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P)
-        const f3 Hs = add(px.Wo, Wi);
-        vmin = min3abs_acc(min3abs_acc(min3abs_acc(vmin, d.x, d.y), d.z, Hs.x), Hs.y, Hs.z);
-        const float dNL = dot(px.Nraw, Wi);
-        if (SKIP) { if (__builtin_amdgcn_ballot_w64((dNL > 0.0f) | !(izmin > 0.0f)) == 0) return; }
-        const float NdotL = saturate(dNL);
-        const float w = (rD * rD) * NdotL;
-        const f3 b = brdf_t(px, Wi, rc);
-        I = lit(I, b, cb, w);
-        if (SKIP) izmin = min3abs(I);
-    }
-}
-template <class RC, bool SKIP>
-VQD void point_light_loop(const Pixel& px, const vqk::DevPointLight* pts, int nP, f3& I, float& vmin) {
-    float izmin = SKIP ? min3abs(I) : 0.0f;
-    for (int p = 0; p < nP; ++p) add_point_light<RC, SKIP>(px, pts[p], I, vmin, izmin);
-}
-
-// SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333 (no range cull)
-VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, f3 acc) {
-    const f3 d = sub(ld3(l.position), px.P);
-    const float D = length_lit(d);
-    const f3 Wi = div_lit(d, D);                             // normalize(l.position - P) as written
-    const float rD = rcp(D);
-    const f3 pd = normalize_lit(sub(px.P, ld3(l.position))); // SpotlightIntensity as written: acos near 1 amplifies every ulp
-    const f3 sd = normalize_lit(ld3(l.spotDir));
-    const float theta = acos_(dot_lit(pd, sd));
-    float cone;
-    if (theta > l.outerConeAngle) cone = 0.0f;
-    else if (theta <= l.innerConeAngle) cone = 1.0f;
-    else cone = 1.0f - fdiv_(theta - l.innerConeAngle, l.outerConeAngle - l.innerConeAngle);
-    const float NdotL = saturate(dot(px.Nraw, Wi));
-    const float w = (cone * (rD * rD)) * NdotL;
-    RcpIEEE rc;
-    return lit(acc, brdf_t(px, Wi, rc), light_cb(l.color, l.brightness), w);
-}
-
-// CalculateDirectionalLightIllumination :334-345
-VQD f3 directional_light(const Pixel& px, const VQ_DirectionalLight& l) {
-    const f3 Wi = normalize_lit(neg(ld3(l.lightDirection)));
-    const float NdotL = saturate(dot(px.Nraw, Wi));
-    RcpIEEE rc;
-    return lit(mk3(0.0f, 0.0f, 0.0f), brdf_t(px, Wi, rc), light_cb(l.color, l.brightness), NdotL);
-}
-
-VQD f3 mul_v_m3(f3 v, float c, float s) {     // mul(v, GetHDRIRotationMatrix) with m = {c,0,s; 0,1,0; -s,0,c}, as written (zero terms kept)
-    return mk3((v.x * c + v.y * 0.0f) + v.z * -s,
-               (v.x * 0.0f + v.y * 1.0f) + v.z * 0.0f,
-               (v.x * s + v.y * 0.0f) + v.z * c);
-}
-
-// CalculateEnvironmentMapIllumination(+_DiffuseOnly), Lighting.hlsl:348-395 ; EnvironmentBRDF BRDF.hlsl:196-207
-VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
-    const float sn = fc->hdriSin, cs = fc->hdriCos;          // sin / cos(-fHDRIOffsetInRadians), correctly rounded, from the host (capi.hip)
-    const float NdotV = saturate(dot_lit(px.Nraw, px.V));    // everything here runs once per pixel: as written (contract v5)
-    const f3 N = mul_v_m3(px.Nraw, cs, sn);
-    const float4 irr = sample_cube_rgba16f(fc->env.diffuse_cube, fc->env.diffuse_res, N);
-    f3 spec = mk3(0, 0, 0); float2 sb = make_float2(0, 0);
-    if (!fc->perView.EnvironmentMapDiffuseOnlyIllumination) {
-        const f3 R = mul_v_m3(reflect_lit(neg(px.V), px.Nraw), cs, sn);
-        const int maxLod = f2i_trunc(fc->perView.MaxEnvMapLODLevels);
-        int mip = f2i_trunc(px.roughness * (float)maxLod);
-        mip = min(max(mip, 0), fc->env.spec_mips - 1);
-        // texel offset of level `mip` in the mip-major cube: sum_{m<mip} 6*(res0>>m)^2; for a power-of-two res0 (every mip
-        // exact) that is 8*(res0^2 - (res0>>mip)^2)
-        const int res0 = fc->env.spec_res0, rm = res0 >> mip;
-        uint32_t off;
-        if ((res0 & (res0 - 1)) == 0) off = 8u * (uint32_t)(res0 * res0 - rm * rm);
-        else { off = 0; for (int m = 0; m < mip; ++m) { const uint32_t r = (uint32_t)(res0 >> m); off += 6u * r * r; } }
-        const float4 sp = sample_cube_rgba16f((const h4*)fc->env.specular_cube + off, rm, R);
-        spec = mk3(sp.x, sp.y, sp.z);
-        sb = sample_2d_rg16f_clamp(fc->env.brdf_lut, fc->env.lut_size, fc->env.lut_size, NdotV, px.roughness);
-    }
-    const float p5 = px.p5ExpLog ? pow5_explog(1.0f - NdotV) : pow5(1.0f - NdotV);   // FresnelWithRoughness :152-156
-    const float omr = 1.0f - px.roughness;
-    const f3 Ks = mk3(px.F0.x + (max_(omr, px.F0.x) - px.F0.x) * p5, px.F0.y + (max_(omr, px.F0.y) - px.F0.y) * p5, px.F0.z + (max_(omr, px.F0.z) - px.F0.z) * p5);
-    const f3 Kd = mk3((1.0f - Ks.x) * px.omm, (1.0f - Ks.y) * px.omm, (1.0f - Ks.z) * px.omm);
-    const f3 diffuse = mk3(irr.x * px.albedo.x, irr.y * px.albedo.y, irr.z * px.albedo.z);
-    const f3 specular = mk3(spec.x * (Ks.x * sb.x + sb.y), spec.y * (Ks.y * sb.x + sb.y), spec.z * (Ks.z * sb.x + sb.y));
-    return mk3(Kd.x * diffuse.x + specular.x, Kd.y * diffuse.y + specular.y, Kd.z * diffuse.z + specular.z);
-}
-
-VQD float4 mul_M_v(const VQ_matrix& M, f3 P) {     // HLSL mul(M, float4(P,1)) == row vector * M_cpu
-    float o[4];
-    for (int j = 0; j < 4; ++j) o[j] = ((P.x * M.m[0][j] + P.y * M.m[1][j]) + P.z * M.m[2][j]) + 1.0f * M.m[3][j];   // as written
-    return make_float4(o[0], o[1], o[2], o[3]);
-}
-
-// SAMPLE_OFFSET_DIRS_NORMALIZED, Lighting.hlsl:123-131
-#define PA 0.5773502691896258f
-#define PB 0.7071067811865475f
-__device__ const float DX[20] = {  PA,  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PB,  PB, -PB, -PB,  PB, -PB,  PB, -PB,  0,  0,  0,  0 };
-__device__ const float DY[20] = {  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PA,  PB, -PB, -PB,  PB,  0,  0,  0,  0,  PB, -PB, -PB,  PB };
-__device__ const float DZ[20] = {  PA,  PA,  PA,  PA, -PA, -PA, -PA, -PA,  0,  0,  0,  0,  PB,  PB, -PB, -PB,  PB,  PB, -PB, -PB };
-#undef PA
-#undef PB
-// OmnidirectionalShadowTestPCF, Lighting.hlsl:110-174
-VQD float omni_pcf(const float* cubeArr, int dim, int index, f3 Lw, float farPlane, float depthBias, float viewDist) {
-    const float diskRadius = (1.0f + fdiv_(viewDist, farPlane)) * 0.125f;
-    const float* cube = cubeArr + (size_t)index * 6 * dim * dim;
-    const float lenLw = length_lit(Lw);
-    float shadow = 0.0f;
-    for (int i = 0; i < 20; ++i) {
-        const f3 sv = mk3(-(Lw.x + DX[i] * diskRadius), -(Lw.y + DY[i] * diskRadius), -(Lw.z + DZ[i] * diskRadius));
-        const float closest = fetch_cube_point(cube, dim, sv) * farPlane;
-        shadow += (lenLw > (closest + depthBias) + 0.001f) ? 1.0f : 0.0f;
-    }
-    return 1.0f - fdiv_(shadow, 20.0f);
-}
-// ShadowTestPCF :177-218 (useTanBias) / ShadowTestPCF_Directional :222-272 (raw bias)
-VQD float pcf_2d(const float* slice, int dim, float2 smDims, float4 lsp, float bias) {
-    const f3 p = mk3(fdiv_(lsp.x, lsp.w), fdiv_(lsp.y, lsp.w), fdiv_(lsp.z, lsp.w));
-    if (p.x < -1.0f || p.x > 1.0f || p.y < -1.0f || p.y > 1.0f || p.z < 0.0f || p.z > 1.0f) return 0.0f;
-    const float tx = rcp(smDims.x), ty = rcp(smDims.y);
-    const float u = 0.5f + p.x * 0.5f, v = 0.5f + p.y * -0.5f;
-    const float ref = p.z - bias;
-    float shadow = 0.0f;
-    for (int x = -2; x <= 2; ++x)
-        for (int y = -2; y <= 2; ++y) {
-            const float closest = fetch_point_wrap(slice, dim, u + (float)x * tx, v + (float)y * ty);
-            shadow += (ref > closest) ? 1.0f : 0.0f;
-        }
-    return 1.0f - fdiv_(shadow, 25.0f);
-}
 
 template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT>
 __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::ShadeArgs a) {
@@ -329,92 +12,8 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     const size_t i = (size_t)y * a.pitch + x;
     const float4 g0 = a.gb0[i], g1 = a.gb1[i], g2 = a.gb2[i], g3 = a.gb3[i];
     const vqk::FrameConstants* fc = a.fc;
-
-    Pixel px;
-    const f3 cam = ld3(fc->perView.CameraPosition);
-    px.p5ExpLog = fc->pow5ExpLog != 0;
-    setup_pixel(px, g0, g1, g2, cam);
-    const float ao = g0.w;
-    // illumination accumulators, ForwardLighting.hlsl:290-293: diffuse*ao + emissive*intensity, as written
-    f3 I = mk3(px.albedo.x * ao + g3.x * g3.w, px.albedo.y * ao + g3.y * g3.w, px.albedo.z * ao + g3.z * g3.w);
-
-    if (HAS_ENV) I = add(I, environment(px, fc));                                             // :299-306
-
-    // non-shadowing point lights :310-313 — point_lights[0..numPointLights) followed by the extension array, packed by
-    // the host into 32-byte records {position, range, color*brightness}
-    const vqk::DevPointLight* pts = (const vqk::DevPointLight*)(fc + 1);
-    const int nP = fc->numPointAll;
-    // Fast loop: unchecked reciprocal / sqrt sequences whose validity is established once per pixel (vmin, see add_point_light). The rare
-    // pixel that fails (roughness outside [0, 1], a light exactly above the pixel on an axis, a range beyond 2^30, NaN inputs) is redone
-    // from the accumulator's value before the loop with IEEE operations; where both are valid the two paths agree bit for bit.
-    // (A software-pipelined prefetch of the next 32-byte record was measured and is not used: 1.034 ms vs 1.022 ms, profiles/r2c_shade_variants.md.)
-    const f3 I0 = I;
-    const bool fast = px.fastOK & (fc->pointFastOK != 0);
-    float vmin = 0.0f;
-    if (fast) {
-        vmin = __builtin_inff();
-        // wave-uniform choice among four forms of the same loop (identical bits wherever more than one applies):
-        //   eps  : some lane has roughness < 0.04 -> the GGX EPSILON early-out stays in, as a select (RcpTrustEps)
-        //   skip : every lane has a finite BRDF and a normal within 60 degrees of the first lane's (a surface, not noise) -> lights behind
-        //          the surface of the whole wave cost the cull, the normalize and one dot product instead of the BRDF
-        const bool eps = __builtin_amdgcn_ballot_w64(px.roughness < 0.04f) != 0;
-        const f3 n0 = mk3(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, px.Nraw.x))),
-                          __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, px.Nraw.y))),
-                          __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, px.Nraw.z))));
-        const bool laneSkipOK = px.skipOK & (dot(px.Nraw, n0) > 0.5f);
-        const bool skip = (fc->pointSkipOK != 0) & !px.p5ExpLog & (__builtin_amdgcn_ballot_w64(!laneSkipOK) == 0);
-        if (skip) { if (eps) point_light_loop<RcpTrustEps, true>(px, pts, nP, I, vmin); else point_light_loop<RcpTrust, true>(px, pts, nP, I, vmin); }
-        else      { if (eps) point_light_loop<RcpTrustEps, false>(px, pts, nP, I, vmin); else point_light_loop<RcpTrust, false>(px, pts, nP, I, vmin); }
-    }
-    if (__builtin_expect(!(vmin >= 0x1p-40f), 0)) {
-        I = I0;
-        RcpIEEE ieee;
-        for (int p = 0; p < nP; ++p) I = point_light_t(px, mk3(pts[p].px, pts[p].py, pts[p].pz), pts[p].range, mk3(pts[p].cbx, pts[p].cby, pts[p].cbz), I, ieee);
-    }
-    const VQ_SceneLighting& L = fc->perFrame.Lights;
-    const int nS = L.numSpotLights;
-    for (int s = 0; s < nS; ++s) I = spot_light(px, L.spot_lights[s], I);                     // :314-317
-
-    if (HAS_CASTERS) {
-        const int nPC = L.numPointCasters;
-        for (int pc = 0; pc < nPC; ++pc) {                                                    // :321-339
-            const VQ_PointLight& l = L.point_casters[pc];
-            const f3 Lw = sub(ld3(l.position), px.P);
-            const float D = length_lit(Lw);
-            if (D < l.range) {
-                const float viewDist = length_lit(sub(px.P, cam));
-                const f3 c = point_light(px, l);
-                const float sh = omni_pcf(fc->sm.point, fc->sm.point_dim, pc, Lw, l.range, l.depthBias, viewDist);
-                I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
-            }
-        }
-        const int nSC = L.numSpotCasters;
-        for (int sc = 0; sc < nSC; ++sc) {                                                    // :342-356
-            const VQ_SpotLight& l = L.spot_casters[sc];
-            const f3 Ln = normalize_lit(sub(ld3(l.position), px.P));
-            const float NdotL = saturate(dot_lit(px.Nraw, Ln));
-            const float4 lsp = mul_M_v(L.shadowViews[sc], px.P);
-            const f3 c = spot_light(px, l, mk3(0.0f, 0.0f, 0.0f));
-            const float bias = l.depthBias * tan_(acos_(NdotL));
-            const float sh = pcf_2d(fc->sm.spot + (size_t)sc * fc->sm.spot_dim * fc->sm.spot_dim, fc->sm.spot_dim,
-                                    make_float2(fc->perFrame.f2SpotLightShadowMapDimensions.x, fc->perFrame.f2SpotLightShadowMapDimensions.y), lsp, bias);
-            I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
-        }
-    }
-    {                                                                                         // :360-377
-        const VQ_DirectionalLight& l = L.directional;
-        if (l.enabled) {
-            float sh = 1.0f;
-            if (HAS_CASTERS && l.shadowing) {
-                const float4 lsp = mul_M_v(L.shadowViewDirectional, px.P);
-                sh = pcf_2d(fc->sm.directional, fc->sm.dir_dim,
-                            make_float2(fc->perFrame.f2DirectionalLightShadowMapDimensions.x, fc->perFrame.f2DirectionalLightShadowMapDimensions.y), lsp, l.depthBias);
-            }
-            const f3 c = directional_light(px, l);
-            I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
-        }
-    }
-    store_px<OUTFMT>(a.out, (size_t)y * a.outPitch + x, make_float4(I.x, I.y, I.z, px.roughness));   // :380
+    const float4 c = shade_pixel<HAS_ENV, HAS_CASTERS>(g0, g1, g2, g3, fc);
+    store_px<OUTFMT>(a.out, (size_t)y * a.outPitch + x, c);
 }
 
 template <bool E, bool C>

@@ -68,6 +68,8 @@ struct GbufArgs {
     int width, height, pitch, outPitch;
 };
 hipError_t launch_gbuffer_from_materials(hipStream_t s, const GbufArgs& a);
+struct FrameConstants;
+hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt);
 hipError_t launch_mip_box_rgba8(hipStream_t s, const void* src, void* dst, int sw, int sh, int dw, int dh);
 hipError_t launch_skydome(hipStream_t s, const float4* eq0, int w0, int h0, const VQ_SkydomeParams& sp, const float4* cov, int covPitch,
                           void* color, int W, int H, int pitch, int fmt);
