@@ -149,8 +149,7 @@ public:
         // above / below before the Y blur, and afterwards composites the finished tiles into pCompositeFrame on CompositeRoot
         // (VQHIP_ALL_RANKS: on every rank). pCompositeFrame: FrameHeight x Width texels of the output format, or nullptr on ranks that
         // do not receive the frame.
-        vqhip_comm* pComm = nullptr;
-        int World = 1, Rank = 0;                                 // the communicator's size and this process's rank in it
+        vqhip_comm* pComm = nullptr;                             // its size and this process's rank are read from it (vqhip_comm_query)
         int FrameHeight = 0;
         int CompositeRoot = 0;
         void* pCompositeFrame = nullptr;
@@ -173,6 +172,20 @@ public:
         const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
         if (!p || !p->pSceneColor || !mTonemapperOut) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
         mOutFormat = p->bHDR ? VQHIP_FMT_RGBA16F : VQHIP_FMT_RGBA8_UNORM;
+        // Row-tiled mode: size and rank come from the communicator itself, and the tile geometry is validated BEFORE anything is enqueued on
+        // it — a rank that fails here has not posted a send its neighbours would wait for.
+        int world = 1, rank = 0;
+        if (p->pComm) {
+            vqhip_comm_info info;
+            mStatus = vqhip_comm_query(p->pComm, &info);
+            if (mStatus != VQHIP_OK) return;
+            world = info.world; rank = info.rank;
+            int row0 = 0, rows = 0;
+            mStatus = vqhip_rowtile(p->FrameHeight, world, rank, &row0, &rows);
+            if (mStatus == VQHIP_OK && rows != (int)mHeight) mStatus = VQHIP_ERR_INVALID_ARG;                 // the pass must have been sized for this tile
+            if (mStatus == VQHIP_OK && (p->CompositeRoot == VQHIP_ALL_RANKS || p->CompositeRoot == rank) && !p->pCompositeFrame) mStatus = VQHIP_ERR_INVALID_ARG;
+            if (mStatus != VQHIP_OK) return;
+        }
         if (p->bEnableGaussianBlur) {
             // CSMain_X -> BlurIntermediate, then CSMain_Y + Tonemapper in one kernel (SceneRendering.cpp:2582-2656): identical bits to
             // the separate dispatches through BlurOutput, which never touches HBM. On the SDR path the Y pass stores through the
@@ -185,11 +198,7 @@ public:
             if (p->pComm) {                                      // exchange 1: the 10 boundary rows of the X-blurred tile (RCCL send/recv on p->Stream)
                 mStatus = vqhip_exchange_blur_halos(p->pComm, p->Stream, mBlurIntermediate, (int)mWidth, (int)mHeight, (int)mWidth, VQHIP_FMT_RGBA16F, mHaloTop, mHaloBottom);
                 if (mStatus != VQHIP_OK) return;
-                int row0 = 0, rows = 0;
-                mStatus = vqhip_rowtile(p->FrameHeight, p->World, p->Rank, &row0, &rows);
-                if (mStatus == VQHIP_OK && rows != (int)mHeight) mStatus = VQHIP_ERR_INVALID_ARG;             // the pass must have been sized for this tile
-                if (mStatus != VQHIP_OK) return;
-                top = p->Rank > 0 ? mHaloTop : nullptr; bottom = p->Rank < p->World - 1 ? mHaloBottom : nullptr; haloRows = (top || bottom) ? VQHIP_HALO_ROWS : 0;
+                top = rank > 0 ? mHaloTop : nullptr; bottom = rank < world - 1 ? mHaloBottom : nullptr; haloRows = (top || bottom) ? VQHIP_HALO_ROWS : 0;
             }
             if (!p->bHDR) {
                 mStatus = vqhip_gaussian_blur_y_tonemap(mCtx, p->Stream, mBlurIntermediate, mTonemapperOut, top, bottom, haloRows, &bp, &p->TonemapperParams,

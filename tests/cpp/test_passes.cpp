@@ -93,7 +93,7 @@ int main(int argc, char** argv) {
         if (vqhip_comm_unique_id(id) != VQHIP_OK || vqhip_comm_create(id, 1, 0, &comm) != VQHIP_OK) { fprintf(stderr, "comm: %s\n", vqhip_last_error(nullptr)); return 6; }
         void* frame = nullptr;
         if (hipMalloc(&frame, (size_t)W * H * 4) != hipSuccess) return 3;
-        pd.pComm = comm; pd.World = 1; pd.Rank = 0; pd.FrameHeight = H; pd.CompositeRoot = 0; pd.pCompositeFrame = frame;
+        pd.pComm = comm; pd.FrameHeight = H; pd.CompositeRoot = 0; pd.pCompositeFrame = frame;
         post.RecordCommands(&pd);
         CHECK(post);
         if (hipStreamSynchronize(stream) != hipSuccess) return 3;

@@ -1,5 +1,5 @@
 """Row-tiled multi-GPU mode on CPU: world_size 2 and 3 over the gloo backend (no GPU). The exchange logic in
-vqengine_amd/tiling.py (blur halo via P2P or one all-gather, composite all-gather) is exercised with the ORACLE doing
+tests/gloo_tiling.py (blur halo via P2P or one all-gather, composite all-gather; the independent second statement of the tiling) is exercised with the ORACLE doing
 the per-tile compute, and the composited frame must equal the single-process full-frame result bit-for-bit."""
 import os
 import socket
@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from tests import gloo_tiling
 from vqengine_amd import abi, synth, tiling
 
 W, TILE_H = 96, 24
@@ -49,19 +50,19 @@ def _worker(rank, world, port, halo_mode, q, comp="allgather"):
         scene = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F)                # no exchange: per-pixel
         x = O.blur_pass(scene, abi.FMT_RGBA16F, 0)                             # no exchange: X pass
         xt = torch.from_numpy(x)
-        fn = tiling.exchange_halos_p2p if halo_mode == "p2p" else tiling.exchange_halos_allgather
+        fn = gloo_tiling.exchange_halos_p2p if halo_mode == "p2p" else gloo_tiling.exchange_halos_allgather
         top, bottom = fn(xt)                                                   # exchange 1: 10-row halos
         assert (top is None) == (rank == 0) and (bottom is None) == (rank == world - 1)
         y = O.blur_pass(x, abi.FMT_RGBA16F, 1, halo_top=top.numpy() if top is not None else None,
                         halo_bottom=bottom.numpy() if bottom is not None else None)
         sdr = torch.from_numpy(O.tonemap(y, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM))
         if comp == "gather":                                                   # exchange 2: composite on rank 0 only
-            frame, work = tiling.composite_to_root(sdr, dst=0, async_op=True)
+            frame, work = gloo_tiling.composite_to_root(sdr, dst=0, async_op=True)
             work.wait()
             assert (frame is None) == (rank != 0)
             q.put((rank, frame.numpy().copy() if frame is not None else None))
         else:                                                                  # exchange 2: all-gather composite
-            frame, work = tiling.composite(sdr, async_op=True)
+            frame, work = gloo_tiling.composite(sdr, async_op=True)
             work.wait()
             q.put((rank, frame.numpy().copy()))
         dist.barrier()
@@ -102,8 +103,7 @@ def test_row_tiling_geometry():
     assert (t.tile_rows, t.row0, t.row1) == (2160, 6480, 8640)
     t = tiling.RowTiling(64, 100, 3, 0)        # uneven heights: the first frame_height % world ranks own one row more (vqhip_rowtile)
     assert (t.row0, t.tile_rows) == (0, 34) and tiling.RowTiling(64, 100, 3, 2).row1 == 100
-    from vqengine_amd import capi
-    with pytest.raises(capi.VQHipError):
+    with pytest.raises(ValueError):
         tiling.RowTiling(64, 16, 2, 0)         # tiles shorter than the 10-row halo
     assert tiling.HALO_ROWS == 10              # KERNEL_RANGE - 1, GaussianBlur.hlsl:54-55
 

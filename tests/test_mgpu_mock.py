@@ -95,12 +95,15 @@ def test_row_tiled_frame_through_the_c_abi(world, H, root, pitch_pad):
 
 
 def test_rowtile_partition_and_errors():
-    from vqengine_amd import capi
+    from vqengine_amd import capi, tiling
     for H, world in ((4320, 8), (2160, 7), (97, 4), (10, 1), (1, 1)):
         rows = [capi.rowtile(H, world, r) for r in range(world)]
+        assert rows == [tiling.rowtile(H, world, r) for r in range(world)]          # the pure-Python split == vqhip_rowtile
         assert rows[0][0] == 0 and sum(n for _, n in rows) == H
         assert all(rows[r][0] + rows[r][1] == rows[r + 1][0] for r in range(world - 1))
         assert max(n for _, n in rows) - min(n for _, n in rows) <= 1
+    with pytest.raises(ValueError):
+        tiling.rowtile(79, 8, 0)
     with pytest.raises(capi.VQHipError):
         capi.rowtile(79, 8, 0)                               # 9-row tiles: shorter than the halo
     with pytest.raises(capi.VQHipError):

@@ -10,7 +10,8 @@ import torch
 from . import abi
 from .abi import (FMT_RGBA32F, FMT_RGBA16F, FMT_RGBA8_UNORM, FMT_RG16F, FMT_RG32F, CONV_WAVE64)
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvqhip.so")
+# $VQHIP_LIBRARY_PATH: another build of the SAME library (the sanitizer build of `make -C vqengine_amd/csrc asan`); never a different implementation
+_LIB_PATH = os.environ.get("VQHIP_LIBRARY_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvqhip.so")
 _lib = None
 
 
