@@ -61,7 +61,7 @@ VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of depende
 XGMI_LINK_GBPS = 153.0          # per direct GPU-GPU link, peak; the tile-curve model also quotes half of it
 WATCHDOG_S = float(os.environ.get("VQ_BENCH_WATCHDOG_S", "30"))
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
-PMC_SOURCES = ["vqengine_amd/csrc/shade.hip", "vqengine_amd/csrc/vq_devmath.h", "vqengine_amd/csrc/vq_sampling.h", "vqengine_amd/csrc/Makefile"]
+PMC_SOURCES = ["vqengine_amd/csrc/shade.hip", "vqengine_amd/csrc/vq_shade.h", "vqengine_amd/csrc/vq_devmath.h", "vqengine_amd/csrc/vq_sampling.h", "vqengine_amd/csrc/Makefile"]
 F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
 
 
@@ -86,7 +86,7 @@ def load_pmc_constants(config, fresnel_pow):
     if entry is None:
         return None, dict(meta, stale=True, why=f"no entry for {config}/{fresnel_pow}")
     if d.get("kernel_sources_sha256") != kernel_source_hash():
-        return None, dict(meta, stale=True, why="shade.hip / vq_devmath.h / vq_sampling.h changed since the counters were collected", now=kernel_source_hash())
+        return None, dict(meta, stale=True, why="shade.hip / vq_shade.h / vq_devmath.h / vq_sampling.h / Makefile changed since the counters were collected", now=kernel_source_hash())
     return entry, dict(meta, stale=False)
 
 
