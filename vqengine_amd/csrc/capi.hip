@@ -46,11 +46,19 @@ struct vqhip_ctx {
 namespace {
 
 thread_local std::string g_lastError;
+thread_local const vqhip_ctx* g_lastErrorCtx = nullptr;     // the context this thread's most recent failure belongs to (vqhip_last_error)
 
 int fail(vqhip_ctx* ctx, int code, const std::string& msg) {
     g_lastError = msg;
+    g_lastErrorCtx = ctx;
     if (ctx) ctx->lastError = msg;
     return code;
+}
+// a call refused because ANOTHER thread is inside the context: the message stays with the refused thread, the context is not written to
+int failRefused(const vqhip_ctx* ctx, const std::string& msg) {
+    g_lastError = msg;
+    g_lastErrorCtx = ctx;
+    return VQHIP_ERR_INVALID_ARG;
 }
 int failHip(vqhip_ctx* ctx, hipError_t e, const char* what) {
     return fail(ctx, VQHIP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -134,7 +142,7 @@ struct CtxGuard {
     }
     ~CtxGuard() { if (c) c->busyDepth.fetch_sub(1, std::memory_order_acq_rel); }
 };
-#define CTX_GUARD(ctx, who) CtxGuard guard_(ctx); if (!guard_.ok) return fail(nullptr, VQHIP_ERR_INVALID_ARG, std::string(who) + ": the context is in use on another thread (one thread at a time per vqhip_ctx)")
+#define CTX_GUARD(ctx, who) CtxGuard guard_(ctx); if (!guard_.ok) return failRefused(ctx, std::string(who) + ": the context is in use on another thread (one thread at a time per vqhip_ctx)")
 
 int mipDim(int d0, int l) { int d = d0 >> l; return d < 1 ? 1 : d; }
 
@@ -184,7 +192,8 @@ extern "C" {
 
 int vqhip_abi_version(void) { return VQHIP_ABI_VERSION; }
 
-const char* vqhip_last_error(const vqhip_ctx* ctx) { return ctx ? ctx->lastError.c_str() : g_lastError.c_str(); }
+// the calling thread's own most recent failure when it belongs to `ctx` (race-free, and the only record of a refused concurrent call), else the context's
+const char* vqhip_last_error(const vqhip_ctx* ctx) { return (!ctx || g_lastErrorCtx == ctx) ? g_lastError.c_str() : ctx->lastError.c_str(); }
 
 int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
     if (!out_ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "vqhip_create: out_ctx is NULL");
