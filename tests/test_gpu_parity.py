@@ -358,11 +358,11 @@ def test_forward_cfg3_full_frame_with_ibl(ctx):
 # post chain
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2160, 3840), (97, 301), (64, 64), (33, 1000), (540, 257), (1440, 2560), (32, 64), (31, 700)])
-@pytest.mark.parametrize("one_kernel", ["0", "1"])
+@pytest.mark.parametrize("one_kernel", ["0", "1", "1c"])
 def test_post_process_one_call_equals_three_dispatches(ctx, shape, one_kernel, monkeypatch):
     """vqhip_post_process against the oracle's three passes, bit for bit, in both of its forms: the default (blur X into the context's scratch,
-    then blur Y + tonemap) and the experimental single kernel (VQHIP_POST_ONE_KERNEL=1, k_post_fused: X blur -> LDS ring -> Y blur -> tonemap
-    table): 4K, sizes that are no multiple of the 256-column strips / 8-row steps / segment height, images smaller than the single kernel
+    then blur Y + tonemap) and the experimental single kernel (VQHIP_POST_ONE_KERNEL=1 / 1c, k_post_chain2: X blur -> LDS ring -> Y blur -> tonemap
+    table, full or compact): 4K, sizes that are no multiple of the 128-column strips / 8-row steps / segment height, images smaller than the single kernel
     accepts, negative and NaN inputs (the half of the table that is not in LDS)."""
     monkeypatch.setenv("VQHIP_POST_ONE_KERNEL", one_kernel)
     h, w = shape

@@ -418,12 +418,12 @@ int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, voi
     if (!enableGaussianBlur) return vqhip_tonemap(ctx, stream, sceneColor, out, width, height, tm, inFmt, outFmt);
     hipStream_t st = (hipStream_t)stream;
     const char* one = std::getenv("VQHIP_POST_ONE_KERNEL");
-    if (one && one[0] == '1' && post_chain_fusable(*tm, inFmt, outFmt, width, height)) {   // experimental single kernel (post.hip:k_post_fused): measured slower, opt-in
+    if (one && one[0] == '1' && post_chain_fusable(*tm, inFmt, outFmt, width, height)) {   // single-kernel form (post.hip: k_post_chain2; "1c": compact tonemap table), measured slower, opt-in
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         int slot = -1;
         const int rc = acquireTonemapLut(ctx, st, *tm, outFmt, &slot);
         if (rc) return rc;
-        const hipError_t e = launch_post_fused(st, sceneColor, out, width, height, ctx->lut[slot].table);
+        const hipError_t e = launch_post_chain2(st, sceneColor, out, width, height, ctx->lut[slot].table, one[1] == 'c');
         if (e != hipSuccess) return failHip(ctx, e, "post chain launch");
         return releaseTonemapLut(ctx, st, slot);
     }

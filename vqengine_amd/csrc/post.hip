@@ -485,124 +485,140 @@ __global__ __launch_bounds__(256, WAVES) void k_blur_y_tonemap_c(const void* __r
 }
 
 // ---- the whole post chain in ONE kernel: CSMain_X -> CSMain_Y -> Tonemapper (RGBA16F scene colour in, RGBA8 out) -----------------------
-// EXPERIMENTAL, opt-in (VQHIP_POST_ONE_KERNEL=1): bit-identical to the dispatches but SLOWER at 4K — 100 us against 58 us for blur X + fused
-// blur Y/tonemap (profiles/r2e_post_chain.md: the row-major ring makes the Y pass 72 strided ds_read_b32 per lane, 8 waves per CU cannot hide
-// it, and the kernel issues ~250 VALU per pixel against a floor of 126 mads). Kept as the measured starting point of DESIGN.md §10.
-// BlurIntermediate and BlurOutput never exist in HBM: 8 B read (+ halo re-reads) and 4 B written per pixel instead of 8+8, 8+4.
-// A persistent 512-lane workgroup owns a column strip of TW = 256 outputs and walks down a segment of rows, RI = 8 input rows per step:
-//   1. the 8 x 276 raw pixels of the step (prefetched into registers one step ahead) are converted ONCE to fp32 and staged in LDS as
-//      three planes (R, G, B): lane (row r, t) reads its 24-pixel window as 6 aligned ds_read_b128 per channel — consecutive lanes read
-//      consecutive float4s, no bank conflicts — filters 4 consecutive outputs, rounds them to fp16 exactly like the store to
-//      BlurIntermediate and writes the rounded values (as fp32: the Y pass then needs no converts) into a 28-row ring of X-blurred rows;
-//   2. lane (column c, group g) streams the 24 ring rows under its 4 output rows through 12 accumulators (each output still sums its 21
-//      taps in the HLSL's order, one mad per tap), rounds to fp16 like the store to BlurOutput and looks the 16 bits up in the tonemap
-//      table — the 32 KB half of it that covers non-negative inputs lives in LDS, negative / NaN-signed inputs read the table in memory.
-// Rows / columns outside the image are clamped when the raw pixels are loaded (CSMain_X :143, CSMain_Y :178), which commutes with the
-// row-wise X pass. Outputs lag the input by 20 rows; two barriers per step. Identical bits to the three dispatches.
-// LDS: 32 KB table + 8 x 3 x 280 fp32 raw + 28 x 3 x 256 fp32 ring = 145 KB: one workgroup (8 waves) per CU.
-namespace pf {
-constexpr int TW = 256, RI = 8, RING = 28, NPX = TW + 2 * R, NPXP = (NPX + 3) & ~3;
-constexpr int LUT_BYTES = 32768;
-constexpr int RAW_FLOATS = RI * 3 * NPXP, RING_FLOATS = RING * 3 * TW;
-constexpr int LDS_BYTES = LUT_BYTES + (RAW_FLOATS + RING_FLOATS) * 4;
+// EXPERIMENTAL, opt-in (VQHIP_POST_ONE_KERNEL=1 / 1c): bit-identical to the dispatches, 12 B/px of HBM traffic instead of 28, but SLOWER at 4K — 60 us against
+// 51 us for blur X + fused blur Y/tonemap (profiles/r3g_post_one_kernel.md): ~212 instructions per pixel at 2 waves per SIMD and two barriers per step
+// issue at ~53 % of the ceiling. BlurIntermediate and BlurOutput never exist in HBM.
+// A 256-lane workgroup owns a strip of TW = 128 columns and a segment of rows, and walks down it RI = 8 input rows per step:
+//   1. the 8 x 148 raw pixels of the step (prefetched into registers one step ahead) are converted ONCE to fp32 and staged in LDS as three planes:
+//      lane (row r, t) reads its 24-pixel window as 6 aligned ds_read_b128 per channel, filters 4 consecutive outputs, rounds them to fp16
+//      exactly like the store to BlurIntermediate and writes them into a 28-row ring of X-blurred rows;
+//   2. lane (column c, group g) streams the 24 ring rows under its 4 output rows through 12 accumulators (each output still sums its 21 taps in the
+//      HLSL's order, one mad per tap), rounds to fp16 like the store to BlurOutput and looks the 16 bits up in the tonemap table.
+// Rows / columns outside the image are clamped when the raw pixels are loaded (CSMain_X :143, CSMain_Y :178), which commutes with the row-wise X
+// pass. Outputs lag the input by 20 rows; two barriers per step.
+//   * one workgroup per (strip, row segment), no persistence: 510 workgroups at 4K = ONE wave of workgroups at two per CU (540 cost +50 %);
+//   * the ring of X-blurred rows holds the BlurIntermediate texels themselves — packed RGBA16F, 8 B per pixel: a column lane fetches its 24-row
+//     window as 24 conflict-free ds_read_b64 (round 2's k_post_fused: 72 ds_read_b32 from fp32 planes, 145 KB of LDS, 8 waves per CU, 97-100 us);
+//   * LDS per workgroup: 14.6 KB raw step (fp32 planes: the X pass reads 24-pixel windows as aligned ds_read_b128) + 28.7 KB ring + the tonemap
+//     table: its positive half (32 KB; negative / NaN-signed codes read the table in memory) -> 75 KB, two workgroups per CU; or the compact table
+//     (8 KB, LUTMODE 1) -> 51 KB, three per CU.
+// Identical bits to the dispatches: every output still sums its 21 taps in the HLSL's order, one mad per tap, and both intermediate images are
+// rounded to fp16 exactly where the reference stores them.
+namespace pc2 {
+constexpr int TW = 128, RI = 8, RING = 28, NPX = TW + 2 * R, NPXP = (NPX + 3) & ~3;      // 148 -> 152
+constexpr int RAW_FLOATS = RI * 3 * NPXP, RING_PX = RING * TW;
+constexpr int LUT_BYTES[2] = { 32768, 8192 };
+constexpr int lds_bytes(int lutmode) { return RAW_FLOATS * 4 + RING_PX * 8 + LUT_BYTES[lutmode]; }
 }
-__global__ __launch_bounds__(512) void k_post_fused(const h4* __restrict__ in, uint32_t* __restrict__ out, int W, int H, const uint8_t* __restrict__ table,
-                                                    int strips, int segRows, int nWG) {
-    using namespace pf;
+template <int LUTMODE>
+__global__ __launch_bounds__(256) void k_post_chain2(const h4* __restrict__ in, uint32_t* __restrict__ out, int W, int H, const uint8_t* __restrict__ table,
+                                                     int strips, int segRows) {
+    using namespace pc2;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    uint8_t* lut = lds;
-    float* raw = (float*)(lds + LUT_BYTES);                 // [RI][3][NPXP]
-    float* ring = raw + RAW_FLOATS;                         // [RING][3][TW]
+    float* raw = (float*)lds;                               // [RI][3][NPXP]
+    uint2* ring = (uint2*)(raw + RAW_FLOATS);               // [RING][TW] packed RGBA16F
+    unsigned char* lut = (unsigned char*)(ring + RING_PX);
     const int tid = threadIdx.x;
-    for (int i = tid * 16; i < LUT_BYTES; i += 512 * 16) *(uint4*)(lut + i) = *(const uint4*)(table + i);
+    {
+        const unsigned char* src = LUTMODE == 0 ? table : table + kCompactOffset;
+        for (int i = tid * 16; i < LUT_BYTES[LUTMODE]; i += 256 * 16) *(uint4*)(lut + i) = *(const uint4*)(src + i);
+    }
     const float w0 = 0.224716f, w1 = 0.191756f, w2 = 0.119146f, w3 = 0.053897f, w4 = 0.017746f, w5 = 0.004252f, w6 = 0.000741f, w7 = 0.000094f,
                 w8 = 0.000009f, w9 = 0.000001f, w10 = 0.0f;                                      // KERNEL_WEIGHTS, GaussianBlur.hlsl:109-111
     const float wt[21] = { w10, w9, w8, w7, w6, w5, w4, w3, w2, w1, w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10 };   // offset -10 .. +10
-
-    for (int wg = blockIdx.x; wg < nWG; wg += gridDim.x) {
-        const int seg = wg / strips, strip = wg - seg * strips;
-        const int x0 = strip * TW, y0 = seg * segRows;
-        const int rows = min(segRows, H - y0);
-        const int nIter = (rows + 2 * R + RI - 1) / RI;
-        h4 pre[5];
-        auto fetch = [&](int it) {                          // raw rows j = it*RI .. +7 of the segment: image row y0 - 10 + j, columns x0 - 10 + p
-            #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int e = tid + 512 * k;                // element of the RI x NPX block
-                if (e < RI * NPX) {
-                    const int r = e / NPX, p = e - r * NPX;
-                    const int y = min(max(y0 - R + it * RI + r, 0), H - 1), x = min(max(x0 - R + p, 0), W - 1);
-                    pre[k] = in[(size_t)y * W + x];
-                }
+    const int seg = blockIdx.x / strips, strip = blockIdx.x - seg * strips;
+    const int x0 = strip * TW, y0 = seg * segRows;
+    const int rows = min(segRows, H - y0);
+    const int nIter = (rows + 2 * R + RI - 1) / RI;
+    h4 pre[5];
+    auto fetch = [&](int it) {                              // raw rows j = it*RI .. +7 of the segment: image row y0 - 10 + j, columns x0 - 10 + p (clamped :143,:178)
+        #pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int e = tid + 256 * k;
+            if (e < RI * NPX) {
+                const int r = e / NPX, p = e - r * NPX;
+                const int y = min(max(y0 - R + it * RI + r, 0), H - 1), x = min(max(x0 - R + p, 0), W - 1);
+                pre[k] = in[(size_t)y * W + x];
             }
-        };
-        fetch(0);
-        for (int it = 0; it < nIter; ++it) {
-            // 1a. stage the prefetched raw pixels as fp32 planes
-            #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int e = tid + 512 * k;
-                if (e < RI * NPX) {
-                    const int r = e / NPX, p = e - r * NPX;
-                    float* dst = raw + (r * 3) * NPXP + p;
-                    dst[0] = (float)pre[k].x; dst[NPXP] = (float)pre[k].y; dst[2 * NPXP] = (float)pre[k].z;
-                }
+        }
+    };
+    fetch(0);
+    for (int it = 0; it < nIter; ++it) {
+        // 1a. stage the prefetched raw pixels as fp32 planes
+        #pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int e = tid + 256 * k;
+            if (e < RI * NPX) {
+                const int r = e / NPX, p = e - r * NPX;
+                float* dst = raw + (r * 3) * NPXP + p;
+                dst[0] = (float)pre[k].x; dst[NPXP] = (float)pre[k].y; dst[2 * NPXP] = (float)pre[k].z;
             }
-            __syncthreads();                                // A: raw visible; the Y pass of the previous step is done with the ring rows X now overwrites
-            if (it + 1 < nIter) fetch(it + 1);
-            // 1b. X pass: lane (r, t) -> outputs 4t .. 4t+3 of raw row r -> ring row (it*RI + r) % RING
-            {
-                const int r = tid >> 6, t = tid & 63;
-                const int slot = (it * RI + r) % RING;
+        }
+        __syncthreads();                                    // A: raw visible; the Y pass of the previous step is done with the ring rows X now overwrites
+        if (it + 1 < nIter) fetch(it + 1);
+        // 1b. X pass: lane (r, t) -> outputs 4t .. 4t+3 of raw row r -> ring row (it*RI + r) % RING as packed RGBA16F (== the store to BlurIntermediate)
+        {
+            const int r = tid >> 5, t = tid & 31;
+            uint32_t hx[4], hy[4], hz[4];
+            #pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float4* src = (const float4*)(raw + (r * 3 + ch) * NPXP) + t;
+                float v[24];
                 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    const float4* src = (const float4*)(raw + (r * 3 + ch) * NPXP) + t;
-                    float v[24];
+                for (int g = 0; g < 6; ++g) { const float4 q = src[g]; v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w; }
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float acc = 0.0f;
                     #pragma unroll
-                    for (int g = 0; g < 6; ++g) { const float4 q = src[g]; v[4 * g] = q.x; v[4 * g + 1] = q.y; v[4 * g + 2] = q.z; v[4 * g + 3] = q.w; }
-                    float o[4];
-                    #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float acc = 0.0f;
-                        #pragma unroll
-                        for (int k = 0; k < 21; ++k) acc = fma_(v[j + k], wt[k], acc);
-                        o[j] = (float)to_f16(acc);          // == the RGBA16F store to BlurIntermediate
-                    }
-                    *((float4*)(ring + (slot * 3 + ch) * TW) + t) = make_float4(o[0], o[1], o[2], o[3]);
+                    for (int k = 0; k < 21; ++k) acc = fma_(v[j + k], wt[k], acc);
+                    const uint32_t h = float_to_half_bits(acc);
+                    if (ch == 0) hx[j] = h; else if (ch == 1) hy[j] = h; else hz[j] = h;
                 }
             }
-            __syncthreads();                                // B: the new ring rows are visible
-            // 2. Y pass + tonemap: lane (c, g) -> output rows ob .. ob+3 of column c, ob = it*RI - 20 + 4g
-            {
-                const int c = tid & 255, g = tid >> 8;
-                const int ob = it * RI - 2 * R + 4 * g;
-                const int x = x0 + c;
-                if (ob + 3 >= 0 && ob < rows && x < W) {
-                    float ax[4] = { 0, 0, 0, 0 }, ay[4] = { 0, 0, 0, 0 }, az[4] = { 0, 0, 0, 0 };
-                    int slot = (ob + RING * 4) % RING;      // ring row of X-blurred row j = ob (ob >= -20)
-                    #pragma unroll
-                    for (int i = 0; i < 24; ++i) {
-                        const float* px = ring + (slot * 3) * TW + c;
-                        const float vx = px[0], vy = px[TW], vz = px[2 * TW];
-                        #pragma unroll
-                        for (int o = 0; o < 4; ++o) {
-                            const int k = i - o;            // tap index of output o for window row i
-                            if (k >= 0 && k <= 20) { ax[o] = fma_(vx, wt[k], ax[o]); ay[o] = fma_(vy, wt[k], ay[o]); az[o] = fma_(vz, wt[k], az[o]); }
-                        }
-                        slot = slot + 1 == RING ? 0 : slot + 1;
-                    }
+            const int slot = (it * RI + r) % RING;
+            uint4* dst = (uint4*)(ring + slot * TW + 4 * t);
+            dst[0] = make_uint4(hx[0] | (hy[0] << 16), hz[0] | 0x3c000000u, hx[1] | (hy[1] << 16), hz[1] | 0x3c000000u);      // alpha := 1
+            dst[1] = make_uint4(hx[2] | (hy[2] << 16), hz[2] | 0x3c000000u, hx[3] | (hy[3] << 16), hz[3] | 0x3c000000u);
+        }
+        __syncthreads();                                    // B: the new ring rows are visible
+        // 2. Y pass + tonemap: lane (c, g) -> output rows ob .. ob+3 of column c, ob = it*RI - 20 + 4g
+        {
+            const int c = tid & (TW - 1), g = tid >> 7;
+            const int ob = it * RI - 2 * R + 4 * g;
+            const int x = x0 + c;
+            if (ob + 3 >= 0 && ob < rows && x < W) {
+                float ax[4] = { 0, 0, 0, 0 }, ay[4] = { 0, 0, 0, 0 }, az[4] = { 0, 0, 0, 0 };
+                int slot = (ob + RING * 4) % RING;          // ring row of X-blurred row j = ob (ob >= -20)
+                #pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    const uint2 q = ring[slot * TW + c];
+                    const float vx = half_bits_to_float(q.x & 0xffffu), vy = half_bits_to_float(q.x >> 16), vz = half_bits_to_float(q.y & 0xffffu);
                     #pragma unroll
                     for (int o = 0; o < 4; ++o) {
-                        const int oy = ob + o;
-                        if (oy < 0 || oy >= rows) continue;
-                        const uint32_t hx = float_to_half_bits(ax[o]), hy = float_to_half_bits(ay[o]), hz = float_to_half_bits(az[o]);   // == the BlurOutput store
-                        const uint32_t tx = hx < 0x8000u ? lut[hx] : table[hx], ty = hy < 0x8000u ? lut[hy] : table[hy], tz = hz < 0x8000u ? lut[hz] : table[hz];
-                        out[(size_t)(y0 + oy) * W + x] = tx | (ty << 8) | (tz << 16) | (255u << 24);     // alpha 1 -> 255
+                        const int k = i - o;                // tap index of output o for window row i
+                        if (k >= 0 && k <= 20) { ax[o] = fma_(vx, wt[k], ax[o]); ay[o] = fma_(vy, wt[k], ay[o]); az[o] = fma_(vz, wt[k], az[o]); }
                     }
+                    slot = slot + 1 == RING ? 0 : slot + 1;
+                }
+                #pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    const int oy = ob + o;
+                    if (oy < 0 || oy >= rows) continue;
+                    const uint32_t bx = float_to_half_bits(ax[o]), by = float_to_half_bits(ay[o]), bz = float_to_half_bits(az[o]);   // == the BlurOutput store
+                    uint32_t px;
+                    if (LUTMODE == 0) {
+                        const uint32_t tx = bx < 0x8000u ? lut[bx] : table[bx], ty = by < 0x8000u ? lut[by] : table[by], tz = bz < 0x8000u ? lut[bz] : table[bz];
+                        px = tx | (ty << 8) | (tz << 16) | (255u << 24);
+                    } else {
+                        uint32_t flags = 0;
+                        px = compact_lookup((const uint32_t*)lut, bx, flags) | (compact_lookup((const uint32_t*)lut, by, flags) << 8) |
+                             (compact_lookup((const uint32_t*)lut, bz, flags) << 16) | (255u << 24);
+                        if (__builtin_expect((flags & (64u << 16)) != 0, 0)) px = (uint32_t)table[bx] | ((uint32_t)table[by] << 8) | ((uint32_t)table[bz] << 16) | (255u << 24);
+                    }
+                    out[(size_t)(y0 + oy) * W + x] = px;     // alpha 1 -> 255
                 }
             }
         }
-        __syncthreads();                                    // the next work item of this workgroup reuses raw / ring
     }
 }
 
@@ -610,24 +626,26 @@ __global__ __launch_bounds__(512) void k_post_fused(const h4* __restrict__ in, u
 
 namespace vqk {
 
-// CSMain_X + CSMain_Y + Tonemapper as ONE kernel (k_post_fused) when the table path applies; `table` = the tonemap table of (p, RGBA8).
+// CSMain_X + CSMain_Y + Tonemapper as ONE kernel (k_post_chain2) when the table path applies; `table` = the tonemap table of (p, RGBA8).
 bool post_chain_fusable(const VQ_TonemapperParams& p, int inFmt, int outFmt, int W, int H) {
     return blur_y_tonemap_uses_lut(p, inFmt, outFmt, (size_t)W * H) && W >= 64 && H >= 32;
 }
-hipError_t launch_post_fused(hipStream_t s, const void* in, void* out, int W, int H, const void* table) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_post_fused, hipFuncAttributeMaxDynamicSharedMemorySize, pf::LDS_BYTES);   // > 64 KB opt-in, per device
-    if (e != hipSuccess) return e;
-    const int strips = (W + pf::TW - 1) / pf::TW;
-    int nseg = (256 + strips - 1) / strips;                  // about one work item per CU
+hipError_t launch_post_chain2(hipStream_t s, const void* in, void* out, int W, int H, const void* table, bool compactLut) {
+    const int strips = (W + pc2::TW - 1) / pc2::TW;
+    int nseg = 512 / strips;                                 // at most two workgroups per CU in ONE wave of workgroups (a second, partial wave costs +50 %)
     if (nseg > (H + 31) / 32) nseg = (H + 31) / 32;          // segments of at least 32 rows: each re-reads 20 halo rows
     if (nseg < 1) nseg = 1;
+    if (const char* e = std::getenv("VQHIP_POST_SEGMENTS")) { const int v = std::atoi(e); if (v > 0) nseg = v; }
     const int segRows = (H + nseg - 1) / nseg;
     nseg = (H + segRows - 1) / segRows;
-    const int nWG = strips * nseg;
-    hipLaunchKernelGGL(k_post_fused, dim3(nWG < 256 ? nWG : 256), dim3(512), pf::LDS_BYTES, s, (const h4*)in, (uint32_t*)out, W, H, (const uint8_t*)table, strips, segRows, nWG);
+    const int ldsBytes = pc2::lds_bytes(compactLut ? 1 : 0);
+    hipError_t e = compactLut ? hipFuncSetAttribute((const void*)k_post_chain2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes)
+                              : hipFuncSetAttribute((const void*)k_post_chain2<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);
+    if (e != hipSuccess) return e;
+    if (compactLut) hipLaunchKernelGGL((k_post_chain2<1>), dim3(strips * nseg), dim3(256), ldsBytes, s, (const h4*)in, (uint32_t*)out, W, H, (const uint8_t*)table, strips, segRows);
+    else            hipLaunchKernelGGL((k_post_chain2<0>), dim3(strips * nseg), dim3(256), ldsBytes, s, (const h4*)in, (uint32_t*)out, W, H, (const uint8_t*)table, strips, segRows);
     return hipGetLastError();
 }
-
 // Which form of the X pass runs is chosen for the FRAME, not for the kernel alone (profiles/r2k_frame_loop.md): the software-pipelined persistent
 // form is the fastest kernel in isolation (25.9 us at 4K with 1 024 workgroups, 27.3 with 2 048), but with many workgroups in flight on real image
 // data it makes the chip throttle, and the shade kernel that follows it runs 2-13 % slower. VQHIP_BLUR_X_WGS overrides the default for tuning:

@@ -95,7 +95,7 @@ hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H,
 hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H, int fmt);
 bool tonemap_uses_lut(const VQ_TonemapperParams& p, int inFmt, int outFmt, size_t nPixels);
 bool post_chain_fusable(const VQ_TonemapperParams& p, int inFmt, int outFmt, int W, int H);
-hipError_t launch_post_fused(hipStream_t s, const void* in, void* out, int W, int H, const void* table);
+hipError_t launch_post_chain2(hipStream_t s, const void* in, void* out, int W, int H, const void* table, bool compactLut);
 bool blur_y_tonemap_uses_lut(const VQ_TonemapperParams& p, int blurFmt, int outFmt, size_t nPixels);
 hipError_t launch_tonemap_lut_build(hipStream_t s, void* table, const VQ_TonemapperParams& p, int outFmt);
 hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, const void* lutTable);
