@@ -223,11 +223,16 @@ class Dist:
             else:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.device_ordinal))
                 self.cpu_group = dist.new_group(backend="gloo")
+                dist.barrier()                               # one RCCL collective of the control plane, before any data-path communicator exists
+                torch.cuda.synchronize()
 
     def barrier(self):
-        if self.world > 1:
-            dist.barrier()
+        """Device idle on this rank, then every rank here (a CPU barrier over gloo), so that no collective of the control plane is ever in
+        flight on a GPU next to the data path's own RCCL transfers (two communicators whose kernels reach different GPUs in different orders
+        are only safe while both kernels can be co-resident)."""
         torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier(group=self.cpu_group)
 
     def max_over_ranks(self, x):
         if self.world == 1:
@@ -594,7 +599,7 @@ def main():
             torch.cuda.synchronize()
             verify = {"mismatching_bytes": int((want != pipe.frame[last]).sum().item()), "frame": [W, frame_h]}
             del gb_full, sc, xb, want
-        dist.barrier()
+        d.barrier()
 
     # 5. the other Fresnel-pow lowering, same invocation, same clocks: `engine_lowering` is the engine-faithful exp2(5*log2 x) form
     second = None
@@ -716,7 +721,7 @@ def main():
                 out["cpu_reference_source"] = {"error": repr(e)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        d.barrier()
         comms.close()
         dist.destroy_process_group()
     ctx.close()
