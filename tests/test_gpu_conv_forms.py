@@ -1,0 +1,110 @@
+"""GPU parity of the round-3 forms of the load-time kernels (conv.hip). Each fast form is the same operations with range tests / branches
+removed where they cannot fire; the general form stays in the binary (VQHIP_*_FORM=general) and is what runs wherever a precondition
+fails. Checked here, through the C ABI:
+  * every form gives identical bits on whole outputs (fast == general == the round-1/2 per-sample kernel), at the reference's sizes;
+  * the fast forms == the CPU oracle on inputs built to hit the rare paths: pole texels (odd cube resolution: a NaN frame), taps on the
+    equirect seam and the poles (zero x / z components, |y| = 1), non-power-of-two chains (fast tap disabled), chains shorter than the
+    sampled mip level, sample counts that are not a multiple of the 512-sample table, both Fresnel lowerings."""
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle_lib as O
+from tests.test_gpu_parity import assert_bits, dev
+from vqengine_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, what):
+    a, b = a.cpu().numpy(), b.cpu().numpy()
+    n, idx = O.bits_equal(a, b)
+    assert n == 0, f"{what}: {n} of {a.size} elements differ, first at {idx.tolist()}"
+
+
+@pytest.mark.parametrize("size,samples,fmt", [(1024, 2048, abi.FMT_RG16F), (96, 700, abi.FMT_RG32F), (33, 100, abi.FMT_RG32F)])
+def test_brdf_lut_forms_identical(ctx, monkeypatch, size, samples, fmt):
+    """Shared-H table + unchecked sample body == the same kernel with every range test == the per-sample kernel of rounds 1-2."""
+    fast = ctx.brdf_lut(size, samples, fmt)
+    for form in ("general", "persample"):
+        monkeypatch.setenv("VQHIP_LUT_FORM", form)
+        _same(ctx.brdf_lut(size, samples, fmt), fast, f"BRDF LUT {size}^2 x {samples} fast vs {form}")
+    monkeypatch.delenv("VQHIP_LUT_FORM")
+    ctx.set_fresnel_pow(True)
+    try:
+        fast = ctx.brdf_lut(size, samples, fmt)
+        monkeypatch.setenv("VQHIP_LUT_FORM", "persample")
+        _same(ctx.brdf_lut(size, samples, fmt), fast, f"BRDF LUT {size}^2 x {samples} exp2/log2 Fresnel, fast vs persample")
+    finally:
+        ctx.set_fresnel_pow(False)
+
+
+@pytest.mark.parametrize("size,samples", [(33, 100), (64, 513), (16, 1500)])
+def test_brdf_lut_fast_vs_oracle_ragged(ctx, size, samples):
+    """Sizes / sample counts off the 256-texel block and the 512-sample table, against the CPU oracle."""
+    assert_bits(ctx.brdf_lut(size, samples, abi.FMT_RG32F), O.brdf_lut(size, samples, abi.FMT_RG32F), f"BRDF LUT {size}^2 x {samples}")
+
+
+def _chain(w, h, seed=0xE9):
+    eq = synth.equirect(w, h, seed=seed)
+    chain_o, n = O.mip_chain(eq)
+    return eq, chain_o, dev(chain_o), n
+
+
+@pytest.mark.parametrize("order", [abi.CONV_WAVE64, abi.CONV_SEQUENTIAL])
+def test_conv_diffuse_forms_identical_cfg4(ctx, monkeypatch, order):
+    """2048^2 equirect -> 6 x 64^2 at step 0.010 (99 382 taps per texel): whole cube, fast tap vs general tap. The sequential order runs
+    one lane per texel for ~0.1 s: a coarser step keeps it short."""
+    _, _, chain_g, n = _chain(2048, 2048)
+    step = 0.010 if order == abi.CONV_WAVE64 else 0.05
+    fast = ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, step, order, abi.FMT_RGBA32F)
+    monkeypatch.setenv("VQHIP_DIFFUSE_FORM", "general")
+    _same(ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, step, order, abi.FMT_RGBA32F), fast, f"cfg4 diffuse fast vs general, order {order}")
+
+
+@pytest.mark.parametrize("res", [1, 3, 5, 8])
+@pytest.mark.parametrize("order", [abi.CONV_WAVE64, abi.CONV_SEQUENTIAL])
+def test_conv_diffuse_pole_texels_and_axis_taps(ctx, res, order):
+    """Odd resolutions put texel centres ON the axes: N = (0, +-1, 0) has no frame (NaN right / up: every tap of those texels takes the general
+    form and yields the oracle's NaN), N = (+-1, 0, 0) / (0, 0, +-1) make taps land exactly on x = 0 / z = 0 / |y| = 1 (atan2_'s axis cases,
+    asin_'s pole): the wave redoes those taps in the general form."""
+    _, chain_o, chain_g, n = _chain(256, 128, seed=0x51)
+    for step in (0.25, 0.05):
+        with np.errstate(all="ignore"):
+            ref = O.conv_diffuse(chain_o, 256, 128, n, res, step, order, abi.FMT_RGBA32F)
+        assert_bits(ctx.conv_diffuse(chain_g, 256, 128, n, res, step, order, abi.FMT_RGBA32F), ref, f"diffuse res={res} step={step} order={order}")
+
+
+@pytest.mark.parametrize("w,h", [(96, 48), (100, 50), (16, 8), (8, 4), (4, 2)])
+def test_conv_diffuse_other_chains(ctx, w, h):
+    """Non-power-of-two chains (the fast tap is off: integer-modulo wrap) and chains whose last level is above mip 3 (the sampled level is
+    clamped to the chain: 1 x 1 ... 2 x 1 images, every tap wraps)."""
+    _, chain_o, chain_g, n = _chain(w, h, seed=0x52)
+    ref = O.conv_diffuse(chain_o, w, h, n, 4, 0.1, abi.CONV_WAVE64, abi.FMT_RGBA32F)
+    assert_bits(ctx.conv_diffuse(chain_g, w, h, n, 4, 0.1, abi.CONV_WAVE64, abi.FMT_RGBA32F), ref, f"diffuse from a {w}x{h} chain ({n} levels)")
+
+
+def test_conv_diffuse_nonfinite_texels(ctx):
+    """inf / NaN texels in the sampled level flow through the same fma chain in both forms."""
+    eq = synth.equirect(128, 64, seed=0x53)
+    eq[10:14, 20:24, 0] = np.inf
+    eq[40, 100, 1] = np.nan
+    chain_o, n = O.mip_chain(eq)
+    with np.errstate(all="ignore"):
+        ref = O.conv_diffuse(chain_o, 128, 64, n, 4, 0.1, abi.CONV_WAVE64, abi.FMT_RGBA32F)
+    assert_bits(ctx.conv_diffuse(dev(chain_o), 128, 64, n, 4, 0.1, abi.CONV_WAVE64, abi.FMT_RGBA32F), ref, "diffuse over inf / NaN texels")
+
+
+@pytest.mark.parametrize("w,h,res0,fmt", [(2048, 2048, 128, abi.FMT_RGBA16F), (128, 64, 32, abi.FMT_RGBA32F), (64, 32, 4, abi.FMT_RGBA32F), (100, 50, 8, abi.FMT_RGBA16F)])
+def test_conv_specular_forms_identical(ctx, monkeypatch, w, h, res0, fmt):
+    """Every mip in one launch with the per-block table of tangent-space half vectors == one launch per mip with ImportanceSampleGGX evaluated
+    per lane and sample (the round-1/2 kernel); the small cases also against the CPU oracle."""
+    _, chain_o, chain_g, n = _chain(w, h, seed=0x54)
+    one, mips = ctx.conv_specular(chain_g, w, h, n, res0, abi.CONV_WAVE64, fmt)
+    monkeypatch.setenv("VQHIP_SPECULAR_FORM", "permip")
+    per, mips2 = ctx.conv_specular(chain_g, w, h, n, res0, abi.CONV_WAVE64, fmt)
+    assert mips == mips2
+    _same(per, one, f"specular {res0}^2 from {w}x{h}: one launch vs per mip")
+    if w <= 128:
+        ref, _ = O.conv_specular(chain_o, w, h, n, res0, abi.CONV_WAVE64, fmt)
+        assert_bits(one, ref, f"specular {res0}^2 from {w}x{h} vs oracle")

@@ -12,6 +12,8 @@
 #include "vq_internal.h"
 #include "vq_devmath.h"
 #include "vq_sampling.h"
+#include <cstdlib>
+#include <cstring>
 
 using namespace vqd;
 
@@ -44,26 +46,127 @@ VQD float G1_env(f3 N, f3 V, float roughness) {                 // Geometry_Smit
     const float NV = max_(0.0f, dot(N, V));
     return div_(NV, fma_(NV, 1.0f - k, k) + 0.0001f);           // (NV*(1-k) + k) as one mad
 }
-// ImportanceSampleGGX, BRDF.hlsl:217-238, with sin/cos(phi) supplied by the caller
-VQD f3 ImportanceSampleGGX(float Xiy, float sinPhi, float cosPhi, f3 N, float roughness) {
+// ImportanceSampleGGX, BRDF.hlsl:217-238, with sin/cos(phi) supplied by the caller — in its two halves: the tangent-space half vector, a function
+// of the sample and the roughness only (:219-227), and its rotation into the frame of N (:229-237). Kernels whose samples / roughness are shared by
+// a whole block evaluate the first half once per block (k_brdf_lut, k_conv_specular_all); the composition is the function as written.
+VQD f3 ggx_sample_tangent(float Xiy, float sinPhi, float cosPhi, float roughness) {
     const float a = roughness * roughness;
     const float cosTheta = sqrt_(fdiv_(1.0f - Xiy, 1.0f + (a * a - 1.0f) * Xiy));
     const float sinTheta = sqrt_(1.0f - cosTheta * cosTheta);
-    const f3 H = mk3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+    return mk3(cosPhi * sinTheta, sinPhi * sinTheta, cosTheta);
+}
+struct TangentFrame { f3 tangent, bitangent; };
+VQD TangentFrame tangent_frame(f3 N) {
     const f3 up = abs_(N.z) < 0.999f ? mk3(0, 0, 1) : mk3(1, 0, 0);
-    const f3 tangent = normalize(cross(up, N));
-    const f3 bitangent = cross(N, tangent);
-    const f3 s = mk3((tangent.x * H.x + bitangent.x * H.y) + N.x * H.z,
-                     (tangent.y * H.x + bitangent.y * H.y) + N.y * H.z,
-                     (tangent.z * H.x + bitangent.z * H.y) + N.z * H.z);
+    TangentFrame fr;
+    fr.tangent = normalize(cross(up, N));
+    fr.bitangent = cross(N, fr.tangent);
+    return fr;
+}
+VQD f3 tangent_to_world(f3 H, const TangentFrame& fr, f3 N) {
+    const f3 s = mk3((fr.tangent.x * H.x + fr.bitangent.x * H.y) + N.x * H.z,
+                     (fr.tangent.y * H.x + fr.bitangent.y * H.y) + N.y * H.z,
+                     (fr.tangent.z * H.x + fr.bitangent.z * H.y) + N.z * H.z);
     return normalize(s);
+}
+VQD f3 ImportanceSampleGGX(float Xiy, float sinPhi, float cosPhi, f3 N, float roughness) {
+    return tangent_to_world(ggx_sample_tangent(Xiy, sinPhi, cosPhi, roughness), tangent_frame(N), N);
 }
 
 // ---- BRDF integration LUT ----------------------------------------------------------------------
-// Block = 256 texels of one row; the per-sample (sin phi, cos phi, Xi.y) table is shared through LDS
-// (every lane reads the same entry: LDS broadcast). 4 KB chunks of 512 samples bound the LDS use.
+// Block = 256 texels of one row, i.e. ONE roughness. The half vector of sample i, ImportanceSampleGGX(Xi_i, N = +Z, roughness)
+// (BRDF.hlsl:217-238: an IEEE division, two square roots, the tangent frame, a normalize — more than half of IntegrateBRDF's
+// arithmetic), depends on the row and the sample only, not on the texel: the block computes each H ONCE (lane j takes samples j,
+// j + 256 of a 512-sample chunk — the same function on the same inputs, hence the same bits as the per-texel evaluation) and
+// every lane reads it back as an LDS broadcast. Per texel and sample that leaves reflect, one normalize, G, the Fresnel power
+// and the two accumulations. G1_env(N, V), the light-independent half of G, is hoisted by hand (LLVM does not move the
+// reciprocal's rare-path branch out of the loop).
+//
+// One sample of IntegrateBRDF (BRDF.hlsl:250-281) for a texel with V = (vx, 0, vz), vz = NdotV. FAST drops what cannot matter when
+//   (a) |H|^2 in [0.98, 1.02] and H.z >= 2^-60   (checked per sample when the chunk's table is built: block-uniform)
+//   (b) NdotV in [2^-60, 1], |V|^2 in [0.98, 1.02] (checked per lane; a lane outside takes the general form for every chunk)
+// hold — always, for the sizes and sample counts the engine uses; the general form is what runs otherwise, and where both apply
+// they give identical bits:
+//   * Lraw = reflect(-V, H) then has |Lraw|^2 in [0.9, 1.2]: normalize's square root and reciprocal are inside the exhaustively
+//     validated domains of sqrt_newton / rcp_newton (vq_devmath.h), no range tests needed; L is finite
+//   * dot(N, L) with N = (0, 0, 1) is fma(1, L.z, fma(0, L.y, 0 * L.x)) = L.z + (+-0) = L.z for the L.z > 0 it is used with and
+//     finite L.x, L.y: G1_env(N, L)'s NV is L.z itself, and L.x, L.y are never formed
+//   * the operand of G1_env(N, L)'s reciprocal, fma(NV, 1-k, k) + 1e-4 with k = roughness^2 / 2 in [0, 1/2] and NV in (0, 1 + 2^-22],
+//     lies in [1e-4, 1.51]; that of G_Vis's, NdotH * NdotV, in [2^-120, 1.01]: both reciprocals are normal numbers
+//   * the V.y = 0 terms of dot(V, H) and dot(H, -V) add +-0 to a partial sum that is followed by +- vz * H.z != 0: dropping them
+//     changes at most the sign of a zero that the next fma absorbs
+template <bool FAST>
+VQD void lut_sample(const float4 hv, f3 V, float NdotV, float k, float omk, float G1V, float roughness, int p5ExpLog, float& F0Scale, float& F0Bias) {
+    const f3 H = mk3(hv.x, hv.y, hv.z);
+    const float NdotH = hv.w;                                   // max(H.z, 0), from the table
+    if (FAST) {
+        const float t = 2.0f * fma_(H.z, -V.z, H.x * -V.x);     // reflect(-V, H): i - n * (2 dot(n, i)), i = -V
+        const f3 Lr = mk3(-V.x - H.x * t, -(H.y * t), -V.z - H.z * t);
+        const float r = rcp_newton(sqrt_newton(dot(Lr, Lr)));
+        const float Lz = Lr.z * r;
+        if (max_(Lz, 0.0f) > 0.0f) {
+            const float VdotH = max_(fma_(V.z, H.z, V.x * H.x), 0.0f);
+            const float G1L = Lz * rcp_newton(fma_(Lz, omk, k) + 0.0001f);
+            const float G = G1V * G1L;
+            const float G_Vis = max_((G * VdotH) * rcp_newton(NdotH * NdotV), 0.0001f);
+            const float Fc = p5ExpLog ? pow5_explog(1.0f - VdotH) : pow5(1.0f - VdotH);
+            F0Scale += (1.0f - Fc) * G_Vis;
+            F0Bias += Fc * G_Vis;
+        }
+    } else {
+        const f3 N = mk3(0.0f, 0.0f, 1.0f);
+        const f3 L = normalize(reflect(neg(V), H));
+        const float NdotL = max_(L.z, 0.0f);
+        const float VdotH = max_(dot(V, H), 0.0f);
+        if (NdotL > 0.0f) {
+            const float G = G1V * G1_env(N, L, roughness);
+            const float G_Vis = max_(div_(G * VdotH, NdotH * NdotV), 0.0001f);
+            const float Fc = p5ExpLog ? pow5_explog(1.0f - VdotH) : pow5(1.0f - VdotH);
+            F0Scale += (1.0f - Fc) * G_Vis;
+            F0Bias += Fc * G_Vis;
+        }
+    }
+}
+
 template <int FMT>
-__global__ __launch_bounds__(256) void k_brdf_lut(void* __restrict__ out, int size, int samples, int p5ExpLog) {
+__global__ __launch_bounds__(256) void k_brdf_lut(void* __restrict__ out, int size, int samples, int p5ExpLog, int allowFast) {
+    __shared__ float4 sH[512];
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const float NdotV = div_((float)x + 0.5f, (float)size);     // CubemapConvolution.hlsl:233-236
+    const float roughness = div_((float)y + 0.5f, (float)size);
+    const f3 V = mk3(sqrt_(1.0f - NdotV * NdotV), 0.0f, NdotV);
+    const f3 N = mk3(0.0f, 0.0f, 1.0f);
+    const float rcount = rcp((float)samples);
+    const float G1V = G1_env(N, V, roughness);
+    const float k = div_(roughness * roughness, 2.0f), omk = 1.0f - k;      // G1_env's k, 1 - k
+    const float vv = dot(V, V);
+    const bool laneBad = !allowFast | !((NdotV >= 0x1p-60f) & (NdotV <= 1.0f) & (vv >= 0.98f) & (vv <= 1.02f) & (k >= 0.0f) & (k <= 0.5f));
+    float F0Scale = 0.0f, F0Bias = 0.0f;
+    for (int base = 0; base < samples; base += 512) {
+        __syncthreads();
+        bool bad = laneBad;
+        for (int j = threadIdx.x; j < 512; j += 256) {
+            const uint32_t i = (uint32_t)(base + j);
+            const float Xix = (float)i * rcount;                // Hammersley, ShadingMath.hlsl:119-127
+            float sp, cp; sincos_((2.0f * PI_) * Xix, &sp, &cp);
+            const f3 H = ImportanceSampleGGX(RadicalInverse_VdC(i), sp, cp, N, roughness);
+            sH[j] = make_float4(H.x, H.y, H.z, max_(H.z, 0.0f));
+            const float hh = dot(H, H);
+            if (base + j < samples) bad |= !((hh >= 0.98f) & (hh <= 1.02f) & (H.z >= 0x1p-60f));
+        }
+        const bool general = __syncthreads_or(bad) != 0;        // block-uniform choice of the loop form (also the barrier behind the table)
+        const int n = min(512, samples - base);
+        if (!general) for (int j = 0; j < n; ++j) lut_sample<true>(sH[j], V, NdotV, k, omk, G1V, roughness, p5ExpLog, F0Scale, F0Bias);
+        else          for (int j = 0; j < n; ++j) lut_sample<false>(sH[j], V, NdotV, k, omk, G1V, roughness, p5ExpLog, F0Scale, F0Bias);
+    }
+    if (x < size) store_px<FMT>(out, (size_t)y * size + x, make_float4(F0Scale * rcount, F0Bias * rcount, 0, 0));
+}
+
+// The round-1/2 form of the same integration: every lane evaluates ImportanceSampleGGX for every sample (the per-sample
+// (sin phi, cos phi, Xi.y) table alone is shared through LDS). Kept for the A/B test of the two forms (VQHIP_LUT_FORM=persample;
+// tests/test_gpu_conv_forms.py: identical bits).
+template <int FMT>
+__global__ __launch_bounds__(256) void k_brdf_lut_persample(void* __restrict__ out, int size, int samples, int p5ExpLog) {
     __shared__ float sSin[512], sCos[512], sXy[512];
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     const float NdotV = div_((float)x + 0.5f, (float)size);     // CubemapConvolution.hlsl:233-236
@@ -113,15 +216,92 @@ __global__ __launch_bounds__(256) void k_mip_min(const float4* __restrict__ src,
 VQD float wave_xor_add(float v, int m) { return v + __shfl_xor(v, m, 64); }
 
 // ---- diffuse irradiance ------------------------------------------------------------------------------
+// One tap of PSMain_DiffuseIrradiance (:146-157) from the rotated tangent-space sample vector: normalize, DirectionToEquirectUV,
+// SampleLevel(uv, 3). General form: every operation with its range tests and special cases (vq_devmath.h / vq_sampling.h).
+VQD f3 diffuse_tap_general(f3 sv, const float4* chain, int w0, int h0, int nMips) {
+    sv = normalize(sv);
+    const float2 uv = DirectionToEquirectUV(sv);
+    const float4 c = sample_equirect_lod(chain, w0, h0, nMips, uv.x, uv.y, 3.0f);                                // mipLevel = 3 :155-157
+    return mk3(c.x, c.y, c.z);
+}
+// Fast form of the same tap: the SAME operations in the same order with (a) the range tests of sqrt_/rcp dropped where the operand's
+// range is known, (b) the branches of atan_/asin_ turned into selects around ONE reciprocal / square root (the untaken side's operand
+// substituted before the operation: -1 * rcp(x) is -rcp(x), the square root of a lane that does not use it is discarded), (c) the mip
+// level, its base and size resolved by the host (lod 3.0 has fraction 0: one level, vq_sampling.h:280), 32-bit byte offsets.
+// Preconditions, established outside the tap loop (k_conv_diffuse): |sv|^2 in [0.9, 1.1] (orthonormal frame, unit table entries), level
+// dimensions powers of two. What the selects cannot express sets `special`, and the caller redoes the tap of the WHOLE WAVE with the general
+// form (wave-uniform branch, rare): a zero or sub-2^-100 x or a zero z (atan2_'s axis cases; keeps y * rcp(x) finite with rcp(x) normal),
+// |y| >= 1 (asin_'s pole / NaN cases; keeps 0.5 (1 - |y|) >= 2^-25 inside sqrt_newton's domain). Where it applies it returns the bits of
+// diffuse_tap_general (tests/test_gpu_conv_forms.py compares whole cubes of the two forms).
+constexpr float kInvNegTwoPi = 1.0f / -TWO_PI_;                  // == rcp(-TWO_PI_): rcp is the correctly rounded quotient, as is the constant division
+constexpr float kInvPi       = 1.0f / PI_;
+struct DiffuseLevel { const char* tex; int W, H, rowShift; float W256, H256; };   // the sampled level: base, size, log2(W) + 4 (byte offset of a row), 256 W, 256 H
+VQD f3 diffuse_tap_fast(f3 sv, const DiffuseLevel& lv, bool& special) {
+    sv = mul(sv, rcp_newton(sqrt_newton(dot(sv, sv))));                                                           // normalize
+    // atan2_(sv.z, sv.x)
+    const float ay = sv.z, axx = sv.x;
+    special |= !(abs_(axx) >= 0x1p-100f) | (ay == 0.0f);
+    const float q = ay * rcp_newton(axx);                                                                         // div_(y, x)
+    const float aq = abs_(q);
+    const bool big = aq > 2.414213562373095f, mid = aq > 0.4142135623730950f;                                     // mid includes big
+    const float xr0 = (big ? -1.0f : aq - 1.0f) * rcp_newton(big ? aq : aq + 1.0f);                               // -rcp(x) | div_(x - 1, x + 1)
+    const float xr = mid ? xr0 : aq;
+    const float y0 = big ? 1.5707963267948966192f : (mid ? 0.7853981633974483096f : 0.0f);
+    const float z = xr * xr;
+    float p = 8.05374449538e-2f;
+    p = fma_(p, z, -1.38776856032E-1f);
+    p = fma_(p, z,  1.99777106478E-1f);
+    p = fma_(p, z, -3.33329491539E-1f);
+    float at = y0 + fma_(p * z, xr, xr);
+    at = (q < 0.0f) ? -at : at;
+    const float PI_F = 3.14159265358979323846f;
+    const float w = (axx < 0.0f) ? ((ay < 0.0f) ? -PI_F : PI_F) : 0.0f;
+    const float ux = w + at;
+    // asin_(-sv.y)
+    const float sx = -sv.y, sa = abs_(sx);
+    special |= !(sa < 1.0f);
+    const bool sbig = sa > 0.5f;
+    const float sz = sbig ? 0.5f * (1.0f - sa) : sa * sa;
+    const float ss = sbig ? sqrt_newton(sz) : sa;
+    const float st = asin_poly(ss, sz);
+    float uy = sbig ? 1.5707963267948966192f - (st + st) : st;
+    uy = (sx < 0.0f) ? -uy : uy;
+    const float u = ux * kInvNegTwoPi + 0.5f, v = uy * kInvPi + 0.5f;                                             // ShadingMath.hlsl:76-79
+    // sample_2d_rgba32f_wrap_t<POT = true> on the resolved level; u, v in [-0.01, 1.01]: the float -> int conversions are in range
+    // fixed8 (vq_sampling.h): floor((u * W - 0.5) * 256 + 0.5). W is a power of two: u * (256 W) is exact and scaling by 256 commutes with the
+    // rounding of the subtraction, so RN(u * W - 0.5) * 256 == fma(u, 256 W, -128) — one operation instead of three, the same value
+    const int fx = (int)__builtin_floorf(fma_(u, lv.W256, -128.0f) + 0.5f);
+    const int fy = (int)__builtin_floorf(fma_(v, lv.H256, -128.0f) + 0.5f);
+    const int ix = fx >> 8, iy = fy >> 8;
+    const float wx = (float)(fx & 255) * 0.00390625f, wy = (float)(fy & 255) * 0.00390625f;
+    const uint32_t x0 = (uint32_t)(ix & (lv.W - 1)) << 4, x1 = (uint32_t)((ix + 1) & (lv.W - 1)) << 4;
+    const uint32_t r0 = (uint32_t)(iy & (lv.H - 1)) << lv.rowShift, r1 = (uint32_t)((iy + 1) & (lv.H - 1)) << lv.rowShift;
+    const float4 c00 = *(const float4*)(lv.tex + (r0 + x0)), c10 = *(const float4*)(lv.tex + (r0 + x1));
+    const float4 c01 = *(const float4*)(lv.tex + (r1 + x0)), c11 = *(const float4*)(lv.tex + (r1 + x1));
+    const float w00 = (1.0f - wx) * (1.0f - wy), w10 = wx * (1.0f - wy), w01 = (1.0f - wx) * wy, w11 = wx * wy;    // blend4
+    return mk3(fma_(w11, c11.x, fma_(w01, c01.x, fma_(w10, c10.x, w00 * c00.x))),
+               fma_(w11, c11.y, fma_(w01, c01.y, fma_(w10, c10.y, w00 * c00.y))),
+               fma_(w11, c11.z, fma_(w01, c01.z, fma_(w10, c10.z, w00 * c00.z))));
+}
+VQD bool near_one(float x) { return (x >= 0.99f) & (x <= 1.01f); }       // false for NaN
+
 // phis/thetas: the fp32 sequences of the float-accumulated loops (CubemapConvolution.hlsl:132-136), built on the host.
-template <bool WAVE, int FMT>
+// FAST: the level is a power-of-two image and the fast tap may run (launch_conv_diffuse_tables); the kernel still checks per block that the
+// theta table holds unit (sin, cos) pairs, per texel that (right, up, N) is an orthonormal frame and per phi that (sin, cos) is a unit pair —
+// a lane failing any of these runs every tap in the general form.
+template <bool WAVE, int FMT, bool FAST>
 __global__ __launch_bounds__(256) void k_conv_diffuse(const float4* __restrict__ chain, int w0, int h0, int nMips, int res,
                                                       const float* __restrict__ phis, int nPhi, const float* __restrict__ thetas, int nTheta,
-                                                      void* __restrict__ out) {
-    extern __shared__ float lds[];                               // sinT[nTheta], cosT[nTheta]
-    float* sinT = lds; float* cosT = lds + nTheta;
-    for (int t = threadIdx.x; t < nTheta; t += 256) { float s, c; sincos_(thetas[t], &s, &c); sinT[t] = s; cosT[t] = c; }
-    __syncthreads();
+                                                      void* __restrict__ out, DiffuseLevel lv) {
+    extern __shared__ float lds[];                               // (sinT, cosT)[nTheta]
+    float2* scT = (float2*)lds;
+    bool tabBad = false;
+    for (int t = threadIdx.x; t < nTheta; t += 256) {
+        float s, c; sincos_(thetas[t], &s, &c); scT[t] = make_float2(s, c);
+        tabBad |= !near_one(fma_(s, s, c * c));
+    }
+    const bool fastBlock = FAST && __syncthreads_or(tabBad) == 0;
+    if (!FAST) __syncthreads();
     const int lane = threadIdx.x & 63;
     const long total = 6L * res * res;
     const long texel = WAVE ? ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) : ((long)blockIdx.x * 256 + threadIdx.x);
@@ -131,17 +311,26 @@ __global__ __launch_bounds__(256) void k_conv_diffuse(const float4* __restrict__
     f3 up = mk3(0, 1, 0);
     const f3 right = normalize(cross(up, N));                    // :122
     up = normalize(cross(N, right));                             // :124
+    const bool frameOK = near_one(dot(N, N)) && near_one(dot(right, right)) && near_one(dot(up, up)) &&
+                         abs_(dot(N, right)) <= 0.01f && abs_(dot(N, up)) <= 0.01f && abs_(dot(right, up)) <= 0.01f;
     float ax = 0.0f, ay = 0.0f, az = 0.0f;
     for (int k = WAVE ? lane : 0; k < nPhi; k += (WAVE ? 64 : 1)) {
         float sinPhi, cosPhi; sincos_(phis[k], &sinPhi, &cosPhi);
+        const bool laneFast = fastBlock && frameOK && near_one(fma_(sinPhi, sinPhi, cosPhi * cosPhi));
         for (int t = 0; t < nTheta; ++t) {
-            const float sinTheta = sinT[t], cosTheta = cosT[t];
+            const float2 sc = scT[t];
+            const float sinTheta = sc.x, cosTheta = sc.y;
             const f3 ts = mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);                                  // :146-150
-            f3 sv = mk3((ts.x * right.x + ts.y * up.x) + ts.z * N.x, (ts.x * right.y + ts.y * up.y) + ts.z * N.y,
-                        (ts.x * right.z + ts.y * up.z) + ts.z * N.z);                                           // :152
-            sv = normalize(sv);
-            const float2 uv = DirectionToEquirectUV(sv);
-            const float4 c = sample_equirect_lod(chain, w0, h0, nMips, uv.x, uv.y, 3.0f);                        // mipLevel = 3 :155-157
+            const f3 sv = mk3((ts.x * right.x + ts.y * up.x) + ts.z * N.x, (ts.x * right.y + ts.y * up.y) + ts.z * N.y,
+                              (ts.x * right.z + ts.y * up.z) + ts.z * N.z);                                     // :152
+            f3 c;
+            if (FAST) {
+                bool special = !laneFast;
+                c = diffuse_tap_fast(sv, lv, special);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) c = diffuse_tap_general(sv, chain, w0, h0, nMips);
+            } else {
+                c = diffuse_tap_general(sv, chain, w0, h0, nMips);
+            }
             ax = ax + (c.x * cosTheta) * sinTheta; ay = ay + (c.y * cosTheta) * sinTheta; az = az + (c.z * cosTheta) * sinTheta;
         }
     }
@@ -196,6 +385,59 @@ __global__ __launch_bounds__(256) void k_conv_specular(const float4* __restrict_
     store_px<FMT>(out, (size_t)texel, make_float4(ax * rw, ay * rw, az * rw, 1.0f));
 }
 
+// All mips of the prefiltered cube in ONE launch, WAVE64 order (one wave per texel): the 7 launches of the per-mip form leave the chip almost
+// empty for the five small mips (24 ... 1 536 waves). Block = 4 consecutive texels of the mip-major cube; every mip holds a multiple of 4 texels
+// (6 r^2, r >= 2), so a block lies in one mip = one roughness: the 512 tangent-space half vectors of (sample, roughness) — sincos_, the Van der Corput
+// reversal, an IEEE division and two square roots per sample — are built once per block into LDS (2 per lane instead of 8 per lane and texel)
+// and the tangent frame of N once per texel. Everything else is the per-mip kernel's arithmetic on the same values: identical bits.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_conv_specular_all(const float4* __restrict__ chain, int w0, int h0, int nMips, int res0, int MIPS, void* __restrict__ out) {
+    __shared__ float4 sHt[512];
+    const uint32_t NUM_SAMPLES = 512;
+    const int lane = threadIdx.x & 63;
+    const long T0 = (long)blockIdx.x * 4;
+    int mip = 0, res = res0; long base = 0;
+    while (mip < MIPS - 1 && T0 >= base + 6L * res * res) { base += 6L * res * res; ++mip; res >>= 1; }
+    const float Roughness = div_((float)mip, (float)(MIPS - 1));                       // EnvironmentMapRendering.cpp:432
+    for (uint32_t i = threadIdx.x; i < NUM_SAMPLES; i += 256) {
+        const float Xix = div_((float)i, (float)NUM_SAMPLES);
+        float sp, cp; sincos_((2.0f * PI_) * Xix, &sp, &cp);
+        const f3 Ht = ggx_sample_tangent(RadicalInverse_VdC(i), sp, cp, Roughness);
+        sHt[i] = make_float4(Ht.x, Ht.y, Ht.z, 0.0f);
+    }
+    __syncthreads();
+    const long texel = T0 + (threadIdx.x >> 6) - base;                                  // within the mip
+    if (texel >= 6L * res * res) return;
+    const int f = (int)(texel / ((long)res * res)), y = (int)((texel / res) % res), x = (int)(texel % res);
+    const f3 N = normalize(cube_texel_dir(f, x, y, res));
+    const f3 V = N;
+    const TangentFrame fr = tangent_frame(N);
+    const float fOmegaP = div_(4.0f * PI_, (6.0f * (float)w0) * (float)h0);            // :203 with TextureDimensionsLOD0 = equirect dims (:433-434)
+    float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;
+    for (uint32_t i = (uint32_t)lane; i < NUM_SAMPLES; i += 64u) {
+        const float4 ht = sHt[i];
+        const f3 H = tangent_to_world(mk3(ht.x, ht.y, ht.z), fr, N);
+        const f3 L = reflect(neg(V), H);
+        const float NdotL = saturate(dot(N, L));
+        if (NdotL > 0.0f) {
+            const float NdotH = saturate(dot(N, H));
+            const float HdotV = saturate(dot(H, V));
+            const float D = NormalDistributionGGX(NdotH, Roughness);
+            const float pdf = div_(D * NdotH, 4.0f * HdotV);
+            const float fOmegaS = rcp(max_((float)NUM_SAMPLES * pdf, 0.00001f));
+            const float fMipLevel = (Roughness == 0.0f) ? 0.0f : max_(0.5f * log2_(div_(fOmegaS, fOmegaP)) + -1.0f, 0.0f);
+            const float2 uv = DirectionToEquirectUV(L);
+            const float4 c = sample_equirect_lod(chain, w0, h0, nMips, uv.x, uv.y, fMipLevel);
+            ax = ax + c.x * NdotL; ay = ay + c.y * NdotL; az = az + c.z * NdotL; aw = aw + NdotL;
+        }
+    }
+    #pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { ax = wave_xor_add(ax, m); ay = wave_xor_add(ay, m); az = wave_xor_add(az, m); aw = wave_xor_add(aw, m); }
+    if (lane != 0) return;
+    const float rw = rcp(max_(aw, 0.0001f));
+    store_px<FMT>(out, (size_t)(base + texel), make_float4(ax * rw, ay * rw, az * rw, 1.0f));
+}
+
 } // namespace
 
 namespace vqk {
@@ -247,8 +489,15 @@ hipError_t launch_unlit_composite(hipStream_t s, const float4* cov, int covPitch
 
 hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt, int p5ExpLog) {
     dim3 grid((size + 255) / 256, size);
-    if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut<3>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
-    else                        hipLaunchKernelGGL((k_brdf_lut<4>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
+    const char* form = std::getenv("VQHIP_LUT_FORM");           // read per launch: tests switch the form inside one process
+    const int allowFast = !(form && !std::strcmp(form, "general"));      // "general": the shared-H kernel with every range test left in
+    if (form && !std::strcmp(form, "persample")) {
+        if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut_persample<3>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
+        else                        hipLaunchKernelGGL((k_brdf_lut_persample<4>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
+        return hipGetLastError();
+    }
+    if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut<3>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog, allowFast);
+    else                        hipLaunchKernelGGL((k_brdf_lut<4>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog, allowFast);
     return hipGetLastError();
 }
 
@@ -258,19 +507,46 @@ hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw,
 }
 
 // phis = device array [nPhi], thetas = device array [nTheta], packed by the caller right behind each other
+template <bool WAVE, int FMT>
+static void launch_conv_diffuse_form(bool fast, dim3 grid, size_t lds, hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
+                                     const float* phis, int nPhi, const float* thetas, int nTheta, void* out, const DiffuseLevel& lv) {
+    if (fast) hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, true>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+    else      hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, false>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+}
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
                                       const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt) {
     const long total = 6L * res * res;
     const size_t lds = (size_t)nTheta * 2 * sizeof(float);
+    // the level SampleLevel(uv, 3) reads (sample_equirect_lod_t: lod clamped to the chain, fraction 0 -> one level) and whether the fast tap applies
+    const int level = nMips - 1 < 3 ? nMips - 1 : 3;
+    auto dim = [](int d0, int l) { const int d = d0 >> l; return d < 1 ? 1 : d; };
+    size_t offPx = 0;
+    for (int l = 0; l < level; ++l) offPx += (size_t)dim(w0, l) * dim(h0, l);
+    DiffuseLevel lv;
+    lv.tex = (const char*)(chain + offPx); lv.W = dim(w0, level); lv.H = dim(h0, level);
+    lv.rowShift = 4; while ((1 << (lv.rowShift - 4)) < lv.W) ++lv.rowShift;
+    lv.W256 = 256.0f * (float)lv.W; lv.H256 = 256.0f * (float)lv.H;
+    const char* form = std::getenv("VQHIP_DIFFUSE_FORM");       // "general": every tap with its range tests and branches (the round-1/2 kernel)
+    const bool fast = ((lv.W & (lv.W - 1)) | (lv.H & (lv.H - 1))) == 0 && (size_t)lv.W * lv.H * 16 < (1ull << 31) && !(form && !std::strcmp(form, "general"));
     if (order == VQHIP_CONV_WAVE64) {
         dim3 grid((unsigned)((total + 3) / 4));
-        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_diffuse<true, 0>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out);
-        else                          hipLaunchKernelGGL((k_conv_diffuse<true, 1>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out);
+        if (fmt == VQHIP_FMT_RGBA32F) launch_conv_diffuse_form<true, 0>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+        else                          launch_conv_diffuse_form<true, 1>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
     } else {
         dim3 grid((unsigned)((total + 255) / 256));
-        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_diffuse<false, 0>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out);
-        else                          hipLaunchKernelGGL((k_conv_diffuse<false, 1>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out);
+        if (fmt == VQHIP_FMT_RGBA32F) launch_conv_diffuse_form<false, 0>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+        else                          launch_conv_diffuse_form<false, 1>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
     }
+    return hipGetLastError();
+}
+
+// WAVE64 order, every mip of the res0 cube (res0 a power of two >= 4: mips res0 ... 2) in one launch; `out` = the mip-major cube
+hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, void* out, int fmt) {
+    long total = 0;
+    for (int m = 0; m < MIPS; ++m) { const long r = res0 >> m; total += 6 * r * r; }
+    dim3 grid((unsigned)((total + 3) / 4));
+    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular_all<0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
+    else                          hipLaunchKernelGGL((k_conv_specular_all<1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
     return hipGetLastError();
 }
 
