@@ -110,7 +110,7 @@ def test_single_gpu_line_carries_the_contract_fields():
     c2 = d["cfg2"]
     assert 0 < c2["shade_ms"] < 1.0 and 0 < c2["hbm_frac"] < 1 and 0 < c2["valu_frac_model"] < 1
     ib = d["ibl_load"]
-    for k in ("mip_chain_ms", "prefilter_ms", "brdf_lut_ms", "conv_diffuse_ms", "conv_specular_ms", "brdf_lut_warm_ms", "total_ms", "conv_diffuse_valu_frac_model"):
+    for k in ("mip_chain_ms", "prefilter_ms", "brdf_lut_ms", "conv_diffuse_ms", "conv_specular_ms", "brdf_lut_warm_ms", "total_ms", "warm_total_ms", "mip_chain_warm_ms", "prefilter_warm_ms", "conv_diffuse_valu_frac_model"):
         assert ib[k] > 0, k
     co = d["coherent_scene"]
     assert 0 < co["shade_ms"] < 5 and 0.05 < co["slow_path_pixel_fraction_round2"] < 0.3

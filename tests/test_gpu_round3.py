@@ -279,3 +279,22 @@ def test_context_refuses_a_second_thread(ctx):
     assert refused[0] + refused[1] > 0, "two threads hammered one context for 3000 calls each and never met"
     ref = O.forward_lighting(synth.gbuffer(W, H), pf, pv, abi.FMT_RGBA16F)
     assert_bits(ctx.forward_lighting(gb, pf, pv, out_fmt=abi.FMT_RGBA16F), ref, "context after the collision")
+
+
+@pytest.mark.parametrize("in_fmt,out_fmt", [(abi.FMT_RGBA32F, abi.FMT_RGBA32F), (abi.FMT_RGBA32F, abi.FMT_RGBA8_UNORM), (abi.FMT_RGBA16F, abi.FMT_RGBA16F)])
+def test_tonemap_direct_special_operands(ctx, in_fmt, out_fmt):
+    """The direct-arithmetic tonemapper takes the short form of pow_ (post.hip:pow_pn) when the base is a positive normal number; zero,
+    negative, denormal, huge, inf and NaN channels must come out of the general routine with the oracle's bits — in the sRGB curve, in
+    ST2084 with the Rec.709 -> Rec.2020 matrix (the HDR default, never a table) and without it."""
+    img = synth.hdr_image(96, 24, scale=20.0).astype(np.float32)
+    sp = np.array([0.0, -0.0, 1e-45, 1e-39, 1.1754944e-38, -1e-39, -0.25, -3.0, 3.0e38, np.inf, -np.inf, np.nan, 65504.0, 1e-30, 1e30, 0.0031308], np.float32)
+    img[0, :16, 0] = sp; img[1, :16, 1] = sp; img[2, :16, 2] = sp; img[3, :16, :3] = sp[:, None]
+    img[4, :16, 0] = sp; img[4, :16, 1] = sp[::-1]
+    img = img.astype(O._NP[in_fmt][0])
+    for p in (abi.TonemapperParams(abi.COLOR_SPACE_REC_709, abi.DISPLAY_CURVE_SRGB, 200.0, 1),
+              abi.TonemapperParams(abi.COLOR_SPACE_REC_709, abi.DISPLAY_CURVE_ST2084, 200.0, 1),
+              abi.TonemapperParams(abi.COLOR_SPACE_REC_709, abi.DISPLAY_CURVE_ST2084, 10000.0, 1),
+              abi.TonemapperParams(abi.COLOR_SPACE_REC_2020, abi.DISPLAY_CURVE_ST2084, 1.0e-3, 1)):
+        with np.errstate(all="ignore"):
+            ref = O.tonemap(img, in_fmt, out_fmt, p)
+        assert_bits(ctx.tonemap(dev(img), in_fmt, out_fmt, p), ref, f"direct tonemap, special operands, in={in_fmt} out={out_fmt} curve={p.OutputDisplayCurveEnum}")

@@ -181,17 +181,40 @@ __global__ __launch_bounds__(256) void k_blur_y(const void* __restrict__ in, voi
 }
 
 // ---- tonemapper ------------------------------------------------------------------------------------
+// pow_(x, y) == exp2_(y * log2_(x)) for the operands the display curves produce. When x is a positive normal number and t = y * log2(x)
+// lies in [-126, 127.5) none of the special cases of log2_ / exp2_ (zero, denormal, negative, inf, NaN base; overflow, underflow, the
+// 2^128 split) can fire, and the routines reduce to the two polynomials: the same operations on the same values, ~28 instead of ~75
+// VALU. Anything else takes pow_ itself (a branch no lane enters in practice). The direct-arithmetic tonemapper — RGBA32F images, and
+// the HDR default ST2084 on Rec.709 content, whose 3x3 matrix rules the 64 K-entry table out — spends 3 to 6 of these per pixel.
+VQD float pow_pn(float x, float y) {
+    const float t = y * log2_normal_bits(__float_as_uint(x), 0);
+    if (__builtin_expect(!((x >= 0x1p-126f) & (x <= 3.4028234663852886e38f) & (t >= -126.0f) & (t < 127.5f)), 0)) return pow_(x, y);
+    const float n = __builtin_rintf(t), f = t - n;
+    float q = 1.535336188319500E-4f;
+    q = fma_(q, f, 1.339887440266574E-3f);
+    q = fma_(q, f, 9.618437357674640E-3f);
+    q = fma_(q, f, 5.550332471162809E-2f);
+    q = fma_(q, f, 2.402264791363012E-1f);
+    q = fma_(q, f, 6.931472028550421E-1f);
+    return fma_(q, f, 1.0f) * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
 VQD float reinhard_srgb(float c, int gamma) {
     float t = div_(c, c + 1.0f);                                              // Tonemap_Reinhard, Tonemapper.hlsl:24-27
-    if (gamma)                                                                // LinearToSRGB, HDR.hlsl:76-80
-        t = (t < 0.0031308f) ? 12.92f * t : 1.055f * pow_(abs_(t), (float)(1.0 / 2.4)) - 0.055f;
+    if (gamma) {                                                              // LinearToSRGB, HDR.hlsl:76-80
+        const bool lin = t < 0.0031308f;                                      // the power of a lane on the linear segment is discarded: give it a base of 1
+        const float pw = pow_pn(lin ? 1.0f : abs_(t), (float)(1.0 / 2.4));
+        t = lin ? 12.92f * t : 1.055f * pw - 0.055f;
+    }
     return t;
 }
 VQD float st2084(float c) {                                                   // LinearToST2084, HDR.hlsl:110-119
     const float m1 = (float)(2610.0 / 4096.0 / 4), m2 = (float)(2523.0 / 4096.0 * 128), c1 = (float)(3424.0 / 4096.0),
                 c2 = (float)(2413.0 / 4096.0 * 32), c3 = (float)(2392.0 / 4096.0 * 32);
-    const float cp = pow_(abs_(c), m1);
-    return pow_(div_(c1 + c2 * cp, 1.0f + c3 * cp), m2);
+    const float a = abs_(c);
+    const bool zero = a == 0.0f;                                              // black: pow_(0, m1) = exp2_(-inf) = 0
+    const float pw = pow_pn(zero ? 1.0f : a, m1);
+    const float cp = zero ? 0.0f : pw;
+    return pow_pn(div_(c1 + c2 * cp, 1.0f + c3 * cp), m2);
 }
 
 VQD float4 tonemap_px(const float4 c, const VQ_TonemapperParams& p) {
