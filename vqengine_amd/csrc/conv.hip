@@ -236,7 +236,10 @@ VQD f3 diffuse_tap_general(f3 sv, const float4* chain, int w0, int h0, int nMips
 constexpr float kInvNegTwoPi = 1.0f / -TWO_PI_;                  // == rcp(-TWO_PI_): rcp is the correctly rounded quotient, as is the constant division
 constexpr float kInvPi       = 1.0f / PI_;
 struct DiffuseLevel { const char* tex; int W, H, rowShift; float W256, H256; };   // the sampled level: base, size, log2(W) + 4 (byte offset of a row), 256 W, 256 H
-VQD f3 diffuse_tap_fast(f3 sv, const DiffuseLevel& lv, bool& special) {
+// the tap in two halves: address arithmetic + the four gathers, then the blend (a loop that requests tap t+1 before it blends tap t was measured: 93
+// VGPRs, 5 waves per SIMD instead of 7, 7.74 against 7.61 ms — the gathers are throughput-, not latency-bound; profiles/r3i_conv_kernels.md)
+struct TapTexels { float4 c00, c10, c01, c11; float wx, wy; };
+VQD TapTexels diffuse_tap_fetch(f3 sv, const DiffuseLevel& lv, bool& special) {
     sv = mul(sv, rcp_newton(sqrt_newton(dot(sv, sv))));                                                           // normalize
     // atan2_(sv.z, sv.x)
     const float ay = sv.z, axx = sv.x;
@@ -276,20 +279,27 @@ VQD f3 diffuse_tap_fast(f3 sv, const DiffuseLevel& lv, bool& special) {
     const float wx = (float)(fx & 255) * 0.00390625f, wy = (float)(fy & 255) * 0.00390625f;
     const uint32_t x0 = (uint32_t)(ix & (lv.W - 1)) << 4, x1 = (uint32_t)((ix + 1) & (lv.W - 1)) << 4;
     const uint32_t r0 = (uint32_t)(iy & (lv.H - 1)) << lv.rowShift, r1 = (uint32_t)((iy + 1) & (lv.H - 1)) << lv.rowShift;
-    const float4 c00 = *(const float4*)(lv.tex + (r0 + x0)), c10 = *(const float4*)(lv.tex + (r0 + x1));
-    const float4 c01 = *(const float4*)(lv.tex + (r1 + x0)), c11 = *(const float4*)(lv.tex + (r1 + x1));
-    const float w00 = (1.0f - wx) * (1.0f - wy), w10 = wx * (1.0f - wy), w01 = (1.0f - wx) * wy, w11 = wx * wy;    // blend4
-    return mk3(fma_(w11, c11.x, fma_(w01, c01.x, fma_(w10, c10.x, w00 * c00.x))),
-               fma_(w11, c11.y, fma_(w01, c01.y, fma_(w10, c10.y, w00 * c00.y))),
-               fma_(w11, c11.z, fma_(w01, c01.z, fma_(w10, c10.z, w00 * c00.z))));
+    TapTexels tt;
+    tt.c00 = *(const float4*)(lv.tex + (r0 + x0)); tt.c10 = *(const float4*)(lv.tex + (r0 + x1));
+    tt.c01 = *(const float4*)(lv.tex + (r1 + x0)); tt.c11 = *(const float4*)(lv.tex + (r1 + x1));
+    tt.wx = wx; tt.wy = wy;
+    return tt;
 }
+VQD f3 diffuse_tap_blend(const TapTexels& q) {
+    const float wx = q.wx, wy = q.wy;
+    const float w00 = (1.0f - wx) * (1.0f - wy), w10 = wx * (1.0f - wy), w01 = (1.0f - wx) * wy, w11 = wx * wy;    // blend4
+    return mk3(fma_(w11, q.c11.x, fma_(w01, q.c01.x, fma_(w10, q.c10.x, w00 * q.c00.x))),
+               fma_(w11, q.c11.y, fma_(w01, q.c01.y, fma_(w10, q.c10.y, w00 * q.c00.y))),
+               fma_(w11, q.c11.z, fma_(w01, q.c01.z, fma_(w10, q.c10.z, w00 * q.c00.z))));
+}
+VQD f3 diffuse_tap_fast(f3 sv, const DiffuseLevel& lv, bool& special) { return diffuse_tap_blend(diffuse_tap_fetch(sv, lv, special)); }
 VQD bool near_one(float x) { return (x >= 0.99f) & (x <= 1.01f); }       // false for NaN
 
 // phis/thetas: the fp32 sequences of the float-accumulated loops (CubemapConvolution.hlsl:132-136), built on the host.
 // FAST: the level is a power-of-two image and the fast tap may run (launch_conv_diffuse_tables); the kernel still checks per block that the
 // theta table holds unit (sin, cos) pairs, per texel that (right, up, N) is an orthonormal frame and per phi that (sin, cos) is a unit pair —
 // a lane failing any of these runs every tap in the general form.
-template <bool WAVE, int FMT, bool FAST>
+template <bool WAVE, int FMT, int FAST>
 __global__ __launch_bounds__(256) void k_conv_diffuse(const float4* __restrict__ chain, int w0, int h0, int nMips, int res,
                                                       const float* __restrict__ phis, int nPhi, const float* __restrict__ thetas, int nTheta,
                                                       void* __restrict__ out, DiffuseLevel lv) {
@@ -317,12 +327,15 @@ __global__ __launch_bounds__(256) void k_conv_diffuse(const float4* __restrict__
     for (int k = WAVE ? lane : 0; k < nPhi; k += (WAVE ? 64 : 1)) {
         float sinPhi, cosPhi; sincos_(phis[k], &sinPhi, &cosPhi);
         const bool laneFast = fastBlock && frameOK && near_one(fma_(sinPhi, sinPhi, cosPhi * cosPhi));
+        auto sample_vec = [&](float2 sc) {                                                                        // :146-152
+            const f3 ts = mk3(sc.x * cosPhi, sc.x * sinPhi, sc.y);
+            return mk3((ts.x * right.x + ts.y * up.x) + ts.z * N.x, (ts.x * right.y + ts.y * up.y) + ts.z * N.y,
+                       (ts.x * right.z + ts.y * up.z) + ts.z * N.z);
+        };
         for (int t = 0; t < nTheta; ++t) {
             const float2 sc = scT[t];
             const float sinTheta = sc.x, cosTheta = sc.y;
-            const f3 ts = mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);                                  // :146-150
-            const f3 sv = mk3((ts.x * right.x + ts.y * up.x) + ts.z * N.x, (ts.x * right.y + ts.y * up.y) + ts.z * N.y,
-                              (ts.x * right.z + ts.y * up.z) + ts.z * N.z);                                     // :152
+            const f3 sv = sample_vec(sc);
             f3 c;
             if (FAST) {
                 bool special = !laneFast;
@@ -508,10 +521,10 @@ hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw,
 
 // phis = device array [nPhi], thetas = device array [nTheta], packed by the caller right behind each other
 template <bool WAVE, int FMT>
-static void launch_conv_diffuse_form(bool fast, dim3 grid, size_t lds, hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
+static void launch_conv_diffuse_form(int fast, dim3 grid, size_t lds, hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
                                      const float* phis, int nPhi, const float* thetas, int nTheta, void* out, const DiffuseLevel& lv) {
-    if (fast) hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, true>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
-    else      hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, false>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+    if (fast)       hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, 1>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+    else            hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, 0>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
 }
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
                                       const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt) {
@@ -527,7 +540,7 @@ hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0
     lv.rowShift = 4; while ((1 << (lv.rowShift - 4)) < lv.W) ++lv.rowShift;
     lv.W256 = 256.0f * (float)lv.W; lv.H256 = 256.0f * (float)lv.H;
     const char* form = std::getenv("VQHIP_DIFFUSE_FORM");       // "general": every tap with its range tests and branches (the round-1/2 kernel)
-    const bool fast = ((lv.W & (lv.W - 1)) | (lv.H & (lv.H - 1))) == 0 && (size_t)lv.W * lv.H * 16 < (1ull << 31) && !(form && !std::strcmp(form, "general"));
+    int fast = ((lv.W & (lv.W - 1)) | (lv.H & (lv.H - 1))) == 0 && (size_t)lv.W * lv.H * 16 < (1ull << 31) && !(form && !std::strcmp(form, "general")) ? 1 : 0;
     if (order == VQHIP_CONV_WAVE64) {
         dim3 grid((unsigned)((total + 3) / 4));
         if (fmt == VQHIP_FMT_RGBA32F) launch_conv_diffuse_form<true, 0>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
