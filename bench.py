@@ -16,6 +16,7 @@ Every invocation (N = 1 included) ALSO times, outside the headline's timed regio
                  (100 cbuffer + 156 extension), 4320/N rows per GPU — STRONG scaling; with shade / halo / composite / latency figures
   (N = 1 only)
   cfg2           BASELINE config 2: 1920x1080, 16 point lights, shade kernel (the size where HBM is the roof that matters)
+  sustained      the headline's own step for ~2 s without interruption (thousands of steps): a long-window cross-check of `value`, visible to rocm-smi
   ibl_load       BASELINE config 4: the load-time IBL stages (min-filter mip chain, diffuse irradiance, specular prefilter, BRDF LUT), timed
   coherent_scene the cfg3 frame on surface-coherent content (synth.gbuffer_rows_coherent) instead of white noise — never the headline
   tile_curve     per-tile step time of the cfg5 frame at 4320/N rows, N = 1, 2, 4, 8, on this one GPU + a labelled MODELLED speed-up
@@ -60,6 +61,7 @@ COLD_STEPS = 20                 # the first steps after the idle set-up phase, t
 VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip)
 XGMI_LINK_GBPS = 153.0          # per direct GPU-GPU link, peak; the tile-curve model also quotes half of it
 WATCHDOG_S = float(os.environ.get("VQ_BENCH_WATCHDOG_S", "30"))
+SUSTAINED_S = float(os.environ.get("VQ_BENCH_SUSTAINED_S", "2.0"))   # length of the `sustained` companion run (0: off)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
 PMC_SOURCES = ["vqengine_amd/csrc/shade.hip", "vqengine_amd/csrc/vq_shade.h", "vqengine_amd/csrc/vq_devmath.h", "vqengine_amd/csrc/vq_sampling.h", "vqengine_amd/csrc/Makefile"]
 F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
@@ -587,6 +589,17 @@ def main():
     # 4. frame latency: one step at a time, nothing in flight before or after it
     frame_latency = pipe.latency()
 
+    # 4b. sustained run: the same step for ~SUSTAINED_S seconds without interruption — a long-window cross-check of `value` (thousands of steps instead
+    #     of K) and a stretch of GPU activity an outside observer (rocm-smi, the driver's clock) can see; never the headline
+    sustained = None
+    if not args.no_extras and SUSTAINED_S > 0:
+        n_sus = int(min(20000, max(200, SUSTAINED_S / (dt / args.steps))))         # the same on every rank: dt is the max over ranks
+        n_sus += n_sus & 1                                                         # the double-buffered composite alternates buffers
+        dt_sus = pipe.timed(n_sus)
+        sustained = {"steps": n_sus, "seconds": round(dt_sus, 4), "ms_per_step": round(dt_sus / n_sus * 1e3, 4),
+                     "value": round(W * frame_h * n_sus / dt_sus / 1e6, 2), "unit": "Mpix/s",
+                     "note": "same step, same buffers, one barrier + synchronize bracket around all of it; after the timed region (power limiter and clocks in their long-run state)"}
+
     verify = None
     if world > 1 and os.environ.get("VQ_BENCH_VERIFY") == "1":
         # debug aid: rank 0 recomputes the WHOLE frame on its own GPU (no tiles, no halos) and compares it byte for byte with the
@@ -687,6 +700,7 @@ def main():
                                                 "the figures above are taken inside the frame loop with an event record between the stages"}}),
                        **({"blur_x_includes": "halo exchange", "composite_ms": round(mean_ms(evd, "comp0", "comp1"), 4)} if world > 1 else {})},
             "frame_latency_ms": round(frame_latency * 1e3, 4),
+            **({"sustained": sustained} if sustained else {}),
             "cold_start": {"steps": COLD_STEPS, "ms_per_step": round(dt_cold / COLD_STEPS * 1e3, 4), "value": round(px_frame * COLD_STEPS / dt_cold / 1e6, 2),
                            "note": "the first steps after the idle set-up phase, before the clocks ramp; `value` is the steady-state figure"},
         }

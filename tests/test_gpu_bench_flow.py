@@ -22,7 +22,7 @@ def _free_port():
 
 
 def _run(ranks, extra_args, **more_env):
-    env = dict(os.environ, VQ_BENCH_SHARE_GPU="1", VQ_BENCH_VERIFY="1", VQ_BENCH_SPINUP="4", MASTER_ADDR="127.0.0.1", **more_env)
+    env = dict(os.environ, VQ_BENCH_SHARE_GPU="1", VQ_BENCH_VERIFY="1", VQ_BENCH_SPINUP="4", VQ_BENCH_SUSTAINED_S="0.05", MASTER_ADDR="127.0.0.1", **more_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "4", "--warmup", "1",
            "--no-cpu-baseline", "--no-second-mode"] + extra_args
@@ -81,7 +81,7 @@ def test_overlap_watchdog_falls_back_to_one_stream_order():
 def test_single_gpu_line_carries_the_contract_fields():
     """`python bench.py` (N = 1, defaults shortened): one JSON line with the driver's contract fields, the roofline and cpu_baseline objects,
     counter constants that belong to the current kernel sources, and the self-audit extras (engine lowering, cold start, isolated post kernels)."""
-    env = dict(os.environ, VQ_BENCH_SPINUP="30")
+    env = dict(os.environ, VQ_BENCH_SPINUP="30", VQ_BENCH_SUSTAINED_S="0.5")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -89,8 +89,10 @@ def test_single_gpu_line_carries_the_contract_fields():
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline", "stages", "engine_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants", "rccl",
-              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve"):
+              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained"):
         assert k in d, k
+    su = d["sustained"]                                      # ~0.5 s of the headline's step here (VQ_BENCH_SUSTAINED_S), same order as `value`
+    assert su["steps"] >= 200 and su["steps"] % 2 == 0 and 0.5 * d["value"] < su["value"] < 1.5 * d["value"]
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "Mpix/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     assert abs(d["value"] - 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
