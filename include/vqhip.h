@@ -570,6 +570,11 @@ typedef struct vqhip_comm_info {
     char    library_path[232];           /* dladdr of ncclSend */
 } vqhip_comm_info;
 VQHIP_API int  vqhip_comm_query(const vqhip_comm* comm, vqhip_comm_info* out_info);
+/* Diagnostic: ONE grouped ncclSend + ncclRecv of `bytes` bytes from this rank to ITSELF, enqueued on `stream` like the exchanges below (RCCL serves
+ * a self-addressed pair as a device copy). A single-GPU host can so check that the point-to-point entry points of the RCCL it bound
+ * (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, stream semantics, byte counts) work from inside libvqhip.so before a multi-GPU frame
+ * depends on them. src and dst: device buffers of `bytes` bytes that do not overlap. */
+VQHIP_API int  vqhip_comm_loopback(vqhip_comm* comm, void* stream, const void* src, void* dst, size_t bytes);
 /* Exchange 1. xblur_tile: this rank's X-blurred tile (tile_rows x width, row_pitch_px pixels per row, fmt RGBA16F | RGBA32F).
  * Sends its first 10 rows to rank-1 and its last 10 rows to rank+1 and receives theirs into halo_top / halo_bottom (dense
  * 10 x width buffers, the layout vqhip_gaussian_blur_y takes; ignored — may be NULL — at the frame's top / bottom edge).

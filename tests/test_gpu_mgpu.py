@@ -31,3 +31,26 @@ def test_world_of_one_through_real_rccl(ctx):
     finally:
         comm.close()
     assert np.frombuffer(uid, np.uint8).size == 128
+
+
+@pytest.mark.parametrize("nbytes", [1 << 10, 10 * 7680 * 8, 33 << 20])
+def test_loopback_send_recv_through_real_rccl(ctx, nbytes):
+    """ncclSend + ncclRecv of the bound RCCL, grouped and addressed to the own rank (vqhip_comm_loopback): the point-to-point entry points the
+    halo exchange and the composite use — here with the message sizes of a cfg5 halo (10 rows of 7680 RGBA16F pixels) and of a 4K RGBA8 tile —
+    run from inside libvqhip.so on a side stream, and the bytes arrive."""
+    comm = capi.Comm(capi.comm_unique_id(), 1, 0)
+    try:
+        q = comm.query()
+        assert q["nranks_seen"] == 1 and q["rank_seen"] == 0 and q["version"] > 0 and "rccl" in q["library_path"].lower()
+        src = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device="cuda")
+        dst = torch.zeros_like(src)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        for _ in range(3):                                                             # back-to-back groups on one stream
+            comm.loopback(src, dst, stream=s.cuda_stream)
+        s.synchronize()
+        assert torch.equal(src, dst)
+        with pytest.raises(capi.VQHipError):
+            comm.loopback(src, None)
+    finally:
+        comm.close()

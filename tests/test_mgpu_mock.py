@@ -40,6 +40,10 @@ def _worker(rank, world, H, root, pitch_pad, conn, q):
         tl = fr.tiling
         info = fr.comm.query()                               # read back from the communicator, not from the arguments
         assert (info["nranks_seen"], info["rank_seen"], info["version"]) == (world, rank, 0) and info["library_path"].endswith("libmock_rccl.so"), info
+        lb_src = np.arange(3001, dtype=np.uint8) + rank      # vqhip_comm_loopback: a grouped send + receive addressed to the own rank
+        lb_dst = np.zeros_like(lb_src)
+        fr.comm.loopback(lb_src, lb_dst)
+        assert np.array_equal(lb_src, lb_dst)
         gb = synth.gbuffer_rows(W, H, tl.row0, tl.row1, seed=0xD157)
         pf, _ = synth.per_frame(points=synth.point_lights(12, seed=0xD157))
         scene = O.forward_lighting(gb, pf, synth.per_view(W, H), abi.FMT_RGBA16F)

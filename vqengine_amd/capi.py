@@ -85,6 +85,7 @@ def load_library():
         "vqhip_comm_destroy": (None, [vp]),
         "vqhip_comm_query": (i32, [vp, C.POINTER(abi.CommInfo)]),
         "vqhip_comm_abort": (i32, [vp]),
+        "vqhip_comm_loopback": (i32, [vp, vp, vp, vp, sz]),
         "vqhip_exchange_blur_halos": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
         "vqhip_composite_tiles": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
     }
@@ -105,7 +106,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_forward_lighting_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
     "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f", "vqhip_hdr_downsize_rgba32f",
     "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections",
-    "vqhip_rowtile", "vqhip_comm_unique_id", "vqhip_comm_create", "vqhip_comm_adopt", "vqhip_comm_destroy", "vqhip_comm_query", "vqhip_comm_abort", "vqhip_exchange_blur_halos",
+    "vqhip_rowtile", "vqhip_comm_unique_id", "vqhip_comm_create", "vqhip_comm_adopt", "vqhip_comm_destroy", "vqhip_comm_query", "vqhip_comm_abort", "vqhip_comm_loopback", "vqhip_exchange_blur_halos",
     "vqhip_composite_tiles",
 ]
 
@@ -200,6 +201,13 @@ class Comm:
             _global_error(rc)
         return {"world": info.world, "rank": info.rank, "nranks_seen": info.nranks_seen, "rank_seen": info.rank_seen,
                 "version": info.rccl_version, "library_path": info.library_path.decode(errors="replace")}
+
+    def loopback(self, src, dst, stream=None):
+        """One grouped ncclSend + ncclRecv from this rank to itself (vqhip_comm_loopback): src -> dst, same byte size, enqueued on `stream`."""
+        n = src.numel() * src.element_size() if hasattr(src, "numel") else src.nbytes
+        rc = self.lib.vqhip_comm_loopback(self._h, stream, _addr(src), _addr(dst), n)
+        if rc != 0:
+            _global_error(rc)
 
     def exchange_blur_halos(self, x_tile, fmt, halo_top, halo_bottom, stream=None):
         """x_tile [rows, W, 4]; halo_top / halo_bottom: preallocated [10, W, 4] buffers (None at the frame's edges)."""

@@ -273,6 +273,19 @@ int vqhip_composite_tiles(vqhip_comm* c, void* stream, const void* tile, int wid
     return VQHIP_OK;
 }
 
+int vqhip_comm_loopback(vqhip_comm* c, void* stream, const void* src, void* dst, size_t bytes) {
+    if (!c || !c->comm || !src || !dst || bytes == 0) return vqk::fail_global(VQHIP_ERR_INVALID_ARG, "vqhip_comm_loopback: bad arguments");
+    Rccl& r = rccl();
+    hipStream_t st = (hipStream_t)stream;
+    RCCL_TRY(r.GroupStart());                               // a send and a receive addressed to the own rank, posted together
+    ncclResult_t e = r.Send(src, bytes, ncclUint8, c->rank, c->comm, st);
+    if (e == ncclSuccess) e = r.Recv(dst, bytes, ncclUint8, c->rank, c->comm, st);
+    const ncclResult_t eg = r.GroupEnd();
+    if (e != ncclSuccess) return failRccl("ncclSend / ncclRecv (loopback)", e);
+    if (eg != ncclSuccess) return failRccl("ncclGroupEnd", eg);
+    return VQHIP_OK;
+}
+
 int vqhip_comm_query(const vqhip_comm* c, vqhip_comm_info* out) {
     if (!c || !out) return vqk::fail_global(VQHIP_ERR_INVALID_ARG, "vqhip_comm_query: NULL argument");
     Rccl& r = rccl();
