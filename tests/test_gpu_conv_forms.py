@@ -53,13 +53,15 @@ def _chain(w, h, seed=0xE9):
 
 @pytest.mark.parametrize("order", [abi.CONV_WAVE64, abi.CONV_SEQUENTIAL])
 def test_conv_diffuse_forms_identical_cfg4(ctx, monkeypatch, order):
-    """2048^2 equirect -> 6 x 64^2 at step 0.010 (99 382 taps per texel): whole cube, fast tap vs general tap. The sequential order runs
+    """2048^2 equirect -> 6 x 64^2 at step 0.010 (99 382 taps per texel): whole cube, the default (branch-free tap on footprint records) vs the other
+    two forms. The sequential order runs
     one lane per texel for ~0.1 s: a coarser step keeps it short."""
     _, _, chain_g, n = _chain(2048, 2048)
     step = 0.010 if order == abi.CONV_WAVE64 else 0.05
     fast = ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, step, order, abi.FMT_RGBA32F)
-    monkeypatch.setenv("VQHIP_DIFFUSE_FORM", "general")
-    _same(ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, step, order, abi.FMT_RGBA32F), fast, f"cfg4 diffuse fast vs general, order {order}")
+    for form in ("general", "texels"):                      # every tap with its branches / the branch-free tap gathering from the level itself
+        monkeypatch.setenv("VQHIP_DIFFUSE_FORM", form)
+        _same(ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, step, order, abi.FMT_RGBA32F), fast, f"cfg4 diffuse records vs {form}, order {order}")
 
 
 @pytest.mark.parametrize("res", [1, 3, 5, 8])
@@ -108,3 +110,21 @@ def test_conv_specular_forms_identical(ctx, monkeypatch, w, h, res0, fmt):
     if w <= 128:
         ref, _ = O.conv_specular(chain_o, w, h, n, res0, abi.CONV_WAVE64, fmt)
         assert_bits(one, ref, f"specular {res0}^2 from {w}x{h} vs oracle")
+
+
+def test_conv_diffuse_records_across_streams_and_chains(ctx):
+    """The footprint records live in one buffer of the context and are rewritten by every call: calls for DIFFERENT chains on different streams must
+    not read each other's records (the second call's stream waits for the first call's kernel)."""
+    _, co_a, cg_a, n_a = _chain(256, 128, seed=0x61)
+    _, co_b, cg_b, n_b = _chain(512, 256, seed=0x62)
+    ref_a = O.conv_diffuse(co_a, 256, 128, n_a, 8, 0.05, abi.CONV_WAVE64, abi.FMT_RGBA32F)
+    ref_b = O.conv_diffuse(co_b, 512, 256, n_b, 8, 0.05, abi.CONV_WAVE64, abi.FMT_RGBA32F)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(3):
+        outs.append((ctx.conv_diffuse(cg_a, 256, 128, n_a, 8, 0.05, abi.CONV_WAVE64, abi.FMT_RGBA32F, stream=s1), ref_a))
+        outs.append((ctx.conv_diffuse(cg_b, 512, 256, n_b, 8, 0.05, abi.CONV_WAVE64, abi.FMT_RGBA32F, stream=s2), ref_b))
+    torch.cuda.synchronize()
+    for k, (got, ref) in enumerate(outs):
+        assert_bits(got, ref, f"interleaved conv_diffuse call {k}")

@@ -28,6 +28,9 @@ struct vqhip_ctx {
     bool slotBusy[kSlots] = {};
     int nextSlot = 0;
     void* scratch = nullptr; size_t scratchBytes = 0;
+    // footprint records of the diffuse convolution (conv.hip:k_diffuse_records): rewritten by every vqhip_conv_diffuse; `recFree` is recorded behind the
+    // kernel that reads them, and the next call's stream waits for it before it overwrites them (calls may come on different streams)
+    void* rec = nullptr; size_t recBytes = 0; hipEvent_t recFree = nullptr; bool recUsed = false;
     int pow5ExpLog = 0;            // vqhip_set_fresnel_pow
     // 65536-entry tonemap tables (post.hip:k_tonemap_lut), cached per (TonemapperParams, output format): the table is built once
     // per parameter set instead of once per frame. Streams that HIT a cached table only wait for the event of its build. A table is replaced
@@ -235,6 +238,8 @@ void vqhip_destroy(vqhip_ctx* ctx) {
     if (ctx->hostRing) (void)hipHostFree(ctx->hostRing);
     if (ctx->devRing) (void)hipFree(ctx->devRing);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->rec) (void)hipFree(ctx->rec);
+    if (ctx->recFree) (void)hipEventDestroy(ctx->recFree);
     for (int i = 0; i < vqhip_ctx::kLuts; ++i) {
         if (ctx->lut[i].table) (void)hipFree(ctx->lut[i].table);
         if (ctx->lut[i].built) (void)hipEventDestroy(ctx->lut[i].built);
@@ -797,8 +802,20 @@ int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, 
     rc = commitSlot(ctx, slot, n * sizeof(float), st);
     if (rc) return rc;
     const float* dtab = (const float*)(ctx->devRing + (size_t)slot * kConstSlotBytes);
-    hipError_t e = launch_conv_diffuse_tables(st, (const float4*)equirect_mips, w0, h0, nMips, diffuseRes, dtab, nPhi, dtab + nPhi, nTheta, order, outCube, fmt);
+    const size_t recNeed = conv_diffuse_record_bytes(w0, h0, nMips);
+    if (recNeed) {
+        if (ctx->recUsed) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->recFree, 0));
+        if (ctx->recBytes < recNeed) {
+            if (ctx->rec) { HIP_TRY(ctx, hipDeviceSynchronize()); HIP_TRY(ctx, hipFree(ctx->rec)); ctx->rec = nullptr; ctx->recBytes = 0; }
+            HIP_TRY(ctx, hipMalloc(&ctx->rec, recNeed));
+            ctx->recBytes = recNeed;
+        }
+        if (!ctx->recFree) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->recFree, hipEventDisableTiming));
+    }
+    hipError_t e = launch_conv_diffuse_tables(st, (const float4*)equirect_mips, w0, h0, nMips, diffuseRes, dtab, nPhi, dtab + nPhi, nTheta, order, outCube, fmt,
+                                              recNeed ? ctx->rec : nullptr);
     if (e != hipSuccess) return failHip(ctx, e, "conv_diffuse launch");
+    if (recNeed) { HIP_TRY(ctx, hipEventRecord(ctx->recFree, st)); ctx->recUsed = true; }
     return releaseSlot(ctx, slot, st);
 }
 

@@ -235,10 +235,11 @@ VQD f3 diffuse_tap_general(f3 sv, const float4* chain, int w0, int h0, int nMips
 // diffuse_tap_general (tests/test_gpu_conv_forms.py compares whole cubes of the two forms).
 constexpr float kInvNegTwoPi = 1.0f / -TWO_PI_;                  // == rcp(-TWO_PI_): rcp is the correctly rounded quotient, as is the constant division
 constexpr float kInvPi       = 1.0f / PI_;
-struct DiffuseLevel { const char* tex; int W, H, rowShift; float W256, H256; };   // the sampled level: base, size, log2(W) + 4 (byte offset of a row), 256 W, 256 H
+struct DiffuseLevel { const char* tex; int W, H, rowShift; float W256, H256; const char* rec; };   // the sampled level: base, size, log2(W) + 4 (byte offset of a row), 256 W, 256 H
 // the tap in two halves: address arithmetic + the four gathers, then the blend (a loop that requests tap t+1 before it blends tap t was measured: 93
 // VGPRs, 5 waves per SIMD instead of 7, 7.74 against 7.61 ms — the gathers are throughput-, not latency-bound; profiles/r3i_conv_kernels.md)
 struct TapTexels { float4 c00, c10, c01, c11; float wx, wy; };
+template <bool REC = false>
 VQD TapTexels diffuse_tap_fetch(f3 sv, const DiffuseLevel& lv, bool& special) {
     sv = mul(sv, rcp_newton(sqrt_newton(dot(sv, sv))));                                                           // normalize
     // atan2_(sv.z, sv.x)
@@ -277,12 +278,19 @@ VQD TapTexels diffuse_tap_fetch(f3 sv, const DiffuseLevel& lv, bool& special) {
     const int fy = (int)__builtin_floorf(fma_(v, lv.H256, -128.0f) + 0.5f);
     const int ix = fx >> 8, iy = fy >> 8;
     const float wx = (float)(fx & 255) * 0.00390625f, wy = (float)(fy & 255) * 0.00390625f;
+    TapTexels tt;
+    tt.wx = wx; tt.wy = wy;
+    if (REC) {                                               // k_diffuse_records: the 2 x 2 texels (rgb) of footprint (x, y), wrap applied, as 48 contiguous bytes
+        const uint32_t idx = ((uint32_t)(iy & (lv.H - 1)) << (lv.rowShift - 4)) + (uint32_t)(ix & (lv.W - 1));
+        const char* r = lv.rec + __umul24(idx, 48u);
+        const float4 a = *(const float4*)r, b = *(const float4*)(r + 16), c = *(const float4*)(r + 32);
+        tt.c00 = make_float4(a.x, a.y, a.z, 0); tt.c10 = make_float4(a.w, b.x, b.y, 0); tt.c01 = make_float4(b.z, b.w, c.x, 0); tt.c11 = make_float4(c.y, c.z, c.w, 0);
+        return tt;
+    }
     const uint32_t x0 = (uint32_t)(ix & (lv.W - 1)) << 4, x1 = (uint32_t)((ix + 1) & (lv.W - 1)) << 4;
     const uint32_t r0 = (uint32_t)(iy & (lv.H - 1)) << lv.rowShift, r1 = (uint32_t)((iy + 1) & (lv.H - 1)) << lv.rowShift;
-    TapTexels tt;
     tt.c00 = *(const float4*)(lv.tex + (r0 + x0)); tt.c10 = *(const float4*)(lv.tex + (r0 + x1));
     tt.c01 = *(const float4*)(lv.tex + (r1 + x0)); tt.c11 = *(const float4*)(lv.tex + (r1 + x1));
-    tt.wx = wx; tt.wy = wy;
     return tt;
 }
 VQD f3 diffuse_tap_blend(const TapTexels& q) {
@@ -292,7 +300,20 @@ VQD f3 diffuse_tap_blend(const TapTexels& q) {
                fma_(w11, q.c11.y, fma_(w01, q.c01.y, fma_(w10, q.c10.y, w00 * q.c00.y))),
                fma_(w11, q.c11.z, fma_(w01, q.c01.z, fma_(w10, q.c10.z, w00 * q.c00.z))));
 }
-VQD f3 diffuse_tap_fast(f3 sv, const DiffuseLevel& lv, bool& special) { return diffuse_tap_blend(diffuse_tap_fetch(sv, lv, special)); }
+template <bool REC = false>
+VQD f3 diffuse_tap_fast(f3 sv, const DiffuseLevel& lv, bool& special) { return diffuse_tap_blend(diffuse_tap_fetch<REC>(sv, lv, special)); }
+// Footprint records of the sampled level: a tap's 2 x 2 texels are 48 contiguous bytes (three 16-byte gathers from one record instead of four
+// 12-byte gathers from two rows): the texture-address unit was the busiest unit of the texel form (79 %), 7.6 -> 6.6 ms with the 3 us pre-pass
+// included (profiles/r3i_conv_kernels.md). rec[3 i .. 3 i + 2] = the rgb of texels (x, y), (x+1, y), (x, y+1), (x+1, y+1) of footprint i = y W + x, WRAP applied
+__global__ __launch_bounds__(256) void k_diffuse_records(const float4* __restrict__ lvl, int W, int H, float4* __restrict__ rec) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int x1 = (x + 1) & (W - 1), y1 = (y + 1) & (H - 1);
+    const float4 c00 = lvl[(size_t)y * W + x], c10 = lvl[(size_t)y * W + x1], c01 = lvl[(size_t)y1 * W + x], c11 = lvl[(size_t)y1 * W + x1];
+    float4* r = rec + 3 * ((size_t)y * W + x);
+    r[0] = make_float4(c00.x, c00.y, c00.z, c10.x); r[1] = make_float4(c10.y, c10.z, c01.x, c01.y); r[2] = make_float4(c01.z, c11.x, c11.y, c11.z);
+}
+
 VQD bool near_one(float x) { return (x >= 0.99f) & (x <= 1.01f); }       // false for NaN
 
 // phis/thetas: the fp32 sequences of the float-accumulated loops (CubemapConvolution.hlsl:132-136), built on the host.
@@ -339,7 +360,7 @@ __global__ __launch_bounds__(256) void k_conv_diffuse(const float4* __restrict__
             f3 c;
             if (FAST) {
                 bool special = !laneFast;
-                c = diffuse_tap_fast(sv, lv, special);
+                c = FAST == 2 ? diffuse_tap_fast<true>(sv, lv, special) : diffuse_tap_fast<false>(sv, lv, special);
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) c = diffuse_tap_general(sv, chain, w0, h0, nMips);
             } else {
                 c = diffuse_tap_general(sv, chain, w0, h0, nMips);
@@ -523,11 +544,25 @@ hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw,
 template <bool WAVE, int FMT>
 static void launch_conv_diffuse_form(int fast, dim3 grid, size_t lds, hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
                                      const float* phis, int nPhi, const float* thetas, int nTheta, void* out, const DiffuseLevel& lv) {
-    if (fast)       hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, 1>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+    if (fast == 2)  hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, 2>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+    else if (fast)  hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, 1>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
     else            hipLaunchKernelGGL((k_conv_diffuse<WAVE, FMT, 0>), grid, dim3(256), lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
 }
+static void diffuse_level(int w0, int h0, int nMips, int* level, int* W, int* H) {
+    *level = nMips - 1 < 3 ? nMips - 1 : 3;                     // SampleLevel(uv, 3): lod clamped to the chain, fraction 0 -> one level (sample_equirect_lod_t)
+    const int w = w0 >> *level, h = h0 >> *level;
+    *W = w < 1 ? 1 : w; *H = h < 1 ? 1 : h;
+}
+// Bytes of the footprint-record buffer launch_conv_diffuse_tables can use for this chain (0: the level it samples is no power-of-two image, or
+// too large for 24-bit record indices: the records do not apply)
+size_t conv_diffuse_record_bytes(int w0, int h0, int nMips) {
+    int level, W, H; diffuse_level(w0, h0, nMips, &level, &W, &H);
+    if (((W & (W - 1)) | (H & (H - 1))) != 0 || (size_t)W * H >= ((size_t)1 << 24)) return 0;
+    return (size_t)W * H * 48;
+}
+// recBuf: NULL, or a device buffer of conv_diffuse_record_bytes() bytes the launch may overwrite (the 2 x 2 footprints of the sampled level)
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
-                                      const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt) {
+                                      const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt, void* recBuf) {
     const long total = 6L * res * res;
     const size_t lds = (size_t)nTheta * 2 * sizeof(float);
     // the level SampleLevel(uv, 3) reads (sample_equirect_lod_t: lod clamped to the chain, fraction 0 -> one level) and whether the fast tap applies
@@ -541,6 +576,11 @@ hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0
     lv.W256 = 256.0f * (float)lv.W; lv.H256 = 256.0f * (float)lv.H;
     const char* form = std::getenv("VQHIP_DIFFUSE_FORM");       // "general": every tap with its range tests and branches (the round-1/2 kernel)
     int fast = ((lv.W & (lv.W - 1)) | (lv.H & (lv.H - 1))) == 0 && (size_t)lv.W * lv.H * 16 < (1ull << 31) && !(form && !std::strcmp(form, "general")) ? 1 : 0;
+    lv.rec = nullptr;
+    if (fast && recBuf && !(form && !std::strcmp(form, "texels"))) {      // "texels": four gathers from the level itself (the first fast form; A/B, tests)
+        hipLaunchKernelGGL(k_diffuse_records, dim3((lv.W + 255) / 256, lv.H), dim3(256), 0, s, (const float4*)lv.tex, lv.W, lv.H, (float4*)recBuf);
+        lv.rec = (const char*)recBuf; fast = 2;
+    }
     if (order == VQHIP_CONV_WAVE64) {
         dim3 grid((unsigned)((total + 3) / 4));
         if (fmt == VQHIP_FMT_RGBA32F) launch_conv_diffuse_form<true, 0>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
