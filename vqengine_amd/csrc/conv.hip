@@ -353,8 +353,10 @@ __global__ __launch_bounds__(256) void k_conv_diffuse(const float4* __restrict__
             return mk3((ts.x * right.x + ts.y * up.x) + ts.z * N.x, (ts.x * right.y + ts.y * up.y) + ts.z * N.y,
                        (ts.x * right.z + ts.y * up.z) + ts.z * N.z);
         };
+        float2 scNext = scT[0];
         for (int t = 0; t < nTheta; ++t) {
-            const float2 sc = scT[t];
+            const float2 sc = scNext;
+            scNext = scT[t + 1 < nTheta ? t + 1 : t];           // the next (sin, cos) pair is requested a whole tap ahead of its first use
             const float sinTheta = sc.x, cosTheta = sc.y;
             const f3 sv = sample_vec(sc);
             f3 c;
