@@ -794,8 +794,8 @@ def ibl_load_report(t):
     out["workload"] = "BASELINE cfg4: 2048^2 RGBA32F equirect -> 12-level min-filter chain, diffuse irradiance 6x64^2 at step 0.010 (99 382 taps/texel) + blur, 7-mip GGX specular 128^2, BRDF LUT 1024^2 x 2048"
     out["note"] = ("mip_chain / prefilter (diffuse + face blur + specular) / brdf_lut are the product calls as build_ibl() issues them, first use of each kernel "
                    "(code load and cold clocks included: total_ms); conv_diffuse / conv_specular / brdf_lut_warm / mip_chain_warm / prefilter_warm are a second "
-                   "run of the stage on its own (warm_total_ms = mip chain + prefilter + LUT of those). The diffuse convolution is co-limited by the "
-                   "texture-address unit (79 % busy) and VALU issue (70 %), profiles/r3i_conv_kernels.md")
+                   "run of the stage on its own (warm_total_ms = mip chain + prefilter + LUT of those). The diffuse convolution gathers from footprint "
+                   "records (three 16-byte gathers per tap) and is co-limited by VALU issue (~80 %) and the texture-address unit (70 % busy), profiles/r3i_conv_kernels.md")
     return out
 
 
