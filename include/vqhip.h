@@ -392,7 +392,10 @@ VQHIP_API size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt);
  * CubemapConvolution.hlsl:PSMain_DiffuseIrradiance :112-163 over all 6 faces.
  * equirect_mips = RGBA32F mip chain (layout of vqhip_mip_chain_min_rgba32f); the shader samples mip 3
  * with a TRILINEAR_WRAP sampler (RootSignatures.cpp:402). step = INTEGRATION_STEP_DIFFUSE_IRRADIANCE
- * (0.050 / 0.025 / 0.010, PipelineStateObjects.cpp:1298-1306). */
+ * (0.050 / 0.025 / 0.010, PipelineStateObjects.cpp:1298-1306).
+ * When the sampled mip is a power-of-two image the call first rewrites it, on `stream`, as 48-byte footprint records in a buffer the context
+ * owns (3 x the mip: 3 MB for a 2048^2 chain) and the taps gather from those; the buffer is rewritten by every call, and a call on another
+ * stream waits (hipStreamWaitEvent) for the previous call's kernel before it does so. */
 VQHIP_API int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
         int diffuseRes, float step, vqhip_conv_order order, void* outCube, vqhip_format fmt);
 
