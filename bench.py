@@ -759,12 +759,16 @@ def shade_only(ctx, d, comms, args, cfg, env, max_env_lod, coherent=False):
     """The shade kernel of `cfg` alone (N = 1): back-to-back launches between two events after a spin-up, with both roofs."""
     p = Pipeline(ctx, d, comms, cfg, args, env=env, max_env_lod=max_env_lod, coherent=coherent)
     out_img = p.scene[0]
-    ms = _time_loop(lambda i: ctx.forward_lighting(p.gb, p.pf, p.pv, out=out_img, out_fmt=F16, extra_point=p.extra, env=p.env), 60, 120)
+    fn = lambda i: ctx.forward_lighting(p.gb, p.pf, p.pv, out=out_img, out_fmt=F16, extra_point=p.extra, env=p.env)  # noqa: E731
+    probe = _time_loop(fn, 20, 20)                           # the spin-up is a TIME, like the headline's (~0.25 s of load to reach the clocks): short kernels get more launches
+    spin = int(min(5000, max(120, 0.25e3 / probe)))
+    n = int(min(2000, max(60, 0.05e3 / probe)))
+    ms = _time_loop(fn, n, spin)
     px, L = p.W * p.rows, cfg["lights"]
     res = {"workload": cfg["workload"] + (" [surface-coherent content]" if coherent else ""), "shade_ms": round(ms, 4), "shade_Mpix_s": round(px / ms / 1e3, 1),
            "hbm_GBps": round(SHADE_BYTES_PER_PX * px / ms / 1e6, 1), "hbm_frac": round(SHADE_BYTES_PER_PX * px / ms / 1e6 / HBM_PEAK_GBPS, 4),
            "valu_frac_model": round((170 * L + 160) * px / ms / 1e9 / VALU_PEAK_TFLOPS, 4), "bytes_per_px": SHADE_BYTES_PER_PX, "flops_per_px_model": 170 * L + 160,
-           "note": "shade kernel only, 60 back-to-back launches after a 120-launch spin-up"}
+           "note": f"shade kernel only, {n} back-to-back launches after a {spin}-launch spin-up (~0.25 s of load)"}
     if coherent:
         r = p.gb[1][..., 3]
         res["slow_path_pixel_fraction_round2"] = round(float((r < 0.04).float().mean().item()), 4)

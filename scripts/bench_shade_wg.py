@@ -1,0 +1,21 @@
+import json, os, sys, torch
+sys.path.insert(0, os.getcwd())
+import bench
+from vqengine_amd import abi, capi, synth
+ctx = capi.Context(0)
+for name in ("cfg2", "cfg3n"):
+    cfg = dict(bench.CONFIGS["cfg2" if name == "cfg2" else "cfg3"])
+    W, H, L = cfg["width"], cfg["height"], cfg["lights"]
+    gb = bench.upload_tile(cfg, H, 0, H)
+    out = capi.empty_image(H, W, abi.FMT_RGBA16F, ctx.device)
+    pv = synth.per_view(W, H)
+    pf, extra = synth.per_frame(points=synth.point_lights(L, seed=cfg["light_seed"]))
+    run = lambda: ctx.forward_lighting(gb, pf, pv, out=out, out_fmt=abi.FMT_RGBA16F, extra_point=extra)
+    for wg in ("256", "128", "64", "256", "128", "64"):
+        os.environ["VQHIP_SHADE_WG"] = wg
+        for _ in range(400): run()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(300): run()
+        b.record(); b.synchronize()
+        print(json.dumps({"cfg": name, "lights": L, "wg": wg, "ms": round(a.elapsed_time(b) / 300, 4)}), flush=True)

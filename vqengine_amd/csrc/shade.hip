@@ -1,12 +1,13 @@
 // shade.hip — forward-PBR lighting kernel for gfx950: ForwardLighting.hlsl:PSMain :289-380 evaluated per G-buffer pixel (SURVEY.md §8a rows
-// A1-A7). One lane per pixel, 256-lane workgroups, float4 SoA plane loads (16 B/lane, fully coalesced); the per-pixel body is vq_shade.h.
+// A1-A7). One lane per pixel, 256-lane workgroups (128 for frames under 4 Mpixel), float4 SoA plane loads (16 B/lane, fully coalesced); the per-pixel body is vq_shade.h.
 #include "vq_shade.h"
+#include <cstdlib>
 
 namespace {
 
 template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT>
 __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::ShadeArgs a) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= a.width) return;
     const size_t i = (size_t)y * a.pitch + x;
@@ -18,8 +19,9 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
 
 template <bool E, bool C>
 hipError_t launch_fmt(hipStream_t s, const vqk::ShadeArgs& a, int outFmt, dim3 grid) {
-    if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_forward_lighting<E, C, 0>), grid, dim3(256), 0, s, a);
-    else                             hipLaunchKernelGGL((k_forward_lighting<E, C, 1>), grid, dim3(256), 0, s, a);
+    const int wg = grid.z; grid.z = 1;
+    if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_forward_lighting<E, C, 0>), grid, dim3(wg), 0, s, a);
+    else                             hipLaunchKernelGGL((k_forward_lighting<E, C, 1>), grid, dim3(wg), 0, s, a);
     return hipGetLastError();
 }
 
@@ -27,7 +29,12 @@ hipError_t launch_fmt(hipStream_t s, const vqk::ShadeArgs& a, int outFmt, dim3 g
 
 namespace vqk {
 hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt) {
-    dim3 grid((a.width + 255) / 256, a.height);
+    // Workgroup = wg consecutive pixels of one row (grid.z carries wg to launch_fmt). 256 for large frames; frames under 4 Mpixel (1080p: 32 400 waves,
+    // 4.5 rounds of the chip at 7 waves per SIMD) run 7.5 % faster with 128-lane workgroups — finer-grained dispatch shortens the tail, and a width
+    // like 1920 is no multiple of 256 (profiles/r3t_shade_wg.jsonl: cfg2 0.0913 -> 0.0845 ms; cfg3 unchanged either way). VQHIP_SHADE_WG overrides.
+    int wg = (size_t)a.width * a.height < ((size_t)4 << 20) ? 128 : 256;
+    if (const char* e = std::getenv("VQHIP_SHADE_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) wg = v; }
+    dim3 grid((a.width + wg - 1) / wg, a.height, wg);
     if (hasEnv) return hasCasters ? launch_fmt<true, true>(s, a, outFmt, grid) : launch_fmt<true, false>(s, a, outFmt, grid);
     return hasCasters ? launch_fmt<false, true>(s, a, outFmt, grid) : launch_fmt<false, false>(s, a, outFmt, grid);
 }
