@@ -105,18 +105,18 @@ def build_ibl(ctx, timings=None):
     e[0].record()
     chain, n = ctx.mip_chain(eq)
     e[1].record()
-    pre = ctx.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_WAVE64)
+    pre = ctx.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_SEQUENTIAL)
     e[2].record()
     lut = ctx.brdf_lut(1024, 2048, abi.FMT_RG16F)
     e[3].record()
     torch.cuda.synchronize()
     if timings is not None:
         timings.update(mip_chain_ms=round(e[0].elapsed_time(e[1]), 4), prefilter_ms=round(e[1].elapsed_time(e[2]), 4), brdf_lut_ms=round(e[2].elapsed_time(e[3]), 4))
-        for name, fn in (("conv_diffuse_ms", lambda: ctx.conv_diffuse(chain, 2048, 2048, n, 64, 0.010, abi.CONV_WAVE64, abi.FMT_RGBA16F)),
-                         ("conv_specular_ms", lambda: ctx.conv_specular(chain, 2048, 2048, n, 128, abi.CONV_WAVE64, abi.FMT_RGBA16F)),
+        for name, fn in (("conv_diffuse_ms", lambda: ctx.conv_diffuse(chain, 2048, 2048, n, 64, 0.010, abi.CONV_SEQUENTIAL, abi.FMT_RGBA16F)),
+                         ("conv_specular_ms", lambda: ctx.conv_specular(chain, 2048, 2048, n, 128, abi.CONV_SEQUENTIAL, abi.FMT_RGBA16F)),
                          ("brdf_lut_warm_ms", lambda: ctx.brdf_lut(1024, 2048, abi.FMT_RG16F)),
                          ("mip_chain_warm_ms", lambda: ctx.mip_chain(eq)),
-                         ("prefilter_warm_ms", lambda: ctx.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_WAVE64))):
+                         ("prefilter_warm_ms", lambda: ctx.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_SEQUENTIAL))):
             a, b = _ev(), _ev()
             a.record(); fn(); b.record(); b.synchronize()
             timings[name] = round(a.elapsed_time(b), 4)

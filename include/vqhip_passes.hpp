@@ -239,7 +239,7 @@ public:
         void* Stream = nullptr;
         const void* pEquirectRGBA32F = nullptr;                  // device, HDRIWidth x HDRIHeight float4 (level 0 only; mips are generated here)
         float DiffuseIntegrationStep = 0.010f;                   // INTEGRATION_STEP_DIFFUSE_IRRADIANCE, PipelineStateObjects.cpp:1298-1306
-        vqhip_conv_order Order = VQHIP_CONV_WAVE64;
+        vqhip_conv_order Order = VQHIP_CONV_SEQUENTIAL;                // the reference's summation order (CubemapConvolution.hlsl:132-163,186-219)
         bool bComputeBRDFLUT = true;                             // LoadDefaultResources does this once (Renderer.cpp:934)
     };
     explicit HipEnvMapPrefilterPass(vqhip_ctx* Ctx) : RenderPassBase(Ctx) {}

@@ -49,6 +49,10 @@ def main():
     sweep("brdf_lut 1024^2 x 2048", "VQHIP_LUT_FORM", ["default", "general", "persample"], lambda: ctx.brdf_lut(1024, 2048, abi.FMT_RG16F))
     sweep("conv_diffuse 6x64^2 step 0.010 wave64", "VQHIP_DIFFUSE_FORM", ["default", "texels", "general"],
           lambda: ctx.conv_diffuse(chain, 2048, 2048, n, 64, 0.010, abi.CONV_WAVE64, abi.FMT_RGBA16F))
+    sweep("conv_diffuse 6x64^2 step 0.010 sequential (the reference's order)", "VQHIP_DIFFUSE_SEQ_FORM", ["default", "lane"],
+          lambda: ctx.conv_diffuse(chain, 2048, 2048, n, 64, 0.010, abi.CONV_SEQUENTIAL, abi.FMT_RGBA16F))
+    sweep("conv_specular 128^2 x 7 sequential", "VQHIP_SPECULAR_FORM", ["default", "permip"],
+          lambda: ctx.conv_specular(chain, 2048, 2048, n, 128, abi.CONV_SEQUENTIAL, abi.FMT_RGBA16F))
     sweep("conv_specular 128^2 x 7 wave64", "VQHIP_SPECULAR_FORM", ["default", "permip"],
           lambda: ctx.conv_specular(chain, 2048, 2048, n, 128, abi.CONV_WAVE64, abi.FMT_RGBA16F))
     ms, _ = timed(lambda: ctx.mip_chain(eq))

@@ -25,7 +25,7 @@ def main():
     t = time.time()
     eq = synth.equirect(2048, 2048)
     chain, n = O.mip_chain(eq)
-    pre = O.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_WAVE64)
+    pre = O.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_SEQUENTIAL)
     lut = O.brdf_lut(1024, 2048, abi.FMT_RG16F)
     path = os.path.join(ROOT, "tests", "golden", "cfg4_env.npz")
     np.savez_compressed(path, diffuse=pre["diffuse_blurred"].view(np.uint16), specular=pre["specular"].view(np.uint16),

@@ -23,7 +23,7 @@ from vqengine_amd import abi, synth  # noqa: E402
 def ibl_inputs():
     eq = synth.equirect(64, 32)
     chain, n = O.mip_chain(eq)
-    pre = O.envmap_prefilter(chain, 64, 32, n, 8, 0.1, 16, abi.CONV_WAVE64)
+    pre = O.envmap_prefilter(chain, 64, 32, n, 8, 0.1, 16, abi.CONV_SEQUENTIAL)
     lut = O.brdf_lut(32, 64, abi.FMT_RG16F)
     return eq, chain, n, pre, lut
 

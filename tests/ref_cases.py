@@ -98,7 +98,7 @@ def check(name, got, ref, tol):
 def small_env():
     eq = synth.equirect(64, 32)
     chain, n = O.mip_chain(eq)
-    pre = O.envmap_prefilter(chain, 64, 32, n, 8, 0.1, 16, abi.CONV_WAVE64)
+    pre = O.envmap_prefilter(chain, 64, 32, n, 8, 0.1, 16, abi.CONV_SEQUENTIAL)
     lut = O.brdf_lut(32, 64, abi.FMT_RG16F)
     return {"diffuse": pre["diffuse_blurred"], "specular": pre["specular"], "spec_res0": 16, "spec_mips": pre["spec_mips"], "lut": lut}
 

@@ -27,8 +27,8 @@ def test_full_frame_chain_matches_oracle(ctx):
     eq_g = ctx.load_hdr(hdr)
     chain_o, n = O.mip_chain(eq_o)
     chain_g, n_g = ctx.mip_chain(eq_g)
-    pre_o = O.envmap_prefilter(chain_o, EW, EH, n, 16, 0.05, 32, abi.CONV_WAVE64)
-    pre_g = ctx.envmap_prefilter(chain_g, EW, EH, n_g, 16, 0.05, 32, abi.CONV_WAVE64)
+    pre_o = O.envmap_prefilter(chain_o, EW, EH, n, 16, 0.05, 32, abi.CONV_SEQUENTIAL)
+    pre_g = ctx.envmap_prefilter(chain_g, EW, EH, n_g, 16, 0.05, 32, abi.CONV_SEQUENTIAL)
     lut_o, lut_g = O.brdf_lut(64, 128, abi.FMT_RG16F), ctx.brdf_lut(64, 128, abi.FMT_RG16F)
     env_o = O.host_envmap(pre_o["diffuse_blurred"], pre_o["specular"], 32, pre_o["spec_mips"], lut_o)
     env_g = capi.make_envmap(pre_g["diffuse_blurred"], pre_g["specular"], 32, pre_g["spec_mips"], lut_g)

@@ -34,8 +34,8 @@ def env_small(ctx):
     chain_o, n = O.mip_chain(eq)
     chain_g, n_g = ctx.mip_chain(dev(eq))
     assert n == n_g
-    pre_o = O.envmap_prefilter(chain_o, 128, 64, n, 16, 0.05, 32, abi.CONV_WAVE64)
-    pre_g = ctx.envmap_prefilter(chain_g, 128, 64, n, 16, 0.05, 32, abi.CONV_WAVE64)
+    pre_o = O.envmap_prefilter(chain_o, 128, 64, n, 16, 0.05, 32, abi.CONV_SEQUENTIAL)
+    pre_g = ctx.envmap_prefilter(chain_g, 128, 64, n, 16, 0.05, 32, abi.CONV_SEQUENTIAL)
     lut_o = O.brdf_lut(64, 128, abi.FMT_RG16F)
     lut_g = ctx.brdf_lut(64, 128, abi.FMT_RG16F)
     return dict(eq=eq, n=n, chain_o=chain_o, chain_g=chain_g, pre_o=pre_o, pre_g=pre_g, lut_o=lut_o, lut_g=lut_g)
@@ -70,15 +70,16 @@ def test_ibl_reference_sizes_cfg4(ctx):
     chain_o, n_o = O.mip_chain(eq)
     assert n == n_o == 12
     assert_bits(chain_g, chain_o, "2048^2 mip chain")
-    diff_g = ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, 0.010, abi.CONV_WAVE64, abi.FMT_RGBA16F).cpu().numpy().reshape(-1, 4)
-    for t0 in (0, 4095, 4096 + 1234, 3 * 4096 + 4000, 5 * 4096 + 64 * 63, 6 * 4096 - 16):
-        ref = O.conv_diffuse(chain_o, 2048, 2048, n, 64, 0.010, abi.CONV_WAVE64, abi.FMT_RGBA16F, t0=t0, t1=t0 + 16).reshape(-1, 4)
-        n_bad, idx = O.bits_equal(diff_g[t0:t0 + 16], ref[t0:t0 + 16])
-        assert n_bad == 0, (t0, n_bad, idx)
-    spec_g, mips = ctx.conv_specular(chain_g, 2048, 2048, n, 128, abi.CONV_WAVE64, abi.FMT_RGBA16F)
-    spec_o, mips_o = O.conv_specular(chain_o, 2048, 2048, n, 128, abi.CONV_WAVE64, abi.FMT_RGBA16F)
-    assert mips == mips_o == 7
-    assert_bits(spec_g, spec_o, "specular 128^2 x 7 mips from the 2048^2 equirect")
+    for order in (abi.CONV_SEQUENTIAL, abi.CONV_WAVE64):             # the reference's order (default) and the optional 64-lane order
+        diff_g = ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, 0.010, order, abi.FMT_RGBA16F).cpu().numpy().reshape(-1, 4)
+        for t0 in (0, 4095, 4096 + 1234, 3 * 4096 + 4000, 5 * 4096 + 64 * 63, 6 * 4096 - 16):
+            ref = O.conv_diffuse(chain_o, 2048, 2048, n, 64, 0.010, order, abi.FMT_RGBA16F, t0=t0, t1=t0 + 16).reshape(-1, 4)
+            n_bad, idx = O.bits_equal(diff_g[t0:t0 + 16], ref[t0:t0 + 16])
+            assert n_bad == 0, (order, t0, n_bad, idx)
+        spec_g, mips = ctx.conv_specular(chain_g, 2048, 2048, n, 128, order, abi.FMT_RGBA16F)
+        spec_o, mips_o = O.conv_specular(chain_o, 2048, 2048, n, 128, order, abi.FMT_RGBA16F)
+        assert mips == mips_o == 7
+        assert_bits(spec_g, spec_o, f"specular 128^2 x 7 mips from the 2048^2 equirect, order {order}")
     f = diff_g.astype(np.float32)
     assert np.isfinite(f).all() and (f[:, :3] >= 0).all() and np.all(f[:, 3] == 1.0)
 
@@ -91,7 +92,7 @@ def test_cfg4_env_matches_golden(ctx):
     g = ref_cases.cfg4_env()
     eq = synth.equirect(2048, 2048)
     chain, n = ctx.mip_chain(dev(eq))
-    pre = ctx.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128, abi.CONV_WAVE64)
+    pre = ctx.envmap_prefilter(chain, 2048, 2048, n, 64, 0.010, 128)
     assert pre["spec_mips"] == g["spec_mips"] == 7
     assert_bits(pre["diffuse_blurred"], g["diffuse"], "cfg4 diffuse irradiance (blurred) 6x64^2")
     assert_bits(pre["specular"], g["specular"], "cfg4 specular 128^2 x 7 mips")
@@ -509,7 +510,7 @@ def test_hip_path_reproduces_golden_fixtures(ctx):
     gdir = os.path.dirname(os.path.abspath(G.__file__))
     eq = synth.equirect(64, 32)
     chain, n = ctx.mip_chain(dev(eq))
-    pre = ctx.envmap_prefilter(chain, 64, 32, n, 8, 0.1, 16, abi.CONV_WAVE64)
+    pre = ctx.envmap_prefilter(chain, 64, 32, n, 8, 0.1, 16)
     lut = ctx.brdf_lut(32, 64, abi.FMT_RG16F)
     fx = np.load(os.path.join(gdir, "ibl_small.npz"))
     assert_bits(chain[64 * 32:], fx["mip_tail"], "golden mip_tail")

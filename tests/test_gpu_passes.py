@@ -21,7 +21,7 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
                             directional=synth.directional_light(), hdri_offset=0.3)
     eq = synth.equirect(EW, EH)
     chain, n = O.mip_chain(eq)
-    pre = O.envmap_prefilter(chain, EW, EH, n, 8, 0.1, 16, abi.CONV_WAVE64)
+    pre = O.envmap_prefilter(chain, EW, EH, n, 8, 0.1, 16, abi.CONV_SEQUENTIAL)
     pv = synth.per_view(W, H, max_env_lod=pre["spec_mips"])
     for k in range(4):
         gb[k].tofile(tmp_path / f"gb{k}.bin")

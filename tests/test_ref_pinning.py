@@ -127,7 +127,7 @@ def test_diffuse_irradiance_convolution():
     assert np.array_equal(got[..., 3], ref[..., 3]) and (ref[..., 3] == 1).all()
     r = rel_err(got[..., :3], ref[..., :3], 1e-4)
     assert np.median(r) < 3e-6 and r.max() < 1e-4, (np.median(r), r.max())       # 99 382-term float sums
-    # the product's default 64-lane order (64 partial sums + butterfly) is the better-conditioned sum: it differs from the
+    # the optional 64-lane order (64 partial sums + butterfly; the default until round 4) is the better-conditioned sum: it differs from the
     # reference's sequential 99 382-term float accumulation by up to about half an RGBA16F ulp (4.9e-4) of the stored texel
     got64 = O.conv_diffuse(chain, w, h, n, res, 0.010, abi.CONV_WAVE64, abi.FMT_RGBA32F)
     r64 = rel_err(got64[..., :3], ref[..., :3], 1e-4)
@@ -161,7 +161,7 @@ def test_specular_prefilter_convolution():
 def _env(res_d=8, res_s=16, lut=32):
     eq = synth.equirect(64, 32)
     chain, n = O.mip_chain(eq)
-    pre = O.envmap_prefilter(chain, 64, 32, n, res_d, 0.1, res_s, abi.CONV_WAVE64)
+    pre = O.envmap_prefilter(chain, 64, 32, n, res_d, 0.1, res_s, abi.CONV_SEQUENTIAL)
     lut_o = O.brdf_lut(lut, 64, abi.FMT_RG16F)
     env = O.host_envmap(pre["diffuse_blurred"], pre["specular"], res_s, pre["spec_mips"], lut_o)
     env._keep = (pre, lut_o)

@@ -8,7 +8,7 @@ import os
 import torch
 
 from . import abi
-from .abi import (FMT_RGBA32F, FMT_RGBA16F, FMT_RGBA8_UNORM, FMT_RG16F, FMT_RG32F, CONV_WAVE64)
+from .abi import (FMT_RGBA32F, FMT_RGBA16F, FMT_RGBA8_UNORM, FMT_RG16F, FMT_RG32F, CONV_SEQUENTIAL)
 
 # $VQHIP_LIBRARY_PATH: another build of the SAME library (the sanitizer build of `make -C vqengine_amd/csrc asan`); never a different implementation
 _LIB_PATH = os.environ.get("VQHIP_LIBRARY_PATH") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvqhip.so")
@@ -536,20 +536,20 @@ class Context:
         self._ck(self.lib.vqhip_unlit_composite(self._h, self._stream(stream), C.byref(cov), C.cast(arr, C.c_void_p), len(colors), _ptr(color), w, h, w, fmt))
         return color
 
-    def conv_diffuse(self, chain, w0, h0, n_mips, res=64, step=0.010, order=CONV_WAVE64, fmt=FMT_RGBA16F, stream=None):
+    def conv_diffuse(self, chain, w0, h0, n_mips, res=64, step=0.010, order=CONV_SEQUENTIAL, fmt=FMT_RGBA16F, stream=None):
         dt, ch = _TORCH_DTYPE[fmt]
         out = torch.empty((6, res, res, ch), dtype=dt, device=self.device)
         self._ck(self.lib.vqhip_conv_diffuse(self._h, self._stream(stream), _ptr(chain), w0, h0, n_mips, res, step, order, _ptr(out), fmt))
         return out
 
-    def conv_specular(self, chain, w0, h0, n_mips, res0=128, order=CONV_WAVE64, fmt=FMT_RGBA16F, stream=None):
+    def conv_specular(self, chain, w0, h0, n_mips, res0=128, order=CONV_SEQUENTIAL, fmt=FMT_RGBA16F, stream=None):
         dt, ch = _TORCH_DTYPE[fmt]
         mips = abi.specular_mip_count(res0)
         out = torch.empty((abi.cube_px(res0, mips), ch), dtype=dt, device=self.device)
         self._ck(self.lib.vqhip_conv_specular(self._h, self._stream(stream), _ptr(chain), w0, h0, n_mips, res0, order, _ptr(out), fmt))
         return out, mips
 
-    def envmap_prefilter(self, chain, w0, h0, n_mips, diffuse_res=64, diffuse_step=0.010, spec_res0=128, order=CONV_WAVE64, stream=None):
+    def envmap_prefilter(self, chain, w0, h0, n_mips, diffuse_res=64, diffuse_step=0.010, spec_res0=128, order=CONV_SEQUENTIAL, stream=None):
         """Returns dict(diffuse_unblurred, diffuse_blurred, specular, spec_mips) of float16 tensors (reference formats)."""
         mips = abi.specular_mip_count(spec_res0)
         d0 = torch.empty((6, diffuse_res, diffuse_res, 4), dtype=torch.float16, device=self.device)

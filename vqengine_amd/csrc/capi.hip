@@ -831,8 +831,8 @@ int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equirect_mips,
     if (order != VQHIP_CONV_SEQUENTIAL && order != VQHIP_CONV_WAVE64) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_specular: bad order");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const char* form = std::getenv("VQHIP_SPECULAR_FORM");                   // "permip": one launch per mip (the round-1/2 form; also what SEQUENTIAL order runs)
-    if (order == VQHIP_CONV_WAVE64 && !(form && !std::strcmp(form, "permip"))) {
-        hipError_t e = launch_conv_specular_all((hipStream_t)stream, (const float4*)equirect_mips, w0, h0, nMips, specRes0, MIPS, outCubeMips, fmt);
+    if (!(form && !std::strcmp(form, "permip"))) {
+        hipError_t e = launch_conv_specular_all((hipStream_t)stream, (const float4*)equirect_mips, w0, h0, nMips, specRes0, MIPS, order, outCubeMips, fmt);
         return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "conv_specular launch");
     }
     const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;

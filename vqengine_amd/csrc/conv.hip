@@ -314,6 +314,7 @@ __global__ __launch_bounds__(256) void k_diffuse_records(const float4* __restric
     r[0] = make_float4(c00.x, c00.y, c00.z, c10.x); r[1] = make_float4(c10.y, c10.z, c01.x, c01.y); r[2] = make_float4(c01.z, c11.x, c11.y, c11.z);
 }
 
+constexpr int kDiffuseOrderedSteps = 2;                         // 16-tap steps per round of k_conv_diffuse_ordered (measured: scripts/bench_ibl_forms.py)
 VQD bool near_one(float x) { return (x >= 0.99f) & (x <= 1.01f); }       // false for NaN
 
 // phis/thetas: the fp32 sequences of the float-accumulated loops (CubemapConvolution.hlsl:132-136), built on the host.
@@ -377,6 +378,120 @@ __global__ __launch_bounds__(256) void k_conv_diffuse(const float4* __restrict__
     }
     const float rn = rcp((float)((long)nPhi * nTheta));          // numSamples :158,162
     store_px<FMT>(out, (size_t)texel, make_float4((PI_ * ax) * rn, (PI_ * ay) * rn, (PI_ * az) * rn, 1.0f));
+}
+
+// ---- diffuse irradiance in the reference's summation order, at wave speed -------------------------------------
+// `irradiance += tap` of CubemapConvolution.hlsl:132-163 is one chain of nPhi * nTheta dependent additions per texel (phi outer, theta inner). The chain
+// is cheap — three additions per tap against ~140 VALU for evaluating the tap — so evaluation and summation are split: a block owns 16 texels; in one
+// step its 256 lanes evaluate 16 CONSECUTIVE taps (flattened index phi * nTheta + theta) of each of the 16 texels and park the weighted rgb in LDS as
+// buf[tap][texel]; after a round of S steps one wave — lane = (texel, channel) — adds the round's 16 S taps to its accumulator IN TAP ORDER (one 4-byte
+// LDS read + one v_add per 16 evaluated taps). Rounds are double-buffered, one barrier per round; the adding wave rotates and the accumulators live in
+// LDS between rounds. Same taps, same order of additions as the one-lane-per-texel form (k_conv_diffuse<false,...>) and the oracle: identical bits.
+// The block's texels are a 4 x 4 patch of a face (neighbouring texels sample neighbouring equirect texels: 8.23 against 8.40 ms for 16 texels of a row).
+// The kernel is bound by the L1 tag-lookup rate, like the WAVE64 form (profiles/r4a_conv_ordered.md: TCP_TOTAL_CACHE_ACCESSES per CU == the kernel's clocks
+// in both): the TA coalesces within the 4 lanes of a quad only, and a quad of 4 consecutive thetas (0.57 degrees apart: 0.8 texels of the 0.70-degree rows
+// of the sampled level) touches 2.8 64-byte lines per gather against 2.15 for the WAVE64 form's 4 consecutive phis (0.57 sin(theta) degrees apart) —
+// that, not the additions (+4 % VALU), is the 1.26 x between the two orders. S = 2 steps per round measured best (1: 8.44, 2: 8.29, 4: 9.07 ms).
+// LDS: buf 2 x 16 x (16 S + 1) float4, acc 64 floats, (sin, cos) tables of theta and phi.
+template <int FMT, int FAST>
+__global__ __launch_bounds__(256) void k_conv_diffuse_ordered(const float4* __restrict__ chain, int w0, int h0, int nMips, int res,
+                                                              const float* __restrict__ phis, int nPhi, const float* __restrict__ thetas, int nTheta,
+                                                              void* __restrict__ out, DiffuseLevel lv, int patch) {
+    constexpr int S = kDiffuseOrderedSteps, TPR = 16 * S;        // taps per texel per round
+    extern __shared__ float4 lds4[];
+    constexpr int BUF = 16 * (TPR + 1);                          // float4s of one tap buffer
+    float4* buf = lds4;                                          // [2][BUF]
+    float*  acc = (float*)(buf + 2 * BUF);                       // [64]: (texel, channel)
+    float2* scT = (float2*)(acc + 64);                           // [nTheta]
+    float2* scP = scT + nTheta;                                  // [nPhi]
+    bool tabBad = false;
+    for (int t = threadIdx.x; t < nTheta + nPhi; t += 256) {
+        float s, c; sincos_(t < nTheta ? thetas[t] : phis[t - nTheta], &s, &c); scT[t] = make_float2(s, c);
+        tabBad |= !near_one(fma_(s, s, c * c));
+    }
+    if (threadIdx.x < 64) acc[threadIdx.x] = 0.0f;
+    const bool fastBlock = (FAST && __syncthreads_or(tabBad) == 0);
+    if (!FAST) __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // a wave = 4 texels x 16 consecutive taps; buf[texel][tap] with the texel stride padded by one slot: the 16 lanes of a 128-bit write pass cover
+    // 256 contiguous bytes and the adder's lanes (texel, channel) fall into distinct banks — no LDS bank conflict (PMC: SQ_LDS_BANK_CONFLICT 0)
+    const int xi  = wave * 4 + (lane >> 4);                      // texel of the block
+    const int j16 = lane & 15;                                   // tap slot of a 16-tap step
+    const int wr0 = xi * (TPR + 1) + j16;
+    // texel list: 4 x 4 patches of a face when the resolution allows it (patch != 0), else 16 consecutive texels of the row-major list
+    const long total = 6L * res * res;
+    auto block_texel = [&](int i) -> long {
+        if (!patch) return (long)blockIdx.x * 16 + i;
+        const int pr = res >> 2;                                 // patches per row
+        const int f = (int)(blockIdx.x / (unsigned)(pr * pr)), pi = (int)(blockIdx.x % (unsigned)(pr * pr));
+        return ((long)f * res + ((pi / pr) * 4 + (i >> 2))) * res + ((pi % pr) * 4 + (i & 3));
+    };
+    const long texel = block_texel(xi);
+    const bool live = texel < total;
+    const long tx = live ? texel : total - 1;
+    const int f = (int)(tx / ((long)res * res)), y = (int)((tx / res) % res), x = (int)(tx % res);
+    const f3 N = normalize(cube_texel_dir(f, x, y, res));        // :114
+    f3 up = mk3(0, 1, 0);
+    const f3 right = normalize(cross(up, N));                    // :122
+    up = normalize(cross(N, right));                             // :124
+    const bool frameOK = near_one(dot(N, N)) && near_one(dot(right, right)) && near_one(dot(up, up)) &&
+                         abs_(dot(N, right)) <= 0.01f && abs_(dot(N, up)) <= 0.01f && abs_(dot(right, up)) <= 0.01f;
+    const bool laneFast = fastBlock && frameOK;
+    const int totalTaps = nPhi * nTheta;
+    const int nRounds = (totalTaps + TPR - 1) / TPR;
+    int k = j16 / nTheta, t = j16 % nTheta;                      // the lane's tap = (phi k, theta t); it advances by 16 per step
+    float2 scPhi = scP[k < nPhi ? k : 0];
+    for (int r = 0; r < nRounds; ++r) {
+        float4* b = buf + (r & 1) * BUF;
+        #pragma unroll
+        for (int s = 0; s < S; ++s) {
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (k < nPhi) {
+                const float2 sc = scT[t];
+                const float sinTheta = sc.x, cosTheta = sc.y, sinPhi = scPhi.x, cosPhi = scPhi.y;
+                const f3 ts = mk3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);                                 // :146-152
+                const f3 sv = mk3((ts.x * right.x + ts.y * up.x) + ts.z * N.x, (ts.x * right.y + ts.y * up.y) + ts.z * N.y,
+                                  (ts.x * right.z + ts.y * up.z) + ts.z * N.z);
+                f3 c;
+                if (FAST) {
+                    bool special = !laneFast;
+                    c = FAST == 2 ? diffuse_tap_fast<true>(sv, lv, special) : diffuse_tap_fast<false>(sv, lv, special);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) c = diffuse_tap_general(sv, chain, w0, h0, nMips);
+                } else {
+                    c = diffuse_tap_general(sv, chain, w0, h0, nMips);
+                }
+                v = make_float4((c.x * cosTheta) * sinTheta, (c.y * cosTheta) * sinTheta, (c.z * cosTheta) * sinTheta, 0.0f);
+                t += 16;
+                if (t >= nTheta) {
+                    do { t -= nTheta; ++k; } while (t >= nTheta);
+                    scPhi = scP[k < nPhi ? k : 0];
+                }
+            }
+            b[wr0 + s * 16] = v;
+        }
+        __syncthreads();
+        if (wave == (r & 3)) {                                   // this round's adder: lane = 4 * texel + channel
+            const float* bf = (const float*)b;
+            float a = acc[lane];
+            const int n = totalTaps - r * TPR;
+            bf += (lane >> 2) * ((TPR + 1) * 4) + (lane & 3);
+            if (n >= TPR) {
+                #pragma unroll
+                for (int j = 0; j < TPR; ++j) a = a + bf[j * 4];
+            } else {
+                for (int j = 0; j < n; ++j) a = a + bf[j * 4];
+            }
+            acc[lane] = a;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && (lane & 3) == 0) {                   // lane = 4 * texel + channel, as the adders left it
+        const long to = block_texel(lane >> 2);
+        if (to < total) {
+            const float rn = rcp((float)((long)nPhi * nTheta));  // numSamples :158,162
+            store_px<FMT>(out, (size_t)to, make_float4((PI_ * acc[lane]) * rn, (PI_ * acc[lane + 1]) * rn, (PI_ * acc[lane + 2]) * rn, 1.0f));
+        }
+    }
 }
 
 // ---- specular prefilter -------------------------------------------------------------------------------
@@ -472,6 +587,81 @@ __global__ __launch_bounds__(256) void k_conv_specular_all(const float4* __restr
     if (lane != 0) return;
     const float rw = rcp(max_(aw, 0.0001f));
     store_px<FMT>(out, (size_t)(base + texel), make_float4(ax * rw, ay * rw, az * rw, 1.0f));
+}
+
+// The specular prefilter in the reference's summation order (`prefilteredColor += ...; totalWeight += NdotL` over i = 0 ... 511, CubemapConvolution.hlsl:
+// 186-219), every mip in one launch: the k_conv_diffuse_ordered scheme. A block owns 8 consecutive texels of the mip-major cube (every mip holds a multiple
+// of 8 texels, so a block has one roughness and builds the 512 tangent-space half vectors once, as k_conv_specular_all does); per step its 256 lanes evaluate
+// 32 consecutive samples of each texel into LDS, a sample the shader skips (NdotL <= 0) parks +0 (x + 0 == x for every accumulator value that can occur:
+// the sums start at +0 and never become -0), and after a round of 64 samples one wave — lane = (texel, channel), 32 lanes — adds them in sample order.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_conv_specular_ordered(const float4* __restrict__ chain, int w0, int h0, int nMips, int res0, int MIPS, void* __restrict__ out) {
+    constexpr int S = 2, TPR = 32 * S;
+    constexpr uint32_t NUM_SAMPLES = 512;
+    __shared__ float4 sHt[512];
+    __shared__ float4 buf[2][TPR * 8];
+    __shared__ float acc[32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int xi = lane >> 3;                                    // texel of the block
+    const int j32 = wave * 8 + (lane & 7);                       // sample slot of a 32-sample step
+    const long T0 = (long)blockIdx.x * 8;
+    int mip = 0, res = res0; long base = 0;
+    while (mip < MIPS - 1 && T0 >= base + 6L * res * res) { base += 6L * res * res; ++mip; res >>= 1; }
+    const float Roughness = div_((float)mip, (float)(MIPS - 1));                       // EnvironmentMapRendering.cpp:432
+    for (uint32_t i = threadIdx.x; i < NUM_SAMPLES; i += 256) {
+        const float Xix = div_((float)i, (float)NUM_SAMPLES);
+        float sp, cp; sincos_((2.0f * PI_) * Xix, &sp, &cp);
+        const f3 Ht = ggx_sample_tangent(RadicalInverse_VdC(i), sp, cp, Roughness);
+        sHt[i] = make_float4(Ht.x, Ht.y, Ht.z, 0.0f);
+    }
+    if (threadIdx.x < 32) acc[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const long texel = T0 + xi - base;                                                  // within the mip
+    const bool live = texel < 6L * res * res;
+    const long tx = live ? texel : 0;
+    const int f = (int)(tx / ((long)res * res)), y = (int)((tx / res) % res), x = (int)(tx % res);
+    const f3 N = normalize(cube_texel_dir(f, x, y, res));
+    const f3 V = N;
+    const TangentFrame fr = tangent_frame(N);
+    const float fOmegaP = div_(4.0f * PI_, (6.0f * (float)w0) * (float)h0);            // :203 with TextureDimensionsLOD0 = equirect dims (:433-434)
+    for (int r = 0; r < (int)NUM_SAMPLES / TPR; ++r) {
+        float4* b = buf[r & 1];
+        #pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t i = (uint32_t)(r * TPR + s * 32 + j32);
+            const float4 ht = sHt[i];
+            const f3 H = tangent_to_world(mk3(ht.x, ht.y, ht.z), fr, N);
+            const f3 L = reflect(neg(V), H);
+            const float NdotL = saturate(dot(N, L));
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (NdotL > 0.0f) {
+                const float NdotH = saturate(dot(N, H));
+                const float HdotV = saturate(dot(H, V));
+                const float D = NormalDistributionGGX(NdotH, Roughness);
+                const float pdf = div_(D * NdotH, 4.0f * HdotV);
+                const float fOmegaS = rcp(max_((float)NUM_SAMPLES * pdf, 0.00001f));
+                const float fMipLevel = (Roughness == 0.0f) ? 0.0f : max_(0.5f * log2_(div_(fOmegaS, fOmegaP)) + -1.0f, 0.0f);
+                const float2 uv = DirectionToEquirectUV(L);
+                const float4 c = sample_equirect_lod(chain, w0, h0, nMips, uv.x, uv.y, fMipLevel);
+                v = make_float4(c.x * NdotL, c.y * NdotL, c.z * NdotL, NdotL);
+            }
+            b[(s * 32 + j32) * 8 + xi] = v;
+        }
+        __syncthreads();
+        if (wave == (r & 3) && lane < 32) {                      // this round's adder: lane = 4 * texel + channel
+            const float* bf = (const float*)b + lane;
+            float a = acc[lane];
+            #pragma unroll
+            for (int j = 0; j < TPR; ++j) a = a + bf[j * 32];
+            acc[lane] = a;
+        }
+    }
+    __syncthreads();
+    const long texelOut = T0 + (lane >> 2);                                             // the adder's lane = 4 * texel + channel
+    if (threadIdx.x < 32 && (lane & 3) == 0 && texelOut - base < 6L * res * res) {
+        const float rw = rcp(max_(acc[lane + 3], 0.0001f));
+        store_px<FMT>(out, (size_t)texelOut, make_float4(acc[lane] * rw, acc[lane + 1] * rw, acc[lane + 2] * rw, 1.0f));
+    }
 }
 
 } // namespace
@@ -587,21 +777,41 @@ hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0
         dim3 grid((unsigned)((total + 3) / 4));
         if (fmt == VQHIP_FMT_RGBA32F) launch_conv_diffuse_form<true, 0>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
         else                          launch_conv_diffuse_form<true, 1>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
-    } else {
-        dim3 grid((unsigned)((total + 255) / 256));
-        if (fmt == VQHIP_FMT_RGBA32F) launch_conv_diffuse_form<false, 0>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
-        else                          launch_conv_diffuse_form<false, 1>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+        return hipGetLastError();
     }
+    // SEQUENTIAL (the reference's order): wave-parallel evaluation + ordered per-texel additions (k_conv_diffuse_ordered) while the (sin, cos) tables
+    // of both loops fit in LDS next to the tap buffers; the one-lane-per-texel kernel otherwise (steps below ~0.002) or when asked for (A/B, tests)
+    const char* seq = std::getenv("VQHIP_DIFFUSE_SEQ_FORM");     // "lane": one lane per texel
+    constexpr int S = kDiffuseOrderedSteps;
+    const size_t ldsOrd = (size_t)2 * 16 * (16 * S + 1) * sizeof(float4) + 64 * sizeof(float) + ((size_t)nTheta + nPhi) * sizeof(float2);
+    if (ldsOrd <= 64 * 1024 && (long)nPhi * nTheta < (1L << 30) && !(seq && !std::strcmp(seq, "lane"))) {
+        const int patch = (res % 4 == 0) ? 1 : 0;
+        dim3 grid((unsigned)((total + 15) / 16));
+        #define VQ_ORD(FMT_, FAST_) hipLaunchKernelGGL((k_conv_diffuse_ordered<FMT_, FAST_>), grid, dim3(256), ldsOrd, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv, patch)
+        if (fmt == VQHIP_FMT_RGBA32F) { if (fast == 2) VQ_ORD(0, 2); else if (fast) VQ_ORD(0, 1); else VQ_ORD(0, 0); }
+        else                          { if (fast == 2) VQ_ORD(1, 2); else if (fast) VQ_ORD(1, 1); else VQ_ORD(1, 0); }
+        #undef VQ_ORD
+        return hipGetLastError();
+    }
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (fmt == VQHIP_FMT_RGBA32F) launch_conv_diffuse_form<false, 0>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
+    else                          launch_conv_diffuse_form<false, 1>(fast, grid, lds, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv);
     return hipGetLastError();
 }
 
-// WAVE64 order, every mip of the res0 cube (res0 a power of two >= 4: mips res0 ... 2) in one launch; `out` = the mip-major cube
-hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, void* out, int fmt) {
+// every mip of the res0 cube (res0 a power of two >= 4: mips res0 ... 2) in one launch, either order; `out` = the mip-major cube
+hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, int order, void* out, int fmt) {
     long total = 0;
     for (int m = 0; m < MIPS; ++m) { const long r = res0 >> m; total += 6 * r * r; }
-    dim3 grid((unsigned)((total + 3) / 4));
-    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular_all<0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
-    else                          hipLaunchKernelGGL((k_conv_specular_all<1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
+    if (order == VQHIP_CONV_WAVE64) {
+        dim3 grid((unsigned)((total + 3) / 4));
+        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular_all<0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
+        else                          hipLaunchKernelGGL((k_conv_specular_all<1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
+    } else {
+        dim3 grid((unsigned)((total + 7) / 8));
+        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular_ordered<0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
+        else                          hipLaunchKernelGGL((k_conv_specular_ordered<1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
+    }
     return hipGetLastError();
 }
 

@@ -106,7 +106,7 @@ hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw,
 size_t conv_diffuse_record_bytes(int w0, int h0, int nMips);
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
                                       const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt, void* recBuf);
-hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, void* out, int fmt);
+hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, int order, void* out, int fmt);
 hipError_t launch_conv_specular(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res, int mip, int MIPS,
                                 int order, void* out, int fmt);
 
