@@ -63,7 +63,8 @@ typedef enum vqhip_format {
     VQHIP_FMT_RGBA16F     = 1,
     VQHIP_FMT_RGBA8_UNORM = 2,
     VQHIP_FMT_RG16F       = 3,
-    VQHIP_FMT_RG32F       = 4
+    VQHIP_FMT_RG32F       = 4,
+    VQHIP_FMT_R10G10B10A2_UNORM = 5   /* Tex_SceneNormals (RenderResources.cpp:185-197): input of vqhip_ssr_environment_fallback only */
 } vqhip_format;
 
 /* ------------------------------------------------------------------------------------------------
@@ -533,6 +534,46 @@ VQHIP_API int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void*
  * (The producer of the reflection radiance, FidelityFX SSSR + denoiser, is out of scope.) fmt: RGBA16F | RGBA32F for both. */
 VQHIP_API int vqhip_apply_reflections(vqhip_ctx* ctx, void* stream, const void* reflectionRadiance, void* sceneColor,
         int width, int height, vqhip_format fmt);
+
+/* ---- SSR's consumption of the specular cube + BRDF LUT ---------------------------
+ * == FFX_SSSRConstants (Source/Renderer/Rendering/RenderPass/ScreenSpaceReflections.h:43-65), the cbuffer `Constants` of
+ * Shaders/ScreenSpaceReflections/Common.hlsl:26-48, byte for byte (XMMATRIX: row-major, 16-aligned), as VQRenderer::RenderReflections fills it
+ * (SceneRendering.cpp:2221-2242). */
+typedef struct VQ_SSSRConstants {
+    VQ_matrix invViewProjection, projection, invProjection, view, invView, prevViewProjection, envMapRotation;
+    uint32_t bufferDimensions[2];
+    float    inverseBufferDimensions[2];
+    float    temporalStabilityFactor, depthBufferThickness, roughnessThreshold, varianceThreshold;
+    uint32_t frameIndex, maxTraversalIntersections, minTraversalOccupancy, mostDetailedMip, samplesPerQuad,
+             temporalVarianceGuidedTracingEnabled, envMapSpecularIrradianceCubemapMipLevelCount;
+    uint32_t pad_[1];
+} VQ_SSSRConstants;
+VQHIP_STATIC_ASSERT(sizeof(VQ_SSSRConstants) == 512, "FFX_SSSRConstants is 7 matrices + 15 dwords, padded to 16");
+VQHIP_STATIC_ASSERT(offsetof(VQ_SSSRConstants, bufferDimensions) == 448 && offsetof(VQ_SSSRConstants, roughnessThreshold) == 472 &&
+                    offsetof(VQ_SSSRConstants, envMapSpecularIrradianceCubemapMipLevelCount) == 504, "FFX_SSSRConstants layout");
+
+/* Replaces the part of the "FFX DNSR ClassifyTiles" dispatch (ScreenSpaceReflections.cpp:262-276) that consumes the prefiltered specular cube and
+ * the BRDF LUT: for every pixel, ClassifyReflectionTiles.hlsl:ClassifyTiles :146-152 + SampleEnvironmentMap :78-94 —
+ *     radiance = (depth < 1 && !(roughness < roughnessThreshold)) ? float4(SampleEnvironmentMap(pixel, roughness, mipCount), 0) : 0
+ * i.e. surfaces too rough for a traced ray get the environment's prefiltered reflection: view-space reflect of the view ray about the G-buffer normal,
+ * g_environment_map.SampleLevel(envMapRotation * R_world, roughness * (mipCount - 1)) — a FRACTIONAL level: trilinear between cube mips, seamless
+ * (csrc/vq_sampling.h:sample_cube_lod_rgba16f) — times EnvironmentBRDF(NdotV, roughness, metallic 1, ...) from the LUT (BRDF.hlsl:196-207).
+ * The ray classification / ray list / denoiser tile list of the same dispatch (wave intrinsics, atomics) and the traced rays are FidelityFX SSSR: out of scope.
+ *   sceneColorRoughness : g_roughness   == the scene colour whose alpha is the roughness (ForwardLighting.hlsl:380), RGBA16F | RGBA32F
+ *   depth               : g_depth_buffer == mip 0 of the depth hierarchy, R32F, NDC z (far plane 1)
+ *   normals             : g_normal      == Tex_SceneNormals, R10G10B10A2_UNORM (one uint32 per pixel, r in bits 0-9) | RGBA32F holding the same [0,1] values
+ *   cb                  : host pointer; invProjection, view, invView, envMapRotation, inverseBufferDimensions, roughnessThreshold and
+ *                         envMapSpecularIrradianceCubemapMipLevelCount are read (mipCount must be in [1, env->spec_mips])
+ *   env                 : specular_cube / spec_res0 / spec_mips and brdf_lut / lut_size are read (device pointers)
+ *   outRadiance         : g_intersection_output, RGBA16F (TexRadiance, ScreenSpaceReflections.cpp:129) | RGBA32F; alpha = 0
+ *   outExtractedRoughness: g_extracted_roughness (CSMain :196), R8_UNORM, one byte per pixel, row pitch = width; may be NULL
+ * Pitches in pixels (0 = width). */
+VQHIP_API int vqhip_ssr_environment_fallback(vqhip_ctx* ctx, void* stream,
+        const void* sceneColorRoughness, vqhip_format sceneFmt, int scenePitchPx,
+        const float* depth, int depthPitchPx,
+        const void* normals, vqhip_format normalFmt, int normalPitchPx,
+        int width, int height, const VQ_SSSRConstants* cb, const vqhip_envmap* env,
+        void* outRadiance, vqhip_format outFmt, int outPitchPx, uint8_t* outExtractedRoughness);
 
 typedef struct VQ_VizParams { int32_t iDrawMode; int32_t iUnpackNormals; float fInputStrength; } VQ_VizParams;
 VQHIP_API int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,

@@ -40,6 +40,7 @@ template <int N, int A, int B, int C> struct sw3 {
     sw3& operator=(const float3& v);
     sw3& operator=(const sw3& o);
     sw3& operator+=(const float3& v);
+    sw3& operator/=(float s) { d[A] /= s; d[B] /= s; d[C] /= s; return *this; }
 };
 template <int N, int A, int B, int C, int D> struct sw4 {
     float d[N];
@@ -131,6 +132,7 @@ struct int3 {
     const int& operator[](int i) const { return d[i]; }
     int3(int a, int b, int c) : d{ a, b, c } {}
     int3(const int2& v, int c) : d{ v.d[0], v.d[1], c } {}
+    int3(const uint2& v, int c);
     explicit int3(int s) : d{ s, s, s } {}
     explicit int3(const uint3& o); explicit int3(const float3& o);
     explicit operator float3() const { return float3((float)d[0], (float)d[1], (float)d[2]); }
@@ -182,6 +184,7 @@ struct uint4 {
 };
 inline int2::int2(const uint2& o) : d{ (int)o.d[0], (int)o.d[1] } {}
 inline int3::int3(const uint3& o) : d{ (int)o.d[0], (int)o.d[1], (int)o.d[2] } {}
+inline int3::int3(const uint2& v, int c) : d{ (int)v.d[0], (int)v.d[1], c } {}
 inline int4::int4(const uint4& o) : d{ (int)o.d[0], (int)o.d[1], (int)o.d[2], (int)o.d[3] } {}
 inline int2::int2(const float2& o) : d{ (int)o.d[0], (int)o.d[1] } {}
 inline int3::int3(const float3& o) : d{ (int)o.d[0], (int)o.d[1], (int)o.d[2] } {}
@@ -385,6 +388,12 @@ inline float4 mul(const float4x4& M, const float4& v) {
     for (int i = 0; i < 4; ++i) r.d[i] = M.m[i][0] * v.x + M.m[i][1] * v.y + M.m[i][2] * v.z + M.m[i][3] * v.w;
     return r;
 }
+// mul(float4x4, float3): HLSL truncates the matrix to its upper-left 3x3 (implicit truncation, warning X3206) — ClassifyReflectionTiles.hlsl:89
+inline float3 mul(const float4x4& M, const float3& v) {
+    float3 r;
+    for (int i = 0; i < 3; ++i) r.d[i] = M.m[i][0] * v.x + M.m[i][1] * v.y + M.m[i][2] * v.z;
+    return r;
+}
 inline float4 mul(const float4& v, const float4x4& M) {
     float4 r;
     for (int c = 0; c < 4; ++c) r.d[c] = v.x * M.m[0][c] + v.y * M.m[1][c] + v.z * M.m[2][c] + v.w * M.m[3][c];
@@ -426,6 +435,15 @@ struct Texture2D {
     float4 operator[](const usw_xy& p) const { return vqref_load_2d(*this, (int)p.d[0], (int)p.d[1], 0); }
     void GetDimensions(uint& w, uint& h) const { vqref_dims_2d(*this, &w, &h); }
 };
+// Texture2D<float>: Load / operator[] return the red channel
+struct Texture2DF : Texture2D {
+    float Load(int3 p) const { return vqref_load_2d(*this, p.x, p.y, p.z).x; }
+    float operator[](uint2 p) const { return vqref_load_2d(*this, (int)p.x, (int)p.y, 0).x; }
+    float operator[](int2 p) const { return vqref_load_2d(*this, p.x, p.y, 0).x; }
+};
+// RWBuffer<T>: declared by shaders whose appends are cut away (hlsl2cpp.py CUTS); never dereferenced with data == nullptr
+#define globallycoherent
+template <class T> struct RWBuffer { T* data = nullptr; T dummy{}; T& operator[](uint i) { return data ? data[i] : dummy; } };
 struct TextureCube {
     const void* res = nullptr; int kind = 0;
     float4 Sample(const SamplerState& s, float3 d) const { return vqref_sample_cube(*this, s, d, kSampleImplicit, 0.0f); }

@@ -47,13 +47,9 @@ float4 vqref_sample_cube(const TextureCube& t, const SamplerState&, float3 d, in
         const vqo::f4 r = vqo::sample_cube_rgba16f((const uint16_t*)e->diffuse_cube, e->diffuse_res, { d.x, d.y, d.z });
         return float4(r.x, r.y, r.z, r.w);
     }
-    if (t.kind == kCubeSpecular) {                                        // SampleLevel with an integral level, clamped by the sampler
-        int mip = mode == kSampleLevel ? (int)arg : 0;
-        if (mip < 0) mip = 0;
-        if (mip > e->spec_mips - 1) mip = e->spec_mips - 1;
-        size_t off = 0;
-        for (int m = 0; m < mip; ++m) { const size_t r = (size_t)(e->spec_res0 >> m); off += 6 * r * r * 4; }
-        const vqo::f4 r = vqo::sample_cube_rgba16f((const uint16_t*)e->specular_cube + off, e->spec_res0 >> mip, { d.x, d.y, d.z });
+    if (t.kind == kCubeSpecular) {                                        // SampleLevel on the mip-major specular cube, lod clamped by the sampler; an integral
+        const float lod = mode == kSampleLevel ? arg : 0.0f;              // lod (Lighting.hlsl:375) reads one level, a fractional one (SSR, ClassifyReflectionTiles.hlsl:89) two
+        const vqo::f4 r = vqo::sample_cube_lod_rgba16f((const uint16_t*)e->specular_cube, e->spec_res0, e->spec_mips, { d.x, d.y, d.z }, lod);
         return float4(r.x, r.y, r.z, r.w);
     }
     return float4(0, 0, 0, 0);

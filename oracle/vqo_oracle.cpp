@@ -503,6 +503,9 @@ void vqo_cube_edge_neighbor(int f, int i, int j, int N, int* out3) { cube_edge_n
 void vqo_sample_cube_rgba16f(const uint16_t* cube, int N, const float* dir, float* out4) {
     f4 c = sample_cube_rgba16f(cube, N, { dir[0], dir[1], dir[2] }); out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = c.w;
 }
+void vqo_sample_cube_lod_rgba16f(const uint16_t* cube, int res0, int nMips, const float* dir, float lod, float* out4) {
+    f4 c = sample_cube_lod_rgba16f(cube, res0, nMips, { dir[0], dir[1], dir[2] }, lod); out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = c.w;
+}
 void vqo_sample_2d_rg16f_clamp(const uint16_t* tex, int W, int H, float u, float v, float* out2) { f2 r = sample_2d_rg16f_clamp(tex, W, H, u, v); out2[0] = r.x; out2[1] = r.y; }
 void vqo_sample_material_tex(const vqhip_texture2d* t, const float* uv, const float* ddx, const float* ddy, float bias, float* out4) {
     f4 c = sample_material_tex(*t, { uv[0], uv[1] }, { ddx[0], ddx[1] }, { ddy[0], ddy[1] }, bias); out4[0] = c.x; out4[1] = c.y; out4[2] = c.z; out4[3] = c.w;
@@ -794,6 +797,63 @@ int vqo_envmap_prefilter(const float* chain, int w0, int h0, int nMips, int diff
         vqo_gaussian_blur_pass(tmpBlur.data(), (uint16_t*)diffuse_blurred + face * faceHalfs, diffuseRes, diffuseRes, VQHIP_FMT_RGBA16F, 1, nullptr, nullptr, 0, nthreads);
     }
     return vqo_conv_specular(chain, w0, h0, nMips, specRes0, order, specular, VQHIP_FMT_RGBA16F, nthreads);
+}
+
+// SSR's environment-map fallback: per pixel, ClassifyReflectionTiles.hlsl:ClassifyTiles :146-152 —
+//   if (is_reflective_surface && !is_glossy_reflection) intersection_output.xyz = SampleEnvironmentMap(...) (:78-94); g_intersection_output = it —
+// and g_extracted_roughness of CSMain :196. IsReflectiveSurface :59-63 (depth < 1), FFX_DNSR_Reflections_IsGlossyReflection Common.hlsl:108-110,
+// FFX_DNSR_Reflections_ScreenSpaceToViewSpace -> InvProjectPosition Common.hlsl:98-104,116-118. Every expression as written (contract v5): the
+// whole function runs once per pixel. mul(M, v) reads the row-major XMMATRIX column-major: the row vector v times M_cpu;
+// mul(g_envMapRotation, float3) truncates the float4x4 to its upper-left 3x3. UNORM10 decodes as c / 1023 (IEEE quotient).
+int vqo_ssr_environment_fallback(const void* scene, int sceneFmt, int scenePitch, const float* depth, int depthPitch, const void* normals, int normalFmt, int normalPitch,
+                                 int W, int H, const VQ_SSSRConstants* cb, const vqhip_envmap* env, void* out, int outFmt, int outPitch, uint8_t* outRoughness, int nthreads) {
+    if (!scene || !depth || !normals || !cb || !env || !out) return -1;
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    if (!scenePitch) scenePitch = W;
+    if (!depthPitch) depthPitch = W;
+    if (!normalPitch) normalPitch = W;
+    if (!outPitch) outPitch = W;
+    auto mulM = [](const VQ_matrix& M, f4 v) {
+        f4 r;
+        float* o = &r.x;
+        for (int j = 0; j < 4; ++j) o[j] = ((v.x * M.m[0][j] + v.y * M.m[1][j]) + v.z * M.m[2][j]) + v.w * M.m[3][j];
+        return r;
+    };
+    const float mipCount = (float)cb->envMapSpecularIrradianceCubemapMipLevelCount;
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const float roughness = load_px(scene, (size_t)y * scenePitch + x, sceneFmt).w;                      // CSMain :193
+            const float z = depth[(size_t)y * depthPitch + x];
+            if (outRoughness) outRoughness[(size_t)y * W + x] = f32_to_unorm8(roughness);                         // :196
+            f4 result = { 0, 0, 0, 0 };
+            if ((z < 1.0f) && !(roughness < cb->roughnessThreshold)) {
+                f3 n01;
+                if (normalFmt == VQHIP_FMT_RGBA32F) { const float* q = (const float*)normals + ((size_t)y * normalPitch + x) * 4; n01 = { q[0], q[1], q[2] }; }
+                else { const uint32_t q = ((const uint32_t*)normals)[(size_t)y * normalPitch + x];
+                       n01 = { fdiv_((float)(q & 1023u), 1023.0f), fdiv_((float)((q >> 10) & 1023u), 1023.0f), fdiv_((float)((q >> 20) & 1023u), 1023.0f) }; }
+                const float u = ((float)x + 0.5f) * cb->inverseBufferDimensions[0], v = ((float)y + 0.5f) * cb->inverseBufferDimensions[1];   // :79
+                const f3 wn = normalize_lit({ 2.0f * n01.x - 1.0f, 2.0f * n01.y - 1.0f, 2.0f * n01.z - 1.0f });                                  // :80
+                const float cy = 1.0f - v;                                                                                                       // Common.hlsl:99-100
+                const f4 pr = mulM(cb->invProjection, { 2.0f * u - 1.0f, 2.0f * cy - 1.0f, z, 1.0f });
+                const f3 ray = { fdiv_(pr.x, pr.w), fdiv_(pr.y, pr.w), fdiv_(pr.z, pr.w) };
+                const f3 dirV = normalize_lit(ray);                                                                                              // :84
+                const f4 nv4 = mulM(cb->view, { wn.x, wn.y, wn.z, 0.0f });                                                                       // :85
+                const f3 nV = { nv4.x, nv4.y, nv4.z };
+                const f3 Rv = reflect_lit(dirV, nV);                                                                                             // :86
+                const f4 rw = mulM(cb->invView, { Rv.x, Rv.y, Rv.z, 0.0f });                                                                     // :87
+                const VQ_matrix& R = cb->envMapRotation;
+                const f3 d = { (rw.x * R.m[0][0] + rw.y * R.m[1][0]) + rw.z * R.m[2][0], (rw.x * R.m[0][1] + rw.y * R.m[1][1]) + rw.z * R.m[2][1],
+                               (rw.x * R.m[0][2] + rw.y * R.m[1][2]) + rw.z * R.m[2][2] };
+                const f4 pre = sample_cube_lod_rgba16f((const uint16_t*)env->specular_cube, env->spec_res0, env->spec_mips, d, roughness * (mipCount - 1.0f));   // :89
+                const float NdotV = saturate(dot_lit(nV, neg(dirV)));                                                                            // :90
+                const f2 sb = sample_2d_rg16f_clamp((const uint16_t*)env->brdf_lut, env->lut_size, env->lut_size, NdotV, roughness);             // :92
+                const f3 c = EnvironmentBRDF(NdotV, roughness, 1.0f, { 0, 0, 0 }, { 0, 0, 0 }, { pre.x, pre.y, pre.z }, sb);                     // :93
+                result = { c.x, c.y, c.z, 0.0f };
+            }
+            store_px(out, (size_t)y * outPitch + x, outFmt, result);                                                                             // :153
+        }
+    return 0;
 }
 
 // Skydome.hlsl:VSMain/PSMain :39-56 as drawn at SceneRendering.cpp:1822-1850. CubemapLookDirection =

@@ -189,6 +189,28 @@ static inline f4 sample_equirect_lod(const float* chain, int w0, int h0, int nMi
     return { fma_(f, b.x, g * a.x), fma_(f, b.y, g * a.y), fma_(f, b.z, g * a.z), fma_(f, b.w, g * a.w) };
 }
 
+// SampleLevel(dir, lod) on a mip-major RGBA16F cube with a MIN_MAG_MIP_LINEAR sampler (ScreenSpaceReflections.cpp:632-648, used by
+// ClassifyReflectionTiles.hlsl:89 with the fractional lod roughness * (mip_count - 1)): lod clamped to the chain, 8-bit level fraction, the two
+// seamless bilinear fetches blended as fma(f, hi, (1-f)*lo) — the rule of sample_equirect_lod above. An integral lod reads one level.
+static inline size_t cube_mip_offset_halfs_(int res0, int mip) {
+    size_t off = 0;
+    for (int m = 0; m < mip; ++m) { const size_t r = (size_t)(res0 >> m); off += 6 * r * r * 4; }
+    return off;
+}
+static inline f4 sample_cube_lod_rgba16f(const uint16_t* cube, int res0, int nMips, f3 dir, float lod) {
+    const float maxl = (float)(nMips - 1);
+    const float l = (lod > 0.0f) ? ((lod < maxl) ? lod : maxl) : 0.0f;     // NaN -> 0
+    const int fl = f2i_floor(l * 256.0f + 0.5f);
+    int lo = fl >> 8;
+    float f = (float)(fl & 255) * 0.00390625f;
+    if (lo >= nMips - 1) { lo = nMips - 1; f = 0.0f; }
+    const f4 a = sample_cube_rgba16f(cube + cube_mip_offset_halfs_(res0, lo), res0 >> lo, dir);
+    if (f == 0.0f) return a;
+    const f4 b = sample_cube_rgba16f(cube + cube_mip_offset_halfs_(res0, lo + 1), res0 >> (lo + 1), dir);
+    const float g = 1.0f - f;
+    return { fma_(f, b.x, g * a.x), fma_(f, b.y, g * a.y), fma_(f, b.z, g * a.z), fma_(f, b.w, g * a.w) };
+}
+
 // ---- material textures (RGBA8_UNORM mip chains, vqo_gbuffer.cpp header) and shadow maps (R32F) ----
 static inline float unorm8_to_float(float c) { return c * rcp(255.0f); }
 

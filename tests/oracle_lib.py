@@ -262,6 +262,20 @@ def hdr_decode(data):
     return out
 
 
+def ssr_environment_fallback(scene, scene_fmt, depth, normals, normal_fmt, cb, env, out_fmt=abi.FMT_RGBA16F, extract_roughness=False, nthreads=0):
+    """env: the abi.EnvMap over host arrays (host_envmap). Returns the radiance image (and the R8_UNORM roughness)."""
+    lib = load()
+    lib.vqo_ssr_environment_fallback.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                 C.POINTER(abi.SSSRConstants), C.POINTER(abi.EnvMap), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    scene, depth, normals = np.ascontiguousarray(scene), np.ascontiguousarray(depth, np.float32), np.ascontiguousarray(normals)
+    h, w = depth.shape
+    out = np_image(h, w, out_fmt)
+    rough = np.zeros((h, w), np.uint8) if extract_roughness else None
+    assert lib.vqo_ssr_environment_fallback(_p(scene), scene_fmt, 0, _p(depth), 0, _p(normals), normal_fmt, 0, w, h, C.byref(cb), C.byref(env),
+                                            _p(out), out_fmt, 0, _p(rough) if rough is not None else None, nthreads) == 0
+    return (out, rough) if extract_roughness else out
+
+
 def visualize(img, in_fmt, params, out_fmt=None, nthreads=0):
     lib = load()
     lib.vqo_visualize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(abi.VizParams), C.c_int, C.c_int, C.c_int]

@@ -105,6 +105,17 @@ def sample_chain(levels, u, v, lod, mode="wrap"):
     return (1 - f) * a + f * b, ta + tb
 
 
+def sample_cube_chain(cubes, d, lod):
+    """cubes: list of float64 [6,N>>m,N>>m,C] (mip 0 first); explicit LOD on a MIN_MAG_MIP_LINEAR sampler: trilinear between two seamless bilinear
+    fetches. Returns (value, taps of both levels)."""
+    lo, f = split_lod(lod, len(cubes))
+    a, ta = sample_cube(cubes[lo], d)
+    if f == 0.0:
+        return a, ta
+    b, tb = sample_cube(cubes[lo + 1], d)
+    return (1 - f) * a + f * b, ta + tb
+
+
 def lod_from_derivatives(ddx, ddy, w, h, bias=0.0):
     """Sample(): LOD = log2 of the longer of the two screen-space derivative vectors in texel units (isotropic), + bias"""
     dx = np.hypot(np.float64(ddx[0]) * w, np.float64(ddx[1]) * h)

@@ -849,6 +849,35 @@ def _cfg4_full_cases():
                       ("ulp16", 1, 0.01), store="f16"))
 
 
+# ---- SSR's environment-map fallback: ClassifyReflectionTiles.hlsl:SampleEnvironmentMap under ClassifyTiles' condition ------------
+def _ssr_cases():
+    def make(tag, W, rows, frame_h, env_fn, seed, tol):
+        def build():
+            e = env_fn()
+            scene, depth, packed, n01 = synth.ssr_surfaces(W, rows, seed=seed)
+            return {"scene": scene.astype(np.float16), "depth": depth, "packed": packed, "n01": n01, "env": e,
+                    "cb": synth.ssr_constants(W, frame_h, e["spec_mips"])}        # rows 0 .. rows-1 of a W x frame_h frame
+
+        def ref(i):
+            from tests import ref_lib as R
+            return R.ssr_environment_fallback(i["scene"].astype(np.float32), i["depth"], i["n01"], i["cb"], host_env(i["env"]))[..., :3]
+
+        def oracle(i):
+            return O.ssr_environment_fallback(i["scene"], F16, i["depth"], i["packed"], abi.FMT_R10G10B10A2_UNORM, i["cb"], host_env(i["env"]), F16)[..., :3]
+
+        def product(ctx, i):
+            keep = []
+            out = ctx.ssr_environment_fallback(_dev(i["scene"]), F16, _dev(i["depth"]), _dev(i["packed"].view(np.int32)), abi.FMT_R10G10B10A2_UNORM, i["cb"],
+                                               dev_env(i["env"], keep), F16)
+            return out.cpu().numpy()[..., :3]
+        CASES.append(Case(tag, build, ref, oracle, product, tol, store="f16"))
+    # measured (scripts/ulp_report.py ssr_): identical halfs on the toy cube; the bands of the BASELINE frames against the cfg4 cube differ in <= 1 ulp
+    make("ssr_env_fallback_160x24", 160, 24, 24, small_env, 0x55E7, ("ulp16", 1, 0.002))
+    make("ssr_env_fallback_1280x16", 1280, 16, 720, cfg4_env, 0x55E8, ("ulp16", 1, 1e-4))         # measured 1.6e-5
+    make("ssr_env_fallback_3840x48", 3840, 48, 2160, cfg4_env, 0x55E9, ("ulp16", 1, 1e-4))        # measured 2.2e-5
+
+
+_ssr_cases()
 _cfg4_full_cases()
 
 BY_NAME = {c.name: c for c in CASES}

@@ -51,6 +51,7 @@ def load(name="shaders"):
             lib.vqref_skydome.argtypes = [vp, i32, i32, vp, i32, i32, vp]
             lib.vqref_visualize.argtypes = [vp, i32, i32, vp, vp]
             lib.vqref_apply_reflections.argtypes = [vp, vp, i32, i32]
+            lib.vqref_ssr_environment_fallback.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
             lib.vqref_unlit_color.argtypes = [vp, vp]
             lib.vqref_fsr_easu.argtypes = [vp, i32, i32, vp, vp, i32, i32]
             lib.vqref_fsr_rcas.argtypes = [vp, i32, i32, vp, vp]
@@ -171,6 +172,16 @@ def apply_reflections(refl, scene):
     refl, scene = _img32(refl), _img32(scene).copy()
     assert load().vqref_apply_reflections(refl.ctypes.data, scene.ctypes.data, scene.shape[1], scene.shape[0]) == 0
     return scene
+
+
+def ssr_environment_fallback(scene, depth, normals01, cb, env):
+    """scene: [H,W,4] values (alpha = roughness); depth: [H,W]; normals01: [H,W,4] the UNORM-decoded [0,1] values; env: abi.EnvMap over host arrays."""
+    scene, normals01 = _img32(scene), _img32(normals01)
+    depth = np.ascontiguousarray(depth, np.float32)
+    out = np.zeros_like(scene)
+    assert load().vqref_ssr_environment_fallback(scene.ctypes.data, depth.ctypes.data, normals01.ctypes.data, scene.shape[1], scene.shape[0],
+                                                 C.addressof(cb), C.addressof(env), out.ctypes.data) == 0
+    return out
 
 
 def fsr_easu(img, out_w, out_h, con):

@@ -19,6 +19,7 @@ def lib():
     lib = O.load()
     vp, f32, i32 = C.c_void_p, C.c_float, C.c_int
     lib.vqo_sample_cube_rgba16f.argtypes = [vp, i32, vp, vp]
+    lib.vqo_sample_cube_lod_rgba16f.argtypes = [vp, i32, i32, vp, f32, vp]
     lib.vqo_sample_equirect_lod.argtypes = [vp, i32, i32, i32, f32, f32, f32, vp]
     lib.vqo_sample_2d_rg16f_clamp.argtypes = [vp, i32, i32, f32, f32, vp]
     lib.vqo_sample_material_tex.argtypes = [vp, vp, vp, vp, f32, vp]
@@ -62,6 +63,26 @@ def test_seamless_cube_bilinear(lib, N):
         want, taps = R.sample_cube(c64, d.astype(np.float64))
         _check(out, want, taps, stats)
     assert stats[1] <= 0.01 * sum(stats), stats
+
+
+@pytest.mark.parametrize("N", [8, 128])
+def test_seamless_cube_trilinear_fractional_lod(lib, N):
+    """SampleLevel(dir, fractional lod) on the mip-major specular cube with a MIN_MAG_MIP_LINEAR sampler — SSR's environment fallback
+    (ClassifyReflectionTiles.hlsl:89: roughness * (mip_count - 1)): 8-bit level fraction, clamp to the chain, one level when the fraction is 0."""
+    rng = np.random.default_rng(100 + N)
+    mips = abi.specular_mip_count(N)
+    cubes = [(rng.random((6, N >> m, N >> m, 4)) * rng.choice([0.1, 1.0, 50.0], (6, N >> m, N >> m, 1))).astype(np.float16) for m in range(mips)]
+    packed = np.concatenate([c.reshape(-1, 4) for c in cubes])
+    c64 = [c.astype(np.float64) for c in cubes]
+    lods = [0.0, 0.5, 1.0, 1.0 / 256, 0.998, 2.25, float(mips - 1) - 0.004, float(mips - 1), float(mips + 2), -1.0, float("nan"), 0.2 * (mips - 1), 0.73 * (mips - 1)]
+    stats = [0, 0]
+    out = np.zeros(4, np.float32)
+    for k, d in enumerate(_directions(rng, N)):
+        lod = np.float32(lods[k % len(lods)])
+        lib.vqo_sample_cube_lod_rgba16f(packed.ctypes.data, N, mips, d.ctypes.data, lod, out.ctypes.data)
+        want, taps = R.sample_cube_chain(c64, d.astype(np.float64), float(lod))
+        _check(out, want, taps, stats)
+    assert stats[1] <= 0.012 * sum(stats), stats
 
 
 def test_equirect_trilinear_wrap_and_lod_clamp(lib):

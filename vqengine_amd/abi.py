@@ -11,6 +11,7 @@ VQHIP_ERR_NO_DEVICE = -4
 VQHIP_ERR_RCCL = -5
 
 FMT_RGBA32F, FMT_RGBA16F, FMT_RGBA8_UNORM, FMT_RG16F, FMT_RG32F = 0, 1, 2, 3, 4
+FMT_R10G10B10A2_UNORM = 5          # Tex_SceneNormals: input of ssr_environment_fallback only
 FMT_BPP = {FMT_RGBA32F: 16, FMT_RGBA16F: 8, FMT_RGBA8_UNORM: 4, FMT_RG16F: 4, FMT_RG32F: 8}
 CONV_SEQUENTIAL, CONV_WAVE64 = 0, 1
 COLOR_SPACE_REC_709, COLOR_SPACE_REC_2020 = 0, 1
@@ -152,6 +153,15 @@ class SkydomeParams(C.Structure):  # VQ_SkydomeParams
                 ("forward", float3), ("pad", C.c_float)]
 
 
+class SSSRConstants(C.Structure):  # VQ_SSSRConstants == FFX_SSSRConstants (ScreenSpaceReflections.h:43-65)
+    _fields_ = [(k, matrix) for k in ("invViewProjection", "projection", "invProjection", "view", "invView", "prevViewProjection", "envMapRotation")] + [
+        ("bufferDimensions", C.c_uint32 * 2), ("inverseBufferDimensions", C.c_float * 2),
+        ("temporalStabilityFactor", C.c_float), ("depthBufferThickness", C.c_float), ("roughnessThreshold", C.c_float), ("varianceThreshold", C.c_float),
+        ("frameIndex", C.c_uint32), ("maxTraversalIntersections", C.c_uint32), ("minTraversalOccupancy", C.c_uint32), ("mostDetailedMip", C.c_uint32),
+        ("samplesPerQuad", C.c_uint32), ("temporalVarianceGuidedTracingEnabled", C.c_uint32), ("envMapSpecularIrradianceCubemapMipLevelCount", C.c_uint32),
+        ("pad_", C.c_uint32)]
+
+
 def _chk(t, size, **offs):
     assert C.sizeof(t) == size, (t.__name__, C.sizeof(t), size)
     for k, v in offs.items():
@@ -171,6 +181,7 @@ _chk(Texture2D, 24, width=8, mips=16)
 _chk(MaterialDesc, 256, texDiffuse=80, texLocalAO=224)
 _chk(TonemapperParams, 16)
 _chk(BlurParams, 8)
+_chk(SSSRConstants, 512, bufferDimensions=448, roughnessThreshold=472, envMapSpecularIrradianceCubemapMipLevelCount=504)
 
 
 def mip_level_count(w, h):

@@ -78,6 +78,8 @@ def load_library():
         "vqhip_fsr_rcas": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(C.c_uint32), i32, i32]),
         "vqhip_visualize": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.VizParams), i32, i32]),
         "vqhip_apply_reflections": (i32, [vp, vp, vp, vp, i32, i32, i32]),
+        "vqhip_ssr_environment_fallback": (i32, [vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, C.POINTER(abi.SSSRConstants), C.POINTER(abi.EnvMap),
+                                                 vp, i32, i32, vp]),
         "vqhip_rowtile": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
         "vqhip_comm_unique_id": (i32, [vp]),
         "vqhip_comm_create": (i32, [vp, i32, i32, C.POINTER(vp)]),
@@ -105,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_forward_lighting_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
     "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f", "vqhip_hdr_downsize_rgba32f",
-    "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections",
+    "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections", "vqhip_ssr_environment_fallback",
     "vqhip_rowtile", "vqhip_comm_unique_id", "vqhip_comm_create", "vqhip_comm_adopt", "vqhip_comm_destroy", "vqhip_comm_query", "vqhip_comm_abort", "vqhip_comm_loopback", "vqhip_exchange_blur_halos",
     "vqhip_composite_tiles",
 ]
@@ -477,6 +479,26 @@ class Context:
         h, w = scene_color.shape[0], scene_color.shape[1]
         self._ck(self.lib.vqhip_apply_reflections(self._h, self._stream(stream), _ptr(reflection), _ptr(scene_color), w, h, fmt))
         return scene_color
+
+    def ssr_environment_fallback(self, scene_color, scene_fmt, depth, normals, normal_fmt, cb, env, out_fmt=None, extract_roughness=False, out=None, stream=None):
+        """ClassifyReflectionTiles.hlsl: the environment-map fallback of SSR's tile classification (SampleEnvironmentMap under the condition of
+        ClassifyTiles :146-152). scene_color: [H,W,4] image whose alpha is the roughness; depth: float32 [H,W]; normals: uint32 [H,W]
+        (R10G10B10A2_UNORM) or float32 [H,W,4]; cb: abi.SSSRConstants; env: abi.EnvMap. Returns the radiance image (and the R8 roughness)."""
+        _check_img(scene_color, scene_fmt, "scene_color")
+        h, w = scene_color.shape[0], scene_color.shape[1]
+        assert depth.dtype == torch.float32 and tuple(depth.shape) == (h, w) and depth.is_contiguous()
+        if normal_fmt == abi.FMT_R10G10B10A2_UNORM:
+            assert normals.dtype in (torch.int32, torch.uint32) and tuple(normals.shape) == (h, w) and normals.is_contiguous()
+        else:
+            _check_img(normals, normal_fmt, "normals", (h, w))
+        out_fmt = FMT_RGBA16F if out_fmt is None else out_fmt
+        if out is None:
+            out = empty_image(h, w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out", (h, w))
+        rough = torch.empty((h, w), dtype=torch.uint8, device=self.device) if extract_roughness else None
+        self._ck(self.lib.vqhip_ssr_environment_fallback(self._h, self._stream(stream), _ptr(scene_color), scene_fmt, 0, _ptr(depth), 0, _ptr(normals), normal_fmt, 0,
+                                                         w, h, C.byref(cb), C.byref(env), _ptr(out), out_fmt, 0, _ptr(rough) if rough is not None else None))
+        return (out, rough) if extract_roughness else out
 
     def visualize(self, src, in_fmt, params, out_fmt=None, out=None, stream=None):
         """Visualization.hlsl:CSMain (debug draw modes). params: abi.VizParams."""

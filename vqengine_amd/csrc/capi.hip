@@ -763,6 +763,35 @@ int vqhip_apply_reflections(vqhip_ctx* ctx, void* stream, const void* reflection
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "apply_reflections launch");
 }
 
+int vqhip_ssr_environment_fallback(vqhip_ctx* ctx, void* stream, const void* sceneColorRoughness, vqhip_format sceneFmt, int scenePitchPx,
+                                   const float* depth, int depthPitchPx, const void* normals, vqhip_format normalFmt, int normalPitchPx,
+                                   int width, int height, const VQ_SSSRConstants* cb, const vqhip_envmap* env,
+                                   void* outRadiance, vqhip_format outFmt, int outPitchPx, uint8_t* outExtractedRoughness) {
+    vqk::Range range_("FFX DNSR ClassifyTiles");
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "ssr_environment_fallback: ctx is NULL");
+    CTX_GUARD(ctx, "ssr_environment_fallback");
+    if (!sceneColorRoughness || !depth || !normals || !cb || !env || !outRadiance || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28))
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "ssr_environment_fallback: bad argument");
+    if (!isImageFmt(sceneFmt) || !isImageFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "ssr_environment_fallback: scene colour and radiance must be RGBA32F or RGBA16F");
+    if (normalFmt != VQHIP_FMT_R10G10B10A2_UNORM && normalFmt != VQHIP_FMT_RGBA32F) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "ssr_environment_fallback: normals must be R10G10B10A2_UNORM or RGBA32F");
+    if (!env->specular_cube || !env->brdf_lut || env->spec_res0 <= 0 || env->spec_mips <= 0 || env->lut_size <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "ssr_environment_fallback: env needs the specular cube and the BRDF LUT");
+    const uint32_t mc = cb->envMapSpecularIrradianceCubemapMipLevelCount;
+    if (mc < 1 || mc > (uint32_t)env->spec_mips) return fail(ctx, VQHIP_ERR_INVALID_ARG, "ssr_environment_fallback: envMapSpecularIrradianceCubemapMipLevelCount must be in [1, env->spec_mips]");
+    auto pitch = [&](int p) { return p ? p : width; };
+    if (pitch(scenePitchPx) < width || pitch(depthPitchPx) < width || pitch(normalPitchPx) < width || pitch(outPitchPx) < width) return fail(ctx, VQHIP_ERR_INVALID_ARG, "ssr_environment_fallback: pitch < width");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    SsrArgs a;
+    a.scene = sceneColorRoughness; a.depth = depth; a.normals = normals; a.out = outRadiance; a.outRoughness = outExtractedRoughness;
+    a.width = width; a.height = height; a.scenePitch = pitch(scenePitchPx); a.depthPitch = pitch(depthPitchPx); a.normalPitch = pitch(normalPitchPx); a.outPitch = pitch(outPitchPx);
+    a.invProj = cb->invProjection; a.view = cb->view; a.invView = cb->invView;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a.rot[i][j] = cb->envMapRotation.m[i][j];
+    a.invDimX = cb->inverseBufferDimensions[0]; a.invDimY = cb->inverseBufferDimensions[1];
+    a.roughnessThreshold = cb->roughnessThreshold; a.mipCount = (float)mc;
+    a.pow5ExpLog = ctx->pow5ExpLog; a.env = *env;
+    hipError_t e = launch_ssr_env_fallback((hipStream_t)stream, a, sceneFmt, normalFmt, outFmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "ssr_environment_fallback launch");
+}
+
 int vqhip_specular_mip_count(int spec_res0) { return vqhip_mip_level_count(spec_res0, spec_res0) - 1; }
 size_t vqhip_cube_bytes(int res0, int nMips, vqhip_format fmt) {
     const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;

@@ -89,6 +89,18 @@ hipError_t launch_fsr_rcas(hipStream_t s, const void* in, void* out, int W, int 
 hipError_t launch_visualize(hipStream_t s, const void* in, void* out, int W, int H, const VQ_VizParams& p, int inFmt, int outFmt);
 hipError_t launch_apply_reflections(hipStream_t s, const void* refl, void* scene, int W, int H, int fmt);
 
+// SSR environment fallback (§8f.4, ssr.hip): what the kernel reads of VQ_SSSRConstants + the resource descriptors, by value
+struct SsrArgs {
+    const void* scene; const float* depth; const void* normals; void* out; uint8_t* outRoughness;
+    int width, height, scenePitch, depthPitch, normalPitch, outPitch;
+    VQ_matrix invProj, view, invView;
+    float rot[3][3];                      // upper-left 3x3 of envMapRotation
+    float invDimX, invDimY, roughnessThreshold, mipCount;
+    int pow5ExpLog;
+    vqhip_envmap env;
+};
+hipError_t launch_ssr_env_fallback(hipStream_t s, const SsrArgs& a, int sceneFmt, int normalFmt, int outFmt);
+
 // launchers (each returns the hipError_t of the launch)
 hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt);
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt);

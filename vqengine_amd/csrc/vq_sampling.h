@@ -212,6 +212,32 @@ VQD float4 sample_cube_rgba16f(const void* cube, int N, f3 dir) {
     return blend4(c[0], c[1], c[2], c[3], wx, wy);
 }
 
+// SampleLevel(dir, lod) on a mip-major RGBA16F cube ([mip][6][r][r], r = res0 >> mip) with a MIN_MAG_MIP_LINEAR sampler (CLAMP addressing has no
+// effect on a cube: edges are seamless): the sampler clamps lod to [0, nMips-1] (NaN -> 0), the level fraction is an 8-bit fixed-point value
+// like the in-level filter fractions — floor(lod * 256 + 0.5) / 256, the rule of sample_equirect_lod_t below and of D3D11.3 functional spec
+// 7.18.10 "LOD fraction: at least 8 bits" — and the two seamless bilinear fetches blend as fma(f, hi, (1 - f) * lo); a zero fraction reads one
+// level only. Used by SSR's environment fallback (ClassifyReflectionTiles.hlsl:91: roughness * (mip_count - 1) is fractional);
+// tests/ref64_sampling.py bounds it against exact float64 trilinear weights.
+VQD uint32_t cube_mip_offset_texels(int res0, int mip) {
+    if ((res0 & (res0 - 1)) == 0) { const int rm = res0 >> mip; return 8u * (uint32_t)(res0 * res0 - rm * rm); }   // 6 * sum_{m<mip} 4^-m res0^2
+    uint32_t off = 0;
+    for (int m = 0; m < mip; ++m) { const uint32_t r = (uint32_t)(res0 >> m); off += 6u * r * r; }
+    return off;
+}
+VQD float4 sample_cube_lod_rgba16f(const void* cube, int res0, int nMips, f3 dir, float lod) {
+    const float maxl = (float)(nMips - 1);
+    const float l = (lod > 0.0f) ? ((lod < maxl) ? lod : maxl) : 0.0f;
+    const int fl = f2i_floor(l * 256.0f + 0.5f);
+    int lo = fl >> 8;
+    float f = (float)(fl & 255) * 0.00390625f;
+    if (lo >= nMips - 1) { lo = nMips - 1; f = 0.0f; }
+    const float4 a = sample_cube_rgba16f((const h4*)cube + cube_mip_offset_texels(res0, lo), res0 >> lo, dir);
+    if (f == 0.0f) return a;
+    const float4 b = sample_cube_rgba16f((const h4*)cube + cube_mip_offset_texels(res0, lo + 1), res0 >> (lo + 1), dir);
+    const float g = 1.0f - f;
+    return make_float4(fma_(f, b.x, g * a.x), fma_(f, b.y, g * a.y), fma_(f, b.z, g * a.z), fma_(f, b.w, g * a.w));
+}
+
 // bilinear CLAMP fetch of an RG16F [H][W] texture
 VQD float2 sample_2d_rg16f_clamp(const void* tex, int W, int H, float u, float v) {
     int ix, iy; float wx, wy;

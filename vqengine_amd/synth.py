@@ -368,3 +368,72 @@ def hdr_file_bytes(rgbe, rle=True, magic=b"#?RADIANCE", extra_header=(b"# synthe
         for k in range(4):
             body += _rle_plane(rgbe[y, :, k])
     return head + bytes(body)
+
+
+# ---- SSR environment fallback: the inputs of ClassifyReflectionTiles.hlsl ---------------------------------------
+def _look_at_lh(eye, at, up):
+    """DirectX::XMMatrixLookAtLH: row-major, row-vector convention (float64)."""
+    eye, at, up = (np.asarray(v, np.float64) for v in (eye, at, up))
+    z = at - eye
+    z /= np.linalg.norm(z)
+    x = np.cross(up, z)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    m = np.eye(4)
+    m[:3, 0], m[:3, 1], m[:3, 2] = x, y, z
+    m[3, :3] = [-x @ eye, -y @ eye, -z @ eye]
+    return m
+
+
+def _perspective_fov_lh(fov_y, aspect, zn, zf):
+    """DirectX::XMMatrixPerspectiveFovLH (float64)."""
+    h = 1.0 / np.tan(0.5 * fov_y)
+    m = np.zeros((4, 4))
+    m[0, 0], m[1, 1], m[2, 2], m[2, 3], m[3, 2] = h / aspect, h, zf / (zf - zn), 1.0, -zn * zf / (zf - zn)
+    return m
+
+
+def _set_matrix(dst, m):
+    for i in range(4):
+        for j in range(4):
+            dst.m[i][j] = float(np.float32(m[i, j]))
+
+
+def ssr_constants(width, height, spec_mips, hdri_yaw=0.3, roughness_threshold=0.2, camera=(3.0, 10.0, -60.0), look_at=(0.0, 2.0, 0.0)):
+    """FFX_SSSRConstants as VQRenderer::RenderReflections fills it (SceneRendering.cpp:2221-2242) for a LookAtLH / PerspectiveFovLH camera;
+    envMapRotation == GetHDRIRotationMatrix (:2185-2195: float cos / sin of -yaw)."""
+    cb = abi.SSSRConstants()
+    view = _look_at_lh(camera, look_at, (0.0, 1.0, 0.0))
+    proj = _perspective_fov_lh(np.pi / 3.0, width / height, 0.1, 1500.0)
+    _set_matrix(cb.view, view)
+    _set_matrix(cb.invView, np.linalg.inv(view))
+    _set_matrix(cb.projection, proj)
+    _set_matrix(cb.invProjection, np.linalg.inv(proj))
+    _set_matrix(cb.invViewProjection, np.linalg.inv(view @ proj))
+    _set_matrix(cb.prevViewProjection, view @ proj)
+    c, s = float(np.cos(np.float32(-hdri_yaw), dtype=np.float32)), float(np.sin(np.float32(-hdri_yaw), dtype=np.float32))
+    rot = np.zeros((4, 4))
+    rot[0, :3], rot[1, :3], rot[2, :3] = [c, 0, s], [0, 1, 0], [-s, 0, c]
+    _set_matrix(cb.envMapRotation, rot)
+    cb.bufferDimensions[0], cb.bufferDimensions[1] = width, height
+    cb.inverseBufferDimensions[0], cb.inverseBufferDimensions[1] = float(np.float32(1.0) / np.float32(width)), float(np.float32(1.0) / np.float32(height))
+    cb.temporalStabilityFactor, cb.depthBufferThickness, cb.roughnessThreshold, cb.varianceThreshold = 0.7, 0.015, roughness_threshold, 0.0
+    cb.maxTraversalIntersections, cb.minTraversalOccupancy, cb.mostDetailedMip, cb.samplesPerQuad = 128, 4, 0, 1
+    cb.envMapSpecularIrradianceCubemapMipLevelCount = spec_mips
+    return cb
+
+
+def ssr_surfaces(width, height, seed=0x55E7, sky_fraction=0.1):
+    """(scene colour float32 [H,W,4] with the roughness in alpha, NDC depth float32 [H,W], normals as R10G10B10A2_UNORM uint32 [H,W] and as the decoded
+    float32 [H,W,4] values): white-noise surfaces — roughness U[0,1] (a fifth below the 0.2 ray threshold), unit normals on the whole sphere encoded
+    n * 0.5 + 0.5 and quantised to 10 bits, depth U[0.9, 1) with `sky_fraction` of the pixels on the far plane (1.0)."""
+    r = _chunk_rng(seed, 0)
+    scene = r.random((height, width, 4), dtype=np.float32) * np.array([4.0, 4.0, 4.0, 1.0], np.float32)
+    depth = (0.9 + 0.0999 * r.random((height, width), dtype=np.float32)).astype(np.float32)
+    depth[r.random((height, width), dtype=np.float32) < sky_fraction] = 1.0
+    n = r.normal(size=(height, width, 3))
+    n /= np.linalg.norm(n, axis=-1, keepdims=True)
+    q = np.clip(np.floor((n * 0.5 + 0.5) * 1023.0 + 0.5), 0, 1023).astype(np.uint32)
+    packed = (q[..., 0] | (q[..., 1] << 10) | (q[..., 2] << 20) | (np.uint32(3) << 30)).astype(np.uint32)
+    n01 = np.concatenate([q.astype(np.float32) / np.float32(1023.0), np.ones((height, width, 1), np.float32)], axis=-1)
+    return scene, depth, packed, n01
