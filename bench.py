@@ -18,6 +18,8 @@ Every invocation (N = 1 included) ALSO times, outside the headline's timed regio
   cfg2           BASELINE config 2: 1920x1080, 16 point lights, shade kernel (the size where HBM is the roof that matters)
   sustained      the headline's own step for ~2 s without interruption (thousands of steps): a long-window cross-check of `value`, visible to rocm-smi
   ibl_load       BASELINE config 4: the load-time IBL stages (min-filter mip chain, diffuse irradiance, specular prefilter, BRDF LUT), timed
+  widened        the SURVEY 8f kernels at 4K: G-buffer producer (textured / texture-less), PSMain as one kernel, skydome, .hdr decode, FSR EASU / RCAS,
+                 SSR environment fallback — ms, algorithmic bytes per pixel, fraction of the HBM spec
   coherent_scene the cfg3 frame on surface-coherent content (synth.gbuffer_rows_coherent) instead of white noise — never the headline
   tile_curve     per-tile step time of the cfg5 frame at 4320/N rows, N = 1, 2, 4, 8, on this one GPU + a labelled MODELLED speed-up
 --config cfg5 makes cfg5 the headline instead (then `scaling` is "strong"); --no-extras skips everything but the headline.
@@ -646,6 +648,7 @@ def main():
         if world == 1:
             extras["cfg2"] = shade_only(ctx, d, comms, args, CONFIGS["cfg2"], None, 0)
             extras["ibl_load"] = ibl_load_report(ibl_t)
+            extras["widened"] = widened_report(ctx, env, pre["spec_mips"])
             if args.config == "cfg3":
                 extras["coherent_scene"] = coherent_scene(ctx, d, comms, args, cfg, env, pre["spec_mips"])
 
@@ -782,6 +785,91 @@ def coherent_scene(ctx, d, comms, args, cfg, env, spec_mips):
     res = shade_only(ctx, d, comms, args, cfg, env, spec_mips, coherent=True)
     res["note"] = ("the cfg3 shade kernel on synth.gbuffer_rows_coherent; slow_path_pixel_fraction_round2 = pixels with roughness < 0.04, which round 2 sent "
                    "through the IEEE light loop wave by wave; now whole waves choose the EPSILON-select / back-facing-skip forms (shade.hip)")
+    return res
+
+
+def _stage_ms(fn, budget_s=0.12):
+    """time of one call of fn in a back-to-back loop: a spin-up and a timed loop sized by TIME (the chip needs sustained load to hold its clocks)"""
+    probe = _time_loop(lambda i: fn(), 3, 2)
+    spin = int(min(2000, max(3, budget_s * 1e3 / probe)))
+    n = int(min(1000, max(5, 0.5 * budget_s * 1e3 / probe)))
+    return _time_loop(lambda i: fn(), n, spin)
+
+
+def widened_report(ctx, env, spec_mips):
+    """The kernels of SURVEY.md 8f (the callers and data formats either side of the hot path) at 4K on this GPU, each with its algorithmic HBM bytes
+    per pixel and the fraction of the 8 TB/s spec they amount to; VALU-bound ones say so. Inputs: 540-row synthetic bands tiled to 2160 rows."""
+    W, H, NM, BAND = 3840, 2160, 12, 540
+    px = W * H
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    tile = lambda a: np.tile(a, (H // BAND,) + (1,) * (a.ndim - 1))   # noqa: E731
+    res = {"frame": [W, H], "note": "back-to-back launches of the one call after a ~0.1 s spin-up; *_hbm_frac = algorithmic bytes / time / 8 TB/s. producer / "
+                                    "skydome / RCAS / SSR fallback are HBM-shaped; the fused PSMain and EASU are VALU-bound (see their notes)"}
+
+    def entry(ms, bytes_px, **kw):
+        return dict(ms=round(ms, 4), Mpix_s=round(px / ms / 1e3, 1), bytes_per_px=bytes_px, GBps=round(px * bytes_px / ms / 1e6, 1),
+                    hbm_frac=round(px * bytes_px / ms / 1e6 / HBM_PEAK_GBPS, 4), **kw)
+    # ---- 8f.1: G-buffer producer, alone and fused with the lighting (PSMain as one kernel)
+    ipd = [dev(tile(p_)) for p_ in synth.interpolants(W, BAND, NM)]
+    ssao = dev(tile(synth.ssao_image(W, BAND)))
+    datas, texsets = synth.material_set(NM, max_dim=1024, same_size=False)
+    dmats, dm0, keep, nmaps = (abi.MaterialDesc * NM)(), (abi.MaterialDesc * NM)(), [], 0
+    for i, (dd, ts) in enumerate(zip(datas, texsets)):
+        dmats[i].data = dd
+        dm0[i].data = dd
+        dm0[i].data.textureConfig = 0.0
+        for slot, img in ts.items():
+            chain_g, nm = ctx.mip_chain_rgba8(dev(img))
+            keep.append(chain_g)
+            setattr(dmats[i], slot, abi.Texture2D(chain_g.data_ptr(), img.shape[1], img.shape[0], nm, 0))
+            nmaps += 1
+    gb = tuple(torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(4))
+    res["gbuffer_producer_textured"] = entry(_stage_ms(lambda: ctx.gbuffer_from_materials(ipd, dmats, 0.055, ssao, out=gb)), 113,
+                                             what=f"vqhip_gbuffer_from_materials: 3 interpolant planes + SSAO -> 4 float4 planes, {NM} materials, {nmaps} RGBA8 mip-chained maps (cache resident)")
+    res["gbuffer_producer_textureless"] = entry(_stage_ms(lambda: ctx.gbuffer_from_materials(ipd, dm0, 0.055, None, out=gb)), 112,
+                                                what="the same call with texture-less materials: the streaming floor of the kernel")
+    pf, extra = synth.per_frame(points=synth.point_lights(64, seed=0x6400), hdri_offset=0.3)
+    pv = synth.per_view(W, H, max_env_lod=spec_mips)
+    scene = capi.empty_image(H, W, F16, ctx.device)
+    ms = _stage_ms(lambda: ctx.forward_lighting_from_materials(ipd, dmats, pf, pv, ssao=ssao, out=scene, out_fmt=F16, extra_point=extra, env=env))
+    res["psmain_fused"] = entry(ms, 57, valu_frac_model=round((170 * 64 + 160) * px / ms / 1e9 / VALU_PEAK_TFLOPS, 4),
+                                what="vqhip_forward_lighting_from_materials: PSMain as ONE kernel (producer + 64 point lights + IBL), 48 + 1 B in, 8 B out; VALU-bound like the headline's shade kernel")
+    del gb, ipd, ssao, keep
+    # ---- 8f.2: skydome, all-sky frame (worst case), RGBA16F target, 2048^2 equirect
+    import math
+    from vqengine_amd import scene as scene_mod
+    eq = dev(synth.equirect(2048, 2048))
+    sp = scene_mod.skydome_params(0.9, -0.2, 0.5, 60.0 * math.pi / 180.0, W, H)
+    res["skydome_all_sky"] = entry(_stage_ms(lambda: ctx.skydome(eq, sp, scene, F16)), 8, what="vqhip_skydome over a frame without geometry: 8 B/px written, equirect taps cache resident")
+    # ---- 8f.3: Radiance .hdr ingest, 2048^2 (256 run-length coded rows, repeated): host header parse + run expansion, device RGBE -> RGBA32F
+    rgbe = synth.float_to_rgbe(synth.equirect(2048, 256)[..., :3])
+    part = synth.hdr_file_bytes(rgbe)
+    body = part[part.index(b"+X 2048\n") + 8:]
+    data = part[:part.index(b"-Y ")] + b"-Y 2048 +X 2048\n" + body * 8
+    ctx.load_hdr(data)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ctx.load_hdr(data)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 3 * 1e3
+    res["hdr_decode_2048"] = {"ms": round(ms, 3), "file_bytes": len(data), "Mpix_s": round(2048 * 2048 / ms / 1e3, 1),
+                              "what": "vqhip_hdr_decode_rgba32f, wall time of the call + stream sync: the run expansion is host code (one thread), the conversion a 20 B/px kernel"}
+    # ---- 8f.4: FSR 1.0 (2560x1440 -> 3840x2160, RGBA8), SSR environment fallback
+    iw, ih = 2560, 1440
+    src = torch.randint(0, 256, (ih, iw, 4), dtype=torch.uint8, device="cuda")
+    up, fin = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda"), torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
+    econ, rcon = capi.fsr_easu_con(iw, ih, W, H), capi.fsr_rcas_con(0.2)
+    res["fsr_easu_1440p_to_4k"] = entry(_stage_ms(lambda: ctx.fsr_easu(src, R8, W, H, con=econ, out=up)), round(4 + iw * ih * 4 / px, 2),
+                                        what="vqhip_fsr_easu RGBA8 -> RGBA8; VALU-bound: ~700 VALU per output pixel (profiles/r3i_conv_kernels.md addendum)")
+    res["fsr_rcas_4k"] = entry(_stage_ms(lambda: ctx.fsr_rcas(up, R8, con=rcon, out=fin)), 8, what="vqhip_fsr_rcas RGBA8 -> RGBA8; VALU-bound: ~300 VALU per pixel")
+    sc, depth, packed, _ = synth.ssr_surfaces(W, BAND)
+    scd, dpd, nmd = dev(tile(sc.astype(np.float16))), dev(tile(depth)), dev(tile(packed.view(np.int32)))
+    cb = synth.ssr_constants(W, H, spec_mips)
+    rad = capi.empty_image(H, W, F16, ctx.device)
+    res["ssr_env_fallback_4k"] = entry(_stage_ms(lambda: ctx.ssr_environment_fallback(scd, F16, dpd, nmd, abi.FMT_R10G10B10A2_UNORM, cb, env, F16, out=rad)), 24,
+                                       what="vqhip_ssr_environment_fallback on white-noise surfaces (72 % of the pixels take the fallback): 8 + 4 + 4 B in, 8 B out; "
+                                            "fractional-LOD seamless cube fetch + LUT per pixel, cache resident")
     return res
 
 

@@ -317,7 +317,24 @@ VQHIP_API int  vqhip_abi_version(void);                          /* == VQHIP_ABI
  *                               values within ~3 binary32 ulps of the product elsewhere (the contract of rounds v1-v3). */
 typedef enum vqhip_fresnel_pow { VQHIP_FRESNEL_POW_PRODUCT = 0, VQHIP_FRESNEL_POW_EXP2_LOG2 = 1 } vqhip_fresnel_pow;
 VQHIP_API int  vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode);
-#define VQHIP_ABI_VERSION 1
+/* The READING of the HLSL intrinsics whose lowering the source does not fix — dot, normalize, length, reflect — in every later
+ * vqhip_forward_lighting / vqhip_gbuffer_from_materials / vqhip_forward_lighting_from_materials / vqhip_ssr_environment_fallback through this context
+ * (the reference's own HLSL is built in both readings: oracle/ref_src/hlsl_shim.h):
+ *   VQHIP_ARITH_LITERAL (default) products and sums rounded one by one, left to right; normalize(v) = v / length(v), one IEEE quotient per component;
+ *   VQHIP_ARITH_DXC     what DXC's HLOperationLower emits (Source/Renderer/Pipeline/ShaderCompileUtils.cpp:53-56 selects no flag that changes it): DXIL Dot3 as
+ *                       the FMA chain fma(az,bz, fma(ay,by, ax*bx)), normalize(v) = v * Rsqrt(dot(v,v)) with a correctly rounded rsqrt, length = sqrt of that dot.
+ * Together with VQHIP_FRESNEL_POW_EXP2_LOG2 this is the second build of the reference's sources (tests/golden/ref_outputs_dxc.npz): each mode is within one
+ * RGBA16F ulp of ITS reading; the two readings lie up to 15 ulps apart on highlight pixels. A maintainer who calibrates against D3D12 WARP
+ * (docs/WARP_CALIBRATION.md) selects whichever WARP turns out to follow. */
+/* Tuning / A-B options of a context, read by the launchers at call time (never from the process environment: getenv racing a host setenv is
+ * undefined behaviour, and VQEngine records on many threads, SceneRendering.cpp:563-706). value NULL, "" or "default" restores the default. Every
+ * form selected here gives the bits of the default form (tests/test_gpu_conv_forms.py, tests/test_gpu_round3.py); unknown keys / values: VQHIP_ERR_INVALID_ARG.
+ *   shade_wg 64|128|256 · psmain_waves 4|5|6 · post_one_kernel 1|1c · post_segments n · blur_x_wgs n · blur_y_wgs n · tonemap_form lut64|compact ·
+ *   blur_y_form c8|c8s|c12|c16|...|lut64 · lut_form general|persample · diffuse_form records|texels|general · diffuse_seq_form ordered|lane · specular_form permip */
+VQHIP_API int  vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value);
+typedef enum vqhip_arithmetic { VQHIP_ARITH_LITERAL = 0, VQHIP_ARITH_DXC = 1 } vqhip_arithmetic;
+VQHIP_API int  vqhip_set_arithmetic(vqhip_ctx* ctx, vqhip_arithmetic mode);
+#define VQHIP_ABI_VERSION 2   /* 2 (round 4): + vqhip_set_arithmetic, vqhip_set_option, vqhip_ssr_environment_fallback, VQHIP_FMT_R10G10B10A2_UNORM; conv order default SEQUENTIAL */
 
 /* Replaces VQRenderer::RenderSceneColor's lit draw loop (SceneRendering.cpp:1619-1785, hot part :1730-1784)
  * == ForwardLighting.hlsl:PSMain :289-380 evaluated for every pixel of the G-buffer.

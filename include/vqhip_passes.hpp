@@ -283,4 +283,47 @@ private:
     void* mChain = nullptr; void* mDiff = nullptr; void* mDiffBlurred = nullptr; void* mBlurTemp = nullptr; void* mSpec = nullptr; void* mLUT = nullptr;
 };
 
+// ---------------------------------------------------------------------------------------------------------------
+// SSR environment fallback == the part of ScreenSpaceReflectionsPass::RecordCommands' "FFX DNSR ClassifyTiles" dispatch
+// (ScreenSpaceReflections.cpp:262-276) that consumes the specular cube + BRDF LUT: pixels too rough for a traced ray get
+// SampleEnvironmentMap (ClassifyReflectionTiles.hlsl:78-94,146-153). FResourceParameters / FDrawParameters keep the fields of
+// ScreenSpaceReflections.h:33-75 this part reads (textures as device pointers, SRVs as the vqhip_envmap). Owns TexRadiance
+// (RGBA16F, :129) and TexExtractedRoughness (R8_UNORM, :135); the radiance is what vqhip_apply_reflections adds to the scene colour
+// when no ray was traced (the traced rays, the denoiser: FidelityFX SSSR, out of scope).
+// ---------------------------------------------------------------------------------------------------------------
+class HipSSREnvironmentFallbackPass : public RenderPassBase {
+public:
+    struct FResourceParameters : public IRenderPassResourceCollection {};
+    struct FDrawParameters : public IRenderPassDrawParameters {
+        void* Stream = nullptr;
+        VQ_SSSRConstants ffxCBuffer = {};                        // == FDrawParameters::ffxCBuffer, filled as RenderReflections does (SceneRendering.cpp:2221-2242)
+        const void* TexSceneColorRoughness = nullptr;            // RGBA16F scene colour, alpha = roughness (HipForwardLightingPass::GetSceneColor())
+        const float* TexDepthHierarchy = nullptr;                // mip 0 of Tex_DownsampledSceneDepth, R32F
+        const void* TexNormals = nullptr;                        // Tex_SceneNormals, R10G10B10A2_UNORM
+        const vqhip_envmap* SRVEnvironmentSpecularIrradianceCubemap_BRDFIntegrationLUT = nullptr;   // the two SRVs of :268-269 (HipEnvMapPrefilterPass::GetEnvironmentMap())
+    };
+    explicit HipSSREnvironmentFallbackPass(vqhip_ctx* Ctx) : RenderPassBase(Ctx) {}
+    ~HipSSREnvironmentFallbackPass() override { OnDestroyWindowSizeDependentResources(); }
+    bool Initialize() override { return mCtx != nullptr; }
+    void Destroy() override { OnDestroyWindowSizeDependentResources(); }
+    void OnCreateWindowSizeDependentResources(unsigned Width, unsigned Height, const IRenderPassResourceCollection* = nullptr) override {
+        OnDestroyWindowSizeDependentResources();
+        mWidth = Width; mHeight = Height;
+        mRadiance = Alloc((size_t)Width * Height * 8); mExtractedRoughness = Alloc((size_t)Width * Height);
+    }
+    void OnDestroyWindowSizeDependentResources() override { Free(mRadiance); Free(mExtractedRoughness); mWidth = mHeight = 0; }
+    void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) override {
+        const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
+        if (!p || !mRadiance) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
+        mStatus = vqhip_ssr_environment_fallback(mCtx, p->Stream, p->TexSceneColorRoughness, VQHIP_FMT_RGBA16F, 0, p->TexDepthHierarchy, 0,
+                                                 p->TexNormals, VQHIP_FMT_R10G10B10A2_UNORM, 0, (int)mWidth, (int)mHeight, &p->ffxCBuffer,
+                                                 p->SRVEnvironmentSpecularIrradianceCubemap_BRDFIntegrationLUT, mRadiance, VQHIP_FMT_RGBA16F, 0, (uint8_t*)mExtractedRoughness);
+    }
+    void* GetRadiance() const { return mRadiance; }                      // RGBA16F
+    void* GetExtractedRoughness() const { return mExtractedRoughness; }  // R8_UNORM
+private:
+    void* mRadiance = nullptr; void* mExtractedRoughness = nullptr;
+    unsigned mWidth = 0, mHeight = 0;
+};
+
 } // namespace vqhip

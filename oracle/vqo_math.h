@@ -77,13 +77,21 @@ static inline f3 neg(f3 a) { return { -a.x, -a.y, -a.z }; }
 static inline float dot(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 static inline float dot4(f4 a, f4 b) { return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x))); }
 static inline f3 normalize(f3 v) { return mul(v, rsqrt(dot(v, v))); }
-// The HLSL AS WRITTEN, for the ill-conditioned chain of the lighting functions (contract v5): dot = x*x' + y*y' + z*z'
-// left to right with every product and sum rounded on its own, normalize(v) = v / length(v) with one IEEE division per component.
-static inline float dot_lit(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
-static inline float dot4_lit(f4 a, f4 b) { return ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
+// The HLSL AS WRITTEN, for the ill-conditioned chain of the lighting functions (contract v5) — in one of the TWO READINGS the HLSL
+// leaves open (vqo_set_arithmetic / vqhip_set_arithmetic; oracle/ref_src/hlsl_shim.h builds the reference's sources in both):
+//   literal (default): dot = x*x' + y*y' + z*z' left to right with every product and sum rounded on its own, normalize(v) = v / length(v)
+//                      with one IEEE division per component;
+//   dxc              : what DXC's HLOperationLower emits — DXIL Dot3 as the FMA chain fma(az,bz, fma(ay,by, ax*bx)), normalize(v) =
+//                      v * Rsqrt(dot(v,v)) with a CORRECTLY ROUNDED rsqrt, length = sqrt of that dot, reflect through that dot. lerp, mul(v, M)
+//                      and the quotients stay as written in both. The DXC reading's pow = exp2(y * log2 x) is the separate switch vqo_set_fresnel_pow.
+inline int g_arith_dxc = 0;
+static inline float rsqrt_cr(float x) { return (float)(1.0 / __builtin_sqrt((double)x)); }   // RN(x^-1/2): the double result is far inside half a binary32 ulp of the true value except for a
+                                                                                              // vanishing set of inputs, none of which exists (tests/test_oracle_math.py checks all 2^24 x 2 significands exactly)
+static inline float dot_lit(f3 a, f3 b) { return g_arith_dxc ? dot(a, b) : (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float dot4_lit(f4 a, f4 b) { return g_arith_dxc ? dot4(a, b) : ((a.x * b.x + a.y * b.y) + a.z * b.z) + a.w * b.w; }
 static inline f3 div_lit(f3 v, float l) { return { fdiv_(v.x, l), fdiv_(v.y, l), fdiv_(v.z, l) }; }
 static inline float length_lit(f3 v) { return sqrt_(dot_lit(v, v)); }
-static inline f3 normalize_lit(f3 v) { return div_lit(v, length_lit(v)); }
+static inline f3 normalize_lit(f3 v) { return g_arith_dxc ? mul(v, rsqrt_cr(dot(v, v))) : div_lit(v, length_lit(v)); }
 static inline float lerp_lit(float a, float b, float t) { return a + t * (b - a); }
 static inline f3 reflect_lit(f3 i, f3 n) { const float t = 2.0f * dot_lit(n, i); return { i.x - t * n.x, i.y - t * n.y, i.z - t * n.z }; }
 static inline float length(f3 v) { return sqrt_(dot(v, v)); }

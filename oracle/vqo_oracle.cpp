@@ -294,7 +294,7 @@ inline f3 CalculatePointLightIllumination(const VQ_PointLight& l, const Surface&
     const f3 Lw = to3(l.position);
     const f3 d = sub(Lw, P);
     const float D = length_lit(d);                           // as written (contract v5): D decides the range cull, Wi feeds the GGX denominator
-    const f3 Wi = div_lit(d, D);                             // normalize(Lw - P) = (Lw - P) / length(Lw - P), one IEEE quotient per component
+    const f3 Wi = g_arith_dxc ? normalize_lit(d) : div_lit(d, D);   // normalize(Lw - P): literal (Lw - P) / length(Lw - P), one IEEE quotient per component (shares D); dxc: its own rsqrt
     const float rD = rcp(D);
     const float NdotL = saturate(dot(s.N, Wi));
     const float w = (rD * rD) * NdotL;                       // AttenuationBRDF: 1/(D*D) as (1/D)*(1/D) (contract v3, insensitive)
@@ -305,7 +305,7 @@ inline f3 CalculatePointLightIllumination(const VQ_PointLight& l, const Surface&
 inline f3 CalculateSpotLightIllumination(const VQ_SpotLight& l, const Surface& s, f3 P, f3 V, f3 acc = { 0, 0, 0 }) {
     const f3 d = sub(to3(l.position), P);
     const float D = length_lit(d);
-    const f3 Wi = div_lit(d, D);
+    const f3 Wi = g_arith_dxc ? normalize_lit(d) : div_lit(d, D);
     const float rD = rcp(D);
     const float cone = SpotlightIntensity(l, P);
     const float NdotL = saturate(dot(s.N, Wi));
@@ -883,6 +883,27 @@ int vqo_skydome(const float* equirect0, int w0, int h0, const VQ_SkydomeParams* 
 }
 
 void vqo_set_fresnel_pow(int expLog) { g_pow5ExpLog = expLog ? 1 : 0; }
+// 0 = literal reading of dot / normalize / length / reflect (default), 1 = the DXC reading (vqo_math.h)
+void vqo_set_arithmetic(int dxc) { g_arith_dxc = dxc ? 1 : 0; }
+int vqo_get_arithmetic(void) { return g_arith_dxc; }
+// normalize() of n 3-vectors in the current reading (tests: Surface.N = normalize(In.WorldSpaceNormal) at the G-buffer boundary, ForwardLighting.hlsl:264)
+void vqo_normalize_lit_array(const float* v, float* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) { const f3 r = normalize_lit({ v[3 * i], v[3 * i + 1], v[3 * i + 2] }); out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z; }
+}
+// rsqrt_cr's definition (float)(1.0 / sqrt((double)x)) against the same quotient in x87 extended precision (64-bit significand: its rounding to binary32
+// is the correct rounding unless the true value lies within 2^-63 of a rounding boundary) for EVERY significand and both exponent parities — rsqrt of
+// 4^k x is 2^-k rsqrt(x) exactly, so two binades cover all normal inputs. Returns the number of disagreements (expected 0).
+long vqo_rsqrt_cr_check(void) {
+    long bad = 0;
+    #pragma omp parallel for reduction(+ : bad) schedule(static)
+    for (long i = 0; i < (1L << 24); ++i) {
+        const float x = u2f(0x3f800000u + (uint32_t)i);                         // [1, 4): two binades
+        const float want = (float)(1.0L / sqrtl((long double)x));
+        if (f2u(rsqrt_cr(x)) != f2u(want)) ++bad;
+    }
+    return bad;
+}
+void vqo_rsqrt_cr_array(const float* x, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = rsqrt_cr(x[i]); }
 
 // Unlit.hlsl:PSMain :58-61 (light gizmo meshes, SceneRendering.cpp:1787-1819) over the engine's coverage plane: ip2.w == -(2+k) -> colors[k]
 int vqo_unlit_composite(const float* coverage_ip2, int cov_pitch, const float* colors, int numColors, void* color, int W, int H, int pitch, int fmt) {

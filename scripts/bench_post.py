@@ -67,13 +67,13 @@ def main():
         return f
     for name, fn, bpp in (("split", split, 44), ("fused-y", fused_y, 28), ("one", one_mode("1"), 12), ("one-compact-table", one_mode("1c"), 12)):
         if hasattr(fn, "mode"):
-            os.environ["VQHIP_POST_ONE_KERNEL"] = fn.mode
+            ctx.set_option_env("VQHIP_POST_ONE_KERNEL", fn.mode)
         ms = timed(fn)
         fn(); torch.cuda.synchronize()
         if ref is None:
             ref = sdr.clone()
         same = bool(torch.equal(ref, sdr))
-        os.environ.pop("VQHIP_POST_ONE_KERNEL", None)
+        ctx.set_option_env("VQHIP_POST_ONE_KERNEL", None)
         print(json.dumps({"variant": name, "size": [W, H], "us": round(ms * 1e3, 2), "algorithmic_B_per_px": bpp, "GBps_algorithmic": round(px * bpp / ms / 1e6, 1),
                           "frac_of_8TBps": round(px * bpp / ms / 1e6 / 8000, 4), "GBps_of_the_28B_chain": round(px * 28 / ms / 1e6, 1),
                           "identical_to_split": same}), flush=True)

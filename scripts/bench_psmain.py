@@ -57,7 +57,7 @@ def main():
             return a.elapsed_time(b) / n
         run(two, 150)
         for waves in os.environ.get("VQ_PSMAIN_WAVES_SWEEP", "4").split(","):
-            os.environ["VQHIP_PSMAIN_WAVES"] = waves
+            ctx.set_option_env("VQHIP_PSMAIN_WAVES", waves)
             t2, tf = [], []
             for _ in range(5):
                 t2.append(round(run(two, 60), 4)); tf.append(round(run(fused, 60), 4))

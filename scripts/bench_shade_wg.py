@@ -16,7 +16,7 @@ for name in ("cfg2", "cfg3n", "cfg3"):
     pf, extra = synth.per_frame(points=synth.point_lights(L, seed=cfg["light_seed"]), hdri_offset=0.3 if env is not None else 0.0)
     run = lambda: ctx.forward_lighting(gb, pf, pv, out=out, out_fmt=abi.FMT_RGBA16F, extra_point=extra, env=env)
     for wg in ("256", "128", "64", "256", "128", "64", "256", "64"):
-        os.environ["VQHIP_SHADE_WG"] = wg
+        ctx.set_option_env("VQHIP_SHADE_WG", wg)
         for _ in range(400): run()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()

@@ -43,7 +43,7 @@ def main():
     print(json.dumps({"what": "blur X", "us": round(ms * 1e3, 2), "frac_of_8TBps": round(px * 16 / ms / 1e6 / 8000, 4)}), flush=True)
     ref = None
     for form in FORMS:
-        os.environ["VQHIP_BLUR_Y_FORM"] = form
+        ctx.set_option_env("VQHIP_BLUR_Y_FORM", form)
         ms = timed(lambda: ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=sdr))
         torch.cuda.synchronize()
         if ref is None:
@@ -74,7 +74,7 @@ def main():
             ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=out[b])
         for rep in range(2):
             for form in frame_forms:
-                os.environ["VQHIP_BLUR_Y_FORM"] = form
+                ctx.set_option_env("VQHIP_BLUR_Y_FORM", form)
                 ms = timed(frame, reps=200, spin=300)
                 print(json.dumps({"what": "cfg3 frame loop", "form": form, "rep": rep, "ms": round(ms, 4), "Mpix_s": round(px / ms / 1e3, 1)}), flush=True)
     ctx.close()

@@ -27,3 +27,16 @@ def ctx():
     c = capi.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture
+def set_opt(ctx):
+    """set_opt(key, value): vqhip_set_option on the session's context for the duration of ONE test (the defaults come back afterwards)"""
+    used = []
+
+    def f(key, value):
+        ctx.set_option(key, value)
+        used.append(key)
+    yield f
+    for k in used:
+        ctx.set_option(k, None)

@@ -85,6 +85,33 @@ int main(int argc, char** argv) {
         if (hipStreamSynchronize(stream) != hipSuccess) return 3;
         writeDev(dir + "/scene_ip_rgba16f.bin", lighting.GetSceneColor(), (size_t)W * H * 8);
     }
+    // --- §8f.4: SSR's environment fallback on the frame just lit (ssr_cb.bin present): scene colour (alpha = roughness) + depth + normals -> radiance
+    if (FILE* probe = fopen((dir + "/ssr_cb.bin").c_str(), "rb")) {
+        fclose(probe);
+        std::vector<char> cb = readFile(dir + "/ssr_cb.bin");
+        if (cb.size() != sizeof(VQ_SSSRConstants)) { fprintf(stderr, "ssr_cb.bin size\n"); return 2; }
+        ld.pInterpolants = nullptr;
+        lighting.RecordCommands(&ld);                            // the G-buffer frame again: its alpha is the roughness the pass reads
+        CHECK(lighting);
+        vqhip::HipSSREnvironmentFallbackPass ssr(ctx);
+        ssr.Initialize();
+        ssr.OnCreateWindowSizeDependentResources(W, H);
+        vqhip::HipSSREnvironmentFallbackPass::FDrawParameters sd;
+        sd.Stream = stream;
+        sd.ffxCBuffer = *(const VQ_SSSRConstants*)cb.data();
+        sd.TexSceneColorRoughness = lighting.GetSceneColor();
+        sd.TexDepthHierarchy = (const float*)upload(readFile(dir + "/ssr_depth.bin"));
+        sd.TexNormals = upload(readFile(dir + "/ssr_normals.bin"));
+        sd.SRVEnvironmentSpecularIrradianceCubemap_BRDFIntegrationLUT = &env;
+        ssr.RecordCommands(&sd);
+        CHECK(ssr);
+        if (hipStreamSynchronize(stream) != hipSuccess) return 3;
+        writeDev(dir + "/ssr_radiance_rgba16f.bin", ssr.GetRadiance(), (size_t)W * H * 8);
+        writeDev(dir + "/ssr_roughness_r8.bin", ssr.GetExtractedRoughness(), (size_t)W * H);
+        ssr.RecordCommands(nullptr);
+        if (ssr.LastStatus() != VQHIP_ERR_INVALID_ARG) return 5;
+        ssr.Destroy();
+    }
     // --- row-tiled mode of the post pass through the real RCCL: a world of one rank (the box has one GPU). No halos, the composite of the
     // single tile is the tile: the frame must equal the SDR image written above.
     if (argc > 6 && std::string(argv[6]) == "rccl") {

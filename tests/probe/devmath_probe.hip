@@ -19,6 +19,7 @@ __global__ void k_probe(int fn, const float* a, const float* b, float* out, size
         case 13: r = (float)unorm8(x); break;
         case 14: r = max_(x, y); break; case 15: r = min_(x, y); break; case 16: r = saturate(x); break;
         case 17: r = (float)f2i_floor(x); break; case 18: r = (float)f2i_trunc(x); break;
+        case 19: r = rsqrt_cr(x); break;
     }
     out[i] = r;
 }
@@ -28,7 +29,7 @@ extern "C" __attribute__((visibility("default"))) int vqprobe_math(int fn, const
 }
 
 // which: 0 rcp() vs 1.0f/x | 1 sqrt_() vs IEEE sqrtf | 2 saturate() vs the select form | 3/4 the unchecked fast paths
-// inside their validated domains (rcp_newton: normal result; sqrt_newton: x in [2^-100, FLT_MAX])
+// inside their validated domains (rcp_newton: normal result; sqrt_newton: x in [2^-100, FLT_MAX]) | 5 rsqrt_cr() vs (float)(1.0 / sqrt((double)x)) | 6 rsqrt_cr_fast in [2^-100, 2^100]
 __global__ void k_exhaust(int which, uint32_t base, unsigned long long* bad, uint32_t* first) {
     const uint32_t u = base + blockIdx.x * blockDim.x + threadIdx.x;
     const float x = __uint_as_float(u);
@@ -39,6 +40,8 @@ __global__ void k_exhaust(int which, uint32_t base, unsigned long long* bad, uin
         case 1:  ref = __builtin_sqrtf(x); got = sqrt_(x); break;
         case 2:  ref = (x > 0.0f) ? ((x < 1.0f) ? x : 1.0f) : 0.0f; got = saturate(x); break;
         case 3:  ref = 1.0f / x; got = rcp_newton(x); inDomain = is_normal(got); break;
+        case 5:  ref = (float)(1.0 / __builtin_sqrt((double)x)); got = rsqrt_cr(x); break;                       // the DXC reading's Rsqrt: definition vs product, all inputs
+        case 6:  ref = (float)(1.0 / __builtin_sqrt((double)x)); got = rsqrt_cr_fast(x); inDomain = rsqrt_cr_fast_ok(x); break;   // the unchecked fast sequence inside its domain
         default: ref = __builtin_sqrtf(x); got = sqrt_newton(x); inDomain = sqrt_fast_ok(x); break;
     }
     if (inDomain && __float_as_uint(ref) != __float_as_uint(got) && !(ref != ref && got != got)) { if (atomicAdd(bad, 1ull) == 0) *first = u; }

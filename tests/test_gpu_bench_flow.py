@@ -60,7 +60,7 @@ def test_every_run_also_times_cfg5_strong_scaling():
     assert abs(c["value"] - 7680 * 4320 / (c["ms_per_step"] * 1e-3) / 1e6) < 0.01 * c["value"]
     assert c["shade_ms"] < c["ms_per_step"] and c["composite_overlapped"] is True
     _check_rccl(d, 3, "one-comm")
-    for k in ("cfg2", "ibl_load", "coherent_scene", "tile_curve"):      # single-GPU objects
+    for k in ("cfg2", "ibl_load", "coherent_scene", "tile_curve", "widened"):      # single-GPU objects
         assert k not in d
 
 
@@ -89,7 +89,7 @@ def test_single_gpu_line_carries_the_contract_fields():
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline", "stages", "engine_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants", "rccl",
-              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained"):
+              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained", "widened"):
         assert k in d, k
     su = d["sustained"]                                      # ~0.5 s of the headline's step here (VQ_BENCH_SUSTAINED_S), same order as `value`
     assert su["steps"] >= 200 and su["steps"] % 2 == 0 and 0.5 * d["value"] < su["value"] < 1.5 * d["value"]
@@ -114,6 +114,10 @@ def test_single_gpu_line_carries_the_contract_fields():
     ib = d["ibl_load"]
     for k in ("mip_chain_ms", "prefilter_ms", "brdf_lut_ms", "conv_diffuse_ms", "conv_specular_ms", "brdf_lut_warm_ms", "total_ms", "warm_total_ms", "mip_chain_warm_ms", "prefilter_warm_ms", "conv_diffuse_valu_frac_model"):
         assert ib[k] > 0, k
+    wd = d["widened"]                                        # the SURVEY 8f kernels at 4K
+    for k in ("gbuffer_producer_textured", "gbuffer_producer_textureless", "psmain_fused", "skydome_all_sky", "fsr_easu_1440p_to_4k", "fsr_rcas_4k", "ssr_env_fallback_4k"):
+        assert 0 < wd[k]["ms"] < 5 and wd[k]["bytes_per_px"] > 0 and 0 < wd[k]["hbm_frac"] < 1, (k, wd[k])
+    assert 0 < wd["hdr_decode_2048"]["ms"] < 500 and wd["psmain_fused"]["ms"] > d["stages"]["shade_ms"] * 0.8
     co = d["coherent_scene"]
     assert 0 < co["shade_ms"] < 5 and 0.05 < co["slow_path_pixel_fraction_round2"] < 0.3
     tc = d["tile_curve"]["tiles"]

@@ -23,17 +23,17 @@ def _same(a, b, what):
 
 
 @pytest.mark.parametrize("size,samples,fmt", [(1024, 2048, abi.FMT_RG16F), (96, 700, abi.FMT_RG32F), (33, 100, abi.FMT_RG32F)])
-def test_brdf_lut_forms_identical(ctx, monkeypatch, size, samples, fmt):
+def test_brdf_lut_forms_identical(ctx, set_opt, size, samples, fmt):
     """Shared-H table + unchecked sample body == the same kernel with every range test == the per-sample kernel of rounds 1-2."""
     fast = ctx.brdf_lut(size, samples, fmt)
     for form in ("general", "persample"):
-        monkeypatch.setenv("VQHIP_LUT_FORM", form)
+        set_opt("lut_form", form)
         _same(ctx.brdf_lut(size, samples, fmt), fast, f"BRDF LUT {size}^2 x {samples} fast vs {form}")
-    monkeypatch.delenv("VQHIP_LUT_FORM")
+    set_opt("lut_form", None)
     ctx.set_fresnel_pow(True)
     try:
         fast = ctx.brdf_lut(size, samples, fmt)
-        monkeypatch.setenv("VQHIP_LUT_FORM", "persample")
+        set_opt("lut_form", "persample")
         _same(ctx.brdf_lut(size, samples, fmt), fast, f"BRDF LUT {size}^2 x {samples} exp2/log2 Fresnel, fast vs persample")
     finally:
         ctx.set_fresnel_pow(False)
@@ -52,7 +52,7 @@ def _chain(w, h, seed=0xE9):
 
 
 @pytest.mark.parametrize("order", [abi.CONV_WAVE64, abi.CONV_SEQUENTIAL])
-def test_conv_diffuse_forms_identical_cfg4(ctx, monkeypatch, order):
+def test_conv_diffuse_forms_identical_cfg4(ctx, set_opt, order):
     """2048^2 equirect -> 6 x 64^2 at step 0.010 (99 382 taps per texel): whole cube, the default (branch-free tap on footprint records) vs the other
     two forms. The sequential order runs
     one lane per texel for ~0.1 s: a coarser step keeps it short."""
@@ -60,7 +60,7 @@ def test_conv_diffuse_forms_identical_cfg4(ctx, monkeypatch, order):
     step = 0.010 if order == abi.CONV_WAVE64 else 0.05
     fast = ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, step, order, abi.FMT_RGBA32F)
     for form in ("general", "texels"):                      # every tap with its branches / the branch-free tap gathering from the level itself
-        monkeypatch.setenv("VQHIP_DIFFUSE_FORM", form)
+        set_opt("diffuse_form", form)
         _same(ctx.conv_diffuse(chain_g, 2048, 2048, n, 64, step, order, abi.FMT_RGBA32F), fast, f"cfg4 diffuse records vs {form}, order {order}")
 
 
@@ -98,12 +98,12 @@ def test_conv_diffuse_nonfinite_texels(ctx):
 
 
 @pytest.mark.parametrize("w,h,res0,fmt", [(2048, 2048, 128, abi.FMT_RGBA16F), (128, 64, 32, abi.FMT_RGBA32F), (64, 32, 4, abi.FMT_RGBA32F), (100, 50, 8, abi.FMT_RGBA16F)])
-def test_conv_specular_forms_identical(ctx, monkeypatch, w, h, res0, fmt):
+def test_conv_specular_forms_identical(ctx, set_opt, w, h, res0, fmt):
     """Every mip in one launch with the per-block table of tangent-space half vectors == one launch per mip with ImportanceSampleGGX evaluated
     per lane and sample (the round-1/2 kernel); the small cases also against the CPU oracle."""
     _, chain_o, chain_g, n = _chain(w, h, seed=0x54)
     one, mips = ctx.conv_specular(chain_g, w, h, n, res0, abi.CONV_WAVE64, fmt)
-    monkeypatch.setenv("VQHIP_SPECULAR_FORM", "permip")
+    set_opt("specular_form", "permip")
     per, mips2 = ctx.conv_specular(chain_g, w, h, n, res0, abi.CONV_WAVE64, fmt)
     assert mips == mips2
     _same(per, one, f"specular {res0}^2 from {w}x{h}: one launch vs per mip")

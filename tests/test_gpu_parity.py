@@ -360,12 +360,12 @@ def test_forward_cfg3_full_frame_with_ibl(ctx):
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2160, 3840), (97, 301), (64, 64), (33, 1000), (540, 257), (1440, 2560), (32, 64), (31, 700)])
 @pytest.mark.parametrize("one_kernel", ["0", "1", "1c"])
-def test_post_process_one_call_equals_three_dispatches(ctx, shape, one_kernel, monkeypatch):
+def test_post_process_one_call_equals_three_dispatches(ctx, shape, one_kernel, set_opt):
     """vqhip_post_process against the oracle's three passes, bit for bit, in both of its forms: the default (blur X into the context's scratch,
-    then blur Y + tonemap) and the experimental single kernel (VQHIP_POST_ONE_KERNEL=1 / 1c, k_post_chain2: X blur -> LDS ring -> Y blur -> tonemap
+    then blur Y + tonemap) and the experimental single kernel (option post_one_kernel = 1 / 1c, k_post_chain2: X blur -> LDS ring -> Y blur -> tonemap
     table, full or compact): 4K, sizes that are no multiple of the 128-column strips / 8-row steps / segment height, images smaller than the single kernel
     accepts, negative and NaN inputs (the half of the table that is not in LDS)."""
-    monkeypatch.setenv("VQHIP_POST_ONE_KERNEL", one_kernel)
+    set_opt("post_one_kernel", None if one_kernel == "0" else one_kernel)
     h, w = shape
     img = synth.hdr_image(w, h, seed=h * 7 + w).astype(np.float16)
     img[h // 3, w // 2, 0] = np.float16(-3.5)          # negative / NaN colours reach the half of the table that is not in LDS
@@ -406,9 +406,9 @@ def test_blur_y_halo_at_the_end_of_an_allocation(ctx, rows):
 @pytest.mark.parametrize("x_wgs", [None, "3", "2048"])             # the X pass's forms: one workgroup per segment (default) / persistent, pipelined
 @pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
 @pytest.mark.parametrize("shape", [(97, 301), (1, 5), (64, 64), (40, 1), (7, 2051)])
-def test_blur(ctx, fmt, shape, x_wgs, monkeypatch):
+def test_blur(ctx, fmt, shape, x_wgs, set_opt):
     if x_wgs is not None:
-        monkeypatch.setenv("VQHIP_BLUR_X_WGS", x_wgs)
+        set_opt("blur_x_wgs", x_wgs)
     h, w = shape
     img = synth.hdr_image(w, h).astype(O._NP[fmt][0])
     x_o = O.blur_pass(img, fmt, 0)

@@ -38,6 +38,12 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
         mats[i].data = d
         mats[i].data.textureConfig = 0.0
     (tmp_path / "materials.bin").write_bytes(bytes(mats))
+    # §8f.4 inputs: FFX_SSSRConstants + depth + packed normals (the roughness comes from the lit frame's alpha)
+    _, depth, packed, _ = synth.ssr_surfaces(W, H, seed=0xCAFE)
+    cb = synth.ssr_constants(W, H, pre["spec_mips"])
+    (tmp_path / "ssr_cb.bin").write_bytes(bytes(cb))
+    depth.tofile(tmp_path / "ssr_depth.bin")
+    packed.tofile(tmp_path / "ssr_normals.bin")
     r = subprocess.run([EXE, str(tmp_path), str(W), str(H), str(EW), str(EH), "rccl"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     diff = np.fromfile(tmp_path / "diffuse_blurred.bin", np.float16).reshape(6, 8, 8, 4)
@@ -50,6 +56,10 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
     got = np.fromfile(tmp_path / "scene_rgba16f.bin", np.float16).reshape(H, W, 4)
     n_bad, idx = O.bits_equal(got, scene)
     assert n_bad == 0, (n_bad, idx)
+    rad, r8 = O.ssr_environment_fallback(scene, abi.FMT_RGBA16F, depth, packed, abi.FMT_R10G10B10A2_UNORM, cb, env, abi.FMT_RGBA16F, extract_roughness=True)
+    n_bad, idx = O.bits_equal(np.fromfile(tmp_path / "ssr_radiance_rgba16f.bin", np.float16).reshape(H, W, 4), rad)
+    assert n_bad == 0, ("ssr radiance", n_bad, idx)
+    assert np.array_equal(np.fromfile(tmp_path / "ssr_roughness_r8.bin", np.uint8).reshape(H, W), r8)
     gb_ip = O.gbuffer_from_materials(ip, mats, pf.fAmbientLightingFactor, None)
     scene_ip = O.forward_lighting(gb_ip, pf, pv, abi.FMT_RGBA16F, env=env)
     got = np.fromfile(tmp_path / "scene_ip_rgba16f.bin", np.float16).reshape(H, W, 4)

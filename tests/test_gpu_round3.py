@@ -127,10 +127,10 @@ def test_forward_skip_keeps_signed_zero_and_nonfinite(ctx):
 # ---------------------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("form", Y_FORMS)
 @pytest.mark.parametrize("shape", [(300, 256), (1080, 1920), (97, 701), (70, 1000), (513, 130)])
-def test_blur_y_tonemap_forms(ctx, form, shape, monkeypatch):
-    """Every form of the fused Y blur + tonemap kernel (VQHIP_BLUR_Y_FORM) == oracle: whole images, odd widths (no 16-byte stores), heights
+def test_blur_y_tonemap_forms(ctx, form, shape, set_opt):
+    """Every form of the fused Y blur + tonemap kernel (option blur_y_form) == oracle: whole images, odd widths (no 16-byte stores), heights
     that are no multiple of the tile, and a row tile with halos."""
-    monkeypatch.setenv("VQHIP_BLUR_Y_FORM", form)
+    set_opt("blur_y_form", form)
     h, w = shape
     F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
     img = synth.hdr_image(w, h, scale=30.0)
@@ -152,11 +152,11 @@ def test_blur_y_tonemap_forms(ctx, form, shape, monkeypatch):
 
 
 @pytest.mark.parametrize("form", ["compact", "lut64"])
-def test_tonemap_compact_table(ctx, form, monkeypatch):
+def test_tonemap_compact_table(ctx, form, set_opt):
     """The compact (2 048-entry) tonemap table == the oracle for EVERY half bit pattern, every per-channel curve, through the standalone
     tonemapper (k_tonemap_c) and through the fused Y kernel (constant columns: the blur of a constant is the constant wherever the 21 mads
     reproduce it)."""
-    monkeypatch.setenv("VQHIP_TONEMAP_FORM", form)
+    set_opt("tonemap_form", form)
     allh = np.arange(65536, dtype=np.uint16).view(np.float16)
     rng = np.random.default_rng(9)
     img = np.empty((259, 257, 4), np.float16)                 # 66 563 px: no multiple of 4

@@ -67,6 +67,8 @@ def load_library():
         "vqhip_mip_chain_bytes_rgba8": (sz, [i32, i32, i32]),
         "vqhip_mip_chain_box_rgba8": (i32, [vp, vp, vp, i32, i32, i32]),
         "vqhip_set_fresnel_pow": (i32, [vp, i32]),
+        "vqhip_set_arithmetic": (i32, [vp, i32]),
+        "vqhip_set_option": (i32, [vp, C.c_char_p, C.c_char_p]),
         "vqhip_unlit_composite": (i32, [vp, vp, C.POINTER(abi.Interpolants), vp, i32, vp, i32, i32, i32, i32]),
         "vqhip_skydome": (i32, [vp, vp, vp, i32, i32, C.POINTER(abi.SkydomeParams), C.POINTER(abi.Interpolants), vp, i32, i32, i32, i32]),
         "vqhip_hdr_parse_header": (i32, [C.c_char_p, sz, C.POINTER(i32), C.POINTER(i32), C.POINTER(sz)]),
@@ -94,7 +96,7 @@ def load_library():
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype, fn.argtypes = res, args
-    if lib.vqhip_abi_version() != 1:
+    if lib.vqhip_abi_version() != abi.ABI_VERSION:
         raise RuntimeError("libvqhip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -106,7 +108,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_forward_lighting_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
-    "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f", "vqhip_hdr_downsize_rgba32f",
+    "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_set_arithmetic", "vqhip_set_option", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f", "vqhip_hdr_downsize_rgba32f",
     "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections", "vqhip_ssr_environment_fallback",
     "vqhip_rowtile", "vqhip_comm_unique_id", "vqhip_comm_create", "vqhip_comm_adopt", "vqhip_comm_destroy", "vqhip_comm_query", "vqhip_comm_abort", "vqhip_comm_loopback", "vqhip_exchange_blur_halos",
     "vqhip_composite_tiles",
@@ -545,6 +547,23 @@ class Context:
     def set_fresnel_pow(self, exp2_log2):
         """False (default): pow(1 - cos, 5) as the product x*((x*x)*(x*x)); True: exp2(5*log2 x), the engine's own DXC lowering."""
         self._ck(self.lib.vqhip_set_fresnel_pow(self._h, 1 if exp2_log2 else 0))
+
+    def set_arithmetic(self, dxc):
+        """False (default): the literal reading of dot / normalize / length / reflect; True: the DXC reading (FMA-chain dot, v * correctly rounded rsqrt)."""
+        self._ck(self.lib.vqhip_set_arithmetic(self._h, abi.ARITH_DXC if dxc else abi.ARITH_LITERAL))
+
+    def set_option(self, key, value):
+        """vqhip_set_option: a tuning / A-B option of this context (include/vqhip.h lists them); value None restores the default."""
+        self._ck(self.lib.vqhip_set_option(self._h, key.encode(), None if value is None else str(value).encode()))
+
+    # the environment variables of rounds 1-3 map onto options (scripts that sweep forms): VQHIP_LUT_FORM -> "lut_form", ...
+    ENV_OPTIONS = {"VQHIP_LUT_FORM": "lut_form", "VQHIP_DIFFUSE_FORM": "diffuse_form", "VQHIP_DIFFUSE_SEQ_FORM": "diffuse_seq_form", "VQHIP_SPECULAR_FORM": "specular_form",
+                   "VQHIP_BLUR_Y_FORM": "blur_y_form", "VQHIP_TONEMAP_FORM": "tonemap_form", "VQHIP_BLUR_X_WGS": "blur_x_wgs", "VQHIP_BLUR_Y_WGS": "blur_y_wgs",
+                   "VQHIP_POST_ONE_KERNEL": "post_one_kernel", "VQHIP_POST_SEGMENTS": "post_segments", "VQHIP_SHADE_WG": "shade_wg", "VQHIP_PSMAIN_WAVES": "psmain_waves"}
+
+    def set_option_env(self, env_name, value):
+        v = None if value in (None, "", "default", "0") and env_name != "VQHIP_BLUR_X_WGS" else value
+        self.set_option(self.ENV_OPTIONS[env_name], v)
 
     def unlit_composite(self, coverage_ip, colors, color, fmt, stream=None):
         """Light gizmo meshes (Unlit.hlsl:PSMain, SceneRendering.cpp:1787-1819): pixels whose ip2.w index is -(2+k) get colors[k]

@@ -32,6 +32,8 @@ struct vqhip_ctx {
     // kernel that reads them, and the next call's stream waits for it before it overwrites them (calls may come on different streams)
     void* rec = nullptr; size_t recBytes = 0; hipEvent_t recFree = nullptr; bool recUsed = false;
     int pow5ExpLog = 0;            // vqhip_set_fresnel_pow
+    int arithDxc = 0;              // vqhip_set_arithmetic
+    vqk::Options opt;              // vqhip_set_option
     // 65536-entry tonemap tables (post.hip:k_tonemap_lut), cached per (TonemapperParams, output format): the table is built once
     // per parameter set instead of once per frame. Streams that HIT a cached table only wait for the event of its build. A table is replaced
     // only when a fifth parameter set shows up: the least recently used one goes (a hit counts as a use), and because its readers may sit on
@@ -336,7 +338,8 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
     a.out = out;
     a.fc = (const FrameConstants*)(ctx->devRing + (size_t)slot * kConstSlotBytes);
     a.width = gb->width; a.height = gb->height; a.pitch = gb->row_pitch_px; a.outPitch = out_row_pitch_px;
-    hipError_t e = launch_forward_lighting(st, a, env != nullptr, casters, outFmt);
+    a.arithDxc = ctx->arithDxc;
+    hipError_t e = launch_forward_lighting(st, a, env != nullptr, casters, outFmt, ctx->opt);
     if (e != hipSuccess) return failHip(ctx, e, "forward_lighting launch");
     return releaseSlot(ctx, slot, st);
 }
@@ -349,7 +352,7 @@ int vqhip_gaussian_blur_x(vqhip_ctx* ctx, void* stream, const void* in, void* ou
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "gaussian_blur_x: fmt must be RGBA32F or RGBA16F");
     if (in == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "gaussian_blur_x: in-place blur is not supported");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = launch_blur_x((hipStream_t)stream, in, out, p->iImageSizeX, p->iImageSizeY, fmt);
+    hipError_t e = launch_blur_x((hipStream_t)stream, in, out, p->iImageSizeX, p->iImageSizeY, fmt, ctx->opt);
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "blur_x launch");
 }
 
@@ -381,7 +384,7 @@ int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const void* in, 
     int slot = -1;
     if (blur_y_tonemap_uses_lut(*tm, blurFmt, outFmt, (size_t)p->iImageSizeX * p->iImageSizeY)) { const int rc = acquireTonemapLut(ctx, (hipStream_t)stream, *tm, outFmt, &slot); if (rc) return rc; }
     hipError_t e = launch_blur_y_tonemap((hipStream_t)stream, in, out, halo_top, halo_bottom, halo_rows, p->iImageSizeX, p->iImageSizeY, *tm, blurFmt, outFmt,
-                                         slot >= 0 ? ctx->lut[slot].table : nullptr);
+                                         slot >= 0 ? ctx->lut[slot].table : nullptr, ctx->opt);
     if (e != hipSuccess) return failHip(ctx, e, "blur_y_tonemap launch");
     return slot >= 0 ? releaseTonemapLut(ctx, (hipStream_t)stream, slot) : VQHIP_OK;
 }
@@ -406,7 +409,7 @@ int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int w
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int slot = -1;
     if (tonemap_uses_lut(*p, inFmt, outFmt, (size_t)width * height)) { const int rc = acquireTonemapLut(ctx, (hipStream_t)stream, *p, outFmt, &slot); if (rc) return rc; }
-    hipError_t e = launch_tonemap((hipStream_t)stream, in, out, width, height, *p, inFmt, outFmt, slot >= 0 ? ctx->lut[slot].table : nullptr);
+    hipError_t e = launch_tonemap((hipStream_t)stream, in, out, width, height, *p, inFmt, outFmt, slot >= 0 ? ctx->lut[slot].table : nullptr, ctx->opt);
     if (e != hipSuccess) return failHip(ctx, e, "tonemap launch");
     return slot >= 0 ? releaseTonemapLut(ctx, (hipStream_t)stream, slot) : VQHIP_OK;
 }
@@ -422,13 +425,12 @@ int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, voi
     if (sceneColor == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "post_process: in-place is not supported");
     if (!enableGaussianBlur) return vqhip_tonemap(ctx, stream, sceneColor, out, width, height, tm, inFmt, outFmt);
     hipStream_t st = (hipStream_t)stream;
-    const char* one = std::getenv("VQHIP_POST_ONE_KERNEL");
-    if (one && one[0] == '1' && post_chain_fusable(*tm, inFmt, outFmt, width, height)) {   // single-kernel form (post.hip: k_post_chain2; "1c": compact tonemap table), measured slower, opt-in
+    if (ctx->opt.postOneKernel && post_chain_fusable(*tm, inFmt, outFmt, width, height)) {   // option "post_one_kernel": single-kernel form (post.hip: k_post_chain2; "1c": compact tonemap table), measured slower, opt-in
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         int slot = -1;
         const int rc = acquireTonemapLut(ctx, st, *tm, outFmt, &slot);
         if (rc) return rc;
-        const hipError_t e = launch_post_chain2(st, sceneColor, out, width, height, ctx->lut[slot].table, one[1] == 'c');
+        const hipError_t e = launch_post_chain2(st, sceneColor, out, width, height, ctx->lut[slot].table, ctx->opt.postOneKernel == 2, ctx->opt);
         if (e != hipSuccess) return failHip(ctx, e, "post chain launch");
         return releaseTonemapLut(ctx, st, slot);
     }
@@ -442,6 +444,52 @@ int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, voi
     return vqhip_gaussian_blur_y_tonemap(ctx, stream, ctx->scratch, out, nullptr, nullptr, 0, &bp, tm, inFmt, outFmt);
 }
 
+int vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "set_option: ctx is NULL");
+    CTX_GUARD(ctx, "set_option");
+    if (!key) return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_option: key is NULL");
+    const std::string k = key, v = (value && std::strcmp(value, "default")) ? value : "";
+    vqk::Options& o = ctx->opt;
+    auto num = [&](int* dst, std::initializer_list<int> allowed) -> int {       // "" -> 0 (default); otherwise a non-negative integer (from `allowed` when given)
+        if (v.empty()) { *dst = 0; return VQHIP_OK; }
+        char* end = nullptr;
+        const long n = std::strtol(v.c_str(), &end, 10);
+        bool ok = end && !*end && n >= 0 && n <= (1 << 24);
+        if (ok && allowed.size()) { ok = false; for (int a : allowed) ok |= a == (int)n; }
+        if (!ok) return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_option: bad value '" + v + "' for " + k);
+        *dst = (int)n; return VQHIP_OK;
+    };
+    auto pick = [&](int* dst, std::initializer_list<const char*> names) -> int {  // names[i] selects value i + 1
+        if (v.empty()) { *dst = 0; return VQHIP_OK; }
+        int i = 1;
+        for (const char* n : names) { if (v == n) { *dst = i; return VQHIP_OK; } ++i; }
+        return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_option: bad value '" + v + "' for " + k);
+    };
+    if (k == "shade_wg") return num(&o.shadeWg, { 0, 64, 128, 256 });
+    if (k == "psmain_waves") return num(&o.psmainWaves, { 0, 4, 5, 6 });
+    if (k == "post_one_kernel") return pick(&o.postOneKernel, { "1", "1c" });
+    if (k == "post_segments") return num(&o.postSegments, {});
+    if (k == "blur_x_wgs") return num(&o.blurXWgs, {});
+    if (k == "blur_y_wgs") return num(&o.blurYWgs, {});
+    if (k == "tonemap_form") { if (v == "lut64") { o.tonemapCompact = 0; return VQHIP_OK; } return pick(&o.tonemapCompact, { "compact" }); }
+    if (k == "blur_y_form") {
+        if (v.size() >= sizeof(o.blurYForm) || (!v.empty() && v != "lut64" && v[0] != 'c')) return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_option: bad value '" + v + "' for blur_y_form");
+        std::snprintf(o.blurYForm, sizeof(o.blurYForm), "%s", v.c_str());
+        return VQHIP_OK;
+    }
+    if (k == "lut_form") return pick(&o.lutForm, { "general", "persample" });
+    if (k == "diffuse_form") { if (v == "records") { o.diffuseForm = 0; return VQHIP_OK; } return pick(&o.diffuseForm, { "texels", "general" }); }
+    if (k == "diffuse_seq_form") { if (v == "ordered") { o.diffuseSeqForm = 0; return VQHIP_OK; } return pick(&o.diffuseSeqForm, { "lane" }); }
+    if (k == "specular_form") return pick(&o.specularForm, { "permip" });
+    return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_option: unknown key '" + k + "'");
+}
+int vqhip_set_arithmetic(vqhip_ctx* ctx, vqhip_arithmetic mode) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "set_arithmetic: ctx is NULL");
+    CTX_GUARD(ctx, "set_arithmetic");
+    if (mode != VQHIP_ARITH_LITERAL && mode != VQHIP_ARITH_DXC) return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_arithmetic: unknown mode");
+    ctx->arithDxc = mode == VQHIP_ARITH_DXC ? 1 : 0;
+    return VQHIP_OK;
+}
 int vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode) {
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "set_fresnel_pow: ctx is NULL");
     CTX_GUARD(ctx, "set_fresnel_pow");
@@ -457,7 +505,7 @@ int vqhip_brdf_lut(vqhip_ctx* ctx, void* stream, void* outRG, int size, int samp
     if (!outRG || size <= 0 || samples <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "brdf_lut: bad argument");
     if (fmt != VQHIP_FMT_RG16F && fmt != VQHIP_FMT_RG32F) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "brdf_lut: fmt must be RG16F or RG32F");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = launch_brdf_lut((hipStream_t)stream, outRG, size, samples, fmt, ctx->pow5ExpLog);
+    hipError_t e = launch_brdf_lut((hipStream_t)stream, outRG, size, samples, fmt, ctx->pow5ExpLog, ctx->opt);
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "brdf_lut launch");
 }
 
@@ -531,6 +579,7 @@ static size_t fillGbufConstants(vqhip_ctx* ctx, int slot, const vqhip_material* 
     std::memset(gc, 0, offsetof(GbufConstants, mats));
     gc->ambient = ambient;
     gc->numMaterials = numMaterials;
+    gc->arithDxc = ctx->arithDxc;
     if (ssao && ssao->texels) gc->ssao = *ssao;
     if (numMaterials > 0) std::memcpy(gc->mats, materials, (size_t)numMaterials * sizeof(vqhip_material));
     return offsetof(GbufConstants, mats) + (size_t)numMaterials * sizeof(vqhip_material);
@@ -595,7 +644,7 @@ int vqhip_forward_lighting_from_materials(vqhip_ctx* ctx, void* stream, const vq
     a.gc = (const GbufConstants*)(ctx->devRing + (size_t)slotG * kConstSlotBytes);
     a.width = in->width; a.height = in->height; a.pitch = in->row_pitch_px; a.outPitch = 0;
     hipError_t e = launch_forward_from_materials(st, a, (const FrameConstants*)(ctx->devRing + (size_t)slotF * kConstSlotBytes), env != nullptr, casters,
-                                                 out, out_row_pitch_px, outFmt);
+                                                 out, out_row_pitch_px, outFmt, ctx->arithDxc, ctx->opt);
     if (e != hipSuccess) return failHip(ctx, e, "forward_lighting_from_materials launch");
     if ((rc = releaseSlot(ctx, slotG, st)) != VQHIP_OK) return rc;
     return releaseSlot(ctx, slotF, st);
@@ -787,7 +836,7 @@ int vqhip_ssr_environment_fallback(vqhip_ctx* ctx, void* stream, const void* sce
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) a.rot[i][j] = cb->envMapRotation.m[i][j];
     a.invDimX = cb->inverseBufferDimensions[0]; a.invDimY = cb->inverseBufferDimensions[1];
     a.roughnessThreshold = cb->roughnessThreshold; a.mipCount = (float)mc;
-    a.pow5ExpLog = ctx->pow5ExpLog; a.env = *env;
+    a.pow5ExpLog = ctx->pow5ExpLog; a.arithDxc = ctx->arithDxc; a.env = *env;
     hipError_t e = launch_ssr_env_fallback((hipStream_t)stream, a, sceneFmt, normalFmt, outFmt);
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "ssr_environment_fallback launch");
 }
@@ -842,7 +891,7 @@ int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, 
         if (!ctx->recFree) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->recFree, hipEventDisableTiming));
     }
     hipError_t e = launch_conv_diffuse_tables(st, (const float4*)equirect_mips, w0, h0, nMips, diffuseRes, dtab, nPhi, dtab + nPhi, nTheta, order, outCube, fmt,
-                                              recNeed ? ctx->rec : nullptr);
+                                              recNeed ? ctx->rec : nullptr, ctx->opt);
     if (e != hipSuccess) return failHip(ctx, e, "conv_diffuse launch");
     if (recNeed) { HIP_TRY(ctx, hipEventRecord(ctx->recFree, st)); ctx->recUsed = true; }
     return releaseSlot(ctx, slot, st);
@@ -859,8 +908,7 @@ int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equirect_mips,
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_specular: fmt must be RGBA32F or RGBA16F");
     if (order != VQHIP_CONV_SEQUENTIAL && order != VQHIP_CONV_WAVE64) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_specular: bad order");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const char* form = std::getenv("VQHIP_SPECULAR_FORM");                   // "permip": one launch per mip (the round-1/2 form; also what SEQUENTIAL order runs)
-    if (!(form && !std::strcmp(form, "permip"))) {
+    if (ctx->opt.specularForm != 1) {                                        // option "specular_form" = "permip": one launch per mip (the round-1/2 form)
         hipError_t e = launch_conv_specular_all((hipStream_t)stream, (const float4*)equirect_mips, w0, h0, nMips, specRes0, MIPS, order, outCubeMips, fmt);
         return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "conv_specular launch");
     }

@@ -713,11 +713,10 @@ hipError_t launch_unlit_composite(hipStream_t s, const float4* cov, int covPitch
     return hipGetLastError();
 }
 
-hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt, int p5ExpLog) {
+hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt, int p5ExpLog, const Options& opt) {
     dim3 grid((size + 255) / 256, size);
-    const char* form = std::getenv("VQHIP_LUT_FORM");           // read per launch: tests switch the form inside one process
-    const int allowFast = !(form && !std::strcmp(form, "general"));      // "general": the shared-H kernel with every range test left in
-    if (form && !std::strcmp(form, "persample")) {
+    const int allowFast = opt.lutForm != 1;                     // option "lut_form" = "general": the shared-H kernel with every range test left in
+    if (opt.lutForm == 2) {                                     // "persample"
         if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut_persample<3>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
         else                        hipLaunchKernelGGL((k_brdf_lut_persample<4>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
         return hipGetLastError();
@@ -754,7 +753,7 @@ size_t conv_diffuse_record_bytes(int w0, int h0, int nMips) {
 }
 // recBuf: NULL, or a device buffer of conv_diffuse_record_bytes() bytes the launch may overwrite (the 2 x 2 footprints of the sampled level)
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
-                                      const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt, void* recBuf) {
+                                      const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt, void* recBuf, const Options& opt) {
     const long total = 6L * res * res;
     const size_t lds = (size_t)nTheta * 2 * sizeof(float);
     // the level SampleLevel(uv, 3) reads (sample_equirect_lod_t: lod clamped to the chain, fraction 0 -> one level) and whether the fast tap applies
@@ -766,10 +765,10 @@ hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0
     lv.tex = (const char*)(chain + offPx); lv.W = dim(w0, level); lv.H = dim(h0, level);
     lv.rowShift = 4; while ((1 << (lv.rowShift - 4)) < lv.W) ++lv.rowShift;
     lv.W256 = 256.0f * (float)lv.W; lv.H256 = 256.0f * (float)lv.H;
-    const char* form = std::getenv("VQHIP_DIFFUSE_FORM");       // "general": every tap with its range tests and branches (the round-1/2 kernel)
-    int fast = ((lv.W & (lv.W - 1)) | (lv.H & (lv.H - 1))) == 0 && (size_t)lv.W * lv.H * 16 < (1ull << 31) && !(form && !std::strcmp(form, "general")) ? 1 : 0;
+    // option "diffuse_form" = "general": every tap with its range tests and branches (the round-1/2 kernel)
+    int fast = ((lv.W & (lv.W - 1)) | (lv.H & (lv.H - 1))) == 0 && (size_t)lv.W * lv.H * 16 < (1ull << 31) && opt.diffuseForm != 2 ? 1 : 0;
     lv.rec = nullptr;
-    if (fast && recBuf && !(form && !std::strcmp(form, "texels"))) {      // "texels": four gathers from the level itself (the first fast form; A/B, tests)
+    if (fast && recBuf && opt.diffuseForm != 1) {               // "texels": four gathers from the level itself (the first fast form; A/B, tests)
         hipLaunchKernelGGL(k_diffuse_records, dim3((lv.W + 255) / 256, lv.H), dim3(256), 0, s, (const float4*)lv.tex, lv.W, lv.H, (float4*)recBuf);
         lv.rec = (const char*)recBuf; fast = 2;
     }
@@ -781,10 +780,9 @@ hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0
     }
     // SEQUENTIAL (the reference's order): wave-parallel evaluation + ordered per-texel additions (k_conv_diffuse_ordered) while the (sin, cos) tables
     // of both loops fit in LDS next to the tap buffers; the one-lane-per-texel kernel otherwise (steps below ~0.002) or when asked for (A/B, tests)
-    const char* seq = std::getenv("VQHIP_DIFFUSE_SEQ_FORM");     // "lane": one lane per texel
     constexpr int S = kDiffuseOrderedSteps;
     const size_t ldsOrd = (size_t)2 * 16 * (16 * S + 1) * sizeof(float4) + 64 * sizeof(float) + ((size_t)nTheta + nPhi) * sizeof(float2);
-    if (ldsOrd <= 64 * 1024 && (long)nPhi * nTheta < (1L << 30) && !(seq && !std::strcmp(seq, "lane"))) {
+    if (ldsOrd <= 64 * 1024 && (long)nPhi * nTheta < (1L << 30) && opt.diffuseSeqForm != 1) {   // option "diffuse_seq_form" = "lane": one lane per texel
         const int patch = (res % 4 == 0) ? 1 : 0;
         dim3 grid((unsigned)((total + 15) / 16));
         #define VQ_ORD(FMT_, FAST_) hipLaunchKernelGGL((k_conv_diffuse_ordered<FMT_, FAST_>), grid, dim3(256), ldsOrd, s, chain, w0, h0, nMips, res, phis, nPhi, thetas, nTheta, out, lv, patch)

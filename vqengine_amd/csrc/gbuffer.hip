@@ -121,12 +121,12 @@ VQD float4 fetch(const void* texels, const Footprint& fp) {
 }
 
 // once per pixel: as written (contract v5) — this normal steers the cube-map taps of the lighting pass
-VQD f3 UnpackNormal(f3 S, f3 worldNormal, f3 worldTangent) {          // ShadingMath.hlsl:44-52
-    S = normalize_lit(mk3(S.x * 2.0f - 1.0f, S.y * 2.0f - 1.0f, S.z * 2.0f - 1.0f));
-    const float nt = dot_lit(worldNormal, worldTangent);
-    const f3 T = normalize_lit(sub(worldTangent, mk3(nt * worldNormal.x, nt * worldNormal.y, nt * worldNormal.z)));
-    const f3 N = normalize_lit(worldNormal);
-    const f3 B = normalize_lit(cross(T, N));
+VQD f3 UnpackNormal(f3 S, f3 worldNormal, f3 worldTangent, bool dxc) {          // ShadingMath.hlsl:44-52; dxc: the reading of dot / normalize (vq_devmath.h)
+    S = normalize_rt(mk3(S.x * 2.0f - 1.0f, S.y * 2.0f - 1.0f, S.z * 2.0f - 1.0f), dxc);
+    const float nt = dot_rt(worldNormal, worldTangent, dxc);
+    const f3 T = normalize_rt(sub(worldTangent, mk3(nt * worldNormal.x, nt * worldNormal.y, nt * worldNormal.z)), dxc);
+    const f3 N = normalize_rt(worldNormal, dxc);
+    const f3 B = normalize_rt(cross(T, N), dxc);
     return mk3((S.x * T.x + S.y * B.x) + S.z * N.x,
                (S.x * T.y + S.y * B.y) + S.z * N.y,
                (S.x * T.z + S.y * B.z) + S.z * N.z);
@@ -235,13 +235,14 @@ VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane
                 emissiveColor = mul(mk3(pow_unit(Emis4.x, 2.2f), pow_unit(Emis4.y, 2.2f), pow_unit(Emis4.z, 2.2f)), memis);
             float roughness = m.roughness, metalness = m.metalness;                        // :252-253
 
-            const f3 N = normalize_lit(mk3(i1.x, i1.y, i1.z));                             // :265
+            const bool dxc = gc->arithDxc != 0;
+            const f3 N = normalize_rt(mk3(i1.x, i1.y, i1.z), dxc);                         // :265
             const f3 Nrm = mk3(Normal4.x, Normal4.y, Normal4.z);
             f3 SurfN = N;                                                                  // :267  length(Normal) < 0.01 ? N : UnpackNormal(...)
-            const bool unpack = !(length_lit(Nrm) < 0.01f);
+            const bool unpack = !(length_rt(Nrm, dxc) < 0.01f);
             if (__builtin_amdgcn_ballot_w64(unpack) != 0) {                                // a real branch: most waves of a normal-map-less material skip it
-                const f3 T = normalize_lit(mk3(i2.x, i2.y, i2.z));                         // :266
-                const f3 U = UnpackNormal(Nrm, N, T);
+                const f3 T = normalize_rt(mk3(i2.x, i2.y, i2.z), dxc);                     // :266
+                const f3 U = UnpackNormal(Nrm, N, T, dxc);
                 if (unpack) SurfN = U;
             }
 
@@ -290,14 +291,14 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
 // PSMain as the engine has it (ForwardLighting.hlsl:226-380): the producer and the lighting body (vq_shade.h) in ONE kernel — the 64-byte record
 // stays in registers instead of making a 128 B/pixel round trip through HBM. Bit-identical to vqhip_gbuffer_from_materials followed by
 // vqhip_forward_lighting (the record is the same fp32 values either way; pixels without geometry shade the all-zero record like the two calls do).
-template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT, int WAVES>
+template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT, int WAVES, int AR>
 __global__ __launch_bounds__(256, WAVES) void k_forward_from_materials(GbufArgs a, const FrameConstants* fc, void* out, int outPitch) {
     int x, y, lane;
     strip_pixel(x, y, lane);
     const bool inside = (x < a.width) & (y < a.height);
     const Record r = produce_record(a, x, y, inside, lane);
     if (!inside) return;
-    const float4 c = shade_pixel<HAS_ENV, HAS_CASTERS>(r.g0, r.g1, r.g2, r.g3, fc);
+    const float4 c = shade_pixel<HAS_ENV, HAS_CASTERS, AR>(r.g0, r.g1, r.g2, r.g3, fc);
     store_px<OUTFMT>(out, (size_t)y * outPitch + x, c);
 }
 
@@ -308,15 +309,15 @@ hipError_t launch_gbuffer_from_materials(hipStream_t s, const GbufArgs& a) {
     return hipGetLastError();
 }
 
-hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt) {
+hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt, int arithDxc, const Options& opt) {
     dim3 grid((a.width + 127) / 128, (a.height + 1) / 2);
     // register budget of the fused kernel: the producer half peaks at ~120 VGPRs (4 waves per SIMD), the lighting half needs 67; VQHIP_PSMAIN_WAVES = 5 / 6
     // caps the kernel at 96 / 80 VGPRs (the producer half then spills a little, the 64-light loop runs at higher occupancy)
-    const char* we = std::getenv("VQHIP_PSMAIN_WAVES");          // read per launch (~0.1 us): tests and benches switch the form inside one process
-    const int wv = we ? std::atoi(we) : VQ_PSMAIN_WAVES_DEFAULT;
-#define FFM(E, C, F) do { if (wv >= 6) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 6>), grid, dim3(256), 0, s, a, fc, out, outPitch); \
-                          else if (wv == 5) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 5>), grid, dim3(256), 0, s, a, fc, out, outPitch); \
-                          else hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 4>), grid, dim3(256), 0, s, a, fc, out, outPitch); } while (0)
+    const int wv = opt.psmainWaves ? opt.psmainWaves : VQ_PSMAIN_WAVES_DEFAULT;      // option "psmain_waves"
+#define FFM(E, C, F) do { if (arithDxc) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, VQ_PSMAIN_WAVES_DEFAULT, 1>), grid, dim3(256), 0, s, a, fc, out, outPitch); /* DXC reading: one occupancy form */ \
+                          else if (wv >= 6) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 6, 0>), grid, dim3(256), 0, s, a, fc, out, outPitch); \
+                          else if (wv == 5) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 5, 0>), grid, dim3(256), 0, s, a, fc, out, outPitch); \
+                          else hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 4, 0>), grid, dim3(256), 0, s, a, fc, out, outPitch); } while (0)
 #define FFM2(E, C) do { if (outFmt == VQHIP_FMT_RGBA32F) FFM(E, C, 0); else FFM(E, C, 1); } while (0)
     if (hasEnv) { if (hasCasters) FFM2(true, true); else FFM2(true, false); }
     else        { if (hasCasters) FFM2(false, true); else FFM2(false, false); }

@@ -653,12 +653,12 @@ namespace vqk {
 bool post_chain_fusable(const VQ_TonemapperParams& p, int inFmt, int outFmt, int W, int H) {
     return blur_y_tonemap_uses_lut(p, inFmt, outFmt, (size_t)W * H) && W >= 64 && H >= 32;
 }
-hipError_t launch_post_chain2(hipStream_t s, const void* in, void* out, int W, int H, const void* table, bool compactLut) {
+hipError_t launch_post_chain2(hipStream_t s, const void* in, void* out, int W, int H, const void* table, bool compactLut, const Options& opt) {
     const int strips = (W + pc2::TW - 1) / pc2::TW;
     int nseg = 512 / strips;                                 // at most two workgroups per CU in ONE wave of workgroups (a second, partial wave costs +50 %)
     if (nseg > (H + 31) / 32) nseg = (H + 31) / 32;          // segments of at least 32 rows: each re-reads 20 halo rows
     if (nseg < 1) nseg = 1;
-    if (const char* e = std::getenv("VQHIP_POST_SEGMENTS")) { const int v = std::atoi(e); if (v > 0) nseg = v; }
+    if (opt.postSegments > 0) nseg = opt.postSegments;
     const int segRows = (H + nseg - 1) / nseg;
     nseg = (H + segRows - 1) / segRows;
     const int ldsBytes = pc2::lds_bytes(compactLut ? 1 : 0);
@@ -671,15 +671,11 @@ hipError_t launch_post_chain2(hipStream_t s, const void* in, void* out, int W, i
 }
 // Which form of the X pass runs is chosen for the FRAME, not for the kernel alone (profiles/r2k_frame_loop.md): the software-pipelined persistent
 // form is the fastest kernel in isolation (25.9 us at 4K with 1 024 workgroups, 27.3 with 2 048), but with many workgroups in flight on real image
-// data it makes the chip throttle, and the shade kernel that follows it runs 2-13 % slower. VQHIP_BLUR_X_WGS overrides the default for tuning:
+// data it makes the chip throttle, and the shade kernel that follows it runs 2-13 % slower. Option "blur_x_wgs" overrides the default for tuning:
 // 0 = one workgroup per 1024-pixel segment (k_blur_x4), n > 0 = n persistent workgroups (k_blur_x4p).
-static int blur_x_workgroups() {                              // read per launch (a getenv is ~0.1 us): tests switch the form inside one process
-    const char* e = std::getenv("VQHIP_BLUR_X_WGS");
-    return e ? std::atoi(e) : 0;
-}
-hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt) {
+hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt, const Options& opt) {
     const int segsPerRow = (W + 1023) / 1024, nSeg = segsPerRow * H;
-    int want = blur_x_workgroups();
+    int want = opt.blurXWgs;
     if (want <= 0 && H > 65535) want = 1024;               // grid.y is limited to 65 535: taller images take the persistent form
     if (want > 0) {
         const int wgs = nSeg < want ? nSeg : want;
@@ -733,12 +729,12 @@ hipError_t launch_tonemap_lut_build(hipStream_t s, void* table, const VQ_Tonemap
 }
 
 // lutTable: NULL, or the table of (p, outFmt) built by launch_tonemap_lut_build (the context caches it per parameter set, capi.hip)
-hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, const void* lutTable) {
+hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, const void* lutTable, const Options& opt) {
     const size_t n = (size_t)W * H;
     if (lutTable && tonemap_uses_lut(p, inFmt, outFmt, n)) {
         if (outFmt == VQHIP_FMT_RGBA8_UNORM) {
-            const char* form = std::getenv("VQHIP_TONEMAP_FORM");       // "compact": k_tonemap_c; default: the 64 KB-table kernel (19.4 vs 22.1 us at 4K)
-            if (form && form[0] == 'c' && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
+            // option "tonemap_form" = "compact": k_tonemap_c; default: the 64 KB-table kernel (19.4 vs 22.1 us at 4K)
+            if (opt.tonemapCompact && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
                 const size_t nQuads = n / 4;
                 const size_t wgs = (nQuads + 255) / 256;
                 hipLaunchKernelGGL(k_tonemap_c, dim3((unsigned)(wgs < 4096 ? (wgs ? wgs : 1) : 4096)), dim3(256), 0, s, (const uint4*)in, (uint4*)out, nQuads, n,
@@ -765,12 +761,12 @@ hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H
 }
 
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
-                                 const VQ_TonemapperParams& p, int fmt, int outFmt, const void* lutTable) {
+                                 const VQ_TonemapperParams& p, int fmt, int outFmt, const void* lutTable, const Options& opt) {
     if (lutTable && blur_y_tonemap_uses_lut(p, fmt, outFmt, (size_t)W * H)) {
         // Form of the kernel (all bit-identical): "cN" / "cNs" = compact table, N output rows per lane (8, 12, 16), s = 16-byte stores through
-        // the LDS staging block; "lut64" = the round-2 kernel with the 64 KB table. VQHIP_BLUR_Y_FORM overrides the default for tuning.
-        const char* form = std::getenv("VQHIP_BLUR_Y_FORM");
-        if (!form || !*form) form = VQ_BLUR_Y_FORM_DEFAULT;
+        // the LDS staging block; "lut64" = the round-2 kernel with the 64 KB table. Option "blur_y_form" overrides the default for tuning.
+        const char* form = opt.blurYForm;
+        if (!*form) form = VQ_BLUR_Y_FORM_DEFAULT;
         if (form[0] == 'c') {
             const int rows = std::atoi(form + 1);
             const bool st16 = std::strchr(form, 's') != nullptr && ((uintptr_t)out & 15) == 0;
@@ -788,7 +784,7 @@ hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const
         }
         const int tilesX = (W + 63) / 64, tilesY = (H + 127) / 128, nTiles = tilesX * tilesY;
         int wgs = 512;                                        // two 64 KB tables per CU
-        if (const char* e = std::getenv("VQHIP_BLUR_Y_WGS")) { const int v = std::atoi(e); if (v > 0) wgs = v; }     // tuning knob, like VQHIP_BLUR_X_WGS
+        if (opt.blurYWgs > 0) wgs = opt.blurYWgs;             // tuning knob, like "blur_x_wgs"
         hipLaunchKernelGGL((k_blur_y_tonemap_lut<16>), dim3(nTiles < wgs ? nTiles : wgs), dim3(512), 0, s, in, out, haloTop, haloBottom, haloRows, W, H,
                            lutTable, tilesX, nTiles);
         return hipGetLastError();

@@ -5,7 +5,7 @@
 
 namespace {
 
-template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT>
+template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT, int AR>
 __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::ShadeArgs a) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
@@ -13,27 +13,32 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     const size_t i = (size_t)y * a.pitch + x;
     const float4 g0 = a.gb0[i], g1 = a.gb1[i], g2 = a.gb2[i], g3 = a.gb3[i];
     const vqk::FrameConstants* fc = a.fc;
-    const float4 c = shade_pixel<HAS_ENV, HAS_CASTERS>(g0, g1, g2, g3, fc);
+    const float4 c = shade_pixel<HAS_ENV, HAS_CASTERS, AR>(g0, g1, g2, g3, fc);
     store_px<OUTFMT>(a.out, (size_t)y * a.outPitch + x, c);
 }
 
 template <bool E, bool C>
 hipError_t launch_fmt(hipStream_t s, const vqk::ShadeArgs& a, int outFmt, dim3 grid) {
     const int wg = grid.z; grid.z = 1;
-    if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_forward_lighting<E, C, 0>), grid, dim3(wg), 0, s, a);
-    else                             hipLaunchKernelGGL((k_forward_lighting<E, C, 1>), grid, dim3(wg), 0, s, a);
+    if (a.arithDxc) {                                        // the DXC reading of dot / normalize (vqhip_set_arithmetic): its own instantiation
+        if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_forward_lighting<E, C, 0, 1>), grid, dim3(wg), 0, s, a);
+        else                             hipLaunchKernelGGL((k_forward_lighting<E, C, 1, 1>), grid, dim3(wg), 0, s, a);
+        return hipGetLastError();
+    }
+    if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_forward_lighting<E, C, 0, 0>), grid, dim3(wg), 0, s, a);
+    else                             hipLaunchKernelGGL((k_forward_lighting<E, C, 1, 0>), grid, dim3(wg), 0, s, a);
     return hipGetLastError();
 }
 
 } // namespace
 
 namespace vqk {
-hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt) {
+hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt, const Options& opt) {
     // Workgroup = wg consecutive pixels of one row (grid.z carries wg to launch_fmt). 256 for large frames; frames under 4 Mpixel (1080p: 32 400 waves,
     // 4.5 rounds of the chip at 7 waves per SIMD) run 7.5 % faster with 128-lane workgroups — finer-grained dispatch shortens the tail, and a width
-    // like 1920 is no multiple of 256 (profiles/r3t_shade_wg.jsonl: cfg2 0.0913 -> 0.0845 ms; cfg3 unchanged either way). VQHIP_SHADE_WG overrides.
+    // like 1920 is no multiple of 256 (profiles/r3t_shade_wg.jsonl: cfg2 0.0913 -> 0.0845 ms; cfg3 unchanged either way). Option "shade_wg" overrides.
     int wg = (size_t)a.width * a.height < ((size_t)4 << 20) ? 128 : 256;
-    if (const char* e = std::getenv("VQHIP_SHADE_WG")) { const int v = std::atoi(e); if (v == 64 || v == 128 || v == 256) wg = v; }
+    if (opt.shadeWg == 64 || opt.shadeWg == 128 || opt.shadeWg == 256) wg = opt.shadeWg;
     dim3 grid((a.width + wg - 1) / wg, a.height, wg);
     if (hasEnv) return hasCasters ? launch_fmt<true, true>(s, a, outFmt, grid) : launch_fmt<true, false>(s, a, outFmt, grid);
     return hasCasters ? launch_fmt<false, true>(s, a, outFmt, grid) : launch_fmt<false, false>(s, a, outFmt, grid);

@@ -42,16 +42,17 @@ __global__ __launch_bounds__(256) void k_ssr_env_fallback(SsrArgs a) {
         else { const uint32_t q = ((const uint32_t*)a.normals)[(size_t)y * a.normalPitch + x];                   // UNORM10 -> float: c / 1023, correctly rounded
                n01 = mk3(fdiv_((float)(q & 1023u), 1023.0f), fdiv_((float)((q >> 10) & 1023u), 1023.0f), fdiv_((float)((q >> 20) & 1023u), 1023.0f)); }
         const float u = ((float)x + 0.5f) * a.invDimX, v = ((float)y + 0.5f) * a.invDimY;                         // :79
-        const f3 wn = normalize_lit(mk3(2.0f * n01.x - 1.0f, 2.0f * n01.y - 1.0f, 2.0f * n01.z - 1.0f));          // :80
+        const bool dxc = a.arithDxc != 0;                                                                         // the reading of dot / normalize / reflect (vq_devmath.h)
+        const f3 wn = normalize_rt(mk3(2.0f * n01.x - 1.0f, 2.0f * n01.y - 1.0f, 2.0f * n01.z - 1.0f), dxc);     // :80
         // FFX_DNSR_Reflections_ScreenSpaceToViewSpace == InvProjectPosition(coord, g_inv_proj), Common.hlsl:98-104,116-118
         const float cy = 1.0f - v;
         const float px = 2.0f * u - 1.0f, py = 2.0f * cy - 1.0f;
         const float4 pr = mul_M_v4(a.invProj, px, py, z, 1.0f);
         const f3 ray = mk3(fdiv_(pr.x, pr.w), fdiv_(pr.y, pr.w), fdiv_(pr.z, pr.w));
-        const f3 dirV = normalize_lit(ray);                                                                       // :84
+        const f3 dirV = normalize_rt(ray, dxc);                                                                       // :84
         const float4 nv4 = mul_M_v4(a.view, wn.x, wn.y, wn.z, 0.0f);                                              // :85
         const f3 nV = mk3(nv4.x, nv4.y, nv4.z);
-        const f3 Rv = reflect_lit(dirV, nV);                                                                      // :86
+        const f3 Rv = reflect_rt(dirV, nV, dxc);                                                                      // :86
         const float4 rw4 = mul_M_v4(a.invView, Rv.x, Rv.y, Rv.z, 0.0f);                                          // :87
         // mul(g_envMapRotation, float3): the float4x4 truncates to its upper-left 3x3 (HLSL's implicit truncation)
         const f3 d = mk3((rw4.x * a.rot[0][0] + rw4.y * a.rot[1][0]) + rw4.z * a.rot[2][0],
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void k_ssr_env_fallback(SsrArgs a) {
                          (rw4.x * a.rot[0][2] + rw4.y * a.rot[1][2]) + rw4.z * a.rot[2][2]);
         const float lod = roughness * (a.mipCount - 1.0f);                                                        // :89
         const float4 pre = sample_cube_lod_rgba16f(a.env.specular_cube, a.env.spec_res0, a.env.spec_mips, d, lod);
-        const float NdotV = saturate(dot_lit(nV, neg(dirV)));                                                     // :90
+        const float NdotV = saturate(dot_rt(nV, neg(dirV), dxc));                                                     // :90
         const float2 sb = sample_2d_rg16f_clamp(a.env.brdf_lut, a.env.lut_size, a.env.lut_size, NdotV, roughness);   // :92, level 0
         // EnvironmentBRDF(NdotV, roughness, metallic = 1, diffuseColor = 0, diffuseIrradiance = 0, pre, sb), BRDF.hlsl:196-207, as written
         const float F0 = lerp_lit(0.04f, 0.0f, 1.0f);

@@ -49,6 +49,21 @@ VQD float sqrt_(float x) {
     if (__builtin_expect(!sqrt_fast_ok(x), 0)) s = __builtin_sqrtf(x);
     return s;
 }
+// RN(x^-1/2). Fast path: v_rsq_f32 seed (1 ulp), then the residual e = 1 - x y^2 and the second-order correction y (1 + e/2 + 3/8 e^2) in BINARY64 — a
+// binary32 correction term is only known to 2^-47 of the result, 2^-23 of an ulp, which mis-rounds a dozen significands; the double result is within
+// 2^-52 relative of the truth. Equal to (float)(1.0 / sqrt((double)x)) (the oracle's and the shim's definition) for EVERY x in [2^-100, 2^100] on gfx950:
+// tests/probe/devmath_probe.hip `rsqrt_cr`, tests/test_gpu_devmath.py::test_rsqrt_cr_exhaustive. Outside (0, denormal, inf, NaN, negative): the definition itself.
+VQD float rsqrt_cr_fast(float x) {
+    const double yd = (double)__builtin_amdgcn_rsqf(x), xd = (double)x;
+    const double e = __builtin_fma(-(xd * yd), yd, 1.0);                 // xd * yd is exact (48 bits)
+    return (float)__builtin_fma(yd * e, __builtin_fma(0.375, e, 0.5), yd);
+}
+VQD bool rsqrt_cr_fast_ok(float x) { return (x >= 0x1p-100f) & (x <= 0x1p100f); }
+VQD float rsqrt_cr(float x) {
+    float r = rsqrt_cr_fast(x);
+    if (__builtin_expect(!rsqrt_cr_fast_ok(x), 0)) r = (float)(1.0 / __builtin_sqrt((double)x));
+    return r;
+}
 // IEEE-754 correctly rounded quotient (v_div_scale/v_div_fmas/v_div_fixup under -fhip-fp32-correctly-rounded-divide-sqrt). Used where
 // the reference's x/x must be EXACTLY 1 (ImportanceSampleGGX at roughness 0, BRDF.hlsl:222): a*rcp(b) gives 1 - 2^-24 there.
 VQD float fdiv_(float a, float b) { return a / b; }
@@ -72,12 +87,14 @@ struct RcpFast {
     VQD float operator()(float b) { const float r = rcp_newton(b); ok = ok & is_normal(r); return r; }
     VQD float sqrt(float x) { ok = ok & sqrt_fast_ok(x); return sqrt_newton(x); }
     VQD float div(float a, float b, float r) { ok = ok & fdiv_rcp_ok(a); return fdiv_rcp(a, b, r); }       // r = (*this)(b)
+    VQD float rsqrt(float x) { ok = ok & rsqrt_cr_fast_ok(x); return rsqrt_cr_fast(x); }                  // DXC reading only
 };
 struct RcpIEEE {
     static constexpr bool kGgxDenomAboveEps = false;
     VQD float operator()(float b) const { return 1.0f / b; }
     VQD float sqrt(float x) const { return __builtin_sqrtf(x); }
     VQD float div(float a, float b, float) const { return a / b; }
+    VQD float rsqrt(float x) const { return (float)(1.0 / __builtin_sqrt((double)x)); }
 };
 VQD float rsqrt(float x) { return rcp(sqrt_(x)); }
 VQD float div_(float a, float b) { return a * rcp(b); }     // HLSL a / b
@@ -111,6 +128,20 @@ VQD f3 div_lit(f3 v, float l) { return mk3(fdiv_(v.x, l), fdiv_(v.y, l), fdiv_(v
 VQD f3 normalize_lit(f3 v) { return div_lit(v, length_lit(v)); }
 VQD float lerp_lit(float a, float b, float t) { return a + t * (b - a); }
 VQD f3 reflect_lit(f3 i, f3 n) { const float t = 2.0f * dot_lit(n, i); return mk3(i.x - t * n.x, i.y - t * n.y, i.z - t * n.z); }
+
+// ---- the SECOND READING of dot / normalize / length / reflect (vqhip_set_arithmetic): what DXC's HLOperationLower emits — DXIL Dot3 as the
+// FMA chain (dot() above), normalize(v) = v * Rsqrt(dot(v, v)) with a CORRECTLY ROUNDED rsqrt, length = sqrt of that dot. The CPU checker restates it (oracle/, test infrastructure);
+// the reference's own HLSL in this reading: oracle/ref_src/hlsl_shim.h VQ_SHIM_DXC.
+// AR = 0: the literal reading (the *_lit functions above), AR = 1: the DXC reading. lerp, mul(v, M) and the quotients are the same in both.
+template <int AR> VQD float dot_r(f3 a, f3 b) { return AR ? dot(a, b) : dot_lit(a, b); }
+template <int AR> VQD float length_r(f3 v) { return sqrt_(dot_r<AR>(v, v)); }
+template <int AR> VQD f3 normalize_r(f3 v) { if (AR) return mul(v, rsqrt_cr(dot(v, v))); return normalize_lit(v); }
+template <int AR> VQD f3 reflect_r(f3 i, f3 n) { const float t = 2.0f * dot_r<AR>(n, i); return mk3(i.x - t * n.x, i.y - t * n.y, i.z - t * n.z); }
+// the same choice at run time (wave-uniform flag) for per-pixel code outside the light loops (gbuffer.hip, ssr.hip)
+VQD float dot_rt(f3 a, f3 b, bool dxc) { return dxc ? dot(a, b) : dot_lit(a, b); }
+VQD float length_rt(f3 v, bool dxc) { return sqrt_(dot_rt(v, v, dxc)); }
+VQD f3 normalize_rt(f3 v, bool dxc) { return dxc ? mul(v, rsqrt_cr(dot(v, v))) : normalize_lit(v); }
+VQD f3 reflect_rt(f3 i, f3 n, bool dxc) { const float t = 2.0f * dot_rt(n, i, dxc); return mk3(i.x - t * n.x, i.y - t * n.y, i.z - t * n.z); }
 
 // float -> int: truncation, NaN -> 0, saturating
 VQD int f2i_trunc(float x) {

@@ -17,6 +17,23 @@ struct Range {
     bool on;
 };
 
+// Tuning / A-B options of one context (vqhip_set_option, include/vqhip.h). Read by the launchers from the context the call came through — never
+// from the process environment: getenv racing a host setenv is undefined behaviour in glibc and the engine is heavily threaded. 0 / "" = the default.
+struct Options {
+    int shadeWg = 0;            // "shade_wg"          : 64 | 128 | 256 lanes per workgroup of the shade kernel (default: by frame size)
+    int psmainWaves = 0;        // "psmain_waves"      : 4 | 5 | 6 waves per SIMD of the fused PSMain kernel
+    int postOneKernel = 0;      // "post_one_kernel"   : 1 = k_post_chain2 (64 KB table), 2 = with the compact table ("1c")
+    int postSegments = 0;       // "post_segments"     : row segments of k_post_chain2
+    int blurXWgs = 0;           // "blur_x_wgs"        : n > 0 = n persistent workgroups (k_blur_x4p)
+    int blurYWgs = 0;           // "blur_y_wgs"        : workgroups of k_blur_y_tonemap_lut
+    int tonemapCompact = 0;     // "tonemap_form"      : "compact" = k_tonemap_c
+    char blurYForm[16] = "";    // "blur_y_form"       : "c8s", "c12", "c16sw5", "lut64", ...
+    int lutForm = 0;            // "lut_form"          : 1 "general", 2 "persample"
+    int diffuseForm = 0;        // "diffuse_form"      : 1 "texels", 2 "general" (default: footprint records)
+    int diffuseSeqForm = 0;     // "diffuse_seq_form"  : 1 "lane" (default: k_conv_diffuse_ordered)
+    int specularForm = 0;       // "specular_form"     : 1 "permip"
+};
+
 // Device-resident per-call constant block == the cbuffers b0/b1 of ForwardLighting.hlsl:76-77 plus the
 // resource descriptors that replace its SRV tables. Uploaded once per vqhip_forward_lighting call into a
 // slot of the context's constant ring (the analogue of the reference's DynamicBufferHeap bump allocation,
@@ -49,6 +66,7 @@ struct ShadeArgs {
     void* out;
     const FrameConstants* fc;   // device
     int width, height, pitch, outPitch;
+    int arithDxc;               // vqhip_set_arithmetic: 0 literal reading, 1 DXC reading (selects the kernel instantiation)
 };
 
 // G-buffer producer (§8f.1): per-call constants in a ring slot — cbPerObject.materialData + descriptor tables of every
@@ -57,7 +75,8 @@ struct alignas(16) GbufConstants {
     float      ambient;          // cbPerFrame.fAmbientLightingFactor
     int32_t    numMaterials;
     vqhip_ssao ssao;             // device pointer or NULL
-    int32_t    pad[2];
+    int32_t    arithDxc;         // vqhip_set_arithmetic: the reading of dot / normalize / length in the producer (wave-uniform run-time flag)
+    int32_t    pad[1];
     vqhip_material mats[1];      // numMaterials entries
 };
 static constexpr int kMaxMaterials = (int)((kConstSlotBytes - offsetof(GbufConstants, mats)) / sizeof(vqhip_material));
@@ -69,7 +88,7 @@ struct GbufArgs {
 };
 hipError_t launch_gbuffer_from_materials(hipStream_t s, const GbufArgs& a);
 struct FrameConstants;
-hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt);
+hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt, int arithDxc, const Options& opt);
 hipError_t launch_mip_box_rgba8(hipStream_t s, const void* src, void* dst, int sw, int sh, int dw, int dh);
 hipError_t launch_skydome(hipStream_t s, const float4* eq0, int w0, int h0, const VQ_SkydomeParams& sp, const float4* cov, int covPitch,
                           void* color, int W, int H, int pitch, int fmt);
@@ -96,28 +115,28 @@ struct SsrArgs {
     VQ_matrix invProj, view, invView;
     float rot[3][3];                      // upper-left 3x3 of envMapRotation
     float invDimX, invDimY, roughnessThreshold, mipCount;
-    int pow5ExpLog;
+    int pow5ExpLog, arithDxc;
     vqhip_envmap env;
 };
 hipError_t launch_ssr_env_fallback(hipStream_t s, const SsrArgs& a, int sceneFmt, int normalFmt, int outFmt);
 
 // launchers (each returns the hipError_t of the launch)
-hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt);
-hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt);
+hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt, const Options& opt);
+hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt, const Options& opt);
 hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H, int fmt);
 bool tonemap_uses_lut(const VQ_TonemapperParams& p, int inFmt, int outFmt, size_t nPixels);
 bool post_chain_fusable(const VQ_TonemapperParams& p, int inFmt, int outFmt, int W, int H);
-hipError_t launch_post_chain2(hipStream_t s, const void* in, void* out, int W, int H, const void* table, bool compactLut);
+hipError_t launch_post_chain2(hipStream_t s, const void* in, void* out, int W, int H, const void* table, bool compactLut, const Options& opt);
 bool blur_y_tonemap_uses_lut(const VQ_TonemapperParams& p, int blurFmt, int outFmt, size_t nPixels);
 hipError_t launch_tonemap_lut_build(hipStream_t s, void* table, const VQ_TonemapperParams& p, int outFmt);
-hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, const void* lutTable);
+hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, const void* lutTable, const Options& opt);
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
-                                 const VQ_TonemapperParams& p, int fmt, int outFmt, const void* lutTable);
-hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt, int pow5ExpLog);
+                                 const VQ_TonemapperParams& p, int fmt, int outFmt, const void* lutTable, const Options& opt);
+hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt, int pow5ExpLog, const Options& opt);
 hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw, int sh, int dw, int dh);
 size_t conv_diffuse_record_bytes(int w0, int h0, int nMips);
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
-                                      const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt, void* recBuf);
+                                      const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt, void* recBuf, const Options& opt);
 hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, int order, void* out, int fmt);
 hipError_t launch_conv_specular(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res, int mip, int MIPS,
                                 int order, void* out, int fmt);

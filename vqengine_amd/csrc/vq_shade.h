@@ -8,6 +8,8 @@
 // the HLSL AS WRITTEN (products / sums rounded one by one, IEEE quotients: the *_lit functions) — one ulp there is tens of RGBA16F
 // ulps of a highlight pixel. The insensitive rest of the light loop keeps the regrouped trees of contract v2-v4 (scalar factors of
 // vector products gathered, a*b+c as one mad, the three divisions of D*G/denom merged into one reciprocal, 1/(D*D) = (1/D)^2):
+// Every function here takes the READING of dot / normalize / length / reflect as the template parameter AR (vq_devmath.h: 0 = literal, the default;
+// 1 = DXC: FMA-chain dot, normalize = v * correctly rounded rsqrt(dot) — vqhip_set_arithmetic); AR = 0 compiles to exactly the round-3 code.
 //   Shaders/BRDF.hlsl:65-79,82-97,118-121,132-136,152-161,163-207
 //   Shaders/Lighting.hlsl:29-32,57-73,110-174,177-272,308-395
 //   Shaders/ForwardLighting.hlsl:284-380
@@ -47,6 +49,7 @@ VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
 VQD float min3abs_acc(float m, float a, float b) { return __builtin_fminf(__builtin_fminf(m, __builtin_fabsf(a)), __builtin_fabsf(b)); }   // m >= 0
 VQD float min3abs(f3 v) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)); }   // one v_min3_f32 with |.| modifiers
 
+template <int AR>
 VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.P = mk3(g0.x, g0.y, g0.z);
     px.Nraw = mk3(g1.x, g1.y, g1.z);
@@ -54,20 +57,20 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     px.albedo = mk3(g2.x, g2.y, g2.z);
     px.metalness = g2.w;
     // once per pixel: as written (contract v5)
-    px.V = normalize_lit(sub(cam, px.P));                    // ForwardLighting.hlsl:285
-    px.Wo = normalize_lit(px.V);                             // BRDF.hlsl:166
-    px.Nn = normalize_lit(px.Nraw);                          // :167
+    px.V = normalize_r<AR>(sub(cam, px.P));                    // ForwardLighting.hlsl:285
+    px.Wo = normalize_r<AR>(px.V);                             // BRDF.hlsl:166
+    px.Nn = normalize_r<AR>(px.Nraw);                          // :167
     px.F0 = mk3(lerp_lit(0.04f, px.albedo.x, px.metalness), lerp_lit(0.04f, px.albedo.y, px.metalness), lerp_lit(0.04f, px.albedo.z, px.metalness));   // :178
     px.omF0 = mk3(1.0f - px.F0.x, 1.0f - px.F0.y, 1.0f - px.F0.z);
     px.omm = 1.0f - px.metalness;
     const float invPI = rcp(PI_);
     px.kA = mk3((px.omm * px.albedo.x) * invPI, (px.omm * px.albedo.y) * invPI, (px.omm * px.albedo.z) * invPI);     // (1-metal)*albedo/PI
-    const float NdotV = saturate(dot_lit(px.Nn, px.Wo));     // :171
+    const float NdotV = saturate(dot_r<AR>(px.Nn, px.Wo));   // :171
     px.NdotV4 = 4.0f * NdotV;
     const float rp1 = px.roughness + 1.0f;                   // Geometry_Smiths_SchlickGGX :92-96
     px.k = (rp1 * rp1) * 0.125f;                             // / 8.0f: exact either way
     px.omk = 1.0f - px.k;
-    const float NV = max_(0.0f, dot_lit(px.Nn, px.Wo));
+    const float NV = max_(0.0f, dot_r<AR>(px.Nn, px.Wo));
     px.G1V = fdiv_(NV, (NV * px.omk + px.k) + 0.0001f);
     const float a = px.roughness * px.roughness;             // NormalDistributionGGX :74-75
     px.a2 = a * a;
@@ -76,7 +79,7 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     // preconditions of the unchecked fast path of add_point_light that depend on the pixel only: roughness in [0, 1] (below 0.04 the GGX
     // EPSILON early-out may fire: such a wave takes the loop form that keeps the early-out as a select, RcpTrustEps) and a finite Wo (with a
     // finite Wi it makes Wo + Wi free of NaN, which the min3 test there cannot see)
-    px.fastOK = (px.roughness >= 0.0f) & (px.roughness <= 1.0f) & (dot_lit(px.Wo, px.Wo) <= 4.0f);       // the comparison is false for a NaN component
+    px.fastOK = (px.roughness >= 0.0f) & (px.roughness <= 1.0f) & (dot_r<AR>(px.Wo, px.Wo) <= 4.0f);       // the comparison is false for a NaN component
     // the skip of back-facing lights (add_point_light<.., true>) needs a finite BRDF whatever the light: finite F0 (hence 1 - F0) and kA
     px.skipOK = ((__builtin_fabsf(px.F0.x) + __builtin_fabsf(px.F0.y) + __builtin_fabsf(px.F0.z)) +
                  (__builtin_fabsf(px.kA.x) + __builtin_fabsf(px.kA.y) + __builtin_fabsf(px.kA.z))) < __builtin_inff();
@@ -85,13 +88,18 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
 // BRDF(s, Wi, V), BRDF.hlsl:163-194. As written: H = normalize(Wo + Wi) (IEEE quotients through rc.div), NdotH, nh2*(a2-1)+1.
 // Regrouped (contract v2-v4): fma(F, sG - kA, kA) with sG = (D*G)*rcp(denom) and the per-pixel kA = ((1-metal)*albedo)*rcp(PI).
 // `rc` is the reciprocal / sqrt / quotient policy (vq_devmath.h).
-template <class R>
+template <int AR, class R>
 VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     const f3 Hs = add(px.Wo, Wi);
-    const float Hl = rc.sqrt(dot_lit(Hs, Hs));               // length(Wo + Wi)
-    const float rH = rc(Hl);
-    const f3 H = mk3(rc.div(Hs.x, Hl, rH), rc.div(Hs.y, Hl, rH), rc.div(Hs.z, Hl, rH));     // :168
-    const float NdotH = saturate(dot_lit(px.Nn, H));         // :169
+    f3 H;                                                    // normalize(Wo + Wi) :168
+    if (AR) {
+        H = mul(Hs, rc.rsqrt(dot(Hs, Hs)));                  // DXC reading: one correctly rounded rsqrt, three products
+    } else {
+        const float Hl = rc.sqrt(dot_lit(Hs, Hs));           // length(Wo + Wi)
+        const float rH = rc(Hl);
+        H = mk3(rc.div(Hs.x, Hl, rH), rc.div(Hs.y, Hl, rH), rc.div(Hs.z, Hl, rH));
+    }
+    const float NdotH = saturate(dot_r<AR>(px.Nn, H));       // :169
     const float dNL = dot(px.Nn, Wi);
     const float NdotL = saturate(dNL);
     // Fresnel_Schlick(H, V, F0) :132-136
@@ -125,24 +133,26 @@ VQD f3 lit(f3 acc, f3 b, f3 cb, float w) { return mk3(fma_(b.x, cb.x * w, acc.x)
 VQD f3 light_cb(const VQ_float3& color, float brightness) { return mk3(color.x * brightness, color.y * brightness, color.z * brightness); }
 
 // CalculatePointLightIllumination, Lighting.hlsl:308-322 (general form, shadow casters)
-template <class R>
+template <int AR, class R>
 VQD f3 point_light_t(const Pixel& px, f3 lpos, float range, f3 cb, f3 acc, R& rc) {
     const f3 d = sub(lpos, px.P);
-    const float D = rc.sqrt(dot_lit(d, d));                  // length(Lw - P) as written; normalize() shares the sqrt
+    const float dd = dot_r<AR>(d, d);
+    const float D = rc.sqrt(dd);                             // length(Lw - P) as written; the literal normalize() shares the sqrt
     if (D < range) {
         const float rD = rc(D);                              // one reciprocal for the quotients of normalize(Lw - P) and for AttenuationBRDF :29-32
-        const f3 Wi = mk3(rc.div(d.x, D, rD), rc.div(d.y, D, rD), rc.div(d.z, D, rD));
+        const f3 Wi = AR ? mul(d, rc.rsqrt(dd)) : mk3(rc.div(d.x, D, rD), rc.div(d.y, D, rD), rc.div(d.z, D, rD));
         const float NdotL = saturate(dot(px.Nraw, Wi));
         const float w = (rD * rD) * NdotL;                   // 1/(D*D) as (1/D)*(1/D) (contract v3)
-        return lit(acc, brdf_t(px, Wi, rc), cb, w);
+        return lit(acc, brdf_t<AR>(px, Wi, rc), cb, w);
     }
     return acc;
 }
+template <int AR>
 VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op validity flag; used for the <= 5 casters
     const f3 zero = mk3(0.0f, 0.0f, 0.0f), cb = light_cb(l.color, l.brightness);
     RcpFast fast;
-    f3 r = point_light_t(px, ld3(l.position), l.range, cb, zero, fast);
-    if (__builtin_expect(!fast.ok, 0)) { RcpIEEE ieee; r = point_light_t(px, ld3(l.position), l.range, cb, zero, ieee); }
+    f3 r = point_light_t<AR>(px, ld3(l.position), l.range, cb, zero, fast);
+    if (__builtin_expect(!fast.ok, 0)) { RcpIEEE ieee; r = point_light_t<AR>(px, ld3(l.position), l.range, cb, zero, ieee); }
     return r;
 }
 
@@ -171,6 +181,7 @@ struct RcpTrust {
     VQD float operator()(float b) const { return rcp_newton(b); }
     VQD float sqrt(float x) const { return sqrt_newton(x); }
     VQD float div(float a, float b, float r) const { return fdiv_rcp(a, b, r); }
+    VQD float rsqrt(float x) const { return rsqrt_cr_fast(x); }      // DXC reading: dd and hh lie in [2^-80, 2^60], inside its validated domain [2^-100, 2^100]
 };
 // The same fast sequences for a wave that holds a pixel of roughness < 0.04 (polished metal, a2 down to 0): there pi t^2 can fall below EPSILON
 // and `if (denom < EPSILON) return 1` (BRDF.hlsl:76) must stay — as a select, like the IEEE form. The reciprocal's operand is then
@@ -188,42 +199,43 @@ struct RcpTrustEps : RcpTrust { static constexpr bool kGgxDenomAboveEps = false;
 // light) is skipped for the wave. Finite b: px.skipOK (finite F0, kA) and the proven ranges above; finite cb: FrameConstants::pointSkipOK;
 // the product form of the Fresnel power only (exp2(5 log2 x) is NaN for the x = -6e-8 that a dot product rounding above 1 yields).
 // On surface-coherent content about half the lights are behind the surface of a whole wave; white-noise normals never take this form.
-template <class RC, bool SKIP>
+template <int AR, class RC, bool SKIP>
 VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I, float& vmin, float& izmin) {
     const f3 lpos = mk3(l.px, l.py, l.pz), cb = mk3(l.cbx, l.cby, l.cbz);
     const f3 d = sub(lpos, px.P);
-    const float dd = dot_lit(d, d);                          // as written: D decides the range cull
+    const float dd = dot_r<AR>(d, d);                        // as written: D decides the range cull
     if (dd < l.rangeSq) {                                    // == (length(Lw - P) < l.range), exactly (host-made threshold): culled lights
         RC rc;                                               // need no square root; wave-coherent (execz skip)
         const float D = sqrt_newton(dd);
         const float rD = rc(D);
-        const f3 Wi = mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P)
+        const f3 Wi = AR ? mul(d, rc.rsqrt(dd)) : mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P) | (Lw - P) * rsqrt
         const f3 Hs = add(px.Wo, Wi);
         vmin = min3abs_acc(min3abs_acc(min3abs_acc(vmin, d.x, d.y), d.z, Hs.x), Hs.y, Hs.z);
         const float dNL = dot(px.Nraw, Wi);
         if (SKIP) { if (__builtin_amdgcn_ballot_w64((dNL > 0.0f) | !(izmin > 0.0f)) == 0) return; }
         const float NdotL = saturate(dNL);
         const float w = (rD * rD) * NdotL;
-        const f3 b = brdf_t(px, Wi, rc);
+        const f3 b = brdf_t<AR>(px, Wi, rc);
         I = lit(I, b, cb, w);
         if (SKIP) izmin = min3abs(I);
     }
 }
-template <class RC, bool SKIP>
+template <int AR, class RC, bool SKIP>
 VQD void point_light_loop(const Pixel& px, const vqk::DevPointLight* pts, int nP, f3& I, float& vmin) {
     float izmin = SKIP ? min3abs(I) : 0.0f;
-    for (int p = 0; p < nP; ++p) add_point_light<RC, SKIP>(px, pts[p], I, vmin, izmin);
+    for (int p = 0; p < nP; ++p) add_point_light<AR, RC, SKIP>(px, pts[p], I, vmin, izmin);
 }
 
 // SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333 (no range cull)
+template <int AR>
 VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, f3 acc) {
     const f3 d = sub(ld3(l.position), px.P);
-    const float D = length_lit(d);
-    const f3 Wi = div_lit(d, D);                             // normalize(l.position - P) as written
+    const float D = length_r<AR>(d);
+    const f3 Wi = AR ? normalize_r<AR>(d) : div_lit(d, D);   // normalize(l.position - P) as written
     const float rD = rcp(D);
-    const f3 pd = normalize_lit(sub(px.P, ld3(l.position))); // SpotlightIntensity as written: acos near 1 amplifies every ulp
-    const f3 sd = normalize_lit(ld3(l.spotDir));
-    const float theta = acos_(dot_lit(pd, sd));
+    const f3 pd = normalize_r<AR>(sub(px.P, ld3(l.position))); // SpotlightIntensity as written: acos near 1 amplifies every ulp
+    const f3 sd = normalize_r<AR>(ld3(l.spotDir));
+    const float theta = acos_(dot_r<AR>(pd, sd));
     float cone;
     if (theta > l.outerConeAngle) cone = 0.0f;
     else if (theta <= l.innerConeAngle) cone = 1.0f;
@@ -231,15 +243,16 @@ VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, f3 acc) {
     const float NdotL = saturate(dot(px.Nraw, Wi));
     const float w = (cone * (rD * rD)) * NdotL;
     RcpIEEE rc;
-    return lit(acc, brdf_t(px, Wi, rc), light_cb(l.color, l.brightness), w);
+    return lit(acc, brdf_t<AR>(px, Wi, rc), light_cb(l.color, l.brightness), w);
 }
 
 // CalculateDirectionalLightIllumination :334-345
+template <int AR>
 VQD f3 directional_light(const Pixel& px, const VQ_DirectionalLight& l) {
-    const f3 Wi = normalize_lit(neg(ld3(l.lightDirection)));
+    const f3 Wi = normalize_r<AR>(neg(ld3(l.lightDirection)));
     const float NdotL = saturate(dot(px.Nraw, Wi));
     RcpIEEE rc;
-    return lit(mk3(0.0f, 0.0f, 0.0f), brdf_t(px, Wi, rc), light_cb(l.color, l.brightness), NdotL);
+    return lit(mk3(0.0f, 0.0f, 0.0f), brdf_t<AR>(px, Wi, rc), light_cb(l.color, l.brightness), NdotL);
 }
 
 VQD f3 mul_v_m3(f3 v, float c, float s) {     // mul(v, GetHDRIRotationMatrix) with m = {c,0,s; 0,1,0; -s,0,c}, as written (zero terms kept)
@@ -249,14 +262,15 @@ VQD f3 mul_v_m3(f3 v, float c, float s) {     // mul(v, GetHDRIRotationMatrix) w
 }
 
 // CalculateEnvironmentMapIllumination(+_DiffuseOnly), Lighting.hlsl:348-395 ; EnvironmentBRDF BRDF.hlsl:196-207
+template <int AR>
 VQD f3 environment(const Pixel& px, const vqk::FrameConstants* fc) {
     const float sn = fc->hdriSin, cs = fc->hdriCos;          // sin / cos(-fHDRIOffsetInRadians), correctly rounded, from the host (capi.hip)
-    const float NdotV = saturate(dot_lit(px.Nraw, px.V));    // everything here runs once per pixel: as written (contract v5)
+    const float NdotV = saturate(dot_r<AR>(px.Nraw, px.V));  // everything here runs once per pixel: as written (contract v5)
     const f3 N = mul_v_m3(px.Nraw, cs, sn);
     const float4 irr = sample_cube_rgba16f(fc->env.diffuse_cube, fc->env.diffuse_res, N);
     f3 spec = mk3(0, 0, 0); float2 sb = make_float2(0, 0);
     if (!fc->perView.EnvironmentMapDiffuseOnlyIllumination) {
-        const f3 R = mul_v_m3(reflect_lit(neg(px.V), px.Nraw), cs, sn);
+        const f3 R = mul_v_m3(reflect_r<AR>(neg(px.V), px.Nraw), cs, sn);
         const int maxLod = f2i_trunc(fc->perView.MaxEnvMapLODLevels);
         int mip = f2i_trunc(px.roughness * (float)maxLod);
         mip = min(max(mip, 0), fc->env.spec_mips - 1);
@@ -294,10 +308,11 @@ __device__ const float DZ[20] = {  PA,  PA,  PA,  PA, -PA, -PA, -PA, -PA,  0,  0
 #undef PA
 #undef PB
 // OmnidirectionalShadowTestPCF, Lighting.hlsl:110-174
+template <int AR>
 VQD float omni_pcf(const float* cubeArr, int dim, int index, f3 Lw, float farPlane, float depthBias, float viewDist) {
     const float diskRadius = (1.0f + fdiv_(viewDist, farPlane)) * 0.125f;
     const float* cube = cubeArr + (size_t)index * 6 * dim * dim;
-    const float lenLw = length_lit(Lw);
+    const float lenLw = length_r<AR>(Lw);
     float shadow = 0.0f;
     for (int i = 0; i < 20; ++i) {
         const f3 sv = mk3(-(Lw.x + DX[i] * diskRadius), -(Lw.y + DY[i] * diskRadius), -(Lw.z + DZ[i] * diskRadius));
@@ -324,17 +339,17 @@ VQD float pcf_2d(const float* slice, int dim, float2 smDims, float4 lsp, float b
 
 // PSMain :289-380 for ONE pixel whose G-buffer record is (g0, g1, g2, g3): returns float4(I_total, roughness) (:380).
 // The wave-uniform choices inside (forms of the point-light loop) are taken over the lanes that are active at the call.
-template <bool HAS_ENV, bool HAS_CASTERS>
+template <bool HAS_ENV, bool HAS_CASTERS, int AR = 0>
 VQD float4 shade_pixel(const float4 g0, const float4 g1, const float4 g2, const float4 g3, const vqk::FrameConstants* fc) {
     Pixel px;
     const f3 cam = ld3(fc->perView.CameraPosition);
     px.p5ExpLog = fc->pow5ExpLog != 0;
-    setup_pixel(px, g0, g1, g2, cam);
+    setup_pixel<AR>(px, g0, g1, g2, cam);
     const float ao = g0.w;
     // illumination accumulators, ForwardLighting.hlsl:290-293: diffuse*ao + emissive*intensity, as written
     f3 I = mk3(px.albedo.x * ao + g3.x * g3.w, px.albedo.y * ao + g3.y * g3.w, px.albedo.z * ao + g3.z * g3.w);
 
-    if (HAS_ENV) I = add(I, environment(px, fc));                                             // :299-306
+    if (HAS_ENV) I = add(I, environment<AR>(px, fc));                                             // :299-306
 
     // non-shadowing point lights :310-313 — point_lights[0..numPointLights) followed by the extension array, packed by
     // the host into 32-byte records {position, range, color*brightness}
@@ -359,38 +374,38 @@ VQD float4 shade_pixel(const float4 g0, const float4 g1, const float4 g2, const 
                           __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, px.Nraw.z))));
         const bool laneSkipOK = px.skipOK & (dot(px.Nraw, n0) > 0.5f);
         const bool skip = (fc->pointSkipOK != 0) & !px.p5ExpLog & (__builtin_amdgcn_ballot_w64(!laneSkipOK) == 0);
-        if (skip) { if (eps) point_light_loop<RcpTrustEps, true>(px, pts, nP, I, vmin); else point_light_loop<RcpTrust, true>(px, pts, nP, I, vmin); }
-        else      { if (eps) point_light_loop<RcpTrustEps, false>(px, pts, nP, I, vmin); else point_light_loop<RcpTrust, false>(px, pts, nP, I, vmin); }
+        if (skip) { if (eps) point_light_loop<AR, RcpTrustEps, true>(px, pts, nP, I, vmin); else point_light_loop<AR, RcpTrust, true>(px, pts, nP, I, vmin); }
+        else      { if (eps) point_light_loop<AR, RcpTrustEps, false>(px, pts, nP, I, vmin); else point_light_loop<AR, RcpTrust, false>(px, pts, nP, I, vmin); }
     }
     if (__builtin_expect(!(vmin >= 0x1p-40f), 0)) {
         I = I0;
         RcpIEEE ieee;
-        for (int p = 0; p < nP; ++p) I = point_light_t(px, mk3(pts[p].px, pts[p].py, pts[p].pz), pts[p].range, mk3(pts[p].cbx, pts[p].cby, pts[p].cbz), I, ieee);
+        for (int p = 0; p < nP; ++p) I = point_light_t<AR>(px, mk3(pts[p].px, pts[p].py, pts[p].pz), pts[p].range, mk3(pts[p].cbx, pts[p].cby, pts[p].cbz), I, ieee);
     }
     const VQ_SceneLighting& L = fc->perFrame.Lights;
     const int nS = L.numSpotLights;
-    for (int s = 0; s < nS; ++s) I = spot_light(px, L.spot_lights[s], I);                     // :314-317
+    for (int s = 0; s < nS; ++s) I = spot_light<AR>(px, L.spot_lights[s], I);                     // :314-317
 
     if (HAS_CASTERS) {
         const int nPC = L.numPointCasters;
         for (int pc = 0; pc < nPC; ++pc) {                                                    // :321-339
             const VQ_PointLight& l = L.point_casters[pc];
             const f3 Lw = sub(ld3(l.position), px.P);
-            const float D = length_lit(Lw);
+            const float D = length_r<AR>(Lw);
             if (D < l.range) {
-                const float viewDist = length_lit(sub(px.P, cam));
-                const f3 c = point_light(px, l);
-                const float sh = omni_pcf(fc->sm.point, fc->sm.point_dim, pc, Lw, l.range, l.depthBias, viewDist);
+                const float viewDist = length_r<AR>(sub(px.P, cam));
+                const f3 c = point_light<AR>(px, l);
+                const float sh = omni_pcf<AR>(fc->sm.point, fc->sm.point_dim, pc, Lw, l.range, l.depthBias, viewDist);
                 I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
             }
         }
         const int nSC = L.numSpotCasters;
         for (int sc = 0; sc < nSC; ++sc) {                                                    // :342-356
             const VQ_SpotLight& l = L.spot_casters[sc];
-            const f3 Ln = normalize_lit(sub(ld3(l.position), px.P));
-            const float NdotL = saturate(dot_lit(px.Nraw, Ln));
+            const f3 Ln = normalize_r<AR>(sub(ld3(l.position), px.P));
+            const float NdotL = saturate(dot_r<AR>(px.Nraw, Ln));
             const float4 lsp = mul_M_v(L.shadowViews[sc], px.P);
-            const f3 c = spot_light(px, l, mk3(0.0f, 0.0f, 0.0f));
+            const f3 c = spot_light<AR>(px, l, mk3(0.0f, 0.0f, 0.0f));
             const float bias = l.depthBias * tan_(acos_(NdotL));
             const float sh = pcf_2d(fc->sm.spot + (size_t)sc * fc->sm.spot_dim * fc->sm.spot_dim, fc->sm.spot_dim,
                                     make_float2(fc->perFrame.f2SpotLightShadowMapDimensions.x, fc->perFrame.f2SpotLightShadowMapDimensions.y), lsp, bias);
@@ -406,7 +421,7 @@ VQD float4 shade_pixel(const float4 g0, const float4 g1, const float4 g2, const 
                 sh = pcf_2d(fc->sm.directional, fc->sm.dir_dim,
                             make_float2(fc->perFrame.f2DirectionalLightShadowMapDimensions.x, fc->perFrame.f2DirectionalLightShadowMapDimensions.y), lsp, l.depthBias);
             }
-            const f3 c = directional_light(px, l);
+            const f3 c = directional_light<AR>(px, l);
             I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
         }
     }
