@@ -631,6 +631,22 @@ def main():
         ctx.set_fresnel_pow(args.fresnel_pow == "exp2_log2")
         second = {"fresnel_pow": other, "value": round(W * frame_h * args.steps / dt2 / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
                   "shade_ms": round(mean_ms(evs2, "t0", "shade"), 4)}
+    # 5b. the other READING of dot / normalize (vqhip_set_arithmetic): DXC's lowering — FMA-chain dot, v * correctly rounded rsqrt — with the exp2/log2
+    # Fresnel power, i.e. the second build of the reference's sources (tests/golden/ref_outputs_dxc.npz); same invocation, same clocks
+    dxc = None
+    if not args.no_second_mode:
+        ctx.set_arithmetic(True); ctx.set_fresnel_pow(True)
+        for i in range(20):
+            pipe.step(i)
+        pipe.drain()
+        evs3 = [{"t0": _ev(), "shade": _ev()} for _ in range(args.steps)]
+        dt3 = pipe.timed(args.steps, evs3)
+        ctx.set_arithmetic(False); ctx.set_fresnel_pow(args.fresnel_pow == "exp2_log2")
+        dxc = {"arithmetic": "dxc", "fresnel_pow": "exp2_log2", "value": round(W * frame_h * args.steps / dt3 / 1e6, 2), "unit": "Mpix/s",
+               "ms_per_step": round(dt3 / args.steps * 1e3, 4), "shade_ms": round(mean_ms(evs3, "t0", "shade"), 4),
+               "note": "vqhip_set_arithmetic(VQHIP_ARITH_DXC) + VQHIP_FRESNEL_POW_EXP2_LOG2: within one RGBA16F ulp of the reference's HLSL in DXC's reading of dot / "
+                       "normalize / pow (tests/test_gpu_arith_modes.py); the headline runs the literal reading. The correctly rounded rsqrt costs a binary64 correction "
+                       "(v_rsq_f32 seed + 5 DP operations), which is why the mode is no faster than the literal quotients"}
 
     # 6. the other BASELINE configs, outside the headline's timed region (every rank takes part in the distributed ones)
     extras = {}
@@ -718,6 +734,8 @@ def main():
                                          "issue rate of the chip (scripts/ubench/valu_ceiling.hip); slot-weighted counts each quarter-rate v_rcp/v_rsq as 4 slots"}
         if second is not None:
             out["engine_lowering" if second["fresnel_pow"] == "exp2_log2" else "product_lowering"] = second
+        if dxc is not None:
+            out["dxc_lowering"] = dxc
         if verify is not None:
             out["verify"] = verify
         out.update(extras)

@@ -70,29 +70,11 @@ int main(int argc, char** argv) {
     writeDev(dir + "/scene_rgba16f.bin", lighting.GetSceneColor(), (size_t)W * H * 8);
     writeDev(dir + "/sdr_rgba8.bin", post.GetOutput(), (size_t)W * H * 4);
     writeDev(dir + "/diffuse_blurred.bin", env.diffuse_cube, (size_t)6 * 8 * 8 * 8);
-    // --- §8f.1 path: rasteriser planes + a material table (texture pointers in materials.bin are NULL: texture-less
-    // materials) -> producer -> lighting inside the same pass
-    if (FILE* probe = fopen((dir + "/ip0.bin").c_str(), "rb")) {
-        fclose(probe);
-        std::vector<char> mats = readFile(dir + "/materials.bin");
-        if (mats.size() % sizeof(vqhip_material) != 0) { fprintf(stderr, "materials.bin size\n"); return 2; }
-        vqhip_interpolants ip = { upload(readFile(dir + "/ip0.bin")), upload(readFile(dir + "/ip1.bin")), upload(readFile(dir + "/ip2.bin")), W, H, W };
-        ld.pInterpolants = &ip;
-        ld.pMaterials = (const vqhip_material*)mats.data();
-        ld.NumMaterials = (int)(mats.size() / sizeof(vqhip_material));
-        lighting.RecordCommands(&ld);
-        CHECK(lighting);
-        if (hipStreamSynchronize(stream) != hipSuccess) return 3;
-        writeDev(dir + "/scene_ip_rgba16f.bin", lighting.GetSceneColor(), (size_t)W * H * 8);
-    }
     // --- §8f.4: SSR's environment fallback on the frame just lit (ssr_cb.bin present): scene colour (alpha = roughness) + depth + normals -> radiance
     if (FILE* probe = fopen((dir + "/ssr_cb.bin").c_str(), "rb")) {
         fclose(probe);
         std::vector<char> cb = readFile(dir + "/ssr_cb.bin");
         if (cb.size() != sizeof(VQ_SSSRConstants)) { fprintf(stderr, "ssr_cb.bin size\n"); return 2; }
-        ld.pInterpolants = nullptr;
-        lighting.RecordCommands(&ld);                            // the G-buffer frame again: its alpha is the roughness the pass reads
-        CHECK(lighting);
         vqhip::HipSSREnvironmentFallbackPass ssr(ctx);
         ssr.Initialize();
         ssr.OnCreateWindowSizeDependentResources(W, H);
@@ -111,6 +93,21 @@ int main(int argc, char** argv) {
         ssr.RecordCommands(nullptr);
         if (ssr.LastStatus() != VQHIP_ERR_INVALID_ARG) return 5;
         ssr.Destroy();
+    }
+    // --- §8f.1 path: rasteriser planes + a material table (texture pointers in materials.bin are NULL: texture-less
+    // materials) -> producer -> lighting inside the same pass
+    if (FILE* probe = fopen((dir + "/ip0.bin").c_str(), "rb")) {
+        fclose(probe);
+        std::vector<char> mats = readFile(dir + "/materials.bin");
+        if (mats.size() % sizeof(vqhip_material) != 0) { fprintf(stderr, "materials.bin size\n"); return 2; }
+        vqhip_interpolants ip = { upload(readFile(dir + "/ip0.bin")), upload(readFile(dir + "/ip1.bin")), upload(readFile(dir + "/ip2.bin")), W, H, W };
+        ld.pInterpolants = &ip;
+        ld.pMaterials = (const vqhip_material*)mats.data();
+        ld.NumMaterials = (int)(mats.size() / sizeof(vqhip_material));
+        lighting.RecordCommands(&ld);
+        CHECK(lighting);
+        if (hipStreamSynchronize(stream) != hipSuccess) return 3;
+        writeDev(dir + "/scene_ip_rgba16f.bin", lighting.GetSceneColor(), (size_t)W * H * 8);
     }
     // --- row-tiled mode of the post pass through the real RCCL: a world of one rank (the box has one GPU). No halos, the composite of the
     // single tile is the tile: the frame must equal the SDR image written above.

@@ -88,7 +88,7 @@ def test_single_gpu_line_carries_the_contract_fields():
     assert len(lines) == 1, "bench.py must print exactly one line on stdout"
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline", "stages", "engine_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants", "rccl",
+              "roofline", "cpu_baseline", "stages", "engine_lowering", "dxc_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants", "rccl",
               "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained", "widened"):
         assert k in d, k
     su = d["sustained"]                                      # ~0.5 s of the headline's step here (VQ_BENCH_SUSTAINED_S), same order as `value`
@@ -103,6 +103,7 @@ def test_single_gpu_line_carries_the_contract_fields():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpix/s" and c["sample"]
     assert d["pmc_constants"]["stale"] is False
     assert d["engine_lowering"]["fresnel_pow"] == "exp2_log2" and 0 < d["engine_lowering"]["value"] < 1.05 * d["value"]
+    assert d["dxc_lowering"]["arithmetic"] == "dxc" and 0.5 * d["value"] < d["dxc_lowering"]["value"] < 1.2 * d["value"]
     iso = d["stages"]["isolated"]
     assert 0 < iso["blur_x_ms"] < 0.2 and 0 < iso["blur_y_tonemap_ms"] < 0.2
     assert d["stages"]["shade_ms"] < d["ms_per_step"]
