@@ -329,8 +329,10 @@ VQHIP_API int  vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode);
 /* Tuning / A-B options of a context, read by the launchers at call time (never from the process environment: getenv racing a host setenv is
  * undefined behaviour, and VQEngine records on many threads, SceneRendering.cpp:563-706). value NULL, "" or "default" restores the default. Every
  * form selected here gives the bits of the default form (tests/test_gpu_conv_forms.py, tests/test_gpu_round3.py); unknown keys / values: VQHIP_ERR_INVALID_ARG.
- *   shade_wg 64|128|256 · psmain_waves 4|5|6 · post_one_kernel 1|1c · post_segments n · blur_x_wgs n · blur_y_wgs n · tonemap_form lut64|compact ·
- *   blur_y_form c8|c8s|c12|c16|...|lut64 · lut_form general|persample · diffuse_form records|texels|general · diffuse_seq_form ordered|lane · specular_form permip */
+ *   shade_wg 64|128|256 · psmain_waves 4|5|6 · blur_x_wgs n · blur_y_wgs n · lut_form general · diffuse_form records|texels|general ·
+ *   diffuse_seq_form ordered|lane
+ * (the non-default values are the general / fallback forms of the same kernels; the measured-and-rejected kernel forms of rounds 2-3 — the one-kernel
+ * post chain, the compact tonemap tables, the per-sample LUT and per-mip specular kernels — were removed in round 4: docs/HISTORY.md). */
 VQHIP_API int  vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value);
 typedef enum vqhip_arithmetic { VQHIP_ARITH_LITERAL = 0, VQHIP_ARITH_DXC = 1 } vqhip_arithmetic;
 VQHIP_API int  vqhip_set_arithmetic(vqhip_ctx* ctx, vqhip_arithmetic mode);
@@ -377,7 +379,12 @@ VQHIP_API int vqhip_gaussian_blur_y_tonemap(vqhip_ctx* ctx, void* stream, const 
         const VQ_BlurParams* blurParams, const VQ_TonemapperParams* tonemapParams, vqhip_format blurFmt, vqhip_format outFmt);
 
 /* Replaces the Tonemapper.hlsl:CSMain dispatch (SceneRendering.cpp:2640-2656).
- * inFmt RGBA16F|RGBA32F; outFmt RGBA8_UNORM (SDR swapchain path) | RGBA16F (HDR path) | RGBA32F. */
+ * inFmt RGBA16F|RGBA32F; outFmt RGBA8_UNORM (SDR swapchain path) | RGBA16F (HDR path) | RGBA32F.
+ * Table cache: the calls that tonemap through a 65 536-entry table (this one, vqhip_gaussian_blur_y_tonemap, vqhip_post_process; RGBA16F input, a curve that
+ * does not mix channels) keep the tables of the FOUR most recent (parameters, output format) sets in the context. A fifth set rebuilds the least recently used
+ * table on the calling stream, behind an event recorded after that table's last reader — no host wait, legal under stream capture — unless the table has been
+ * read from more than one stream: then the call waits for the whole device once (hipDeviceSynchronize: a host stall, and an error under stream capture).
+ * An application that animates tonemapper parameters from several streams should serialise those calls on one stream. */
 VQHIP_API int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int width, int height,
         const VQ_TonemapperParams* params, vqhip_format inFmt, vqhip_format outFmt);
 
@@ -385,8 +392,7 @@ VQHIP_API int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* 
  * when bEnableGaussianBlur, then "TonemapperCS"): sceneColor -> out. BlurIntermediate lives in a scratch buffer of the context; for the
  * reference's formats (RGBA16F scene colour, RGBA8 SDR target) and a display curve that does not mix channels (sRGB, LINEAR, ST2084 on Rec.2020
  * content) the Y pass and the tonemapper are one kernel and BlurOutput never exists. Identical bits to vqhip_gaussian_blur_x -> _y ->
- * vqhip_tonemap (the intermediate roundings to the blur format are reproduced). enableGaussianBlur == 0: the tonemapper alone.
- * VQHIP_POST_ONE_KERNEL=1 in the environment selects an experimental single-kernel form (X-blurred rows in LDS): same bits, measured slower. */
+ * vqhip_tonemap (the intermediate roundings to the blur format are reproduced). enableGaussianBlur == 0: the tonemapper alone. */
 VQHIP_API int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, void* out, int width, int height,
         const VQ_TonemapperParams* tonemapParams, int enableGaussianBlur, vqhip_format inFmt, vqhip_format outFmt);
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Load-time kernels of BASELINE config 4 (2048^2 equirect -> 64^2 diffuse at step 0.010, 128^2 x 7 specular, 1024^2 x 2048 BRDF LUT), one box:
-warm time of every form of each kernel (options lut_form, diffuse_form, diffuse_seq_form, specular_form) and bit-equality with the first form.
+warm time of every form of each kernel (options lut_form, diffuse_form, diffuse_seq_form) and bit-equality with the first form.
 Prints one JSON line per measurement."""
 import json
 import os
@@ -43,15 +43,14 @@ def main():
     x = torch.empty(64 << 20, device="cuda")
     for _ in range(200):                                   # spin the clocks up
         x.mul_(1.0001)
-    sweep(ctx, "brdf_lut 1024^2 x 2048", "VQHIP_LUT_FORM", ["default", "general", "persample"], lambda: ctx.brdf_lut(1024, 2048, abi.FMT_RG16F))
+    sweep(ctx, "brdf_lut 1024^2 x 2048", "VQHIP_LUT_FORM", ["default", "general"], lambda: ctx.brdf_lut(1024, 2048, abi.FMT_RG16F))
     sweep(ctx, "conv_diffuse 6x64^2 step 0.010 wave64", "VQHIP_DIFFUSE_FORM", ["default", "texels", "general"],
           lambda: ctx.conv_diffuse(chain, 2048, 2048, n, 64, 0.010, abi.CONV_WAVE64, abi.FMT_RGBA16F))
     sweep(ctx, "conv_diffuse 6x64^2 step 0.010 sequential (the reference's order)", "VQHIP_DIFFUSE_SEQ_FORM", ["default", "lane"],
           lambda: ctx.conv_diffuse(chain, 2048, 2048, n, 64, 0.010, abi.CONV_SEQUENTIAL, abi.FMT_RGBA16F))
-    sweep(ctx, "conv_specular 128^2 x 7 sequential", "VQHIP_SPECULAR_FORM", ["default", "permip"],
-          lambda: ctx.conv_specular(chain, 2048, 2048, n, 128, abi.CONV_SEQUENTIAL, abi.FMT_RGBA16F))
-    sweep(ctx, "conv_specular 128^2 x 7 wave64", "VQHIP_SPECULAR_FORM", ["default", "permip"],
-          lambda: ctx.conv_specular(chain, 2048, 2048, n, 128, abi.CONV_WAVE64, abi.FMT_RGBA16F))
+    for order, tag in ((abi.CONV_SEQUENTIAL, "sequential"), (abi.CONV_WAVE64, "wave64")):
+        ms, _ = timed(lambda: ctx.conv_specular(chain, 2048, 2048, n, 128, order, abi.FMT_RGBA16F))
+        print(json.dumps({"what": f"conv_specular 128^2 x 7 {tag}", "form": "default", "ms": round(ms, 4)}), flush=True)
     ms, _ = timed(lambda: ctx.mip_chain(eq))
     print(json.dumps({"what": "mip_chain 2048^2 (incl. the level-0 copy)", "ms": round(ms, 4)}), flush=True)
 

@@ -5,6 +5,9 @@ They exist only where /root/reference does (this container). available() gates t
 produce (tests/golden/ref_*.npz, made by tests/golden/make_ref_fixtures.py) travel to the GPU box instead."""
 import ctypes as C
 import os
+import shutil
+import tempfile
+import threading
 
 import numpy as np
 
@@ -13,6 +16,16 @@ from vqengine_amd import abi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_DIR = os.path.join(ROOT, "oracle", "_ref")
 _libs = {}
+_tls = threading.local()
+_copy_dir = None
+
+
+def use_private_copy(copy_id):
+    """The translated shaders keep their cbuffers / SRVs in globals, so ONE loaded library serves one thread. A thread that calls this first gets its own
+    copy of every library it loads afterwards (the .so copied under a temporary name: a second dlopen of the same file would share the globals) —
+    how bench.py's cpu_reference_source runs the reference's HLSL on all host cores."""
+    _tls.copy_id = copy_id
+
 
 
 def available(name="shaders"):
@@ -20,8 +33,18 @@ def available(name="shaders"):
 
 
 def load(name="shaders"):
-    if name not in _libs:
-        lib = C.CDLL(os.path.join(REF_DIR, f"libvqref_{name}.so"))
+    global _copy_dir
+    copy_id = getattr(_tls, "copy_id", None)
+    key, path = name, os.path.join(REF_DIR, f"libvqref_{name}.so")
+    if copy_id is not None:
+        key = (name, copy_id)
+        if key not in _libs:
+            if _copy_dir is None:
+                _copy_dir = tempfile.mkdtemp(prefix="vqref_copies_")
+            path = shutil.copy(path, os.path.join(_copy_dir, f"libvqref_{name}.{copy_id}.so"))
+    name_key = key
+    if name_key not in _libs:
+        lib = C.CDLL(path)
         vp, f32, i32, u32 = C.c_void_p, C.c_float, C.c_int32, C.c_uint32
         if name == "mip":
             lib.vqref_mip_image.argtypes = [vp, vp, C.c_uint, C.c_uint, C.c_uint]
@@ -55,8 +78,8 @@ def load(name="shaders"):
             lib.vqref_unlit_color.argtypes = [vp, vp]
             lib.vqref_fsr_easu.argtypes = [vp, i32, i32, vp, vp, i32, i32]
             lib.vqref_fsr_rcas.argtypes = [vp, i32, i32, vp, vp]
-        _libs[name] = lib
-    return _libs[name]
+        _libs[name_key] = lib
+    return _libs[name_key]
 
 
 def _ref(x):

@@ -24,19 +24,17 @@ def _same(a, b, what):
 
 @pytest.mark.parametrize("size,samples,fmt", [(1024, 2048, abi.FMT_RG16F), (96, 700, abi.FMT_RG32F), (33, 100, abi.FMT_RG32F)])
 def test_brdf_lut_forms_identical(ctx, set_opt, size, samples, fmt):
-    """Shared-H table + unchecked sample body == the same kernel with every range test == the per-sample kernel of rounds 1-2."""
-    fast = ctx.brdf_lut(size, samples, fmt)
-    for form in ("general", "persample"):
-        set_opt("lut_form", form)
-        _same(ctx.brdf_lut(size, samples, fmt), fast, f"BRDF LUT {size}^2 x {samples} fast vs {form}")
-    set_opt("lut_form", None)
-    ctx.set_fresnel_pow(True)
-    try:
-        fast = ctx.brdf_lut(size, samples, fmt)
-        set_opt("lut_form", "persample")
-        _same(ctx.brdf_lut(size, samples, fmt), fast, f"BRDF LUT {size}^2 x {samples} exp2/log2 Fresnel, fast vs persample")
-    finally:
-        ctx.set_fresnel_pow(False)
+    """Shared-H table + unchecked sample body == the same kernel with every range test left in (option lut_form = general), in both Fresnel-pow modes.
+    (The per-sample kernel of rounds 1-2 gave the same bits until it was removed in round 4.)"""
+    for explog in (False, True):
+        ctx.set_fresnel_pow(explog)
+        try:
+            set_opt("lut_form", None)
+            fast = ctx.brdf_lut(size, samples, fmt)
+            set_opt("lut_form", "general")
+            _same(ctx.brdf_lut(size, samples, fmt), fast, f"BRDF LUT {size}^2 x {samples} fast vs general, exp2/log2 Fresnel {explog}")
+        finally:
+            ctx.set_fresnel_pow(False)
 
 
 @pytest.mark.parametrize("size,samples", [(33, 100), (64, 513), (16, 1500)])
@@ -97,19 +95,16 @@ def test_conv_diffuse_nonfinite_texels(ctx):
     assert_bits(ctx.conv_diffuse(dev(chain_o), 128, 64, n, 4, 0.1, abi.CONV_WAVE64, abi.FMT_RGBA32F), ref, "diffuse over inf / NaN texels")
 
 
-@pytest.mark.parametrize("w,h,res0,fmt", [(2048, 2048, 128, abi.FMT_RGBA16F), (128, 64, 32, abi.FMT_RGBA32F), (64, 32, 4, abi.FMT_RGBA32F), (100, 50, 8, abi.FMT_RGBA16F)])
-def test_conv_specular_forms_identical(ctx, set_opt, w, h, res0, fmt):
-    """Every mip in one launch with the per-block table of tangent-space half vectors == one launch per mip with ImportanceSampleGGX evaluated
-    per lane and sample (the round-1/2 kernel); the small cases also against the CPU oracle."""
+@pytest.mark.parametrize("order", [abi.CONV_SEQUENTIAL, abi.CONV_WAVE64])
+@pytest.mark.parametrize("w,h,res0,fmt", [(128, 64, 32, abi.FMT_RGBA32F), (64, 32, 4, abi.FMT_RGBA32F), (100, 50, 8, abi.FMT_RGBA16F), (256, 256, 64, abi.FMT_RGBA16F)])
+def test_conv_specular_all_mips_in_one_launch(ctx, w, h, res0, fmt, order):
+    """Every mip in one launch with the per-block table of tangent-space half vectors (k_conv_specular_all / k_conv_specular_ordered) against the CPU
+    oracle, both summation orders, odd chains and the smallest cube. (The per-mip kernels of rounds 1-3 gave the same bits until they were removed.)"""
     _, chain_o, chain_g, n = _chain(w, h, seed=0x54)
-    one, mips = ctx.conv_specular(chain_g, w, h, n, res0, abi.CONV_WAVE64, fmt)
-    set_opt("specular_form", "permip")
-    per, mips2 = ctx.conv_specular(chain_g, w, h, n, res0, abi.CONV_WAVE64, fmt)
-    assert mips == mips2
-    _same(per, one, f"specular {res0}^2 from {w}x{h}: one launch vs per mip")
-    if w <= 128:
-        ref, _ = O.conv_specular(chain_o, w, h, n, res0, abi.CONV_WAVE64, fmt)
-        assert_bits(one, ref, f"specular {res0}^2 from {w}x{h} vs oracle")
+    one, mips = ctx.conv_specular(chain_g, w, h, n, res0, order, fmt)
+    ref, mips_o = O.conv_specular(chain_o, w, h, n, res0, order, fmt)
+    assert mips == mips_o
+    assert_bits(one, ref, f"specular {res0}^2 from {w}x{h}, order {order} vs oracle")
 
 
 def test_conv_diffuse_records_across_streams_and_chains(ctx):

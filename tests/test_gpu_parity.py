@@ -359,13 +359,10 @@ def test_forward_cfg3_full_frame_with_ibl(ctx):
 # post chain
 # ---------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape", [(2160, 3840), (97, 301), (64, 64), (33, 1000), (540, 257), (1440, 2560), (32, 64), (31, 700)])
-@pytest.mark.parametrize("one_kernel", ["0", "1", "1c"])
-def test_post_process_one_call_equals_three_dispatches(ctx, shape, one_kernel, set_opt):
-    """vqhip_post_process against the oracle's three passes, bit for bit, in both of its forms: the default (blur X into the context's scratch,
-    then blur Y + tonemap) and the experimental single kernel (option post_one_kernel = 1 / 1c, k_post_chain2: X blur -> LDS ring -> Y blur -> tonemap
-    table, full or compact): 4K, sizes that are no multiple of the 128-column strips / 8-row steps / segment height, images smaller than the single kernel
-    accepts, negative and NaN inputs (the half of the table that is not in LDS)."""
-    set_opt("post_one_kernel", None if one_kernel == "0" else one_kernel)
+def test_post_process_one_call_equals_three_dispatches(ctx, shape):
+    """vqhip_post_process (blur X into the context's scratch, then blur Y + tonemap in one kernel) against the oracle's three passes, bit for bit: 4K,
+    sizes that are no multiple of the tiles, small images, negative and NaN inputs. (The experimental single-kernel chain of rounds 2-3 was measured
+    slower — 60 against 51 us at 4K, profiles/r3g_post_one_kernel.md — and removed in round 4.)"""
     h, w = shape
     img = synth.hdr_image(w, h, seed=h * 7 + w).astype(np.float16)
     img[h // 3, w // 2, 0] = np.float16(-3.5)          # negative / NaN colours reach the half of the table that is not in LDS

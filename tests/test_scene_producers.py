@@ -59,7 +59,7 @@ def test_material_cbuffer_data():
     d = m.get_cbuffer_data()
     assert d.textureConfig == float(cfg) and (d.uvScaleOffset.x, d.uvScaleOffset.w) == (2.0, 0.25)
     assert [scene.has_map(cfg, b) for b in range(9)] == [1, 0, 0, 0, 1, 0, 0, 1, 1]
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="gbuffer_from_materials"):      # textured materials are the producer kernel's, and the message says so
         scene.gbuffer_from_material(d, np.zeros((1, 3)), np.ones((1, 3)), 0.055)
 
 

@@ -557,9 +557,8 @@ class Context:
         self._ck(self.lib.vqhip_set_option(self._h, key.encode(), None if value is None else str(value).encode()))
 
     # the environment variables of rounds 1-3 map onto options (scripts that sweep forms): VQHIP_LUT_FORM -> "lut_form", ...
-    ENV_OPTIONS = {"VQHIP_LUT_FORM": "lut_form", "VQHIP_DIFFUSE_FORM": "diffuse_form", "VQHIP_DIFFUSE_SEQ_FORM": "diffuse_seq_form", "VQHIP_SPECULAR_FORM": "specular_form",
-                   "VQHIP_BLUR_Y_FORM": "blur_y_form", "VQHIP_TONEMAP_FORM": "tonemap_form", "VQHIP_BLUR_X_WGS": "blur_x_wgs", "VQHIP_BLUR_Y_WGS": "blur_y_wgs",
-                   "VQHIP_POST_ONE_KERNEL": "post_one_kernel", "VQHIP_POST_SEGMENTS": "post_segments", "VQHIP_SHADE_WG": "shade_wg", "VQHIP_PSMAIN_WAVES": "psmain_waves"}
+    ENV_OPTIONS = {"VQHIP_LUT_FORM": "lut_form", "VQHIP_DIFFUSE_FORM": "diffuse_form", "VQHIP_DIFFUSE_SEQ_FORM": "diffuse_seq_form",
+                   "VQHIP_BLUR_X_WGS": "blur_x_wgs", "VQHIP_BLUR_Y_WGS": "blur_y_wgs", "VQHIP_SHADE_WG": "shade_wg", "VQHIP_PSMAIN_WAVES": "psmain_waves"}
 
     def set_option_env(self, env_name, value):
         v = None if value in (None, "", "default", "0") and env_name != "VQHIP_BLUR_X_WGS" else value

@@ -36,26 +36,32 @@ struct vqhip_ctx {
     vqk::Options opt;              // vqhip_set_option
     // 65536-entry tonemap tables (post.hip:k_tonemap_lut), cached per (TonemapperParams, output format): the table is built once
     // per parameter set instead of once per frame. Streams that HIT a cached table only wait for the event of its build. A table is replaced
-    // only when a fifth parameter set shows up: the least recently used one goes (a hit counts as a use), and because its readers may sit on
-    // any number of streams the replacement waits for the whole device once (hipDeviceSynchronize) instead of tracking one event per reader.
+    // only when a fifth parameter set shows up: the least recently used one goes (a hit counts as a use). Every use records the slot's `lastUse` event
+    // behind the kernel that read the table; the rebuild makes ITS stream wait for that event — no host stall, legal under stream capture. Only a table
+    // that has been read from MORE THAN ONE stream (one event cannot cover readers on several streams) is replaced after a device-wide wait.
     static constexpr int kLuts = 4;
     struct TonemapLut { void* table = nullptr; VQ_TonemapperParams key{}; int outFmt = -1; bool valid = false;
-                        hipEvent_t built = nullptr; bool used = false; uint64_t lastUseTick = 0; } lut[kLuts];
+                        hipEvent_t built = nullptr, lastUse = nullptr; hipStream_t lastStream = nullptr; bool used = false, multiStream = false;
+                        uint64_t lastUseTick = 0; } lut[kLuts];
     uint64_t lutTick = 0;
     // one thread at a time per context: entry points detect a second thread inside the same context and refuse it
-    std::atomic<int> busyDepth{0};
-    std::thread::id busyThread;
+    std::atomic<uint64_t> owner{0};            // token of the thread inside an entry point (0: nobody); acquired by CAS, cleared by the outermost guard
+    int ownerDepth = 0;                        // nesting depth: touched by the owner only
+    uint64_t generation = 0;                   // distinguishes this context from an earlier one at the same address (vqhip_last_error)
     std::string lastError;
 };
 
 namespace {
 
 thread_local std::string g_lastError;
-thread_local const vqhip_ctx* g_lastErrorCtx = nullptr;     // the context this thread's most recent failure belongs to (vqhip_last_error)
+thread_local const vqhip_ctx* g_lastErrorCtx = nullptr;     // the context this thread's most recent failure belongs to (vqhip_last_error) ...
+thread_local uint64_t g_lastErrorGen = 0;                   // ... and its generation: a later context at the same address does not inherit the message
+std::atomic<uint64_t> g_ctxGeneration{1};
 
 int fail(vqhip_ctx* ctx, int code, const std::string& msg) {
     g_lastError = msg;
     g_lastErrorCtx = ctx;
+    g_lastErrorGen = ctx ? ctx->generation : 0;
     if (ctx) ctx->lastError = msg;
     return code;
 }
@@ -63,6 +69,7 @@ int fail(vqhip_ctx* ctx, int code, const std::string& msg) {
 int failRefused(const vqhip_ctx* ctx, const std::string& msg) {
     g_lastError = msg;
     g_lastErrorCtx = ctx;
+    g_lastErrorGen = ctx ? ctx->generation : 0;
     return VQHIP_ERR_INVALID_ARG;
 }
 int failHip(vqhip_ctx* ctx, hipError_t e, const char* what) {
@@ -103,8 +110,8 @@ int ensureScratch(vqhip_ctx* ctx, size_t bytes) {
 }
 
 // The tonemap table of (p, outFmt), ready to be read by work enqueued on `st` after this call: a cached table makes `st` wait for the
-// event of its build (it may have happened on another stream); a miss rebuilds the LEAST RECENTLY USED slot on `st` — after a device-wide
-// wait when that table has ever been read (its readers may be on other streams).
+// event of its build (it may have happened on another stream); a miss rebuilds the LEAST RECENTLY USED slot on `st` — behind the slot's last-use
+// event when all its readers were on one stream, after a device-wide wait when they were on several (releaseTonemapLut keeps the record).
 int acquireTonemapLut(vqhip_ctx* ctx, hipStream_t st, const VQ_TonemapperParams& p, int outFmt, int* slotOut) {
     int victim = 0;
     for (int i = 0; i < vqhip_ctx::kLuts; ++i) {
@@ -112,7 +119,6 @@ int acquireTonemapLut(vqhip_ctx* ctx, hipStream_t st, const VQ_TonemapperParams&
         if (L.valid && L.outFmt == outFmt && std::memcmp(&L.key, &p, sizeof(p)) == 0) {
             HIP_TRY(ctx, hipStreamWaitEvent(st, L.built, 0));
             L.lastUseTick = ++ctx->lutTick;
-            L.used = true;
             *slotOut = i;
             return VQHIP_OK;
         }
@@ -120,32 +126,48 @@ int acquireTonemapLut(vqhip_ctx* ctx, hipStream_t st, const VQ_TonemapperParams&
         else if (ctx->lut[victim].valid && L.lastUseTick < ctx->lut[victim].lastUseTick) victim = i;
     }
     auto& L = ctx->lut[victim];
-    if (L.valid && L.used) HIP_TRY(ctx, hipDeviceSynchronize());
+    if (L.valid && L.used) {
+        if (L.multiStream) HIP_TRY(ctx, hipDeviceSynchronize());            // readers on several streams: one event does not cover them (documented in vqhip.h)
+        else HIP_TRY(ctx, hipStreamWaitEvent(st, L.lastUse, 0));              // the rebuild queues behind the last kernel that read the table
+    }
     L.valid = false;
     hipError_t e = launch_tonemap_lut_build(st, L.table, p, outFmt);
     if (e != hipSuccess) return failHip(ctx, e, "tonemap table build launch");
     HIP_TRY(ctx, hipEventRecord(L.built, st));
-    L.key = p; L.outFmt = outFmt; L.valid = true; L.used = true; L.lastUseTick = ++ctx->lutTick;
+    L.key = p; L.outFmt = outFmt; L.valid = true; L.used = false; L.multiStream = false; L.lastStream = nullptr; L.lastUseTick = ++ctx->lutTick;
     *slotOut = victim;
     return VQHIP_OK;
 }
-int releaseTonemapLut(vqhip_ctx*, hipStream_t, int) { return VQHIP_OK; }
+// called behind the kernel that read table `slot` on `st`
+int releaseTonemapLut(vqhip_ctx* ctx, hipStream_t st, int slot) {
+    auto& L = ctx->lut[slot];
+    if (L.used && L.lastStream != st) L.multiStream = true;
+    HIP_TRY(ctx, hipEventRecord(L.lastUse, st));
+    L.used = true; L.lastStream = st;
+    return VQHIP_OK;
+}
 
 // RAII marker of "this thread is inside an entry point of ctx". A second THREAD entering the same context while one is inside is refused
 // (VQHIP_ERR_INVALID_ARG) instead of corrupting the constant ring / table cache; nested calls of the same thread (vqhip_post_process ->
 // vqhip_gaussian_blur_x) pass. The context may migrate between threads, it just cannot be shared at the same time.
+// Ownership is ONE atomic word holding a per-thread token: a thread enters by CAS 0 -> its token, so there is no window in which another thread can
+// read a stale owner; a nested call recognises its own token and bumps a depth counter only the owner touches; the outermost guard clears the word.
+uint64_t threadToken() {
+    static std::atomic<uint64_t> next{1};
+    thread_local const uint64_t t = next.fetch_add(1, std::memory_order_relaxed);
+    return t;
+}
 struct CtxGuard {
     vqhip_ctx* c; bool ok;
     explicit CtxGuard(vqhip_ctx* ctx) : c(ctx), ok(true) {
         if (!c) return;
-        const std::thread::id me = std::this_thread::get_id();
-        int d = c->busyDepth.load(std::memory_order_acquire);
-        if (d > 0 && c->busyThread == me) { c->busyDepth.store(d + 1, std::memory_order_release); return; }
-        int expected = 0;
-        if (!c->busyDepth.compare_exchange_strong(expected, 1, std::memory_order_acq_rel)) { ok = false; c = nullptr; return; }
-        c->busyThread = me;
+        const uint64_t me = threadToken();
+        if (c->owner.load(std::memory_order_acquire) == me) { ++c->ownerDepth; return; }      // nested call of the owner
+        uint64_t expected = 0;
+        if (!c->owner.compare_exchange_strong(expected, me, std::memory_order_acq_rel)) { ok = false; c = nullptr; return; }
+        c->ownerDepth = 1;
     }
-    ~CtxGuard() { if (c) c->busyDepth.fetch_sub(1, std::memory_order_acq_rel); }
+    ~CtxGuard() { if (c && --c->ownerDepth == 0) c->owner.store(0, std::memory_order_release); }
 };
 #define CTX_GUARD(ctx, who) CtxGuard guard_(ctx); if (!guard_.ok) return failRefused(ctx, std::string(who) + ": the context is in use on another thread (one thread at a time per vqhip_ctx)")
 
@@ -198,7 +220,7 @@ extern "C" {
 int vqhip_abi_version(void) { return VQHIP_ABI_VERSION; }
 
 // the calling thread's own most recent failure when it belongs to `ctx` (race-free, and the only record of a refused concurrent call), else the context's
-const char* vqhip_last_error(const vqhip_ctx* ctx) { return (!ctx || g_lastErrorCtx == ctx) ? g_lastError.c_str() : ctx->lastError.c_str(); }
+const char* vqhip_last_error(const vqhip_ctx* ctx) { return (!ctx || (g_lastErrorCtx == ctx && g_lastErrorGen == ctx->generation)) ? g_lastError.c_str() : ctx->lastError.c_str(); }
 
 int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
     if (!out_ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "vqhip_create: out_ctx is NULL");
@@ -214,6 +236,7 @@ int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
     HIP_TRY(nullptr, hipSetDevice(device_ordinal));
     vqhip_ctx* ctx = new vqhip_ctx();
     ctx->device = device_ordinal;
+    ctx->generation = g_ctxGeneration.fetch_add(1, std::memory_order_relaxed);
     const size_t ringBytes = kConstSlotBytes * vqhip_ctx::kSlots;
     if ((e = hipHostMalloc((void**)&ctx->hostRing, ringBytes, hipHostMallocDefault)) != hipSuccess ||
         (e = hipMalloc((void**)&ctx->devRing, ringBytes)) != hipSuccess) {
@@ -222,7 +245,8 @@ int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
         return rc;
     }
     for (int i = 0; i < vqhip_ctx::kLuts; ++i)
-        if ((e = hipMalloc(&ctx->lut[i].table, 131072)) != hipSuccess || (e = hipEventCreateWithFlags(&ctx->lut[i].built, hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "vqhip_create: tonemap tables"); vqhip_destroy(ctx); return rc; }
+        if ((e = hipMalloc(&ctx->lut[i].table, 131072)) != hipSuccess || (e = hipEventCreateWithFlags(&ctx->lut[i].built, hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->lut[i].lastUse, hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "vqhip_create: tonemap tables"); vqhip_destroy(ctx); return rc; }
     for (int i = 0; i < vqhip_ctx::kSlots; ++i)
         if ((e = hipEventCreateWithFlags(&ctx->slotEvent[i], hipEventDisableTiming)) != hipSuccess ||
             (e = hipEventCreateWithFlags(&ctx->copyEvent[i], hipEventDisableTiming)) != hipSuccess) { int rc = failHip(nullptr, e, "hipEventCreate"); vqhip_destroy(ctx); return rc; }
@@ -233,6 +257,7 @@ int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
 
 void vqhip_destroy(vqhip_ctx* ctx) {
     if (!ctx) return;
+    if (g_lastErrorCtx == ctx) g_lastErrorCtx = nullptr;     // this thread's message dies with the context (other threads: the generation check)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < vqhip_ctx::kSlots; ++i) { if (ctx->slotEvent[i]) (void)hipEventDestroy(ctx->slotEvent[i]); if (ctx->copyEvent[i]) (void)hipEventDestroy(ctx->copyEvent[i]); }
@@ -245,6 +270,7 @@ void vqhip_destroy(vqhip_ctx* ctx) {
     for (int i = 0; i < vqhip_ctx::kLuts; ++i) {
         if (ctx->lut[i].table) (void)hipFree(ctx->lut[i].table);
         if (ctx->lut[i].built) (void)hipEventDestroy(ctx->lut[i].built);
+        if (ctx->lut[i].lastUse) (void)hipEventDestroy(ctx->lut[i].lastUse);
     }
     delete ctx;
 }
@@ -424,16 +450,6 @@ int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, voi
     if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "post_process: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
     if (sceneColor == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "post_process: in-place is not supported");
     if (!enableGaussianBlur) return vqhip_tonemap(ctx, stream, sceneColor, out, width, height, tm, inFmt, outFmt);
-    hipStream_t st = (hipStream_t)stream;
-    if (ctx->opt.postOneKernel && post_chain_fusable(*tm, inFmt, outFmt, width, height)) {   // option "post_one_kernel": single-kernel form (post.hip: k_post_chain2; "1c": compact tonemap table), measured slower, opt-in
-        HIP_TRY(ctx, hipSetDevice(ctx->device));
-        int slot = -1;
-        const int rc = acquireTonemapLut(ctx, st, *tm, outFmt, &slot);
-        if (rc) return rc;
-        const hipError_t e = launch_post_chain2(st, sceneColor, out, width, height, ctx->lut[slot].table, ctx->opt.postOneKernel == 2, ctx->opt);
-        if (e != hipSuccess) return failHip(ctx, e, "post chain launch");
-        return releaseTonemapLut(ctx, st, slot);
-    }
     // blur X into a BlurIntermediate held in the context's scratch buffer, then blur Y + tonemap in one kernel (or two: HDR / RGBA32F targets)
     const size_t bpp = inFmt == VQHIP_FMT_RGBA32F ? 16 : 8;
     const int rc0 = ensureScratch(ctx, (size_t)width * height * bpp);
@@ -467,20 +483,11 @@ int vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value) {
     };
     if (k == "shade_wg") return num(&o.shadeWg, { 0, 64, 128, 256 });
     if (k == "psmain_waves") return num(&o.psmainWaves, { 0, 4, 5, 6 });
-    if (k == "post_one_kernel") return pick(&o.postOneKernel, { "1", "1c" });
-    if (k == "post_segments") return num(&o.postSegments, {});
     if (k == "blur_x_wgs") return num(&o.blurXWgs, {});
     if (k == "blur_y_wgs") return num(&o.blurYWgs, {});
-    if (k == "tonemap_form") { if (v == "lut64") { o.tonemapCompact = 0; return VQHIP_OK; } return pick(&o.tonemapCompact, { "compact" }); }
-    if (k == "blur_y_form") {
-        if (v.size() >= sizeof(o.blurYForm) || (!v.empty() && v != "lut64" && v[0] != 'c')) return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_option: bad value '" + v + "' for blur_y_form");
-        std::snprintf(o.blurYForm, sizeof(o.blurYForm), "%s", v.c_str());
-        return VQHIP_OK;
-    }
-    if (k == "lut_form") return pick(&o.lutForm, { "general", "persample" });
+    if (k == "lut_form") return pick(&o.lutForm, { "general" });
     if (k == "diffuse_form") { if (v == "records") { o.diffuseForm = 0; return VQHIP_OK; } return pick(&o.diffuseForm, { "texels", "general" }); }
     if (k == "diffuse_seq_form") { if (v == "ordered") { o.diffuseSeqForm = 0; return VQHIP_OK; } return pick(&o.diffuseSeqForm, { "lane" }); }
-    if (k == "specular_form") return pick(&o.specularForm, { "permip" });
     return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_option: unknown key '" + k + "'");
 }
 int vqhip_set_arithmetic(vqhip_ctx* ctx, vqhip_arithmetic mode) {
@@ -858,9 +865,10 @@ static int checkChain(vqhip_ctx* ctx, const void* chain, int w0, int h0, int nMi
 int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
                        int diffuseRes, float step, vqhip_conv_order order, void* outCube, vqhip_format fmt) {
     vqk::Range range_("DiffuseIrradianceCubemap");
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "conv_diffuse: ctx is NULL");
+    CTX_GUARD(ctx, "conv_diffuse");                          // before anything writes the context's error string
     int rc = checkChain(ctx, equirect_mips, w0, h0, nMips, "conv_diffuse");
     if (rc) return rc;
-    CTX_GUARD(ctx, "conv_diffuse");
     if (!outCube || diffuseRes <= 0 || !(step > 0.0f)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_diffuse: bad argument");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_diffuse: fmt must be RGBA32F or RGBA16F");
     if (order != VQHIP_CONV_SEQUENTIAL && order != VQHIP_CONV_WAVE64) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_diffuse: bad order");
@@ -900,27 +908,17 @@ int vqhip_conv_diffuse(vqhip_ctx* ctx, void* stream, const void* equirect_mips, 
 int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,
                         int specRes0, vqhip_conv_order order, void* outCubeMips, vqhip_format fmt) {
     vqk::Range range_("SpecularIrradianceCubemap");
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "conv_specular: ctx is NULL");
+    CTX_GUARD(ctx, "conv_specular");
     int rc = checkChain(ctx, equirect_mips, w0, h0, nMips, "conv_specular");
     if (rc) return rc;
-    CTX_GUARD(ctx, "conv_specular");
     const int MIPS = vqhip_specular_mip_count(specRes0);
     if (!outCubeMips || specRes0 < 4 || (specRes0 & (specRes0 - 1)) || MIPS < 2) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_specular: specRes0 must be a power of two >= 4");
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_specular: fmt must be RGBA32F or RGBA16F");
     if (order != VQHIP_CONV_SEQUENTIAL && order != VQHIP_CONV_WAVE64) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_specular: bad order");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->opt.specularForm != 1) {                                        // option "specular_form" = "permip": one launch per mip (the round-1/2 form)
-        hipError_t e = launch_conv_specular_all((hipStream_t)stream, (const float4*)equirect_mips, w0, h0, nMips, specRes0, MIPS, order, outCubeMips, fmt);
-        return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "conv_specular launch");
-    }
-    const size_t bpp = fmt == VQHIP_FMT_RGBA32F ? 16 : 8;
-    size_t off = 0;
-    for (int mip = 0; mip < MIPS; ++mip) {                                   // EnvironmentMapRendering.cpp:413-464
-        const int r = specRes0 >> mip;
-        hipError_t e = launch_conv_specular((hipStream_t)stream, (const float4*)equirect_mips, w0, h0, nMips, r, mip, MIPS, order, (char*)outCubeMips + off, fmt);
-        if (e != hipSuccess) return failHip(ctx, e, "conv_specular launch");
-        off += (size_t)6 * r * r * bpp;
-    }
-    return VQHIP_OK;
+    hipError_t e = launch_conv_specular_all((hipStream_t)stream, (const float4*)equirect_mips, w0, h0, nMips, specRes0, MIPS, order, outCubeMips, fmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "conv_specular launch");
 }
 
 int vqhip_envmap_prefilter(vqhip_ctx* ctx, void* stream, const void* equirect_mips, int w0, int h0, int nMips,

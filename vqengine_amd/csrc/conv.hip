@@ -162,47 +162,6 @@ __global__ __launch_bounds__(256) void k_brdf_lut(void* __restrict__ out, int si
     if (x < size) store_px<FMT>(out, (size_t)y * size + x, make_float4(F0Scale * rcount, F0Bias * rcount, 0, 0));
 }
 
-// The round-1/2 form of the same integration: every lane evaluates ImportanceSampleGGX for every sample (the per-sample
-// (sin phi, cos phi, Xi.y) table alone is shared through LDS). Kept for the A/B test of the two forms (VQHIP_LUT_FORM=persample;
-// tests/test_gpu_conv_forms.py: identical bits).
-template <int FMT>
-__global__ __launch_bounds__(256) void k_brdf_lut_persample(void* __restrict__ out, int size, int samples, int p5ExpLog) {
-    __shared__ float sSin[512], sCos[512], sXy[512];
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    const float NdotV = div_((float)x + 0.5f, (float)size);     // CubemapConvolution.hlsl:233-236
-    const float roughness = div_((float)y + 0.5f, (float)size);
-    const f3 V = mk3(sqrt_(1.0f - NdotV * NdotV), 0.0f, NdotV);
-    const f3 N = mk3(0.0f, 0.0f, 1.0f);
-    const float rcount = rcp((float)samples);
-    float F0Scale = 0.0f, F0Bias = 0.0f;
-    for (int base = 0; base < samples; base += 512) {
-        __syncthreads();
-        for (int j = threadIdx.x; j < 512; j += 256) {
-            const uint32_t i = (uint32_t)(base + j);
-            const float Xix = (float)i * rcount;                // Hammersley, ShadingMath.hlsl:119-127
-            float sp, cp; sincos_((2.0f * PI_) * Xix, &sp, &cp);
-            sSin[j] = sp; sCos[j] = cp; sXy[j] = RadicalInverse_VdC(i);
-        }
-        __syncthreads();
-        const int n = min(512, samples - base);
-        for (int j = 0; j < n; ++j) {                           // IntegrateBRDF, BRDF.hlsl:250-281
-            const f3 H = ImportanceSampleGGX(sXy[j], sSin[j], sCos[j], N, roughness);
-            const f3 L = normalize(reflect(neg(V), H));
-            const float NdotL = max_(L.z, 0.0f);
-            const float NdotH = max_(H.z, 0.0f);
-            const float VdotH = max_(dot(V, H), 0.0f);
-            if (NdotL > 0.0f) {
-                const float G = G1_env(N, V, roughness) * G1_env(N, L, roughness);
-                const float G_Vis = max_(div_(G * VdotH, NdotH * NdotV), 0.0001f);
-                const float Fc = p5ExpLog ? pow5_explog(1.0f - VdotH) : pow5(1.0f - VdotH);
-                F0Scale += (1.0f - Fc) * G_Vis;
-                F0Bias += Fc * G_Vis;
-            }
-        }
-    }
-    if (x < size) store_px<FMT>(out, (size_t)y * size + x, make_float4(F0Scale * rcount, F0Bias * rcount, 0, 0));
-}
-
 // ---- min-filter mip ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mip_min(const float4* __restrict__ src, float4* __restrict__ dst, int sw, int sh, int dw, int dh) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -495,47 +454,6 @@ __global__ __launch_bounds__(256) void k_conv_diffuse_ordered(const float4* __re
 }
 
 // ---- specular prefilter -------------------------------------------------------------------------------
-template <bool WAVE, int FMT>
-__global__ __launch_bounds__(256) void k_conv_specular(const float4* __restrict__ chain, int w0, int h0, int nMips, int res, int mip, int MIPS,
-                                                       void* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const long total = 6L * res * res;
-    const long texel = WAVE ? ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) : ((long)blockIdx.x * 256 + threadIdx.x);
-    if (texel >= total) return;
-    const int f = (int)(texel / ((long)res * res)), y = (int)((texel / res) % res), x = (int)(texel % res);
-    const float Roughness = div_((float)mip, (float)(MIPS - 1));                       // EnvironmentMapRendering.cpp:432
-    const f3 N = normalize(cube_texel_dir(f, x, y, res));
-    const f3 V = N;
-    const float fOmegaP = div_(4.0f * PI_, (6.0f * (float)w0) * (float)h0);            // :203 with TextureDimensionsLOD0 = equirect dims (:433-434)
-    const uint32_t NUM_SAMPLES = 512;
-    float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;
-    for (uint32_t i = WAVE ? (uint32_t)lane : 0u; i < NUM_SAMPLES; i += (WAVE ? 64u : 1u)) {
-        const float Xix = div_((float)i, (float)NUM_SAMPLES);
-        float sp, cp; sincos_((2.0f * PI_) * Xix, &sp, &cp);
-        const f3 H = ImportanceSampleGGX(RadicalInverse_VdC(i), sp, cp, N, Roughness);
-        const f3 L = reflect(neg(V), H);
-        const float NdotL = saturate(dot(N, L));
-        if (NdotL > 0.0f) {
-            const float NdotH = saturate(dot(N, H));
-            const float HdotV = saturate(dot(H, V));
-            const float D = NormalDistributionGGX(NdotH, Roughness);
-            const float pdf = div_(D * NdotH, 4.0f * HdotV);
-            const float fOmegaS = rcp(max_((float)NUM_SAMPLES * pdf, 0.00001f));
-            const float fMipLevel = (Roughness == 0.0f) ? 0.0f : max_(0.5f * log2_(div_(fOmegaS, fOmegaP)) + -1.0f, 0.0f);
-            const float2 uv = DirectionToEquirectUV(L);
-            const float4 c = sample_equirect_lod(chain, w0, h0, nMips, uv.x, uv.y, fMipLevel);
-            ax = ax + c.x * NdotL; ay = ay + c.y * NdotL; az = az + c.z * NdotL; aw = aw + NdotL;
-        }
-    }
-    if (WAVE) {
-        #pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) { ax = wave_xor_add(ax, m); ay = wave_xor_add(ay, m); az = wave_xor_add(az, m); aw = wave_xor_add(aw, m); }
-        if (lane != 0) return;
-    }
-    const float rw = rcp(max_(aw, 0.0001f));
-    store_px<FMT>(out, (size_t)texel, make_float4(ax * rw, ay * rw, az * rw, 1.0f));
-}
-
 // All mips of the prefiltered cube in ONE launch, WAVE64 order (one wave per texel): the 7 launches of the per-mip form leave the chip almost
 // empty for the five small mips (24 ... 1 536 waves). Block = 4 consecutive texels of the mip-major cube; every mip holds a multiple of 4 texels
 // (6 r^2, r >= 2), so a block lies in one mip = one roughness: the 512 tangent-space half vectors of (sample, roughness) — sincos_, the Van der Corput
@@ -716,11 +634,6 @@ hipError_t launch_unlit_composite(hipStream_t s, const float4* cov, int covPitch
 hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt, int p5ExpLog, const Options& opt) {
     dim3 grid((size + 255) / 256, size);
     const int allowFast = opt.lutForm != 1;                     // option "lut_form" = "general": the shared-H kernel with every range test left in
-    if (opt.lutForm == 2) {                                     // "persample"
-        if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut_persample<3>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
-        else                        hipLaunchKernelGGL((k_brdf_lut_persample<4>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog);
-        return hipGetLastError();
-    }
     if (fmt == VQHIP_FMT_RG16F) hipLaunchKernelGGL((k_brdf_lut<3>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog, allowFast);
     else                        hipLaunchKernelGGL((k_brdf_lut<4>), grid, dim3(256), 0, s, out, size, samples, p5ExpLog, allowFast);
     return hipGetLastError();
@@ -809,21 +722,6 @@ hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, 
         dim3 grid((unsigned)((total + 7) / 8));
         if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular_ordered<0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
         else                          hipLaunchKernelGGL((k_conv_specular_ordered<1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_conv_specular(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res, int mip, int MIPS,
-                                int order, void* out, int fmt) {
-    const long total = 6L * res * res;
-    if (order == VQHIP_CONV_WAVE64) {
-        dim3 grid((unsigned)((total + 3) / 4));
-        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular<true, 0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res, mip, MIPS, out);
-        else                          hipLaunchKernelGGL((k_conv_specular<true, 1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res, mip, MIPS, out);
-    } else {
-        dim3 grid((unsigned)((total + 255) / 256));
-        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular<false, 0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res, mip, MIPS, out);
-        else                          hipLaunchKernelGGL((k_conv_specular<false, 1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res, mip, MIPS, out);
     }
     return hipGetLastError();
 }

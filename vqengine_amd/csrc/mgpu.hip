@@ -113,7 +113,8 @@ int ensureStage(Rccl& r, vqhip_comm* c, hipStream_t st, size_t bytes) {
         const hipError_t e = hipStreamWaitEvent(st, c->stageFree, 0);
         if (e != hipSuccess) return vqk::fail_global(VQHIP_ERR_HIP, std::string("vqhip_exchange_blur_halos: hipStreamWaitEvent: ") + hipGetErrorString(e));
     }
-    if (c->stageBytes >= bytes) return VQHIP_OK;
+    if (c->stage && c->stageBytes >= bytes) return VQHIP_OK;
+    c->stageBytes = 0;                                       // the old block goes: a failed allocation below must not leave its size behind
     if (r.hostBuffers) { std::free(c->stage); c->stage = (char*)std::malloc(bytes); if (!c->stage) return vqk::fail_global(VQHIP_ERR_HIP, "staging allocation failed"); }
     else {
         if (c->stage) { (void)hipEventSynchronize(c->stageFree); (void)hipFree(c->stage); c->stage = nullptr; }

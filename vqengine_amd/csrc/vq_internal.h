@@ -22,16 +22,11 @@ struct Range {
 struct Options {
     int shadeWg = 0;            // "shade_wg"          : 64 | 128 | 256 lanes per workgroup of the shade kernel (default: by frame size)
     int psmainWaves = 0;        // "psmain_waves"      : 4 | 5 | 6 waves per SIMD of the fused PSMain kernel
-    int postOneKernel = 0;      // "post_one_kernel"   : 1 = k_post_chain2 (64 KB table), 2 = with the compact table ("1c")
-    int postSegments = 0;       // "post_segments"     : row segments of k_post_chain2
     int blurXWgs = 0;           // "blur_x_wgs"        : n > 0 = n persistent workgroups (k_blur_x4p)
     int blurYWgs = 0;           // "blur_y_wgs"        : workgroups of k_blur_y_tonemap_lut
-    int tonemapCompact = 0;     // "tonemap_form"      : "compact" = k_tonemap_c
-    char blurYForm[16] = "";    // "blur_y_form"       : "c8s", "c12", "c16sw5", "lut64", ...
-    int lutForm = 0;            // "lut_form"          : 1 "general", 2 "persample"
+    int lutForm = 0;            // "lut_form"          : 1 "general" (every range test left in)
     int diffuseForm = 0;        // "diffuse_form"      : 1 "texels", 2 "general" (default: footprint records)
     int diffuseSeqForm = 0;     // "diffuse_seq_form"  : 1 "lane" (default: k_conv_diffuse_ordered)
-    int specularForm = 0;       // "specular_form"     : 1 "permip"
 };
 
 // Device-resident per-call constant block == the cbuffers b0/b1 of ForwardLighting.hlsl:76-77 plus the
@@ -125,8 +120,6 @@ hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEn
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt, const Options& opt);
 hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H, int fmt);
 bool tonemap_uses_lut(const VQ_TonemapperParams& p, int inFmt, int outFmt, size_t nPixels);
-bool post_chain_fusable(const VQ_TonemapperParams& p, int inFmt, int outFmt, int W, int H);
-hipError_t launch_post_chain2(hipStream_t s, const void* in, void* out, int W, int H, const void* table, bool compactLut, const Options& opt);
 bool blur_y_tonemap_uses_lut(const VQ_TonemapperParams& p, int blurFmt, int outFmt, size_t nPixels);
 hipError_t launch_tonemap_lut_build(hipStream_t s, void* table, const VQ_TonemapperParams& p, int outFmt);
 hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, const void* lutTable, const Options& opt);
@@ -138,7 +131,5 @@ size_t conv_diffuse_record_bytes(int w0, int h0, int nMips);
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
                                       const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt, void* recBuf, const Options& opt);
 hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, int order, void* out, int fmt);
-hipError_t launch_conv_specular(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res, int mip, int MIPS,
-                                int order, void* out, int fmt);
 
 } // namespace vqk

@@ -234,8 +234,9 @@ def gbuffer_from_material(material_data, world_pos, world_normal, ambient_factor
       gb0 = (P, ao) with ao = fAmbientLightingFactor * ssao (:247,280-281; SSAO target cleared to 1 when off, SceneRendering.cpp:1543-1553)
       gb1 = (normalize(N), roughness)   gb2 = (diffuse, metalness)   gb3 = (emissiveColor, emissiveIntensity)
     world_pos / world_normal: float arrays [..., 3]. Returns 4 float32 arrays [..., 4]."""
-    if int(material_data.textureConfig) != 0:
-        raise NotImplementedError("textured materials need the G-buffer producer kernel (SURVEY.md §8f item 1)")
+    if int(material_data.textureConfig) != 0:         # a host-side helper for TEXTURE-LESS materials only; materials with maps go through the producer kernel:
+        raise ValueError("gbuffer_from_material() covers texture-less materials; pass textured materials to capi.Context.gbuffer_from_materials "
+                         "(vqhip_gbuffer_from_materials) or capi.Context.forward_lighting_from_materials, which sample the maps on the GPU")
     P = np.asarray(world_pos, np.float32)
     N = np.asarray(world_normal, np.float32)
     shape = P.shape[:-1]
