@@ -131,7 +131,8 @@ def test_set_arithmetic_and_set_option_argument_checks(ctx):
     assert ctx.lib.vqhip_set_option(ctx._h, b"shade_wg", b"100") == abi.VQHIP_ERR_INVALID_ARG
     assert ctx.lib.vqhip_set_option(ctx._h, b"lut_form", b"bogus") == abi.VQHIP_ERR_INVALID_ARG
     assert ctx.lib.vqhip_set_option(ctx._h, None, b"1") == abi.VQHIP_ERR_INVALID_ARG
-    for k, v in (("shade_wg", "128"), ("blur_y_form", "c8s"), ("diffuse_form", "texels"), ("post_one_kernel", "1c")):
+    assert ctx.lib.vqhip_set_option(ctx._h, b"post_one_kernel", b"1") == abi.VQHIP_ERR_INVALID_ARG      # a form removed in round 4 is an unknown key
+    for k, v in (("shade_wg", "128"), ("blur_y_wgs", "300"), ("diffuse_form", "texels"), ("diffuse_seq_form", "lane"), ("lut_form", "general"), ("psmain_waves", "6")):
         ctx.set_option(k, v)
         ctx.set_option(k, None)
         ctx.set_option(k, "default")
