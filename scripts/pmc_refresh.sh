@@ -25,6 +25,14 @@ run cfg5_product_valu  "SQ_INSTS_VALU SQ_WAVES" "--config cfg5"
 run cfg5_product_trans "SQ_INSTS_VALU_TRANS"    "--config cfg5"
 run cfg5_product_fetch "FETCH_SIZE"             "--config cfg5"
 run cfg5_product_write "WRITE_SIZE"             "--config cfg5"
+run2() {  # cfg2: the shade kernel alone (scripts/run_cfg2_once.py)
+  rm -rf gpurun_out/pmc/$1
+  timeout 300 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d gpurun_out/pmc/$1 -- python scripts/run_cfg2_once.py > /dev/null 2>&1
+  echo "pass $1 rc=$?"
+}
+run2 cfg2_product_valu  "SQ_INSTS_VALU SQ_WAVES"
+run2 cfg2_product_fetch "FETCH_SIZE"
+run2 cfg2_product_write "WRITE_SIZE"
 python - <<PY
 import csv, glob, json, os, statistics as st, sys
 sys.path.insert(0, os.getcwd())
@@ -38,7 +46,7 @@ def med(tag, counter):
 out = {"kernel_sources_sha256": bench.kernel_source_hash(), "measured_at_commit": os.environ.get("VQ_COMMIT", "unknown"),
        "profile": "scripts/pmc_refresh.sh: rocprofv3 --pmc <counter> --kernel-trace, one pass per counter group, medians over the shade launches of bench.py --steps 6",
        "sources": bench.PMC_SOURCES}
-for key, tag in (("cfg3/product", "cfg3_product"), ("cfg3/exp2_log2", "cfg3_exp2"), ("cfg3_coherent/product", "cfg3c_product"), ("cfg5/product", "cfg5_product")):
+for key, tag in (("cfg3/product", "cfg3_product"), ("cfg3/exp2_log2", "cfg3_exp2"), ("cfg3_coherent/product", "cfg3c_product"), ("cfg5/product", "cfg5_product"), ("cfg2/product", "cfg2_product")):
     valu, waves = med(tag + "_valu", "SQ_INSTS_VALU"), med(tag + "_valu", "SQ_WAVES")
     if not valu or not waves:
         print("no VALU counters for", key); continue
