@@ -1,10 +1,13 @@
 #!/bin/bash
 # Where the shade kernel's cycles go (run on the GPU box): SQ busy / wave / instruction-issue counters, one rocprofv3 pass per group.
+# usage: bash scripts/pmc_shade_util.sh [cfg2]   (cfg2: the 1080p / 16-light launch of scripts/run_cfg2_once.py instead of the cfg3 headline)
 cd /tmp && export TMPDIR=/tmp && cd ${GRAFT_REPO_ROOT:-/root/repo}
 i=0
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY"; do
+CMD="python bench.py --no-cpu-baseline --no-second-mode --no-extras --steps 10 --warmup 3"
+[ "$1" = "cfg2" ] && CMD="env VQ_CFG2_REPS=200 python scripts/run_cfg2_once.py"
+for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_WAVES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_SALU SQ_WAIT_INST_LDS SQ_IFETCH SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC" "GRBM_GUI_ACTIVE SQ_LEVEL_WAVES SQ_ACCUM_PREV_HIRES"; do
   i=$((i+1)); rm -rf gpurun_out/pmc_util_$i
-  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmc_util_$i -- python bench.py --no-cpu-baseline --no-second-mode --steps 10 --warmup 3 > /dev/null 2>gpurun_out/pmc_util_$i.err
+  timeout 200 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d gpurun_out/pmc_util_$i -- $CMD > /dev/null 2>gpurun_out/pmc_util_$i.err
   echo "group $i rc=$? : $grp"
 done
 python - <<PY
