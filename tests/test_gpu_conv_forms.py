@@ -75,13 +75,37 @@ def test_conv_diffuse_pole_texels_and_axis_taps(ctx, res, order):
         assert_bits(ctx.conv_diffuse(chain_g, 256, 128, n, res, step, order, abi.FMT_RGBA32F), ref, f"diffuse res={res} step={step} order={order}")
 
 
+@pytest.mark.parametrize("order", [abi.CONV_SEQUENTIAL, abi.CONV_WAVE64])
 @pytest.mark.parametrize("w,h", [(96, 48), (100, 50), (16, 8), (8, 4), (4, 2)])
-def test_conv_diffuse_other_chains(ctx, w, h):
+def test_conv_diffuse_other_chains(ctx, w, h, order):
     """Non-power-of-two chains (the fast tap is off: integer-modulo wrap) and chains whose last level is above mip 3 (the sampled level is
     clamped to the chain: 1 x 1 ... 2 x 1 images, every tap wraps)."""
     _, chain_o, chain_g, n = _chain(w, h, seed=0x52)
-    ref = O.conv_diffuse(chain_o, w, h, n, 4, 0.1, abi.CONV_WAVE64, abi.FMT_RGBA32F)
-    assert_bits(ctx.conv_diffuse(chain_g, w, h, n, 4, 0.1, abi.CONV_WAVE64, abi.FMT_RGBA32F), ref, f"diffuse from a {w}x{h} chain ({n} levels)")
+    ref = O.conv_diffuse(chain_o, w, h, n, 4, 0.1, order, abi.FMT_RGBA32F)
+    assert_bits(ctx.conv_diffuse(chain_g, w, h, n, 4, 0.1, order, abi.FMT_RGBA32F), ref, f"diffuse from a {w}x{h} chain ({n} levels), order {order}")
+
+
+@pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+@pytest.mark.parametrize("res,step", [(1, 0.3), (2, 0.11), (3, 0.7), (5, 0.05), (6, 1.2), (12, 0.031), (16, 0.2)])
+def test_conv_diffuse_ordered_ragged_shapes(ctx, set_opt, res, step, fmt):
+    """k_conv_diffuse_ordered where nothing divides evenly: cubes of 6 ... 1 536 texels (partial blocks; resolutions that are no multiple of 4 use the
+    row-major texel list instead of 4 x 4 patches), steps whose theta count is below the 16 taps of a step (a lane's tap wraps over several phis at once),
+    a last round of fewer than 32 taps, both storage formats — against the oracle and against the one-lane-per-texel kernel of the same order."""
+    _, chain_o, chain_g, n = _chain(256, 128, seed=0x57)
+    with np.errstate(all="ignore"):
+        ref = O.conv_diffuse(chain_o, 256, 128, n, res, step, abi.CONV_SEQUENTIAL, fmt)
+    got = ctx.conv_diffuse(chain_g, 256, 128, n, res, step, abi.CONV_SEQUENTIAL, fmt)
+    assert_bits(got, ref, f"ordered diffuse res={res} step={step}")
+    set_opt("diffuse_seq_form", "lane")
+    _same(ctx.conv_diffuse(chain_g, 256, 128, n, res, step, abi.CONV_SEQUENTIAL, fmt), got, f"ordered vs lane form, res={res} step={step}")
+
+
+def test_conv_diffuse_step_too_small_for_the_lds_tables_falls_back(ctx):
+    """a step whose (sin, cos) tables of both loops exceed the ordered kernel's LDS budget runs the one-lane-per-texel kernel: same bits as the oracle"""
+    _, chain_o, chain_g, n = _chain(64, 32, seed=0x58)
+    step = 0.0012                                            # 5 236 phis + 1 309 thetas = 52 KB of tables next to 17 KB of tap buffers: over 64 KB
+    ref = O.conv_diffuse(chain_o, 64, 32, n, 1, step, abi.CONV_SEQUENTIAL, abi.FMT_RGBA32F)
+    assert_bits(ctx.conv_diffuse(chain_g, 64, 32, n, 1, step, abi.CONV_SEQUENTIAL, abi.FMT_RGBA32F), ref, "diffuse, step 0.0012 (lane fallback)")
 
 
 def test_conv_diffuse_nonfinite_texels(ctx):
