@@ -879,7 +879,18 @@ def widened_report(ctx, env, spec_mips):
     ms = _stage_ms(lambda: ctx.forward_lighting_from_materials(ipd, dmats, pf, pv, ssao=ssao, out=scene, out_fmt=F16, extra_point=extra, env=env))
     res["psmain_fused"] = entry(ms, 57, valu_frac_model=round((170 * 64 + 160) * px / ms / 1e9 / VALU_PEAK_TFLOPS, 4),
                                 what="vqhip_forward_lighting_from_materials: PSMain as ONE kernel (producer + 64 point lights + IBL), 48 + 1 B in, 8 B out; VALU-bound like the headline's shade kernel")
-    del gb, ipd, ssao, keep
+    # the same draw with its other render targets bound (OUTPUT_ALBEDO + OUTPUT_MOTION_VECTORS, ForwardLighting.hlsl:382-389), and the Z pre-pass's normals
+    svc, svp = (dev(tile(a_)) for a_ in synth.clip_positions(W, BAND))
+    tg, _alb, _mv = ctx._psmain_targets(H, W, F16, abi.FMT_RG16F, svc, svp)
+    ms_mrt = _stage_ms(lambda: ctx.forward_lighting_from_materials(ipd, dmats, pf, pv, ssao=ssao, out=scene, out_fmt=F16, extra_point=extra, env=env, _targets=tg))
+    res["psmain_fused_mrt"] = entry(ms_mrt, 101, extra_ms_over_psmain_fused=round(ms_mrt - ms, 4),
+                                    what="vqhip_forward_lighting_from_materials_mrt: the same kernel also writing SV_TARGET1 (albedo, metalness: RGBA16F) and the motion "
+                                         "vectors (RG16F, from two float4 clip-position planes): + 32 B in, + 12 B out per pixel")
+    nrm = torch.empty((H, W), dtype=torch.int32, device="cuda")
+    res["scene_normals_prepass"] = entry(_stage_ms(lambda: ctx.scene_normals_from_materials(ipd, dmats, out=nrm)), 52,
+                                         what="vqhip_scene_normals_from_materials (DepthPrePass.hlsl:PSMain): 3 interpolant planes -> Tex_SceneNormals R10G10B10A2, normal maps "
+                                              "(+ diffuse alpha of masked materials) cache resident: 48 B in, 4 B out")
+    del gb, ipd, ssao, keep, svc, svp, _alb, _mv, nrm
     # ---- 8f.2: skydome, all-sky frame (worst case), RGBA16F target, 2048^2 equirect
     import math
     from vqengine_amd import scene as scene_mod

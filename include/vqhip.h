@@ -64,7 +64,7 @@ typedef enum vqhip_format {
     VQHIP_FMT_RGBA8_UNORM = 2,
     VQHIP_FMT_RG16F       = 3,
     VQHIP_FMT_RG32F       = 4,
-    VQHIP_FMT_R10G10B10A2_UNORM = 5   /* Tex_SceneNormals (RenderResources.cpp:185-197): input of vqhip_ssr_environment_fallback only */
+    VQHIP_FMT_R10G10B10A2_UNORM = 5   /* Tex_SceneNormals (RenderResources.cpp:185-197): output of vqhip_scene_normals_from_materials, input of vqhip_ssr_environment_fallback */
 } vqhip_format;
 
 /* ------------------------------------------------------------------------------------------------
@@ -336,7 +336,8 @@ VQHIP_API int  vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode);
 VQHIP_API int  vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value);
 typedef enum vqhip_arithmetic { VQHIP_ARITH_LITERAL = 0, VQHIP_ARITH_DXC = 1 } vqhip_arithmetic;
 VQHIP_API int  vqhip_set_arithmetic(vqhip_ctx* ctx, vqhip_arithmetic mode);
-#define VQHIP_ABI_VERSION 2   /* 2 (round 4): + vqhip_set_arithmetic, vqhip_set_option, vqhip_ssr_environment_fallback, VQHIP_FMT_R10G10B10A2_UNORM; conv order default SEQUENTIAL */
+#define VQHIP_ABI_VERSION 2   /* 2 (round 4): + vqhip_set_arithmetic, vqhip_set_option, vqhip_ssr_environment_fallback, VQHIP_FMT_R10G10B10A2_UNORM; conv order default SEQUENTIAL;
+                               * later in round 4, additions only: vqhip_forward_lighting_mrt, vqhip_forward_lighting_from_materials_mrt, vqhip_scene_normals_from_materials */
 
 /* Replaces VQRenderer::RenderSceneColor's lit draw loop (SceneRendering.cpp:1619-1785, hot part :1730-1784)
  * == ForwardLighting.hlsl:PSMain :289-380 evaluated for every pixel of the G-buffer.
@@ -353,6 +354,33 @@ VQHIP_API int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream,
         const VQ_PointLight* extraPoint, int numExtraPoint,
         const vqhip_envmap* env, const vqhip_shadowmaps* sm,
         void* out, int out_row_pitch_px, vqhip_format outFmt);
+
+/* The other render targets of the same draw: the PSO permutations OUTPUT_ALBEDO / OUTPUT_MOTION_VECTORS of ForwardLighting.hlsl
+ * (PipelineStateObjects.cpp:1499-1504,1547-1563; PSOutput :57-68; written at :382-389; bound by RenderSceneColor, SceneRendering.cpp:1647-1680):
+ *   albedo_metallic : SV_TARGET1 = float4(Surface.diffuseColor, Surface.metalness) (:383) — Tex_SceneVisualization, RGBA16F (RenderResources.cpp:171-175)
+ *                     | RGBA32F; NULL = the permutation without OUTPUT_ALBEDO
+ *   motion_vectors  : float2(svPositionCurr.xy / svPositionCurr.w - svPositionPrev.xy / svPositionPrev.w) (:387) — Tex_SceneMotionVectors, RG16F
+ *                     (RenderResources.cpp:178-182) | RG32F; NULL = the permutation without OUTPUT_MOTION_VECTORS
+ *   svPositionCurr / svPositionPrev : two more planes of the rasteriser's output (PSInput :49-52, TEXCOORD1 / TEXCOORD2): the interpolated clip-space
+ *                     positions mul(matWorldViewProj, v) and mul(matWorldViewProjPrev, v) of TransformVertex :172-185, float4 per pixel, sv_pitch_px
+ *                     pixels per row (0 = width). Required iff motion_vectors is set.
+ * Every pixel of the frame is written from the planes as given (a rasteriser leaves uncovered pixels at the clear value: give them equal
+ * positions with w = 1, or composite afterwards). Device pointers; pitches in pixels (0 = width). */
+typedef struct vqhip_psmain_targets {
+    void*       albedo_metallic;  vqhip_format albedo_fmt;  int32_t albedo_pitch_px;
+    void*       motion_vectors;   vqhip_format motion_fmt;  int32_t motion_pitch_px;
+    const void* svPositionCurr;   const void*  svPositionPrev;  int32_t sv_pitch_px;  int32_t pad_;
+} vqhip_psmain_targets;
+VQHIP_STATIC_ASSERT(sizeof(vqhip_psmain_targets) == 56, "vqhip_psmain_targets");
+
+/* vqhip_forward_lighting + the extra targets, in the same kernel (the G-buffer record is in registers: + 8 B/pixel written for SV_TARGET1,
+ * + 32 B read and 4 B written per pixel for the motion vectors). targets == NULL or both outputs NULL: exactly vqhip_forward_lighting. */
+VQHIP_API int vqhip_forward_lighting_mrt(vqhip_ctx* ctx, void* stream,
+        const vqhip_gbuffer* gb,
+        const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+        const VQ_PointLight* extraPoint, int numExtraPoint,
+        const vqhip_envmap* env, const vqhip_shadowmaps* sm,
+        void* out, int out_row_pitch_px, vqhip_format outFmt, const vqhip_psmain_targets* targets);
 
 /* Replaces the GaussianBlur.hlsl CSMain_X / CSMain_Y dispatches (EnvironmentMapRendering.cpp:279-373,
  * SceneRendering.cpp:2582-2638): 21-tap separable Gaussian, clamp-to-edge, alpha := 1.
@@ -469,6 +497,29 @@ VQHIP_API int vqhip_forward_lighting_from_materials(vqhip_ctx* ctx, void* stream
         const VQ_PointLight* extraPoint, int numExtraPoint,
         const vqhip_envmap* env, const vqhip_shadowmaps* sm,
         void* out, int out_row_pitch_px, vqhip_format outFmt);
+/* the same with the extra render targets of the draw (vqhip_psmain_targets above); bit-identical to vqhip_gbuffer_from_materials + vqhip_forward_lighting_mrt */
+VQHIP_API int vqhip_forward_lighting_from_materials_mrt(vqhip_ctx* ctx, void* stream,
+        const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials, const vqhip_ssao* ssao,
+        const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+        const VQ_PointLight* extraPoint, int numExtraPoint,
+        const vqhip_envmap* env, const vqhip_shadowmaps* sm,
+        void* out, int out_row_pitch_px, vqhip_format outFmt, const vqhip_psmain_targets* targets);
+
+/* Replaces the pixel shader of the Z pre-pass (VQRenderer::RenderDepthPrePass, SceneRendering.cpp:1264-1360; Shaders/DepthPrePass.hlsl:PSMain :153-171) for
+ * every pixel of the interpolant planes: Tex_SceneNormals, the packed surface normals that SSR (`g_normal` of vqhip_ssr_environment_fallback) and
+ * FFX-CACAO read —
+ *     float4((SurfaceN + 1) * 0.5, 1),   SurfaceN = length(Normal) < 0.01 ? normalize(WorldSpaceNormal) : UnpackNormal(Normal, N, T)
+ * the surface normal of ForwardLighting.hlsl:265-267, except that the normal map is fetched with Sample — no normalMapMipBias (:164) — and the diffuse map
+ * only for the alpha test of the "_AlphaMasked" PSOs (VQHIP_MATERIAL_ALPHA_MASKED, :157-161). Pixels without geometry and discarded fragments keep the
+ * target's clear value 0 (SceneRendering.cpp:1289-1300). The coverage plane in->ip2.w is NOT modified (the lighting pass repeats the discard itself).
+ *   out    : outFmt R10G10B10A2_UNORM — the reference's format (RenderResources.cpp:185-197, PipelineStateObjects.cpp:1634-1635): one uint32 per pixel,
+ *            r in bits 0-9, g 10-19, b 20-29, alpha 30-31 (1 -> 3); float -> UNORM n = trunc(saturate(c) * (2^n - 1) + 0.5) —
+ *            or RGBA32F holding the unquantised float4 (w = 1 covered / 0 not). out_row_pitch_px pixels per row (0 = width).
+ *   materials : HOST array, as for vqhip_gbuffer_from_materials; vqhip_set_arithmetic selects the reading of normalize / dot here too.
+ * The depth half of the pre-pass (the rasteriser's z) stays with the caller, like the interpolant planes. */
+VQHIP_API int vqhip_scene_normals_from_materials(vqhip_ctx* ctx, void* stream,
+        const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
+        void* out, vqhip_format outFmt, int out_row_pitch_px);
 
 /* Replaces VQ_DXGI_UTILS::MipImage's 4-byte branch (DXGIUtils.cpp:264-285) as driven by
  * TextureManager::GenerateMips: each channel = (sum of the 2x2 block) / 4, integer division.

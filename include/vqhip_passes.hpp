@@ -91,6 +91,11 @@ public:
         int NumExtraPointLights = 0;
         const vqhip_envmap* pEnvironmentMap = nullptr;           // nullptr == bDrawEnvironmentMap false (NullCubemapSRV, :1698-1709)
         const vqhip_shadowmaps* pShadowMaps = nullptr;
+        // the draw's other render targets (SceneRendering.cpp:1640-1641,1662-1663 -> PSO permutations OUTPUT_ALBEDO / OUTPUT_MOTION_VECTORS)
+        bool bUseVisualizationRenderTarget = false;              // SV_TARGET1 = (albedo, metalness) into Tex_SceneVisualization (RGBA16F)
+        bool bRenderMotionVectors = false;                       // motion vectors into Tex_SceneMotionVectors (RG16F); needs the two planes below
+        const void* pSvPositionCurr = nullptr;                   // PSInput.svPositionCurr / svPositionPrev (ForwardLighting.hlsl:49-52): float4 per pixel, tightly packed
+        const void* pSvPositionPrev = nullptr;
     };
     explicit HipForwardLightingPass(vqhip_ctx* Ctx) : RenderPassBase(Ctx) {}
     ~HipForwardLightingPass() override { OnDestroyWindowSizeDependentResources(); }
@@ -102,7 +107,7 @@ public:
         mSceneColor = Alloc((size_t)Width * Height * 8);
     }
     void OnDestroyWindowSizeDependentResources() override {
-        Free(mSceneColor);
+        Free(mSceneColor); Free(mSceneVisualization); Free(mSceneMotionVectors);
         for (void*& g : mGB) Free(g);
         mWidth = mHeight = 0;
     }
@@ -118,14 +123,28 @@ public:
                                                    p->pPerFrame->fAmbientLightingFactor, p->pScreenSpaceAO, &gb);
             if (mStatus != VQHIP_OK) return;
         }
-        mStatus = vqhip_forward_lighting(mCtx, p->Stream, &gb, p->pPerFrame, p->pPerView, p->pExtraPointLights, p->NumExtraPointLights,
-                                         p->pEnvironmentMap, p->pShadowMaps, mSceneColor, (int)mWidth, VQHIP_FMT_RGBA16F);
+        vqhip_psmain_targets t = {};
+        if (p->bUseVisualizationRenderTarget) {
+            if (!mSceneVisualization) mSceneVisualization = Alloc((size_t)mWidth * mHeight * 8);
+            t.albedo_metallic = mSceneVisualization; t.albedo_fmt = VQHIP_FMT_RGBA16F;
+        }
+        if (p->bRenderMotionVectors) {
+            if (!mSceneMotionVectors) mSceneMotionVectors = Alloc((size_t)mWidth * mHeight * 4);
+            t.motion_vectors = mSceneMotionVectors; t.motion_fmt = VQHIP_FMT_RG16F;
+            t.svPositionCurr = p->pSvPositionCurr; t.svPositionPrev = p->pSvPositionPrev;
+        }
+        mStatus = vqhip_forward_lighting_mrt(mCtx, p->Stream, &gb, p->pPerFrame, p->pPerView, p->pExtraPointLights, p->NumExtraPointLights,
+                                             p->pEnvironmentMap, p->pShadowMaps, mSceneColor, (int)mWidth, VQHIP_FMT_RGBA16F, &t);
     }
     void* GetSceneColor() const { return mSceneColor; }          // RGBA16F, width*height
+    void* GetSceneVisualization() const { return mSceneVisualization; }   // RGBA16F (albedo, metalness); nullptr until a draw asked for it
+    void* GetSceneMotionVectors() const { return mSceneMotionVectors; }   // RG16F; nullptr until a draw asked for it
     unsigned Width() const { return mWidth; }
     unsigned Height() const { return mHeight; }
 private:
     void* mSceneColor = nullptr;
+    void* mSceneVisualization = nullptr;                         // Tex_SceneVisualization (RenderResources.cpp:171-175)
+    void* mSceneMotionVectors = nullptr;                         // Tex_SceneMotionVectors (RenderResources.cpp:178-182)
     void* mGB[4] = { nullptr, nullptr, nullptr, nullptr };       // G-buffer planes of the §8f.1 producer path
     unsigned mWidth = 0, mHeight = 0;
 };
@@ -323,6 +342,40 @@ public:
     void* GetExtractedRoughness() const { return mExtractedRoughness; }  // R8_UNORM
 private:
     void* mRadiance = nullptr; void* mExtractedRoughness = nullptr;
+    unsigned mWidth = 0, mHeight = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// Z pre-pass colour target == the pixel-shader half of VQRenderer::RenderDepthPrePass (SceneRendering.cpp:1264-1360, DepthPrePass.hlsl:PSMain): owns
+// Tex_SceneNormals (R10G10B10A2_UNORM, RenderResources.cpp:185-197) — HipSSREnvironmentFallbackPass::FDrawParameters::TexNormals. The depth target of the
+// same draws is the rasteriser's and stays with the caller, like the interpolant planes.
+// ---------------------------------------------------------------------------------------------------------------
+class HipDepthPrePassNormals : public RenderPassBase {
+public:
+    struct FDrawParameters : public IRenderPassDrawParameters {
+        void* Stream = nullptr;
+        const vqhip_interpolants* pInterpolants = nullptr;       // the rasterised PSInput (DepthPrePass.hlsl:38-49: the same five attributes the lit draws get)
+        const vqhip_material* pMaterials = nullptr;              // cbPerObject.materialData + texDiffuse / texNormals of every material on screen
+        int NumMaterials = 0;
+    };
+    explicit HipDepthPrePassNormals(vqhip_ctx* Ctx) : RenderPassBase(Ctx) {}
+    ~HipDepthPrePassNormals() override { OnDestroyWindowSizeDependentResources(); }
+    bool Initialize() override { return mCtx != nullptr; }
+    void Destroy() override { OnDestroyWindowSizeDependentResources(); }
+    void OnCreateWindowSizeDependentResources(unsigned Width, unsigned Height, const IRenderPassResourceCollection* = nullptr) override {
+        OnDestroyWindowSizeDependentResources();
+        mWidth = Width; mHeight = Height;
+        mSceneNormals = Alloc((size_t)Width * Height * 4);
+    }
+    void OnDestroyWindowSizeDependentResources() override { Free(mSceneNormals); mWidth = mHeight = 0; }
+    void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) override {
+        const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
+        if (!p || !mSceneNormals) { mStatus = VQHIP_ERR_INVALID_ARG; return; }
+        mStatus = vqhip_scene_normals_from_materials(mCtx, p->Stream, p->pInterpolants, p->pMaterials, p->NumMaterials, mSceneNormals, VQHIP_FMT_R10G10B10A2_UNORM, (int)mWidth);
+    }
+    void* GetSceneNormals() const { return mSceneNormals; }      // R10G10B10A2_UNORM, width*height uint32
+private:
+    void* mSceneNormals = nullptr;
     unsigned mWidth = 0, mHeight = 0;
 };
 

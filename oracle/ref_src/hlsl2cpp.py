@@ -44,6 +44,7 @@ CUTS = [
      "ClassifyTiles / CSMain: wave intrinsics (WaveReadLaneAt, WavePrefixCountBits ...); the three lines of ClassifyTiles that call SampleEnvironmentMap "
      "(:146-152) are restated by the harness ref_ssr.cpp, like the rasteriser around PSMain"),
     ("ForwardLighting.hlsl", "PSInput TransformVertex(", "PSOutput PSMain(", "vertex stage: outside the path, uses float4x3 casts of the world matrices"),
+    ("DepthPrePass.hlsl", "PSInput TransformVertex(", "float4 PSMain(PSInput In)", "vertex stage + the Tessellation.hlsl include: outside the path (as for ForwardLighting.hlsl)"),
     ("CubemapConvolution.hlsl", "GSOut VSMain_PerFace(", "float4 PSMain_DiffuseIrradiance(", "vertex / geometry stages (TriangleStream): the cube rasterisation is the harness's"),
 ]
 

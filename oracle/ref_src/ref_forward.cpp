@@ -96,9 +96,30 @@ extern "C" {
 // PSMain over an image of interpolants (include/vqhip.h vqhip_interpolants) + material table: the reference's whole pixel
 // shader, i.e. what the oracle splits into vqo_gbuffer_from_materials + vqo_forward_lighting. out = RGBA32F [H][W][4].
 // Pixels whose material index is outside the table get zeros (no geometry; not a reference concept).
+// The permutation with the other render targets (the "mrt" build: -DOUTPUT_ALBEDO=1 -DOUTPUT_MOTION_VECTORS=1, PipelineStateObjects.cpp:1547-1563):
+//   svCurr / svPrev : float4 planes = PSInput.svPositionCurr / svPositionPrev (:49-52), svPitch pixels per row
+//   outAlbedo [H][W][4], outMotion [H][W][2] : PSOutput.albedo_metallic / motion_vectors as float32 (the render targets' fp16 rounding is the caller's)
+static int psmainImage(const vqhip_interpolants* in, const vqhip_material* mats, int nMats, const vqhip_ssao* ssao,
+                       const VQ_PerFrameData* pf, const VQ_PerViewLightingData* pv, const vqhip_envmap* env, const vqhip_shadowmaps* sm, float* out,
+                       const float* svCurr, const float* svPrev, int svPitch, float* outAlbedo, float* outMotion);
 int vqref_forward_psmain(const vqhip_interpolants* in, const vqhip_material* mats, int nMats, const vqhip_ssao* ssao,
                          const VQ_PerFrameData* pf, const VQ_PerViewLightingData* pv, const vqhip_envmap* env,
                          const vqhip_shadowmaps* sm, float* out) {
+    return psmainImage(in, mats, nMats, ssao, pf, pv, env, sm, out, nullptr, nullptr, 0, nullptr, nullptr);
+}
+int vqref_forward_psmain_mrt(const vqhip_interpolants* in, const vqhip_material* mats, int nMats, const vqhip_ssao* ssao,
+                             const VQ_PerFrameData* pf, const VQ_PerViewLightingData* pv, const vqhip_envmap* env, const vqhip_shadowmaps* sm, float* out,
+                             const float* svCurr, const float* svPrev, int svPitch, float* outAlbedo, float* outMotion) {
+#if PS_OUTPUT_ALBEDO_METALLIC && PS_OUTPUT_MOTION_VECTORS
+    if (!svCurr || !svPrev || !outAlbedo || !outMotion) return -1;
+    return psmainImage(in, mats, nMats, ssao, pf, pv, env, sm, out, svCurr, svPrev, svPitch, outAlbedo, outMotion);
+#else
+    return -3;                                              // this build is a permutation without the extra targets
+#endif
+}
+static int psmainImage(const vqhip_interpolants* in, const vqhip_material* mats, int nMats, const vqhip_ssao* ssao,
+                       const VQ_PerFrameData* pf, const VQ_PerViewLightingData* pv, const vqhip_envmap* env, const vqhip_shadowmaps* sm, float* out,
+                       const float* svCurr, const float* svPrev, int svPitch, float* outAlbedo, float* outMotion) {
     if (!in || !pf || !pv || !out) return -1;
     fillFrame(*pf, *pv);
     bindScene(env, sm);
@@ -112,7 +133,14 @@ int vqref_forward_psmain(const vqhip_interpolants* in, const vqhip_material* mat
             const size_t o = ((size_t)y * P + x) * 4;
             float* dst = out + ((size_t)y * W + x) * 4;
             const int idx = matIndex(ip2, o);
-            if (idx < 0 || idx >= nMats) { dst[0] = dst[1] = dst[2] = dst[3] = 0.0f; continue; }
+            float* dstA = outAlbedo ? outAlbedo + ((size_t)y * W + x) * 4 : nullptr;
+            float* dstM = outMotion ? outMotion + ((size_t)y * W + x) * 2 : nullptr;
+            if (idx < 0 || idx >= nMats) {
+                dst[0] = dst[1] = dst[2] = dst[3] = 0.0f;
+                if (dstA) dstA[0] = dstA[1] = dstA[2] = dstA[3] = 0.0f;
+                if (dstM) dstM[0] = dstM[1] = 0.0f;                                  // the targets' clear value (SceneRendering.cpp:1659-1668)
+                continue;
+            }
             const vqhip_material& mt = mats[idx];
             fillMaterial(mt.data);
             bindTex(texDiffuse, mt.texDiffuse); bindTex(texNormals, mt.texNormals); bindTex(texEmissive, mt.texEmissive);
@@ -138,10 +166,20 @@ int vqref_forward_psmain(const vqhip_interpolants* in, const vqhip_material* mat
             In.WorldSpaceNormal = float3(ip1[o], ip1[o + 1], ip1[o + 2]);
             In.WorldSpaceTangent = float3(ip2[o], ip2[o + 1], ip2[o + 2]);
             In.uv = float2(ip0[o + 3], ip1[o + 3]);
+#if PS_OUTPUT_MOTION_VECTORS
+            if (svCurr) {
+                const float* c = svCurr + ((size_t)y * svPitch + x) * 4; const float* p = svPrev + ((size_t)y * svPitch + x) * 4;
+                In.svPositionCurr = float4(c[0], c[1], c[2], c[3]); In.svPositionPrev = float4(p[0], p[1], p[2], p[3]);
+            }
+#endif
             g_ctx.discarded = false;
             const PSOutput r = PSMain(In);
             if (g_ctx.discarded) { dst[0] = dst[1] = dst[2] = dst[3] = -1.0f; continue; }      // sentinel: no colour is negative
             dst[0] = r.color.x; dst[1] = r.color.y; dst[2] = r.color.z; dst[3] = r.color.w;
+#if PS_OUTPUT_ALBEDO_METALLIC && PS_OUTPUT_MOTION_VECTORS
+            if (dstA) { dstA[0] = r.albedo_metallic.x; dstA[1] = r.albedo_metallic.y; dstA[2] = r.albedo_metallic.z; dstA[3] = r.albedo_metallic.w; }
+            if (dstM) { dstM[0] = r.motion_vectors.x; dstM[1] = r.motion_vectors.y; }
+#endif
         }
     return 0;
 }

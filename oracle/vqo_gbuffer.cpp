@@ -64,6 +64,47 @@ inline f2 uv_transformed(const Planes& p, int x, int y, const VQ_MaterialData& m
     return { p.ip0[o + 3] * m.uvScaleOffset.x + m.uvScaleOffset.z, p.ip1[o + 3] * m.uvScaleOffset.y + m.uvScaleOffset.w };
 }
 
+// implicit derivatives of the transformed uv over the pixel's 2x2 quad (contract above): 0 where the neighbour is off the image or another material
+inline void quad_derivatives(const Planes& in, int x, int y, int idx, const VQ_MaterialData& m, f2* ddx, f2* ddy) {
+    *ddx = { 0, 0 }; *ddy = { 0, 0 };
+    const int xa = x & ~1, xb = x | 1, ya = y & ~1, yb = y | 1;
+    if (xb < in.W && mat_index(in, xa, y) == idx && mat_index(in, xb, y) == idx) {
+        const f2 a = uv_transformed(in, xa, y, m), b = uv_transformed(in, xb, y, m);
+        *ddx = { b.x - a.x, b.y - a.y };
+    }
+    if (yb < in.H && mat_index(in, x, ya) == idx && mat_index(in, x, yb) == idx) {
+        const f2 a = uv_transformed(in, x, ya, m), b = uv_transformed(in, x, yb, m);
+        *ddy = { b.x - a.x, b.y - a.y };
+    }
+}
+
+// DepthPrePass.hlsl:PSMain :153-171 for one pixel: the packed surface normal (SurfaceN + 1) * 0.5 that the Z pre-pass writes to Tex_SceneNormals — the
+// `g_normal` of SSR (vqo_ssr_environment_fallback) and of FFX-CACAO. Same surface normal as ForwardLighting.hlsl:265-267, but the normal map is fetched
+// with Sample (no normalMapMipBias, :163) and the diffuse map only for the alpha test of the "_AlphaMasked" permutation (:157-161).
+// Returns false for a pixel without geometry or a discarded fragment (the target keeps its clear value 0, SceneRendering.cpp:1289-1300).
+bool scene_normal_pixel(const Planes& in, int x, int y, const vqhip_material* mats, int nMats, float* n01) {
+    const int idx = mat_index(in, x, y);
+    if (idx < 0 || idx >= nMats) return false;
+    const vqhip_material& mt = mats[idx];
+    const VQ_MaterialData& m = mt.data;
+    const size_t o = ((size_t)y * in.pitch + x) * 4;
+    const f2 uv = uv_transformed(in, x, y, m);                                          // :155
+    f2 ddx, ddy;
+    quad_derivatives(in, x, y, idx, m, &ddx, &ddy);
+    if (mt.texDiffuse.reserved & VQHIP_MATERIAL_ALPHA_MASKED) {                         // #if ENABLE_ALPHA_MASK :157-161
+        const int TEX_CFG = f2i_trunc(m.textureConfig);
+        const f4 AlbedoAlpha = sample_material_tex(mt.texDiffuse, uv, ddx, ddy, 0.0f);
+        if (has_bit(TEX_CFG, 0) && AlbedoAlpha.w < 0.01f) return false;
+    }
+    const f4 Normal4 = sample_material_tex(mt.texNormals, uv, ddx, ddy, 0.0f);          // :164
+    const f3 N = normalize_lit(f3{ in.ip1[o], in.ip1[o + 1], in.ip1[o + 2] });          // :165
+    const f3 T = normalize_lit(f3{ in.ip2[o], in.ip2[o + 1], in.ip2[o + 2] });          // :166
+    const f3 Nrm = { Normal4.x, Normal4.y, Normal4.z };
+    const f3 S = (length_lit(Nrm) < 0.01f) ? N : UnpackNormal(Nrm, N, T);               // :167
+    n01[0] = (S.x + 1.0f) * 0.5f; n01[1] = (S.y + 1.0f) * 0.5f; n01[2] = (S.z + 1.0f) * 0.5f;   // :168
+    return true;
+}
+
 // returns true when the fragment is discarded (ENABLE_ALPHA_MASK permutation, ForwardLighting.hlsl:237-240)
 bool gbuffer_pixel(const Planes& in, int x, int y, const vqhip_material* mats, int nMats, float ambient,
                    const vqhip_ssao* ssao, float* o0, float* o1, float* o2, float* o3) {
@@ -77,18 +118,8 @@ bool gbuffer_pixel(const Planes& in, int x, int y, const vqhip_material* mats, i
     const size_t o = ((size_t)y * in.pitch + x) * 4;
 
     const f2 uv = uv_transformed(in, x, y, m);
-    f2 ddx = { 0, 0 }, ddy = { 0, 0 };
-    {
-        const int xa = x & ~1, xb = x | 1, ya = y & ~1, yb = y | 1;
-        if (xb < in.W && mat_index(in, xa, y) == idx && mat_index(in, xb, y) == idx) {
-            const f2 a = uv_transformed(in, xa, y, m), b = uv_transformed(in, xb, y, m);
-            ddx = { b.x - a.x, b.y - a.y };
-        }
-        if (yb < in.H && mat_index(in, x, ya) == idx && mat_index(in, x, yb) == idx) {
-            const f2 a = uv_transformed(in, x, ya, m), b = uv_transformed(in, x, yb, m);
-            ddy = { b.x - a.x, b.y - a.y };
-        }
-    }
+    f2 ddx, ddy;
+    quad_derivatives(in, x, y, idx, m, &ddx, &ddy);
     const int TEX_CFG = f2i_trunc(m.textureConfig);                                   // :227
 
     f4 AlbedoAlpha   = sample_material_tex(mt.texDiffuse,        uv, ddx, ddy, 0.0f); // :229
@@ -159,6 +190,27 @@ int vqo_gbuffer_from_materials(const vqhip_interpolants* in, const vqhip_materia
     for (int y = 0; y < in->height; ++y)
         for (int x = 0; x < in->width; ++x)
             if (discarded[(size_t)y * in->width + x]) { const int32_t m1 = -1; std::memcpy(ip2 + ((size_t)y * in->row_pitch_px + x) * 4 + 3, &m1, 4); }
+    return 0;
+}
+
+// DepthPrePass.hlsl:PSMain over the interpolant planes: out = Tex_SceneNormals, R10G10B10A2_UNORM (one uint32 per pixel, r in bits 0-9, alpha 1 -> 3;
+// RenderResources.cpp:185-197, PipelineStateObjects.cpp:1634-1635) or RGBA32F holding the unquantised float4(SurfaceN, 1); tightly packed rows.
+// float -> UNORM n: trunc(saturate(c) * (2^n - 1) + 0.5), NaN -> 0 (D3D11.3 §3.2.3.6, the rule of f32_to_unorm8).
+int vqo_scene_normals_from_materials(const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials, void* out, int outFmt, int nthreads) {
+    if (!in || !out || (numMaterials > 0 && !materials)) return -1;
+    if (outFmt != VQHIP_FMT_R10G10B10A2_UNORM && outFmt != VQHIP_FMT_RGBA32F) return -3;
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    const Planes p = { (const float*)in->ip0, (const float*)in->ip1, (const float*)in->ip2, in->width, in->height, in->row_pitch_px };
+    auto un10 = [](float c) -> uint32_t { const float s = c > 0.0f ? (c < 1.0f ? c : 1.0f) : 0.0f; return (uint32_t)(int)(s * 1023.0f + 0.5f); };
+    #pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int y = 0; y < in->height; ++y)
+        for (int x = 0; x < in->width; ++x) {
+            float n[3] = { 0, 0, 0 };
+            const bool covered = scene_normal_pixel(p, x, y, materials, numMaterials, n);
+            const size_t q = (size_t)y * in->width + x;
+            if (outFmt == VQHIP_FMT_RGBA32F) { float* d = (float*)out + q * 4; d[0] = n[0]; d[1] = n[1]; d[2] = n[2]; d[3] = covered ? 1.0f : 0.0f; }
+            else ((uint32_t*)out)[q] = covered ? (un10(n[0]) | (un10(n[1]) << 10) | (un10(n[2]) << 20) | (3u << 30)) : 0u;
+        }
     return 0;
 }
 

@@ -535,6 +535,29 @@ int vqo_forward_lighting(const vqhip_gbuffer* gb, const VQ_PerFrameData* perFram
     return 0;
 }
 
+// The other render targets of PSMain (ForwardLighting.hlsl:PSOutput :57-68), per pixel of a G-buffer:
+//   outAlbedo  = float4(Surface.diffuseColor, Surface.metalness)                                                   :383  (the G-buffer's gb2, include/vqhip.h)
+//   outMotion  = float2(svPositionCurr.xy / svPositionCurr.w - svPositionPrev.xy / svPositionPrev.w)               :387
+// svCurr / svPrev: float4 planes (PSInput :49-52), svPitch pixels per row; either output may be NULL; outputs are tightly packed.
+int vqo_psmain_extra_targets(const vqhip_gbuffer* gb, const float* svCurr, const float* svPrev, int svPitch,
+                             void* outAlbedo, int albedoFmt, void* outMotion, int motionFmt) {
+    if (!gb) return -1;
+    if (outAlbedo && albedoFmt != VQHIP_FMT_RGBA32F && albedoFmt != VQHIP_FMT_RGBA16F) return -3;
+    if (outMotion && ((motionFmt != VQHIP_FMT_RG32F && motionFmt != VQHIP_FMT_RG16F) || !svCurr || !svPrev)) return -3;
+    const int W = gb->width, H = gb->height, pitch = gb->row_pitch_px;
+    const f4* g2 = (const f4*)gb->gb2;
+    const f4* c4 = (const f4*)svCurr; const f4* p4 = (const f4*)svPrev;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (outAlbedo) store_px(outAlbedo, (size_t)y * W + x, albedoFmt, g2[(size_t)y * pitch + x]);
+            if (outMotion) {
+                const f4 c = c4[(size_t)y * svPitch + x], p = p4[(size_t)y * svPitch + x];
+                store_px(outMotion, (size_t)y * W + x, motionFmt, { c.x / c.w - p.x / p.w, c.y / c.w - p.y / p.w, 0.0f, 0.0f });
+            }
+        }
+    return 0;
+}
+
 // GaussianBlur.hlsl:CSMain_X :120-151 / CSMain_Y :155-187. dir 0 = X, 1 = Y.
 // halo_top/halo_bottom: optional rows outside the tile for the Y pass (row-tiled multi-GPU mode).
 int vqo_gaussian_blur_pass(const void* in, void* out, int W, int H, int fmt, int dir,

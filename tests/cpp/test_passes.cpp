@@ -104,10 +104,40 @@ int main(int argc, char** argv) {
         ld.pInterpolants = &ip;
         ld.pMaterials = (const vqhip_material*)mats.data();
         ld.NumMaterials = (int)(mats.size() / sizeof(vqhip_material));
+        // the Z pre-pass's colour target on the same planes (RenderDepthPrePass): Tex_SceneNormals
+        {
+            vqhip::HipDepthPrePassNormals zpp(ctx);
+            zpp.Initialize();
+            zpp.OnCreateWindowSizeDependentResources(W, H);
+            vqhip::HipDepthPrePassNormals::FDrawParameters zd;
+            zd.Stream = stream; zd.pInterpolants = &ip; zd.pMaterials = ld.pMaterials; zd.NumMaterials = ld.NumMaterials;
+            zpp.RecordCommands(&zd);
+            CHECK(zpp);
+            if (hipStreamSynchronize(stream) != hipSuccess) return 3;
+            writeDev(dir + "/scene_normals_r10g10b10a2.bin", zpp.GetSceneNormals(), (size_t)W * H * 4);
+            zpp.RecordCommands(nullptr);
+            if (zpp.LastStatus() != VQHIP_ERR_INVALID_ARG) return 5;
+            zpp.Destroy();
+        }
+        // the draw's other render targets (sv_curr.bin present): RenderSceneColor with bUseVisualizationRenderTarget + bRenderMotionVectors (SceneRendering.cpp:1640-1663)
+        bool mrt = false;
+        if (FILE* sv = fopen((dir + "/sv_curr.bin").c_str(), "rb")) {
+            fclose(sv); mrt = true;
+            ld.bUseVisualizationRenderTarget = true; ld.bRenderMotionVectors = true;
+            ld.pSvPositionCurr = upload(readFile(dir + "/sv_curr.bin")); ld.pSvPositionPrev = upload(readFile(dir + "/sv_prev.bin"));
+        }
         lighting.RecordCommands(&ld);
         CHECK(lighting);
         if (hipStreamSynchronize(stream) != hipSuccess) return 3;
         writeDev(dir + "/scene_ip_rgba16f.bin", lighting.GetSceneColor(), (size_t)W * H * 8);
+        if (mrt) {
+            writeDev(dir + "/scene_viz_rgba16f.bin", lighting.GetSceneVisualization(), (size_t)W * H * 8);
+            writeDev(dir + "/scene_mv_rg16f.bin", lighting.GetSceneMotionVectors(), (size_t)W * H * 4);
+            ld.pSvPositionCurr = nullptr;                   // motion vectors without the clip positions: refused, not crashed
+            lighting.RecordCommands(&ld);
+            if (lighting.LastStatus() != VQHIP_ERR_INVALID_ARG) return 5;
+            ld.bRenderMotionVectors = false; ld.bUseVisualizationRenderTarget = false;
+        }
     }
     // --- row-tiled mode of the post pass through the real RCCL: a world of one rank (the box has one GPU). No halos, the composite of the
     // single tile is the tile: the frame must equal the SDR image written above.

@@ -16,6 +16,7 @@ int main() {
     mRenderPasses.push_back(std::make_shared<vqhip::HipPostProcessPass>(nullptr));
     mRenderPasses.push_back(std::make_shared<vqhip::HipEnvMapPrefilterPass>(nullptr));
     mRenderPasses.push_back(std::make_shared<vqhip::HipSSREnvironmentFallbackPass>(nullptr));
+    mRenderPasses.push_back(std::make_shared<vqhip::HipDepthPrePassNormals>(nullptr));
     for (std::shared_ptr<::IRenderPass>& pPass : mRenderPasses) {                    // the loop of Renderer.cpp:590-593
         if (pPass->Initialize()) { std::fprintf(stderr, "Initialize() must fail without a context\n"); return 1; }
         if (!pPass->CollectPSOCreationParameters().empty()) return 2;

@@ -110,6 +110,38 @@ def forward_lighting(gb, per_frame, per_view, out_fmt=abi.FMT_RGBA16F, extra_poi
     return out
 
 
+def scene_normals_from_materials(ip, materials, out_fmt=abi.FMT_R10G10B10A2_UNORM, nthreads=0):
+    """DepthPrePass.hlsl:PSMain over the interpolant planes: uint32 [H,W] (R10G10B10A2_UNORM, r in bits 0-9) or float32 [H,W,4]"""
+    lib = load()
+    ip = [np.ascontiguousarray(p, np.float32) for p in ip]
+    h, w = ip[0].shape[:2]
+    out = np.empty((h, w), np.uint32) if out_fmt == abi.FMT_R10G10B10A2_UNORM else np.empty((h, w, 4), np.float32)
+    inter = abi.Interpolants(_p(ip[0]), _p(ip[1]), _p(ip[2]), w, h, w)
+    n = len(materials) if materials is not None else 0
+    lib.vqo_scene_normals_from_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    rc = lib.vqo_scene_normals_from_materials(C.byref(inter), materials if n else None, n, _p(out), out_fmt, nthreads)
+    assert rc == 0, rc
+    return out
+
+
+def psmain_extra_targets(gb, sv_curr=None, sv_prev=None, albedo_fmt=abi.FMT_RGBA16F, motion_fmt=abi.FMT_RG16F):
+    """the lit draw's other render targets (ForwardLighting.hlsl:382-389) from a G-buffer: (albedo_metallic | None, motion_vectors | None); a format None skips the target"""
+    lib = load()
+    gb = [np.ascontiguousarray(g, np.float32) for g in gb]
+    h, w = gb[0].shape[:2]
+    g = abi.GBuffer(_p(gb[0]), _p(gb[1]), _p(gb[2]), _p(gb[3]), w, h, w)
+    alb = np_image(h, w, albedo_fmt) if albedo_fmt is not None else None
+    mv = None
+    if motion_fmt is not None:
+        sv_curr, sv_prev = np.ascontiguousarray(sv_curr, np.float32), np.ascontiguousarray(sv_prev, np.float32)
+        mv = np_image(h, w, motion_fmt)
+    lib.vqo_psmain_extra_targets.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    rc = lib.vqo_psmain_extra_targets(C.byref(g), _p(sv_curr) if mv is not None else None, _p(sv_prev) if mv is not None else None, w,
+                                      _p(alb), albedo_fmt or 0, _p(mv), motion_fmt or 0)
+    assert rc == 0, rc
+    return alb, mv
+
+
 def host_envmap(diffuse_cube, spec_cube, spec_res0, spec_mips, lut):
     """abi.EnvMap over numpy float16 arrays (caller keeps them alive)."""
     return abi.EnvMap(_p(diffuse_cube), diffuse_cube.shape[1], _p(spec_cube), spec_res0, spec_mips, _p(lut), lut.shape[0])

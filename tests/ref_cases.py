@@ -341,6 +341,118 @@ CASES.append(_psmain_case())
 CASES.append(_psmain_case(alpha_masked=True))
 
 
+def _psmain_mrt_case():
+    """PSMain in the OUTPUT_ALBEDO + OUTPUT_MOTION_VECTORS permutation (ForwardLighting.hlsl:57-68,382-389; PipelineStateObjects.cpp:1499-1504): SV_TARGET1 =
+    (Surface.diffuseColor, Surface.metalness) of the textured materials and the motion vectors from two interpolated clip positions. Compared: the valid pixels'
+    albedo_metallic (RGBA16F target) followed by their motion vectors (RG16F target), as one vector of halfs."""
+    base = _psmain_case()
+    W, H, NM = 48, 32, 5
+
+    def build():
+        i = base.build()
+        i["sv_curr"], i["sv_prev"] = synth.clip_positions(W, H)
+        return i
+
+    def valid(i):
+        idx = i["ip"][2][..., 3].view(np.int32)
+        return (idx >= 0) & (idx < NM)
+
+    def pack(i, alb, mv):
+        v = valid(i)
+        return np.concatenate([np.asarray(alb, np.float32)[v].ravel(), np.asarray(mv, np.float32)[v].ravel()])
+
+    def host_mats(i):
+        hc = []
+        for ts in i["tex"]:
+            cs = {}
+            for slot, img in ts.items():
+                chain, n = O.mip_chain_rgba8(img)
+                cs[slot] = (chain, img.shape[1], img.shape[0], n)
+            hc.append(cs)
+        return O.host_materials(i["datas"], hc)
+
+    def ref(i):
+        from tests import ref_lib as R
+        _, alb, mv = R.forward_psmain_mrt([p.copy() for p in i["ip"]], i["sv_curr"], i["sv_prev"], host_mats(i), i["pf"], i["pv"], ssao=i["ssao"], env=host_env(i["env"]))
+        return pack(i, alb, mv)
+
+    def oracle(i):
+        gb = O.gbuffer_from_materials([p.copy() for p in i["ip"]], host_mats(i), i["pf"].fAmbientLightingFactor, ssao=i["ssao"])
+        alb, mv = O.psmain_extra_targets(gb, i["sv_curr"], i["sv_prev"])
+        return pack(i, alb, mv)
+
+    def product(ctx, i):
+        keep = []
+        dm = (abi.MaterialDesc * NM)()
+        for k, (d, ts) in enumerate(zip(i["datas"], i["tex"])):
+            dm[k].data = d
+            for slot, img in ts.items():
+                chain, n = ctx.mip_chain_rgba8(_dev(img))
+                keep.append(chain)
+                setattr(dm[k], slot, abi.Texture2D(chain.data_ptr(), img.shape[1], img.shape[0], n, 0))
+        _, alb, mv = ctx.forward_lighting_from_materials_mrt([_dev(p) for p in i["ip"]], dm, i["pf"], i["pv"], albedo_fmt=F16, motion_fmt=abi.FMT_RG16F,
+                                                             sv_curr=_dev(i["sv_curr"]), sv_prev=_dev(i["sv_prev"]), ssao=_dev(i["ssao"]), out_fmt=F16,
+                                                             env=dev_env(i["env"], keep))
+        return pack(i, alb.cpu().numpy(), mv.cpu().numpy())
+    return Case("psmain_mrt_targets", build, ref, oracle, product, ("ulp16", 0, 0.0))          # measured: identical halfs
+
+
+CASES.append(_psmain_mrt_case())
+
+
+def pack_r10g10b10a2(rgba):
+    """what a store to an R10G10B10A2_UNORM target keeps of float4 values: trunc(saturate(c) * (2^n - 1) + 0.5) per channel (D3D11.3 §3.2.3.6; NaN -> 0),
+    r in bits 0-9, g 10-19, b 20-29, a 30-31"""
+    c = np.clip(np.nan_to_num(np.asarray(rgba, np.float32), nan=0.0), 0.0, 1.0).astype(np.float32)
+    u = (c[..., :3] * np.float32(1023.0) + np.float32(0.5)).astype(np.uint32)
+    a = (c[..., 3] * np.float32(3.0) + np.float32(0.5)).astype(np.uint32)
+    return u[..., 0] | (u[..., 1] << np.uint32(10)) | (u[..., 2] << np.uint32(20)) | (a << np.uint32(30))
+
+
+def _prepass_case(alpha_masked=False):
+    """DepthPrePass.hlsl:PSMain (:153-171) on the textured-material view of the psmain cases: Tex_SceneNormals as the R10G10B10A2_UNORM words the Z pre-pass
+    stores — the `g_normal` input of SSR. Materials carry normalMapMipBias 0.75 / 1 / -0.5, which this shader must NOT apply (:164 is Sample)."""
+    base = _psmain_case(alpha_masked)
+    NM = 5
+
+    def host_mats(i):
+        hc = []
+        for ts in i["tex"]:
+            cs = {}
+            for slot, img in ts.items():
+                chain, n = O.mip_chain_rgba8(img)
+                cs[slot] = (chain, img.shape[1], img.shape[0], n)
+            hc.append(cs)
+        m = O.host_materials(i["datas"], hc)
+        for k in range(NM):
+            m[k].texDiffuse.reserved = abi.MATERIAL_ALPHA_MASKED if alpha_masked else 0
+        return m
+
+    def ref(i):
+        from tests import ref_lib as R
+        return pack_r10g10b10a2(R.prepass_normals(i["ip"], host_mats(i), alpha_masked=alpha_masked))
+
+    def oracle(i):
+        return O.scene_normals_from_materials(i["ip"], host_mats(i))
+
+    def product(ctx, i):
+        keep = []
+        dm = (abi.MaterialDesc * NM)()
+        for k, (d, ts) in enumerate(zip(i["datas"], i["tex"])):
+            dm[k].data = d
+            for slot, img in ts.items():
+                chain, n = ctx.mip_chain_rgba8(_dev(img))
+                keep.append(chain)
+                setattr(dm[k], slot, abi.Texture2D(chain.data_ptr(), img.shape[1], img.shape[0], n, 0))
+            dm[k].texDiffuse.reserved = abi.MATERIAL_ALPHA_MASKED if alpha_masked else 0
+        return ctx.scene_normals_from_materials([_dev(p) for p in i["ip"]], dm).cpu().numpy().view(np.uint32)
+    return Case("prepass_normals_alpha_masked" if alpha_masked else "prepass_normals", base.build, ref, oracle, product, "exact")
+
+
+CASES.append(_prepass_case())
+CASES.append(_prepass_case(alpha_masked=True))
+
+
 def _lut_case():
     rows = [0, 20, 77, 512, 1023]
     xs = np.concatenate([[0, 1, 1022, 1023], np.arange(5, 1024, 41)]).astype(np.int32)

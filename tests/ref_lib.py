@@ -57,6 +57,9 @@ def load(name="shaders"):
             lib.vqref_forward_from_gbuffer.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
         elif name == "shaders_am":
             lib.vqref_forward_psmain.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
+            lib.vqref_prepass_normals.argtypes = [vp, vp, i32, vp]
+        elif name == "shaders_mrt":
+            lib.vqref_forward_psmain_mrt.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
         else:
             lib.vqref_forward_psmain.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp]
             lib.vqref_forward_from_gbuffer.argtypes = [vp, vp, vp, vp, i32, vp, vp, vp]
@@ -75,6 +78,7 @@ def load(name="shaders"):
             lib.vqref_visualize.argtypes = [vp, i32, i32, vp, vp]
             lib.vqref_apply_reflections.argtypes = [vp, vp, i32, i32]
             lib.vqref_ssr_environment_fallback.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+            lib.vqref_prepass_normals.argtypes = [vp, vp, i32, vp]
             lib.vqref_unlit_color.argtypes = [vp, vp]
             lib.vqref_fsr_easu.argtypes = [vp, i32, i32, vp, vp, i32, i32]
             lib.vqref_fsr_rcas.argtypes = [vp, i32, i32, vp, vp]
@@ -131,6 +135,37 @@ def forward_psmain(ip, materials, per_frame, per_view, ssao=None, env=None, shad
                                      _ref(env), _ref(shadow), out.ctypes.data)
     assert rc == 0
     return out
+
+
+def prepass_normals(ip, materials, alpha_masked=False):
+    """DepthPrePass.hlsl:PSMain per pixel of the interpolant planes: float32 [H,W,4] = float4(SurfaceN * 0.5 + 0.5, 1); 0 where nothing is drawn.
+    alpha_masked: the ENABLE_ALPHA_MASK permutation (libvqref_shaders_am.so)."""
+    ip = [np.ascontiguousarray(p, np.float32) for p in ip]
+    h, w = ip[0].shape[:2]
+    out = np.empty((h, w, 4), np.float32)
+    inter = abi.Interpolants(ip[0].ctypes.data, ip[1].ctypes.data, ip[2].ctypes.data, w, h, w)
+    n = len(materials) if materials is not None else 0
+    assert load("shaders_am" if alpha_masked else "shaders").vqref_prepass_normals(C.byref(inter), materials if n else None, n, out.ctypes.data) == 0
+    return out
+
+
+def forward_psmain_mrt(ip, sv_curr, sv_prev, materials, per_frame, per_view, ssao=None, env=None, shadow=None):
+    """PSMain in the OUTPUT_ALBEDO + OUTPUT_MOTION_VECTORS permutation (libvqref_shaders_mrt.so): (color [H,W,4], albedo_metallic [H,W,4], motion_vectors [H,W,2]),
+    float32; pixels without geometry hold the targets' clear value 0."""
+    ip = [np.ascontiguousarray(p, np.float32) for p in ip]
+    sv_curr, sv_prev = np.ascontiguousarray(sv_curr, np.float32), np.ascontiguousarray(sv_prev, np.float32)
+    h, w = ip[0].shape[:2]
+    out, alb, mv = np.empty((h, w, 4), np.float32), np.empty((h, w, 4), np.float32), np.empty((h, w, 2), np.float32)
+    inter = abi.Interpolants(ip[0].ctypes.data, ip[1].ctypes.data, ip[2].ctypes.data, w, h, w)
+    s = None
+    if ssao is not None:
+        ssao = np.ascontiguousarray(ssao, np.uint8)
+        s = abi.SSAO(ssao.ctypes.data, ssao.shape[1], ssao.shape[0])
+    n = len(materials) if materials is not None else 0
+    rc = load("shaders_mrt").vqref_forward_psmain_mrt(C.byref(inter), materials if n else None, n, _ref(s), C.byref(per_frame), C.byref(per_view), _ref(env), _ref(shadow),
+                                                      out.ctypes.data, sv_curr.ctypes.data, sv_prev.ctypes.data, w, alb.ctypes.data, mv.ctypes.data)
+    assert rc == 0, rc
+    return out, alb, mv
 
 
 def conv_diffuse(chain, w0, h0, n_mips, res, t0=0, t1=-1):

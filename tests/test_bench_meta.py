@@ -37,6 +37,7 @@ def test_every_invocation_reports_the_other_baseline_configs():
     for key in ('extras["cfg5_strong"]', 'extras["tile_curve"]', 'extras["cfg2"]', 'extras["ibl_load"]', 'extras["coherent_scene"]', 'extras["widened"]', '"rccl": comms.info()'):
         assert key in src, key
     # every SURVEY 8f kernel rides in the driver-run line
-    for key in ("gbuffer_producer_textured", "gbuffer_producer_textureless", "psmain_fused", "skydome_all_sky", "hdr_decode_2048", "fsr_easu_1440p_to_4k", "fsr_rcas_4k", "ssr_env_fallback_4k"):
+    for key in ("gbuffer_producer_textured", "gbuffer_producer_textureless", "psmain_fused", "skydome_all_sky", "hdr_decode_2048", "fsr_easu_1440p_to_4k", "fsr_rcas_4k", "ssr_env_fallback_4k",
+                "psmain_fused_mrt", "scene_normals_prepass"):
         assert f'res["{key}"]' in src, key
     assert 'default="auto"' in src and "completes_within" in src          # the overlapped composite runs under a watchdog by default

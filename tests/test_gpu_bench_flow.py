@@ -116,9 +116,11 @@ def test_single_gpu_line_carries_the_contract_fields():
     for k in ("mip_chain_ms", "prefilter_ms", "brdf_lut_ms", "conv_diffuse_ms", "conv_specular_ms", "brdf_lut_warm_ms", "total_ms", "warm_total_ms", "mip_chain_warm_ms", "prefilter_warm_ms", "conv_diffuse_valu_frac_model"):
         assert ib[k] > 0, k
     wd = d["widened"]                                        # the SURVEY 8f kernels at 4K
-    for k in ("gbuffer_producer_textured", "gbuffer_producer_textureless", "psmain_fused", "skydome_all_sky", "fsr_easu_1440p_to_4k", "fsr_rcas_4k", "ssr_env_fallback_4k"):
+    for k in ("gbuffer_producer_textured", "gbuffer_producer_textureless", "psmain_fused", "skydome_all_sky", "fsr_easu_1440p_to_4k", "fsr_rcas_4k", "ssr_env_fallback_4k",
+              "psmain_fused_mrt", "scene_normals_prepass"):
         assert 0 < wd[k]["ms"] < 5 and wd[k]["bytes_per_px"] > 0 and 0 < wd[k]["hbm_frac"] < 1, (k, wd[k])
     assert 0 < wd["hdr_decode_2048"]["ms"] < 500 and wd["psmain_fused"]["ms"] > d["stages"]["shade_ms"] * 0.8
+    assert wd["psmain_fused_mrt"]["ms"] > wd["psmain_fused"]["ms"] * 0.9 and wd["scene_normals_prepass"]["ms"] < wd["gbuffer_producer_textured"]["ms"] * 1.2
     co = d["coherent_scene"]
     assert 0 < co["shade_ms"] < 5 and 0.05 < co["slow_path_pixel_fraction_round2"] < 0.3
     tc = d["tile_curve"]["tiles"]

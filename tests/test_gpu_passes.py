@@ -44,6 +44,8 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
     (tmp_path / "ssr_cb.bin").write_bytes(bytes(cb))
     depth.tofile(tmp_path / "ssr_depth.bin")
     packed.tofile(tmp_path / "ssr_normals.bin")
+    sv_curr, sv_prev = synth.clip_positions(W, H)             # PSInput.svPositionCurr / Prev for the pass's motion-vector target
+    sv_curr.tofile(tmp_path / "sv_curr.bin"); sv_prev.tofile(tmp_path / "sv_prev.bin")
     r = subprocess.run([EXE, str(tmp_path), str(W), str(H), str(EW), str(EH), "rccl"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     diff = np.fromfile(tmp_path / "diffuse_blurred.bin", np.float16).reshape(6, 8, 8, 4)
@@ -65,6 +67,12 @@ def test_cpp_pass_adaptors(tmp_path, ctx):
     got = np.fromfile(tmp_path / "scene_ip_rgba16f.bin", np.float16).reshape(H, W, 4)
     n_bad, idx = O.bits_equal(got, scene_ip)
     assert n_bad == 0, (n_bad, idx)
+    assert np.array_equal(np.fromfile(tmp_path / "scene_normals_r10g10b10a2.bin", np.uint32).reshape(H, W), O.scene_normals_from_materials(ip, mats))
+    viz, mv = O.psmain_extra_targets(gb_ip, sv_curr, sv_prev)                    # Tex_SceneVisualization / Tex_SceneMotionVectors of the same draw
+    n_bad, idx = O.bits_equal(np.fromfile(tmp_path / "scene_viz_rgba16f.bin", np.float16).reshape(H, W, 4), viz)
+    assert n_bad == 0, ("albedo / metalness target", n_bad, idx)
+    n_bad, idx = O.bits_equal(np.fromfile(tmp_path / "scene_mv_rg16f.bin", np.float16).reshape(H, W, 2), mv)
+    assert n_bad == 0, ("motion vectors", n_bad, idx)
     sdr = O.tonemap(O.gaussian_blur(scene, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
     got = np.fromfile(tmp_path / "sdr_rgba8.bin", np.uint8).reshape(H, W, 4)
     assert np.array_equal(got, sdr)

@@ -1,0 +1,152 @@
+"""-m gpu: the lit draw's other render targets (ForwardLighting.hlsl:PSOutput :57-68, written :382-389; vqhip_psmain_targets) through the C ABI:
+SV_TARGET1 = (albedo, metalness) and the motion vectors come out of the SAME kernel as the scene colour — bit for bit the CPU oracle, the scene colour
+untouched by their presence, the one-kernel PSMain identical to producer + lighting, pitches, both storage formats, the argument checks. The reference's
+own outputs for this permutation: tests/test_ref_fixtures.py (case psmain_mrt_targets)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests import oracle_lib as O
+from tests import ref_cases
+from vqengine_amd import abi, capi, synth
+
+pytestmark = pytest.mark.gpu
+dev = ref_cases._dev
+
+
+def assert_bits(got, ref, what):
+    n, idx = O.bits_equal(got.cpu().numpy() if hasattr(got, "cpu") else got, ref)
+    assert n == 0, f"{what}: {n} mismatching elements, first {idx.tolist()}"
+
+
+def _frame(W, H, n_lights=5, seed=0x717):
+    gb = synth.gbuffer(W, H, seed=seed)
+    pf, _ = synth.per_frame(points=synth.point_lights(n_lights, seed=seed))
+    pv = synth.per_view(W, H)
+    cur, prev = synth.clip_positions(W, H, seed=seed)
+    return gb, pf, pv, cur, prev
+
+
+@pytest.mark.parametrize("W,H", [(1920, 1080), (333, 37), (64, 1)])
+@pytest.mark.parametrize("albedo_fmt,motion_fmt", [(abi.FMT_RGBA16F, abi.FMT_RG16F), (abi.FMT_RGBA32F, abi.FMT_RG32F)])
+def test_forward_lighting_mrt_matches_oracle(ctx, W, H, albedo_fmt, motion_fmt):
+    gb, pf, pv, cur, prev = _frame(W, H)
+    gbd = [dev(g) for g in gb]
+    plain = ctx.forward_lighting(gbd, pf, pv)
+    out, alb, mv = ctx.forward_lighting_mrt(gbd, pf, pv, albedo_fmt=albedo_fmt, motion_fmt=motion_fmt, sv_curr=dev(cur), sv_prev=dev(prev))
+    want_a, want_m = O.psmain_extra_targets(gb, cur, prev, albedo_fmt, motion_fmt)
+    assert_bits(alb, want_a, f"albedo / metalness {W}x{H}")
+    assert_bits(mv, want_m, f"motion vectors {W}x{H}")
+    assert torch.equal(out.view(torch.int16), plain.view(torch.int16)), "the scene colour changed with extra targets bound"
+    assert (np.abs(want_m.astype(np.float32)) > 0).mean() > 0.9
+
+
+def test_one_target_at_a_time_and_both_arithmetic_readings(ctx):
+    """only SV_TARGET1 (OUTPUT_ALBEDO without OUTPUT_MOTION_VECTORS) and only the motion vectors; the DXC reading has its own instantiation of the kernel"""
+    gb, pf, pv, cur, prev = _frame(500, 20, seed=0x99)
+    gbd = [dev(g) for g in gb]
+    want_a, want_m = O.psmain_extra_targets(gb, cur, prev)
+    for dxc in (False, True):
+        ctx.set_arithmetic(dxc)
+        try:
+            plain = ctx.forward_lighting(gbd, pf, pv)
+            out, alb, mv = ctx.forward_lighting_mrt(gbd, pf, pv, motion_fmt=None)
+            assert mv is None
+            assert_bits(alb, want_a, "albedo only")
+            assert torch.equal(out.view(torch.int16), plain.view(torch.int16))
+            out, alb, mv = ctx.forward_lighting_mrt(gbd, pf, pv, albedo_fmt=None, motion_fmt=abi.FMT_RG16F, sv_curr=dev(cur), sv_prev=dev(prev))
+            assert alb is None
+            assert_bits(mv, want_m, "motion vectors only")
+            assert torch.equal(out.view(torch.int16), plain.view(torch.int16))
+        finally:
+            ctx.set_arithmetic(False)
+
+
+def test_special_clip_positions(ctx):
+    """negative w (behind the camera), huge and denormal components, a quotient that overflows: the same halfs / floats as the oracle's IEEE quotients"""
+    W, H = 128, 4
+    gb, pf, pv, cur, prev = _frame(W, H, seed=0x31)
+    cur[0, :16, 3] *= -1.0
+    prev[0, 16:32, 3] = np.float32(1e-30)
+    cur[1, :8, 0] = np.float32(3e38); cur[1, :8, 3] = np.float32(0.5)          # x / w overflows to inf; inf - finite = inf
+    prev[1, 8:16, :2] = np.float32(1e-42)                                      # denormal numerators
+    cur[2, :8, 3] = np.float32(65504.0 * 4)
+    gbd = [dev(g) for g in gb]
+    for afmt, mfmt in ((abi.FMT_RGBA16F, abi.FMT_RG16F), (abi.FMT_RGBA32F, abi.FMT_RG32F)):
+        with np.errstate(all="ignore"):
+            _, want_m = O.psmain_extra_targets(gb, cur, prev, afmt, mfmt)
+        _, _, mv = ctx.forward_lighting_mrt(gbd, pf, pv, albedo_fmt=afmt, motion_fmt=mfmt, sv_curr=dev(cur), sv_prev=dev(prev))
+        assert np.isinf(want_m.astype(np.float32)).any() and not np.isnan(want_m.astype(np.float32)).any()
+        assert_bits(mv, want_m, f"special clip positions, fmt {mfmt}")
+
+
+def test_pitched_targets_through_the_raw_abi(ctx):
+    """albedo_pitch_px / motion_pitch_px / sv_pitch_px larger than the width: rows land at their pitch and the padding is untouched"""
+    W, H, PA, PM, PS = 100, 9, 128, 112, 104
+    gb, pf, pv, cur, prev = _frame(W, H, seed=0x44)
+    gbd = [dev(g) for g in gb]
+    want_a, want_m = O.psmain_extra_targets(gb, cur, prev)
+    curp = np.zeros((H, PS, 4), np.float32); curp[:, :W] = cur
+    prevp = np.ones((H, PS, 4), np.float32); prevp[:, :W] = prev
+    dc, dp = dev(curp), dev(prevp)
+    alb = torch.full((H, PA, 4), -2.0, dtype=torch.float16, device="cuda")
+    mv = torch.full((H, PM, 2), -2.0, dtype=torch.float16, device="cuda")
+    out = capi.empty_image(H, W, abi.FMT_RGBA16F, "cuda")
+    t = abi.PsmainTargets(alb.data_ptr(), abi.FMT_RGBA16F, PA, mv.data_ptr(), abi.FMT_RG16F, PM, dc.data_ptr(), dp.data_ptr(), PS, 0)
+    g = abi.GBuffer(gbd[0].data_ptr(), gbd[1].data_ptr(), gbd[2].data_ptr(), gbd[3].data_ptr(), W, H, W)
+    rc = ctx.lib.vqhip_forward_lighting_mrt(ctx._h, None, C.byref(g), C.byref(pf), C.byref(pv), None, 0, None, None, out.data_ptr(), W, abi.FMT_RGBA16F, C.byref(t))
+    assert rc == 0, ctx.lib.vqhip_last_error(ctx._h)
+    torch.cuda.synchronize()
+    assert_bits(alb[:, :W].contiguous(), want_a, "pitched albedo")
+    assert_bits(mv[:, :W].contiguous(), want_m, "pitched motion vectors")
+    assert (alb[:, W:] == -2.0).all() and (mv[:, W:] == -2.0).all()
+
+
+def test_psmain_one_kernel_with_targets_equals_the_two_calls(ctx):
+    """vqhip_forward_lighting_from_materials_mrt == vqhip_gbuffer_from_materials + vqhip_forward_lighting_mrt, all three targets, textured materials"""
+    c = [c for c in ref_cases.CASES if c.name == "psmain_mrt_targets"][0]
+    i = c.build()
+    W, H = i["ip"][0].shape[1], i["ip"][0].shape[0]
+    keep = []
+    dm = (abi.MaterialDesc * len(i["datas"]))()
+    for k, (d, ts) in enumerate(zip(i["datas"], i["tex"])):
+        dm[k].data = d
+        for slot, img in ts.items():
+            chain, n = ctx.mip_chain_rgba8(dev(img))
+            keep.append(chain)
+            setattr(dm[k], slot, abi.Texture2D(chain.data_ptr(), img.shape[1], img.shape[0], n, 0))
+    env = ref_cases.dev_env(i["env"], keep)
+    cur, prev, ssao = dev(i["sv_curr"]), dev(i["sv_prev"]), dev(i["ssao"])
+    for afmt, mfmt in ((abi.FMT_RGBA16F, abi.FMT_RG16F), (abi.FMT_RGBA32F, abi.FMT_RG32F)):
+        one = ctx.forward_lighting_from_materials_mrt([dev(p) for p in i["ip"]], dm, i["pf"], i["pv"], albedo_fmt=afmt, motion_fmt=mfmt, sv_curr=cur, sv_prev=prev,
+                                                      ssao=ssao, env=env)
+        gb = ctx.gbuffer_from_materials([dev(p) for p in i["ip"]], dm, i["pf"].fAmbientLightingFactor, ssao)
+        two = ctx.forward_lighting_mrt(gb, i["pf"], i["pv"], albedo_fmt=afmt, motion_fmt=mfmt, sv_curr=cur, sv_prev=prev, env=env)
+        for a, b, what in zip(one, two, ("scene colour", "albedo / metalness", "motion vectors")):
+            assert_bits(a, b.cpu().numpy(), f"one kernel vs two calls: {what}")
+        assert_bits(one[1], gb[2].cpu().numpy().astype(np.float16) if afmt == abi.FMT_RGBA16F else gb[2].cpu().numpy(), "SV_TARGET1 is the G-buffer's gb2")
+
+
+def test_argument_checks(ctx):
+    gb, pf, pv, cur, prev = _frame(64, 4)
+    gbd = [dev(g) for g in gb]
+    g = abi.GBuffer(gbd[0].data_ptr(), gbd[1].data_ptr(), gbd[2].data_ptr(), gbd[3].data_ptr(), 64, 4, 64)
+    out = capi.empty_image(4, 64, abi.FMT_RGBA16F, "cuda")
+    buf = torch.zeros((4, 64, 4), dtype=torch.float32, device="cuda")
+
+    def call(t):
+        return ctx.lib.vqhip_forward_lighting_mrt(ctx._h, None, C.byref(g), C.byref(pf), C.byref(pv), None, 0, None, None, out.data_ptr(), 64, abi.FMT_RGBA16F,
+                                                  C.byref(t) if t is not None else None)
+    assert call(None) == 0                                   # no targets: vqhip_forward_lighting
+    assert call(abi.PsmainTargets()) == 0                    # nothing bound
+    assert call(abi.PsmainTargets(buf.data_ptr(), abi.FMT_RGBA8_UNORM, 0, None, 0, 0, None, None, 0, 0)) == abi.VQHIP_ERR_UNSUPPORTED
+    assert b"albedo_fmt" in ctx.lib.vqhip_last_error(ctx._h)
+    assert call(abi.PsmainTargets(buf.data_ptr(), abi.FMT_RGBA16F, 32, None, 0, 0, None, None, 0, 0)) == abi.VQHIP_ERR_INVALID_ARG
+    assert call(abi.PsmainTargets(None, 0, 0, buf.data_ptr(), abi.FMT_RG16F, 0, None, None, 0, 0)) == abi.VQHIP_ERR_INVALID_ARG
+    assert b"svPositionCurr" in ctx.lib.vqhip_last_error(ctx._h)
+    assert call(abi.PsmainTargets(None, 0, 0, buf.data_ptr(), abi.FMT_RGBA16F, 0, buf.data_ptr(), buf.data_ptr(), 0, 0)) == abi.VQHIP_ERR_UNSUPPORTED
+    assert call(abi.PsmainTargets(None, 0, 0, buf.data_ptr(), abi.FMT_RG16F, 0, buf.data_ptr(), buf.data_ptr(), 63, 0)) == abi.VQHIP_ERR_INVALID_ARG
+    assert call(abi.PsmainTargets(buf.data_ptr(), abi.FMT_RGBA16F, 0, buf.data_ptr(), abi.FMT_RG32F, 0, buf.data_ptr(), buf.data_ptr(), 0, 0)) == 0
+    torch.cuda.synchronize()

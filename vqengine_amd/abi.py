@@ -115,6 +115,14 @@ class GBuffer(C.Structure):
                 ("width", C.c_int32), ("height", C.c_int32), ("row_pitch_px", C.c_int32)]
 
 
+class PsmainTargets(C.Structure):    # vqhip_psmain_targets: the lit draw's other render targets (ForwardLighting.hlsl:57-68,382-389)
+    _fields_ = [("albedo_metallic", C.c_void_p), ("albedo_fmt", C.c_int32), ("albedo_pitch_px", C.c_int32),
+                ("motion_vectors", C.c_void_p), ("motion_fmt", C.c_int32), ("motion_pitch_px", C.c_int32),
+                ("svPositionCurr", C.c_void_p), ("svPositionPrev", C.c_void_p), ("sv_pitch_px", C.c_int32), ("pad_", C.c_int32)]
+
+
+assert C.sizeof(PsmainTargets) == 56
+
 class CommInfo(C.Structure):    # vqhip_comm_info
     _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("nranks_seen", C.c_int32), ("rank_seen", C.c_int32),
                 ("rccl_version", C.c_int32), ("reserved", C.c_int32), ("library_path", C.c_char * 232)]

@@ -42,6 +42,8 @@ def load_library():
         "vqhip_last_error": (C.c_char_p, [vp]),
         "vqhip_forward_lighting": (i32, [vp, vp, C.POINTER(abi.GBuffer), C.POINTER(abi.PerFrameData), C.POINTER(abi.PerViewLightingData),
                                          vp, i32, C.POINTER(abi.EnvMap), C.POINTER(abi.ShadowMaps), vp, i32, i32]),
+        "vqhip_forward_lighting_mrt": (i32, [vp, vp, C.POINTER(abi.GBuffer), C.POINTER(abi.PerFrameData), C.POINTER(abi.PerViewLightingData),
+                                             vp, i32, C.POINTER(abi.EnvMap), C.POINTER(abi.ShadowMaps), vp, i32, i32, C.POINTER(abi.PsmainTargets)]),
         "vqhip_gaussian_blur": (i32, [vp, vp, vp, vp, vp, C.POINTER(abi.BlurParams), i32]),
         "vqhip_gaussian_blur_x": (i32, [vp, vp, vp, vp, C.POINTER(abi.BlurParams), i32]),
         "vqhip_gaussian_blur_y": (i32, [vp, vp, vp, vp, vp, vp, i32, C.POINTER(abi.BlurParams), i32]),
@@ -64,6 +66,10 @@ def load_library():
         "vqhip_forward_lighting_from_materials": (i32, [vp, vp, C.POINTER(abi.Interpolants), C.POINTER(abi.MaterialDesc), i32, C.POINTER(abi.SSAO),
                                                         C.POINTER(abi.PerFrameData), C.POINTER(abi.PerViewLightingData), vp, i32,
                                                         C.POINTER(abi.EnvMap), C.POINTER(abi.ShadowMaps), vp, i32, i32]),
+        "vqhip_forward_lighting_from_materials_mrt": (i32, [vp, vp, C.POINTER(abi.Interpolants), C.POINTER(abi.MaterialDesc), i32, C.POINTER(abi.SSAO),
+                                                            C.POINTER(abi.PerFrameData), C.POINTER(abi.PerViewLightingData), vp, i32,
+                                                            C.POINTER(abi.EnvMap), C.POINTER(abi.ShadowMaps), vp, i32, i32, C.POINTER(abi.PsmainTargets)]),
+        "vqhip_scene_normals_from_materials": (i32, [vp, vp, C.POINTER(abi.Interpolants), C.POINTER(abi.MaterialDesc), i32, vp, i32, i32]),
         "vqhip_mip_chain_bytes_rgba8": (sz, [i32, i32, i32]),
         "vqhip_mip_chain_box_rgba8": (i32, [vp, vp, vp, i32, i32, i32]),
         "vqhip_set_fresnel_pow": (i32, [vp, i32]),
@@ -103,7 +109,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = [
-    "vqhip_abi_version", "vqhip_create", "vqhip_destroy", "vqhip_last_error", "vqhip_forward_lighting",
+    "vqhip_abi_version", "vqhip_create", "vqhip_destroy", "vqhip_last_error", "vqhip_forward_lighting", "vqhip_forward_lighting_mrt", "vqhip_forward_lighting_from_materials_mrt", "vqhip_scene_normals_from_materials",
     "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_gaussian_blur_y_tonemap", "vqhip_tonemap", "vqhip_post_process", "vqhip_brdf_lut",
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
@@ -294,7 +300,32 @@ class Context:
             raise VQHipError(rc, (self.lib.vqhip_last_error(self._h) or b"").decode())
 
     # ---- forward lighting (RenderSceneColor, SceneRendering.cpp:1619) --------------------------------------
-    def forward_lighting(self, gb, per_frame, per_view, out=None, out_fmt=FMT_RGBA16F, extra_point=None, env=None, shadow=None, stream=None):
+    def _psmain_targets(self, h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev):
+        """vqhip_psmain_targets + the tensors it points at: (struct, albedo_metallic | None, motion_vectors | None)"""
+        t = abi.PsmainTargets()
+        albedo = motion = None
+        if albedo_fmt is not None:
+            albedo = empty_image(h, w, albedo_fmt, self.device)
+            t.albedo_metallic, t.albedo_fmt, t.albedo_pitch_px = albedo.data_ptr(), albedo_fmt, w
+        if motion_fmt is not None:
+            if sv_curr is None or sv_prev is None:
+                raise ValueError("motion vectors need sv_curr and sv_prev (float32 cuda [H,W,4])")
+            _check_img(sv_curr, FMT_RGBA32F, "sv_curr", (h, w)); _check_img(sv_prev, FMT_RGBA32F, "sv_prev", (h, w))
+            motion = empty_image(h, w, motion_fmt, self.device)
+            t.motion_vectors, t.motion_fmt, t.motion_pitch_px = motion.data_ptr(), motion_fmt, w
+            t.svPositionCurr, t.svPositionPrev, t.sv_pitch_px = sv_curr.data_ptr(), sv_prev.data_ptr(), w
+        return t, albedo, motion
+
+    def forward_lighting_mrt(self, gb, per_frame, per_view, albedo_fmt=FMT_RGBA16F, motion_fmt=None, sv_curr=None, sv_prev=None, out=None,
+                             out_fmt=FMT_RGBA16F, extra_point=None, env=None, shadow=None, stream=None):
+        """forward_lighting + the draw's other render targets (ForwardLighting.hlsl:382-389) from the same kernel: returns (out, albedo_metallic, motion_vectors);
+        albedo_fmt / motion_fmt None = that target not bound (-> None)."""
+        h, w = gb[0].shape[0], gb[0].shape[1]
+        t, albedo, motion = self._psmain_targets(h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev)
+        out = self.forward_lighting(gb, per_frame, per_view, out=out, out_fmt=out_fmt, extra_point=extra_point, env=env, shadow=shadow, stream=stream, _targets=t)
+        return out, albedo, motion
+
+    def forward_lighting(self, gb, per_frame, per_view, out=None, out_fmt=FMT_RGBA16F, extra_point=None, env=None, shadow=None, stream=None, _targets=None):
         """gb: tuple of 4 float32 cuda tensors [H,W,4] (gb0..gb3). env: abi.EnvMap or None. Returns out tensor."""
         g0, g1, g2, g3 = gb
         h, w = g0.shape[0], g0.shape[1]
@@ -309,9 +340,9 @@ class Context:
         if extra_point is not None and len(extra_point):
             n_extra = len(extra_point)
             extra_ptr = C.cast(extra_point, C.c_void_p)
-        rc = self.lib.vqhip_forward_lighting(self._h, self._stream(stream), C.byref(gbuf), C.byref(per_frame), C.byref(per_view),
-                                             extra_ptr, n_extra, C.byref(env) if env is not None else None,
-                                             C.byref(shadow) if shadow is not None else None, _ptr(out), out.shape[1], out_fmt)
+        args = (self._h, self._stream(stream), C.byref(gbuf), C.byref(per_frame), C.byref(per_view), extra_ptr, n_extra, C.byref(env) if env is not None else None,
+                C.byref(shadow) if shadow is not None else None, _ptr(out), out.shape[1], out_fmt)
+        rc = self.lib.vqhip_forward_lighting(*args) if _targets is None else self.lib.vqhip_forward_lighting_mrt(*args, C.byref(_targets))
         self._ck(rc)
         return out
 
@@ -425,8 +456,29 @@ class Context:
                                                        float(ambient), C.byref(s) if s is not None else None, C.byref(gbuf)))
         return out
 
+    def scene_normals_from_materials(self, ip, materials, out_fmt=abi.FMT_R10G10B10A2_UNORM, out=None, stream=None):
+        """The Z pre-pass's colour target (DepthPrePass.hlsl:PSMain): Tex_SceneNormals as int32 [H,W] (R10G10B10A2_UNORM bits; torch has no uint32) or
+        float32 [H,W,4]. ip / materials as for gbuffer_from_materials (ip2 is not modified)."""
+        for i, t in enumerate(ip):
+            _check_img(t, FMT_RGBA32F, f"ip{i}")
+        h, w = ip[0].shape[0], ip[0].shape[1]
+        if out is None:
+            out = (torch.empty((h, w), dtype=torch.int32, device=self.device) if out_fmt == abi.FMT_R10G10B10A2_UNORM
+                   else empty_image(h, w, FMT_RGBA32F, self.device))
+        inter = abi.Interpolants(ip[0].data_ptr(), ip[1].data_ptr(), ip[2].data_ptr(), w, h, w)
+        n = len(materials) if materials is not None else 0
+        self._ck(self.lib.vqhip_scene_normals_from_materials(self._h, self._stream(stream), C.byref(inter), materials if n else None, n, _ptr(out), out_fmt, w))
+        return out
+
+    def forward_lighting_from_materials_mrt(self, ip, materials, per_frame, per_view, albedo_fmt=FMT_RGBA16F, motion_fmt=None, sv_curr=None, sv_prev=None,
+                                            **kw):
+        """forward_lighting_from_materials + the draw's other render targets: returns (out, albedo_metallic, motion_vectors)"""
+        h, w = ip[0].shape[0], ip[0].shape[1]
+        t, albedo, motion = self._psmain_targets(h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev)
+        return self.forward_lighting_from_materials(ip, materials, per_frame, per_view, _targets=t, **kw), albedo, motion
+
     def forward_lighting_from_materials(self, ip, materials, per_frame, per_view, ssao=None, out=None, out_fmt=FMT_RGBA16F, extra_point=None,
-                                        env=None, shadow=None, stream=None):
+                                        env=None, shadow=None, stream=None, _targets=None):
         """PSMain in one kernel: gbuffer_from_materials(ip, materials, per_frame.fAmbientLightingFactor, ssao) + forward_lighting, the G-buffer
         record never leaving registers. Same bits as the two calls."""
         for i, t in enumerate(ip):
@@ -445,10 +497,11 @@ class Context:
         n_extra, extra_ptr = 0, C.c_void_p(None)
         if extra_point is not None and len(extra_point):
             n_extra, extra_ptr = len(extra_point), C.cast(extra_point, C.c_void_p)
-        self._ck(self.lib.vqhip_forward_lighting_from_materials(
-            self._h, self._stream(stream), C.byref(inter), materials if n else None, n, C.byref(s) if s is not None else None,
-            C.byref(per_frame), C.byref(per_view), extra_ptr, n_extra, C.byref(env) if env is not None else None,
-            C.byref(shadow) if shadow is not None else None, _ptr(out), out.shape[1], out_fmt))
+        args = (self._h, self._stream(stream), C.byref(inter), materials if n else None, n, C.byref(s) if s is not None else None,
+                C.byref(per_frame), C.byref(per_view), extra_ptr, n_extra, C.byref(env) if env is not None else None,
+                C.byref(shadow) if shadow is not None else None, _ptr(out), out.shape[1], out_fmt)
+        self._ck(self.lib.vqhip_forward_lighting_from_materials(*args) if _targets is None
+                 else self.lib.vqhip_forward_lighting_from_materials_mrt(*args, C.byref(_targets)))
         return out
 
     # ---- FSR 1.0 (SceneRendering.cpp:2695-2784) -----------------------------------------------

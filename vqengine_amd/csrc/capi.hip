@@ -336,11 +336,44 @@ static size_t fillFrameConstants(vqhip_ctx* ctx, int slot, const VQ_PerFrameData
     return sizeof(FrameConstants) + (size_t)nPts * sizeof(DevPointLight);
 }
 
+// vqhip_psmain_targets -> kernel arguments; NULL / no output bound: all-zero (the kernels then touch nothing)
+static int fillMrt(vqhip_ctx* ctx, const char* who, const vqhip_psmain_targets* t, int width, MrtArgs* m) {
+    std::memset(m, 0, sizeof(*m));
+    if (!t || (!t->albedo_metallic && !t->motion_vectors)) return VQHIP_OK;
+    const std::string w(who);
+    if (t->albedo_metallic) {
+        if (t->albedo_fmt != VQHIP_FMT_RGBA16F && t->albedo_fmt != VQHIP_FMT_RGBA32F) return fail(ctx, VQHIP_ERR_UNSUPPORTED, w + ": albedo_fmt must be RGBA16F or RGBA32F");
+        m->albedoPitch = t->albedo_pitch_px ? t->albedo_pitch_px : width;
+        if (m->albedoPitch < width) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": albedo_pitch_px below the width");
+        m->albedo = t->albedo_metallic; m->albedoF32 = t->albedo_fmt == VQHIP_FMT_RGBA32F;
+    }
+    if (t->motion_vectors) {
+        if (t->motion_fmt != VQHIP_FMT_RG16F && t->motion_fmt != VQHIP_FMT_RG32F) return fail(ctx, VQHIP_ERR_UNSUPPORTED, w + ": motion_fmt must be RG16F or RG32F");
+        if (!t->svPositionCurr || !t->svPositionPrev) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": motion_vectors needs svPositionCurr and svPositionPrev");
+        m->motionPitch = t->motion_pitch_px ? t->motion_pitch_px : width;
+        m->svPitch = t->sv_pitch_px ? t->sv_pitch_px : width;
+        if (m->motionPitch < width || m->svPitch < width) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": motion_pitch_px / sv_pitch_px below the width");
+        m->motion = t->motion_vectors; m->motionF32 = t->motion_fmt == VQHIP_FMT_RG32F;
+        m->svCurr = (const float4*)t->svPositionCurr; m->svPrev = (const float4*)t->svPositionPrev;
+    }
+    return VQHIP_OK;
+}
+
 int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb,
         const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
         const VQ_PointLight* extraPoint, int numExtraPoint,
         const vqhip_envmap* env, const vqhip_shadowmaps* sm,
         void* out, int out_row_pitch_px, vqhip_format outFmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "forward_lighting: ctx is NULL");
+    CTX_GUARD(ctx, "forward_lighting");
+    return vqhip_forward_lighting_mrt(ctx, stream, gb, perFrame, perView, extraPoint, numExtraPoint, env, sm, out, out_row_pitch_px, outFmt, nullptr);
+}
+
+int vqhip_forward_lighting_mrt(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb,
+        const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+        const VQ_PointLight* extraPoint, int numExtraPoint,
+        const vqhip_envmap* env, const vqhip_shadowmaps* sm,
+        void* out, int out_row_pitch_px, vqhip_format outFmt, const vqhip_psmain_targets* targets) {
     vqk::Range range_("RenderSceneColor");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "forward_lighting: ctx is NULL");
     CTX_GUARD(ctx, "forward_lighting");
@@ -351,6 +384,8 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
     bool casters = false;
     int rc = validateLighting(ctx, "forward_lighting", perFrame, perView, extraPoint, numExtraPoint, env, sm, outFmt, &casters);
     if (rc) return rc;
+    MrtArgs mrt;
+    if ((rc = fillMrt(ctx, "forward_lighting", targets, gb->width, &mrt)) != VQHIP_OK) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     int slot;
@@ -360,6 +395,7 @@ int vqhip_forward_lighting(vqhip_ctx* ctx, void* stream, const vqhip_gbuffer* gb
     rc = commitSlot(ctx, slot, bytes, st);
     if (rc) return rc;
     ShadeArgs a;
+    a.mrt = mrt;
     a.gb0 = (const float4*)gb->gb0; a.gb1 = (const float4*)gb->gb1; a.gb2 = (const float4*)gb->gb2; a.gb3 = (const float4*)gb->gb3;
     a.out = out;
     a.fc = (const FrameConstants*)(ctx->devRing + (size_t)slot * kConstSlotBytes);
@@ -622,12 +658,53 @@ int vqhip_gbuffer_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_inter
     return releaseSlot(ctx, slot, st);
 }
 
+// The colour target of the Z pre-pass (DepthPrePass.hlsl:PSMain :153-171; VQRenderer::RenderDepthPrePass, SceneRendering.cpp:1264-1360): Tex_SceneNormals.
+int vqhip_scene_normals_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
+                                       void* out, vqhip_format outFmt, int out_row_pitch_px) {
+    vqk::Range range_("RenderDepthPrePass");             // SceneRendering.cpp:1273
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "scene_normals_from_materials: ctx is NULL");
+    CTX_GUARD(ctx, "scene_normals_from_materials");
+    if (!out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "scene_normals_from_materials: out is NULL");
+    if (outFmt != VQHIP_FMT_R10G10B10A2_UNORM && outFmt != VQHIP_FMT_RGBA32F)
+        return fail(ctx, VQHIP_ERR_UNSUPPORTED, "scene_normals_from_materials: outFmt must be R10G10B10A2_UNORM or RGBA32F");
+    int rc = validateProducer(ctx, "scene_normals_from_materials", in, materials, numMaterials, nullptr);
+    if (rc) return rc;
+    const int pitch = out_row_pitch_px ? out_row_pitch_px : in->width;
+    if (pitch < in->width) return fail(ctx, VQHIP_ERR_INVALID_ARG, "scene_normals_from_materials: bad output pitch");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    int slot;
+    rc = acquireSlot(ctx, &slot);
+    if (rc) return rc;
+    const size_t bytes = fillGbufConstants(ctx, slot, materials, numMaterials, 0.0f, nullptr);
+    rc = commitSlot(ctx, slot, bytes, st);
+    if (rc) return rc;
+    GbufArgs a;
+    a.ip0 = (const float4*)in->ip0; a.ip1 = (const float4*)in->ip1; a.ip2 = (const float4*)in->ip2;
+    a.gb0 = a.gb1 = a.gb2 = a.gb3 = nullptr;
+    a.gc = (const GbufConstants*)(ctx->devRing + (size_t)slot * kConstSlotBytes);
+    a.width = in->width; a.height = in->height; a.pitch = in->row_pitch_px; a.outPitch = pitch;
+    hipError_t e = launch_scene_normals_from_materials(st, a, out, outFmt);
+    if (e != hipSuccess) return failHip(ctx, e, "scene_normals_from_materials launch");
+    return releaseSlot(ctx, slot, st);
+}
+
 // PSMain as the engine runs it (ForwardLighting.hlsl:226-380, the lit draws of RenderSceneColor, SceneRendering.cpp:1619-1760): interpolants +
 // materials in, scene colour out, one kernel — the G-buffer record stays in registers. Two ring slots: the producer's constants and the lighting's.
 int vqhip_forward_lighting_from_materials(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
         const vqhip_ssao* ssao, const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
         const VQ_PointLight* extraPoint, int numExtraPoint, const vqhip_envmap* env, const vqhip_shadowmaps* sm,
         void* out, int out_row_pitch_px, vqhip_format outFmt) {
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "forward_lighting_from_materials: ctx is NULL");
+    CTX_GUARD(ctx, "forward_lighting_from_materials");
+    return vqhip_forward_lighting_from_materials_mrt(ctx, stream, in, materials, numMaterials, ssao, perFrame, perView, extraPoint, numExtraPoint, env, sm,
+                                                     out, out_row_pitch_px, outFmt, nullptr);
+}
+
+int vqhip_forward_lighting_from_materials_mrt(vqhip_ctx* ctx, void* stream, const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials,
+        const vqhip_ssao* ssao, const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,
+        const VQ_PointLight* extraPoint, int numExtraPoint, const vqhip_envmap* env, const vqhip_shadowmaps* sm,
+        void* out, int out_row_pitch_px, vqhip_format outFmt, const vqhip_psmain_targets* targets) {
     vqk::Range range_("RenderSceneColor");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "forward_lighting_from_materials: ctx is NULL");
     CTX_GUARD(ctx, "forward_lighting_from_materials");
@@ -638,6 +715,8 @@ int vqhip_forward_lighting_from_materials(vqhip_ctx* ctx, void* stream, const vq
     bool casters = false;
     rc = validateLighting(ctx, "forward_lighting_from_materials", perFrame, perView, extraPoint, numExtraPoint, env, sm, outFmt, &casters);
     if (rc) return rc;
+    MrtArgs mrt;
+    if ((rc = fillMrt(ctx, "forward_lighting_from_materials", targets, in->width, &mrt)) != VQHIP_OK) return rc;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
     int slotG, slotF;
@@ -651,7 +730,7 @@ int vqhip_forward_lighting_from_materials(vqhip_ctx* ctx, void* stream, const vq
     a.gc = (const GbufConstants*)(ctx->devRing + (size_t)slotG * kConstSlotBytes);
     a.width = in->width; a.height = in->height; a.pitch = in->row_pitch_px; a.outPitch = 0;
     hipError_t e = launch_forward_from_materials(st, a, (const FrameConstants*)(ctx->devRing + (size_t)slotF * kConstSlotBytes), env != nullptr, casters,
-                                                 out, out_row_pitch_px, outFmt, ctx->arithDxc, ctx->opt);
+                                                 out, out_row_pitch_px, outFmt, ctx->arithDxc, ctx->opt, mrt);
     if (e != hipSuccess) return failHip(ctx, e, "forward_lighting_from_materials launch");
     if ((rc = releaseSlot(ctx, slotG, st)) != VQHIP_OK) return rc;
     return releaseSlot(ctx, slotF, st);

@@ -25,6 +25,7 @@
 //
 // Arithmetic/sampling contract: DESIGN.md "G-buffer producer".
 #include "vq_shade.h"          // vq_internal.h, vq_devmath.h, vq_sampling.h + the lighting body of the fused kernel
+#include "vq_mrt.h"
 
 #include <cstdlib>
 #ifndef VQ_PSMAIN_WAVES_DEFAULT
@@ -153,7 +154,11 @@ struct MaterialSampler {
 
 // The G-buffer record of pixel (x, y) — the state of PSMain at ForwardLighting.hlsl:284-293 — for the lane's pixel of the wave's 32x2 strip;
 // all-zero for a pixel without geometry or a discarded fragment. Every lane of the wave must call it (quad swaps, ballots).
+// PREPASS: the Z pre-pass's pixel shader instead (DepthPrePass.hlsl:PSMain :153-171): only g1 = float4((SurfaceN + 1) * 0.5, 1) is produced (0 = not covered);
+// the diffuse map is fetched for the alpha test of the "_AlphaMasked" permutation alone, the normal map WITHOUT normalMapMipBias (:164 is Sample), the
+// coverage plane is left as it is (the lighting pass repeats the discard itself, ForwardLighting.hlsl:237-240).
 struct Record { float4 g0, g1, g2, g3; };
+template <bool PREPASS = false>
 VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane) {
     const GbufConstants* __restrict__ gc = a.gc;
     Record rec;
@@ -202,10 +207,11 @@ VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane
             float Metalness = 0.0f, Roughness = 0.0f, LocalAO = 0.0f;
             const vqhip_texture2d* slots = &mt.texDiffuse;             // t0,t1,t2,t4,t5,t6,t7 are consecutive in vqhip_material
             #pragma unroll 1
-            for (int k = 0; k < 7; ++k) {
+            for (int k = 0; k < (PREPASS ? 2 : 7); ++k) {
                 const int bit = (0x2845710 >> (4 * k)) & 15;           // Has*Map bit of slot k: 0,1,7,5,4,8,2
                 if (k != 1 && !has_bit(TEX_CFG, bit)) continue;
-                const float4 r = ms.sample(slots[k], k == 1 ? m.normalMapMipBias : 0.0f);
+                if (PREPASS && k == 0 && !(mt.texDiffuse.reserved & VQHIP_MATERIAL_ALPHA_MASKED)) continue;      // DepthPrePass.hlsl:157-161: #if ENABLE_ALPHA_MASK
+                const float4 r = ms.sample(slots[k], (k == 1 && !PREPASS) ? m.normalMapMipBias : 0.0f);
                 switch (k) {
                     case 0: AlbedoAlpha = r; break;
                     case 1: Normal4 = r; break;
@@ -221,7 +227,7 @@ VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane
             // the fragment is gone: zero record, and the pixel's index in the coverage plane becomes "no geometry" (quad partners keep the
             // index they read before, like the helper lanes of a discarded fragment keep serving derivatives)
             if ((mt.texDiffuse.reserved & VQHIP_MATERIAL_ALPHA_MASKED) && has_bit(TEX_CFG, 0) && AlbedoAlpha.w < 0.01f) {
-                ((float*)((char*)a.ip2 + o))[3] = __int_as_float(-1);            // the record stays all-zero
+                if (!PREPASS) ((float*)((char*)a.ip2 + o))[3] = __int_as_float(-1);            // the record stays all-zero
                 todo = false;
                 continue;
             }
@@ -251,7 +257,7 @@ VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane
             if (has_bit(TEX_CFG, 5)) metalness *= Metalness;                               // :271
             if (has_bit(TEX_CFG, 8)) { roughness *= ORM.y; metalness *= ORM.z; }           // :272-277
 
-            if (gc->ssao.texels) {                                                         // :280-281, POINT_WRAP
+            if (!PREPASS && gc->ssao.texels) {                                             // :280-281, POINT_WRAP
                 const float su = div_(((float)x + 0.5f) + 0.5f, (float)a.width), sv = div_(((float)y + 0.5f) + 0.5f, (float)a.height);
                 // coordinate snapped to 8 fractional bits before the floor (these coordinates sit exactly on texel borders)
                 // su, sv are in (0, 1] so the texel index is in [0, dim]: WRAP is one conditional subtract (== the modulo)
@@ -259,6 +265,11 @@ VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane
                 tx = tx >= gc->ssao.width ? tx - gc->ssao.width : tx;
                 ty = ty >= gc->ssao.height ? ty - gc->ssao.height : ty;
                 ao *= (float)((const uint8_t*)gc->ssao.texels)[(uint32_t)ty * (uint32_t)gc->ssao.width + (uint32_t)tx] * 0.0039215688593685627f;
+            }
+            if (PREPASS) {                                                                // DepthPrePass.hlsl:168-169 (the rest of this body is dead code here)
+                rec.g1 = make_float4((SurfN.x + 1.0f) * 0.5f, (SurfN.y + 1.0f) * 0.5f, (SurfN.z + 1.0f) * 0.5f, 1.0f);
+                todo = false;
+                continue;
             }
             rec.g0 = make_float4(i0.x, i0.y, i0.z, ao);                                  // :284
             rec.g1 = make_float4(SurfN.x, SurfN.y, SurfN.z, roughness);
@@ -282,22 +293,38 @@ __global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
     int x, y, lane;
     strip_pixel(x, y, lane);
     const bool inside = (x < a.width) & (y < a.height);
-    const Record r = produce_record(a, x, y, inside, lane);
+    const Record r = produce_record<false>(a, x, y, inside, lane);
     if (!inside) return;
     const uint32_t q = (__umul24(y, a.outPitch) + (uint32_t)x) << 4;
     *(float4*)((char*)a.gb0 + q) = r.g0; *(float4*)((char*)a.gb1 + q) = r.g1; *(float4*)((char*)a.gb2 + q) = r.g2; *(float4*)((char*)a.gb3 + q) = r.g3;
+}
+
+// The Z pre-pass's colour target (DepthPrePass.hlsl:PSMain; VQRenderer::RenderDepthPrePass, SceneRendering.cpp:1264-1360): Tex_SceneNormals, R10G10B10A2_UNORM
+// (float -> UNORM n: trunc(saturate(c) * (2^n - 1) + 0.5)) or the unquantised float4; pixels nothing is drawn on keep the clear value 0 (:1289-1300).
+template <int OUTFMT>
+__global__ __launch_bounds__(256) void k_scene_normals_from_materials(GbufArgs a, void* out) {
+    int x, y, lane;
+    strip_pixel(x, y, lane);
+    const bool inside = (x < a.width) & (y < a.height);
+    const float4 n = produce_record<true>(a, x, y, inside, lane).g1;
+    if (!inside) return;
+    const size_t q = (size_t)y * a.outPitch + x;
+    if (OUTFMT == VQHIP_FMT_RGBA32F) { ((float4*)out)[q] = n; return; }
+    const uint32_t r = (uint32_t)(int)(saturate(n.x) * 1023.0f + 0.5f), g = (uint32_t)(int)(saturate(n.y) * 1023.0f + 0.5f), b = (uint32_t)(int)(saturate(n.z) * 1023.0f + 0.5f);
+    ((uint32_t*)out)[q] = n.w != 0.0f ? (r | (g << 10) | (b << 20) | (3u << 30)) : 0u;
 }
 
 // PSMain as the engine has it (ForwardLighting.hlsl:226-380): the producer and the lighting body (vq_shade.h) in ONE kernel — the 64-byte record
 // stays in registers instead of making a 128 B/pixel round trip through HBM. Bit-identical to vqhip_gbuffer_from_materials followed by
 // vqhip_forward_lighting (the record is the same fp32 values either way; pixels without geometry shade the all-zero record like the two calls do).
 template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT, int WAVES, int AR>
-__global__ __launch_bounds__(256, WAVES) void k_forward_from_materials(GbufArgs a, const FrameConstants* fc, void* out, int outPitch) {
+__global__ __launch_bounds__(256, WAVES) void k_forward_from_materials(GbufArgs a, const FrameConstants* fc, void* out, int outPitch, MrtArgs mrt) {
     int x, y, lane;
     strip_pixel(x, y, lane);
     const bool inside = (x < a.width) & (y < a.height);
-    const Record r = produce_record(a, x, y, inside, lane);
+    const Record r = produce_record<false>(a, x, y, inside, lane);
     if (!inside) return;
+    write_extra_targets(mrt, x, y, r.g2);
     const float4 c = shade_pixel<HAS_ENV, HAS_CASTERS, AR>(r.g0, r.g1, r.g2, r.g3, fc);
     store_px<OUTFMT>(out, (size_t)y * outPitch + x, c);
 }
@@ -309,15 +336,22 @@ hipError_t launch_gbuffer_from_materials(hipStream_t s, const GbufArgs& a) {
     return hipGetLastError();
 }
 
-hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt, int arithDxc, const Options& opt) {
+hipError_t launch_scene_normals_from_materials(hipStream_t s, const GbufArgs& a, void* out, int outFmt) {
+    dim3 grid((a.width + 127) / 128, (a.height + 1) / 2);
+    if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL(k_scene_normals_from_materials<VQHIP_FMT_RGBA32F>, grid, dim3(256), 0, s, a, out);
+    else                             hipLaunchKernelGGL(k_scene_normals_from_materials<VQHIP_FMT_R10G10B10A2_UNORM>, grid, dim3(256), 0, s, a, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt, int arithDxc, const Options& opt, const MrtArgs& mrt) {
     dim3 grid((a.width + 127) / 128, (a.height + 1) / 2);
     // register budget of the fused kernel: the producer half peaks at ~120 VGPRs (4 waves per SIMD), the lighting half needs 67; VQHIP_PSMAIN_WAVES = 5 / 6
     // caps the kernel at 96 / 80 VGPRs (the producer half then spills a little, the 64-light loop runs at higher occupancy)
     const int wv = opt.psmainWaves ? opt.psmainWaves : VQ_PSMAIN_WAVES_DEFAULT;      // option "psmain_waves"
-#define FFM(E, C, F) do { if (arithDxc) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, VQ_PSMAIN_WAVES_DEFAULT, 1>), grid, dim3(256), 0, s, a, fc, out, outPitch); /* DXC reading: one occupancy form */ \
-                          else if (wv >= 6) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 6, 0>), grid, dim3(256), 0, s, a, fc, out, outPitch); \
-                          else if (wv == 5) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 5, 0>), grid, dim3(256), 0, s, a, fc, out, outPitch); \
-                          else hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 4, 0>), grid, dim3(256), 0, s, a, fc, out, outPitch); } while (0)
+#define FFM(E, C, F) do { if (arithDxc) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, VQ_PSMAIN_WAVES_DEFAULT, 1>), grid, dim3(256), 0, s, a, fc, out, outPitch, mrt); /* DXC reading: one occupancy form */ \
+                          else if (wv >= 6) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 6, 0>), grid, dim3(256), 0, s, a, fc, out, outPitch, mrt); \
+                          else if (wv == 5) hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 5, 0>), grid, dim3(256), 0, s, a, fc, out, outPitch, mrt); \
+                          else hipLaunchKernelGGL((k_forward_from_materials<E, C, F, 4, 0>), grid, dim3(256), 0, s, a, fc, out, outPitch, mrt); } while (0)
 #define FFM2(E, C) do { if (outFmt == VQHIP_FMT_RGBA32F) FFM(E, C, 0); else FFM(E, C, 1); } while (0)
     if (hasEnv) { if (hasCasters) FFM2(true, true); else FFM2(true, false); }
     else        { if (hasCasters) FFM2(false, true); else FFM2(false, false); }

@@ -1,33 +1,38 @@
 // shade.hip — forward-PBR lighting kernel for gfx950: ForwardLighting.hlsl:PSMain :289-380 evaluated per G-buffer pixel (SURVEY.md §8a rows
 // A1-A7). One lane per pixel, 256-lane workgroups (128 for frames under 4 Mpixel), float4 SoA plane loads (16 B/lane, fully coalesced); the per-pixel body is vq_shade.h.
 #include "vq_shade.h"
+#include "vq_mrt.h"
 #include <cstdlib>
 
 namespace {
 
-template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT, int AR>
+template <bool HAS_ENV, bool HAS_CASTERS, int OUTFMT, int AR, bool MRT>
 __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::ShadeArgs a) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= a.width) return;
     const size_t i = (size_t)y * a.pitch + x;
     const float4 g0 = a.gb0[i], g1 = a.gb1[i], g2 = a.gb2[i], g3 = a.gb3[i];
+    if (MRT) vqk::write_extra_targets(a.mrt, x, y, g2);      // SV_TARGET1 / motion vectors of the same draw (vqhip_forward_lighting_mrt): its own instantiation,
+                                                             // the kernel without them is instruction for instruction what it was
     const vqk::FrameConstants* fc = a.fc;
     const float4 c = shade_pixel<HAS_ENV, HAS_CASTERS, AR>(g0, g1, g2, g3, fc);
     store_px<OUTFMT>(a.out, (size_t)y * a.outPitch + x, c);
 }
 
+template <bool E, bool C, int AR, bool MRT>
+hipError_t launch_k(hipStream_t s, const vqk::ShadeArgs& a, int outFmt, dim3 grid, int wg) {
+    if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_forward_lighting<E, C, 0, AR, MRT>), grid, dim3(wg), 0, s, a);
+    else                             hipLaunchKernelGGL((k_forward_lighting<E, C, 1, AR, MRT>), grid, dim3(wg), 0, s, a);
+    return hipGetLastError();
+}
 template <bool E, bool C>
 hipError_t launch_fmt(hipStream_t s, const vqk::ShadeArgs& a, int outFmt, dim3 grid) {
     const int wg = grid.z; grid.z = 1;
-    if (a.arithDxc) {                                        // the DXC reading of dot / normalize (vqhip_set_arithmetic): its own instantiation
-        if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_forward_lighting<E, C, 0, 1>), grid, dim3(wg), 0, s, a);
-        else                             hipLaunchKernelGGL((k_forward_lighting<E, C, 1, 1>), grid, dim3(wg), 0, s, a);
-        return hipGetLastError();
-    }
-    if (outFmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_forward_lighting<E, C, 0, 0>), grid, dim3(wg), 0, s, a);
-    else                             hipLaunchKernelGGL((k_forward_lighting<E, C, 1, 0>), grid, dim3(wg), 0, s, a);
-    return hipGetLastError();
+    const bool mrt = a.mrt.albedo || a.mrt.motion;
+    if (a.arithDxc)                                          // the DXC reading of dot / normalize (vqhip_set_arithmetic): its own instantiation
+        return mrt ? launch_k<E, C, 1, true>(s, a, outFmt, grid, wg) : launch_k<E, C, 1, false>(s, a, outFmt, grid, wg);
+    return mrt ? launch_k<E, C, 0, true>(s, a, outFmt, grid, wg) : launch_k<E, C, 0, false>(s, a, outFmt, grid, wg);
 }
 
 } // namespace

@@ -56,12 +56,20 @@ struct alignas(16) DevPointLight { float px, py, pz, range; float cbx, cby, cbz,
 static constexpr int    kMaxExtraPointLights = 1024;
 static constexpr size_t kConstSlotBytes = (sizeof(FrameConstants) + (VQ_NUM_LIGHTS__POINT + kMaxExtraPointLights) * sizeof(DevPointLight) + 255) & ~(size_t)255;
 
+// the draw's other render targets (vqhip_psmain_targets, include/vqhip.h): pointers NULL = target not bound (wave-uniform tests in the kernels)
+struct MrtArgs {
+    void* albedo; void* motion;                     // SV_TARGET1 (ForwardLighting.hlsl:383), motion vectors (:387)
+    const float4* svCurr; const float4* svPrev;     // PSInput :49-52
+    int albedoPitch, motionPitch, svPitch;
+    int albedoF32, motionF32;                       // storage: 0 = RGBA16F / RG16F (the reference's formats), 1 = RGBA32F / RG32F
+};
 struct ShadeArgs {
     const float4* gb0; const float4* gb1; const float4* gb2; const float4* gb3;
     void* out;
     const FrameConstants* fc;   // device
     int width, height, pitch, outPitch;
     int arithDxc;               // vqhip_set_arithmetic: 0 literal reading, 1 DXC reading (selects the kernel instantiation)
+    MrtArgs mrt;                // last: the kernels without extra targets keep their argument offsets
 };
 
 // G-buffer producer (§8f.1): per-call constants in a ring slot — cbPerObject.materialData + descriptor tables of every
@@ -82,8 +90,9 @@ struct GbufArgs {
     int width, height, pitch, outPitch;
 };
 hipError_t launch_gbuffer_from_materials(hipStream_t s, const GbufArgs& a);
+hipError_t launch_scene_normals_from_materials(hipStream_t s, const GbufArgs& a, void* out, int outFmt);   // a.gb* unused, a.outPitch = pitch of `out`
 struct FrameConstants;
-hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt, int arithDxc, const Options& opt);
+hipError_t launch_forward_from_materials(hipStream_t s, const GbufArgs& a, const FrameConstants* fc, bool hasEnv, bool hasCasters, void* out, int outPitch, int outFmt, int arithDxc, const Options& opt, const MrtArgs& mrt);
 hipError_t launch_mip_box_rgba8(hipStream_t s, const void* src, void* dst, int sw, int sh, int dw, int dh);
 hipError_t launch_skydome(hipStream_t s, const float4* eq0, int w0, int h0, const VQ_SkydomeParams& sp, const float4* cov, int covPitch,
                           void* color, int W, int H, int pitch, int fmt);

@@ -269,6 +269,26 @@ def interpolants(width, height, n_materials, seed=0x1A7E):
     return ip0, ip1, ip2
 
 
+def clip_positions(width, height, seed=0x5C11):
+    """PSInput.svPositionCurr / svPositionPrev (ForwardLighting.hlsl:49-52) of a synthetic view: clip-space positions whose xy / w land near the pixel's NDC
+    position, w = view depth in [0.3, 120] growing towards the top of the image like synth.interpolants; the previous frame is the same geometry under a
+    slightly different camera (a few pixels of motion, more for near geometry). Two float32 arrays [H,W,4]."""
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0x2B]))
+    ys, xs = np.meshgrid(np.arange(height, dtype=np.float32), np.arange(width, dtype=np.float32), indexing="ij")
+    t, s = (ys + 0.5) / height, (xs + 0.5) / width
+    w = (0.3 + 120.0 * (1.0 - t) ** 3).astype(np.float32)
+    cur = np.empty((height, width, 4), np.float32)
+    cur[..., 0] = (2.0 * s - 1.0) * w
+    cur[..., 1] = (1.0 - 2.0 * t) * w
+    cur[..., 2] = w - 0.1
+    cur[..., 3] = w
+    prev = cur.copy()
+    prev[..., 0] += np.float32(0.03) + 0.002 * (r.random((height, width), dtype=np.float32) - 0.5)
+    prev[..., 1] -= np.float32(0.011) + 0.002 * (r.random((height, width), dtype=np.float32) - 0.5)
+    prev[..., 3] *= np.float32(1.004)
+    return cur, prev
+
+
 def material_set(n, seed=0x3A7, max_dim=256, same_size=False):
     """n materials: (list of abi.MaterialData, list of {slot: uint8 [H,W,4] level 0}) with power-of-two texture sizes
     (non-square allowed), random scalar parameters and uv tiling. textureConfig normally mirrors the bound maps
