@@ -337,7 +337,8 @@ VQHIP_API int  vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* val
 typedef enum vqhip_arithmetic { VQHIP_ARITH_LITERAL = 0, VQHIP_ARITH_DXC = 1 } vqhip_arithmetic;
 VQHIP_API int  vqhip_set_arithmetic(vqhip_ctx* ctx, vqhip_arithmetic mode);
 #define VQHIP_ABI_VERSION 2   /* 2 (round 4): + vqhip_set_arithmetic, vqhip_set_option, vqhip_ssr_environment_fallback, VQHIP_FMT_R10G10B10A2_UNORM; conv order default SEQUENTIAL;
-                               * later in round 4, additions only: vqhip_forward_lighting_mrt, vqhip_forward_lighting_from_materials_mrt, vqhip_scene_normals_from_materials */
+                               * later in round 4, additions only: vqhip_forward_lighting_mrt, vqhip_forward_lighting_from_materials_mrt, vqhip_scene_normals_from_materials,
+                               * vqhip_composite_reflections; vqhip_visualize reads R10G10B10A2 / RG16F / RG32F inputs */
 
 /* Replaces VQRenderer::RenderSceneColor's lit draw loop (SceneRendering.cpp:1619-1785, hot part :1730-1784)
  * == ForwardLighting.hlsl:PSMain :289-380 evaluated for every pixel of the G-buffer.
@@ -602,11 +603,22 @@ VQHIP_API int vqhip_fsr_rcas(vqhip_ctx* ctx, void* stream, const void* in, void*
  * :34-120. VQ_VizParams == FPostProcessParameters::FVizualizationParams (the cbuffer :26-31); iDrawMode uses the SHADER's
  * numbering (:71-80): 1 DEPTH pow(r,500), 2 NORMALS, 3 ROUGHNESS / 4 METALLIC (alpha), 5 AO (red), 6 ALBEDO / 7 REFLECTIONS
  * (rgb), 8 MOTION_VECTORS; anything else (including 0) writes magenta. Output alpha = input alpha. The caller binds the
- * image the reference's switch selects (:2555-2565); single-channel sources are passed expanded to (r,0,0,1). */
+ * image the reference's switch selects (:2555-2565) in the format that target has: inFmt RGBA8_UNORM | RGBA16F | RGBA32F (scene colour, Tex_SceneVisualization of
+ * vqhip_forward_lighting_mrt, reflections), R10G10B10A2_UNORM (Tex_SceneNormals of vqhip_scene_normals_from_materials: c / 1023, alpha / 3), RG16F | RG32F
+ * (Tex_SceneMotionVectors: the missing channels read 0 and 1 like a typed SRV load); single-channel sources are passed expanded to (r,0,0,1).
+ * outFmt RGBA8_UNORM | RGBA16F | RGBA32F. */
 /* Replaces ApplyReflectionsPass::RecordCommands (ApplyReflections.cpp:45-80) == ApplyReflections.hlsl:CSMain :30-50 without
  * COMPOSITE_BOUNDING_VOLUMES: sceneColor.rgb += reflectionRadiance.rgb, alpha (roughness) kept; in place on the scene colour.
  * (The producer of the reflection radiance, FidelityFX SSSR + denoiser, is out of scope.) fmt: RGBA16F | RGBA32F for both. */
 VQHIP_API int vqhip_apply_reflections(vqhip_ctx* ctx, void* stream, const void* reflectionRadiance, void* sceneColor,
+        int width, int height, vqhip_format fmt);
+/* Replaces VQRenderer::CompositeReflections (SceneRendering.cpp:2362-2403): ApplyReflectionsPass in the permutation its parameters select
+ * (ApplyReflections.cpp:62-68). boundingVolumes == NULL: vqhip_apply_reflections. Otherwise "[PSO] ApplyReflectionsAndBoundingVolumes"
+ * (COMPOSITE_BOUNDING_VOLUMES, ApplyReflections.hlsl:44-48): Tex_SceneColorBoundingVolumes (the light-bounds target of RenderLightBounds,
+ * same format as the scene colour) is blended over the sum,
+ *     rgb = BV.rgb * BV.a + (scene.rgb + reflection.rgb) * (1 - BV.a),   alpha = BV.a,
+ * every product and sum rounded on its own, as written. In place on sceneColor; the inputs must not alias it. fmt: RGBA16F | RGBA32F for all three. */
+VQHIP_API int vqhip_composite_reflections(vqhip_ctx* ctx, void* stream, const void* reflectionRadiance, const void* boundingVolumes, void* sceneColor,
         int width, int height, vqhip_format fmt);
 
 /* ---- SSR's consumption of the specular cube + BRDF LUT ---------------------------

@@ -22,6 +22,11 @@ namespace sky {
 namespace reflections {
 #include "ApplyReflections.hlsl"
 }
+#define COMPOSITE_BOUNDING_VOLUMES 1          // "[PSO] ApplyReflectionsAndBoundingVolumes" (ApplyReflections.cpp:82-86): the same source, second permutation
+namespace reflections_bv {
+#include "ApplyReflections.hlsl"
+}
+#undef COMPOSITE_BOUNDING_VOLUMES
 namespace viz {
 #include "Visualization.hlsl"
 }
@@ -117,6 +122,18 @@ int vqref_apply_reflections(const float* refl, float* scene, int W, int H) {
     reflections::TexSceneColor.data = (float4*)scene; reflections::TexSceneColor.width = W; reflections::TexSceneColor.height = H;
     for (int y = 0; y < H; ++y)
         for (int x = 0; x < W; ++x) { const uint3 z(0, 0, 0); reflections::CSMain(z, z, uint3((uint)x, (uint)y, 0)); }
+    return 0;
+}
+
+// the COMPOSITE_BOUNDING_VOLUMES permutation: scene = BV.rgb * BV.a + (scene + reflections) * (1 - BV.a), alpha = BV.a
+int vqref_apply_reflections_bv(const float* refl, const float* bv, float* scene, int W, int H) {
+    if (!refl || !bv || !scene) return -1;
+    const Image src{ refl, W, H }, bvI{ bv, W, H };
+    reflections_bv::TexReflectionRadiance.res = &src; reflections_bv::TexReflectionRadiance.kind = kTexImage;
+    reflections_bv::TexBoundingVolumes.res = &bvI; reflections_bv::TexBoundingVolumes.kind = kTexImage;
+    reflections_bv::TexSceneColor.data = (float4*)scene; reflections_bv::TexSceneColor.width = W; reflections_bv::TexSceneColor.height = H;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) { const uint3 z(0, 0, 0); reflections_bv::CSMain(z, z, uint3((uint)x, (uint)y, 0)); }
     return 0;
 }
 

@@ -228,6 +228,12 @@ int vqo_visualize(const void* in, void* out, int W, int H, const VQ_VizParams* p
             f4 t;
             if (inFmt == VQHIP_FMT_RGBA32F) { const float* q = (const float*)in + i * 4; t = { q[0], q[1], q[2], q[3] }; }
             else if (inFmt == VQHIP_FMT_RGBA16F) { const uint16_t* q = (const uint16_t*)in + i * 4; t = { f16_to_f32(q[0]), f16_to_f32(q[1]), f16_to_f32(q[2]), f16_to_f32(q[3]) }; }
+            else if (inFmt == VQHIP_FMT_RG16F) { const uint16_t* q = (const uint16_t*)in + i * 2; t = { f16_to_f32(q[0]), f16_to_f32(q[1]), 0.0f, 1.0f }; }   // Tex_SceneMotionVectors: missing channels read (0, 1)
+            else if (inFmt == VQHIP_FMT_RG32F) { const float* q = (const float*)in + i * 2; t = { q[0], q[1], 0.0f, 1.0f }; }
+            else if (inFmt == VQHIP_FMT_R10G10B10A2_UNORM) {                                                                     // Tex_SceneNormals: UNORM n -> float = c / (2^n - 1)
+                const uint32_t q = ((const uint32_t*)in)[i];
+                t = { fdiv_((float)(q & 1023u), 1023.0f), fdiv_((float)((q >> 10) & 1023u), 1023.0f), fdiv_((float)((q >> 20) & 1023u), 1023.0f), fdiv_((float)(q >> 30), 3.0f) };
+            }
             else { const uint8_t* q = (const uint8_t*)in + i * 4; const float s = rcp(255.0f); t = { q[0] * s, q[1] * s, q[2] * s, q[3] * s }; }
             f3 o;
             switch (p->iDrawMode) {

@@ -311,12 +311,28 @@ def ssr_environment_fallback(scene, scene_fmt, depth, normals, normal_fmt, cb, e
 def visualize(img, in_fmt, params, out_fmt=None, nthreads=0):
     lib = load()
     lib.vqo_visualize.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(abi.VizParams), C.c_int, C.c_int, C.c_int]
-    out_fmt = in_fmt if out_fmt is None else out_fmt
+    if out_fmt is None:
+        out_fmt = in_fmt if in_fmt in (abi.FMT_RGBA32F, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM) else abi.FMT_RGBA16F
     img = np.ascontiguousarray(img)
     h, w = img.shape[:2]
     out = np_image(h, w, out_fmt)
     assert lib.vqo_visualize(_p(img), _p(out), w, h, C.byref(params), in_fmt, out_fmt, nthreads) == 0
     return out
+
+
+def composite_reflections(refl, scene, fmt, bounding_volumes=None):
+    """ApplyReflections.hlsl:CSMain :30-50 restated in numpy binary32, one rounding per operation, the result rounded (RNE) to the target's storage format:
+    scene.rgb + reflection.rgb (alpha kept); with the light-bounds image (COMPOSITE_BOUNDING_VOLUMES, :44-48): BV.rgb * BV.a + that * (1 - BV.a), alpha = BV.a."""
+    dt = _NP[fmt][0]
+    f = np.float32
+    with np.errstate(all="ignore"):
+        s, r = np.asarray(scene).astype(f), np.asarray(refl).astype(f)
+        rgb, a = s[..., :3] + r[..., :3], s[..., 3:4]
+        if bounding_volumes is not None:
+            b = np.asarray(bounding_volumes).astype(f)
+            rgb = (b[..., :3] * b[..., 3:4]).astype(f) + (rgb * (f(1.0) - b[..., 3:4]).astype(f)).astype(f)
+            a = b[..., 3:4]
+        return np.concatenate([rgb, a], -1).astype(dt)
 
 
 def fsr_easu_con(in_w, in_h, out_w, out_h):

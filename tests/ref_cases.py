@@ -453,6 +453,26 @@ CASES.append(_prepass_case())
 CASES.append(_prepass_case(alpha_masked=True))
 
 
+def _composite_reflections_case():
+    """VQRenderer::CompositeReflections with the light-bounds image: ApplyReflections.hlsl compiled with COMPOSITE_BOUNDING_VOLUMES (:44-48), RGBA16F targets"""
+    def build():
+        r = np.random.default_rng(21)
+        bv = hdr_scene(40, 24, 33)
+        bv[..., 3] = r.random((24, 40)).astype(np.float16)
+        bv[::3, ::2, 3] = 0.0
+        bv[1::3, ::2, 3] = 1.0
+        return {"scene": hdr_scene(40, 24, 31), "refl": hdr_scene(40, 24, 32), "bv": bv}
+
+    def ref(i):
+        from tests import ref_lib as R
+        return R.apply_reflections_bv(i["refl"].astype(np.float32), i["bv"].astype(np.float32), i["scene"].astype(np.float32))
+    return Case("composite_reflections_bounding_volumes", build, ref, lambda i: O.composite_reflections(i["refl"], i["scene"], F16, i["bv"]),
+                lambda ctx, i: ctx.composite_reflections(_dev(i["refl"]), _dev(i["scene"]), F16, _dev(i["bv"])).cpu().numpy(), ("ulp16", 0, 0.0))
+
+
+CASES.append(_composite_reflections_case())
+
+
 def _lut_case():
     rows = [0, 20, 77, 512, 1023]
     xs = np.concatenate([[0, 1, 1022, 1023], np.arange(5, 1024, 41)]).astype(np.int32)

@@ -77,6 +77,7 @@ def load(name="shaders"):
             lib.vqref_skydome.argtypes = [vp, i32, i32, vp, i32, i32, vp]
             lib.vqref_visualize.argtypes = [vp, i32, i32, vp, vp]
             lib.vqref_apply_reflections.argtypes = [vp, vp, i32, i32]
+            lib.vqref_apply_reflections_bv.argtypes = [vp, vp, vp, i32, i32]
             lib.vqref_ssr_environment_fallback.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
             lib.vqref_prepass_normals.argtypes = [vp, vp, i32, vp]
             lib.vqref_unlit_color.argtypes = [vp, vp]
@@ -229,6 +230,13 @@ def visualize(img, params):
 def apply_reflections(refl, scene):
     refl, scene = _img32(refl), _img32(scene).copy()
     assert load().vqref_apply_reflections(refl.ctypes.data, scene.ctypes.data, scene.shape[1], scene.shape[0]) == 0
+    return scene
+
+
+def apply_reflections_bv(refl, bv, scene):
+    """ApplyReflections.hlsl:CSMain compiled with COMPOSITE_BOUNDING_VOLUMES: returns the composited scene (float32 values)"""
+    refl, bv, scene = _img32(refl), _img32(bv), _img32(scene).copy()
+    assert load().vqref_apply_reflections_bv(refl.ctypes.data, bv.ctypes.data, scene.ctypes.data, scene.shape[1], scene.shape[0]) == 0
     return scene
 
 

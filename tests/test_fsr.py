@@ -229,3 +229,21 @@ def test_rcas_sharpens_an_edge_and_keeps_flat_regions():
     flat = out[4:12, 4:12, :3]
     assert np.abs(flat - 0.25).max() < 2e-3                                 # APrxMedRcp error only
     assert out[8, 15, 0] < 0.25 and out[8, 16, 0] > 0.75                     # undershoot / overshoot across the edge
+
+
+def test_visualization_reads_packed_normals_and_two_channel_targets():
+    """vqo_visualize on the formats the draw modes' SRVs have (SceneRendering.cpp:2555-2566): R10G10B10A2_UNORM decodes c / 1023 (alpha / 3), RG16F / RG32F read
+    (r, g, 0, 1) — each == the RGBA32F path on the decoded values, and the decode == the SSR fallback's (one correctly rounded quotient)."""
+    r = np.random.default_rng(9)
+    q = r.integers(0, 2 ** 32, (7, 11), dtype=np.uint32)
+    dec = np.stack([(q & 1023), (q >> 10) & 1023, (q >> 20) & 1023], -1).astype(np.float64) / 1023.0
+    dec4 = np.concatenate([dec, ((q >> 30).astype(np.float64) / 3.0)[..., None]], -1).astype(F)          # float64 quotient rounded once == the IEEE float quotient here
+    for p in (abi.VizParams(2, 0, 1.0), abi.VizParams(2, 1, 1.0), abi.VizParams(3, 0, 1.0)):
+        assert np.array_equal(O.visualize(q, abi.FMT_R10G10B10A2_UNORM, p, abi.FMT_RGBA32F), O.visualize(dec4, abi.FMT_RGBA32F, p, abi.FMT_RGBA32F))
+    mv = (r.random((7, 11, 2), dtype=F) - F(0.5)) * F(0.1)
+    full = np.concatenate([mv, np.zeros((7, 11, 1), F), np.ones((7, 11, 1), F)], -1)
+    p = abi.VizParams(8, 0, 25.0)
+    assert np.array_equal(O.visualize(mv, abi.FMT_RG32F, p, abi.FMT_RGBA32F), O.visualize(full, abi.FMT_RGBA32F, p, abi.FMT_RGBA32F))
+    h = mv.astype(np.float16)
+    fullh = np.concatenate([h.astype(F), np.zeros((7, 11, 1), F), np.ones((7, 11, 1), F)], -1)
+    assert np.array_equal(O.visualize(h, abi.FMT_RG16F, p), O.visualize(fullh, abi.FMT_RGBA32F, p, abi.FMT_RGBA16F))

@@ -87,6 +87,38 @@ def test_visualize_matches_oracle(ctx, in_fmt, out_fmt):
         assert n == 0, (mode, n, idx)
 
 
+def test_visualize_reads_the_targets_the_draw_modes_bind(ctx):
+    """SceneRendering.cpp:2555-2566: NORMALS shows Tex_SceneNormals (R10G10B10A2), MOTION_VECTORS Tex_SceneMotionVectors (RG16F), ALBEDO / METALLIC
+    Tex_SceneVisualization (RGBA16F) — here the product's own vqhip_scene_normals_from_materials / vqhip_forward_lighting_mrt outputs, visualised, == the oracle chain."""
+    from tests.test_gpu_gbuffer import build_materials
+    from vqengine_amd import synth
+    W, H, NM = 200, 48, 4
+    ip = synth.interpolants(W, H, NM)
+    _, _, hmats, dmats, keep = build_materials(ctx, NM, max_dim=64)
+    cur, prev = synth.clip_positions(W, H)
+    pf, _ = synth.per_frame(points=synth.point_lights(3))
+    pv = synth.per_view(W, H)
+    ipd = [dev(p) for p in ip]
+    nrm = ctx.scene_normals_from_materials(ipd, dmats)
+    _, alb, mv = ctx.forward_lighting_from_materials_mrt(ipd, dmats, pf, pv, motion_fmt=abi.FMT_RG16F, sv_curr=dev(cur), sv_prev=dev(prev))
+    nrm_o = O.scene_normals_from_materials(ip, hmats)
+    gb_o = O.gbuffer_from_materials([p.copy() for p in ip], hmats, pf.fAmbientLightingFactor, None)
+    alb_o, mv_o = O.psmain_extra_targets(gb_o, cur, prev)
+    for src, src_o, fmt, modes in ((nrm, nrm_o, abi.FMT_R10G10B10A2_UNORM, ((2, 0, 1.0), (2, 1, 1.0))), (mv, mv_o, abi.FMT_RG16F, ((8, 0, 40.0),)),
+                                   (alb, alb_o, abi.FMT_RGBA16F, ((6, 0, 1.0), (4, 0, 1.0)))):
+        for mode, unpack, strength in modes:
+            p = abi.VizParams(mode, unpack, strength)
+            for out_fmt in (abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM):
+                n, idx = O.bits_equal(ctx.visualize(src, fmt, p, out_fmt).cpu().numpy(), O.visualize(src_o, fmt, p, out_fmt))
+                assert n == 0, (fmt, mode, out_fmt, n, idx)
+    mv32 = O.psmain_extra_targets(gb_o, cur, prev, None, abi.FMT_RG32F)[1]
+    p = abi.VizParams(8, 0, 40.0)
+    n, idx = O.bits_equal(ctx.visualize(dev(mv32), abi.FMT_RG32F, p, abi.FMT_RGBA32F).cpu().numpy(), O.visualize(mv32, abi.FMT_RG32F, p, abi.FMT_RGBA32F))
+    assert n == 0, (n, idx)
+    out = O.visualize(mv_o, abi.FMT_RG16F, p, abi.FMT_RGBA32F)
+    assert (out[..., 2] == 0.5).all() and (out[..., 3] == 1.0).all()                     # typed load of a two-channel target: b = 0, a = 1
+
+
 @pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
 def test_apply_reflections(ctx, fmt):
     """ApplyReflections.hlsl:30-50: one IEEE add per colour channel in fp32, result rounded to the target format, alpha kept."""
@@ -100,6 +132,31 @@ def test_apply_reflections(ctx, fmt):
     got = ctx.apply_reflections(dev(refl), dev(scene), fmt).cpu().numpy()
     n, idx = O.bits_equal(got, exp)
     assert n == 0, (n, idx)
+
+
+@pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
+def test_composite_reflections_with_bounding_volumes(ctx, fmt):
+    """VQRenderer::CompositeReflections, the COMPOSITE_BOUNDING_VOLUMES permutation (ApplyReflections.hlsl:44-48): BV.rgb * BV.a + (scene + refl) * (1 - BV.a),
+    alpha = BV.a — every operation rounded on its own; without the image it is vqhip_apply_reflections; aliasing inputs are refused."""
+    dt = _NP[fmt]
+    W, H = 1921, 23
+    scene = synth.hdr_image(W, H, seed=3).astype(dt)
+    refl = synth.hdr_image(W, H, seed=4, scale=0.5).astype(dt)
+    bv = synth.hdr_image(W, H, seed=5, scale=0.25).astype(dt)
+    r = np.random.default_rng(5)
+    bv[..., 3] = r.random((H, W)).astype(dt)
+    bv[::3, ::2, 3] = 0.0
+    bv[1::3, ::2, 3] = 1.0
+    bv[2, 5] = (np.inf, 1.0, np.nan, 0.5)
+    refl[5, 7] = (np.inf, -1.0, np.nan, 9.0)
+    n, idx = O.bits_equal(ctx.composite_reflections(dev(refl), dev(scene), fmt, dev(bv)).cpu().numpy(), O.composite_reflections(refl, scene, fmt, bv))
+    assert n == 0, (n, idx)
+    n, idx = O.bits_equal(ctx.composite_reflections(dev(refl), dev(scene), fmt).cpu().numpy(), ctx.apply_reflections(dev(refl), dev(scene), fmt).cpu().numpy())
+    assert n == 0, (n, idx)
+    s = dev(scene)
+    assert ctx.lib.vqhip_composite_reflections(ctx._h, None, C.c_void_p(s.data_ptr()), None, C.c_void_p(s.data_ptr()), W, H, fmt) == abi.VQHIP_ERR_INVALID_ARG
+    assert ctx.lib.vqhip_composite_reflections(ctx._h, None, C.c_void_p(dev(refl).data_ptr()), C.c_void_p(s.data_ptr()), C.c_void_p(s.data_ptr()), W, H, fmt) == abi.VQHIP_ERR_INVALID_ARG
+    assert ctx.lib.vqhip_composite_reflections(ctx._h, None, C.c_void_p(dev(refl).data_ptr()), None, C.c_void_p(s.data_ptr()), W, H, abi.FMT_RGBA8_UNORM) == abi.VQHIP_ERR_UNSUPPORTED
 
 
 def test_fsr_abi_errors(ctx):

@@ -383,6 +383,18 @@ def test_apply_reflections():
     assert np.array_equal(ref, want)
 
 
+def test_apply_reflections_with_bounding_volumes():
+    """the COMPOSITE_BOUNDING_VOLUMES permutation (ApplyReflections.hlsl:44-48) against the numpy statement the GPU tests check the product with"""
+    scene, refl, bv = (_hdr_scene(seed=s).astype(np.float32) for s in (13, 14, 15))
+    r = np.random.default_rng(3)
+    bv[..., 3] = r.random(bv.shape[:2]).astype(np.float32)
+    bv[::4, ::3, 3] = 0.0
+    bv[1::4, ::3, 3] = 1.0
+    ref = R.apply_reflections_bv(refl, bv, scene)
+    assert np.array_equal(ref.view(np.uint32), O.composite_reflections(refl, scene, abi.FMT_RGBA32F, bv).view(np.uint32))
+    assert np.array_equal(ref[..., 3], bv[..., 3]) and np.array_equal(ref[::4, ::3, :3], (scene + refl)[::4, ::3, :3])
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # VQ_DXGI_UTILS::MipImage (DXGIUtils.cpp:250-318), the reference's C++ compiled as is
 # ---------------------------------------------------------------------------------------------------------------------

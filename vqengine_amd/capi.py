@@ -86,6 +86,7 @@ def load_library():
         "vqhip_fsr_rcas": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(C.c_uint32), i32, i32]),
         "vqhip_visualize": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.VizParams), i32, i32]),
         "vqhip_apply_reflections": (i32, [vp, vp, vp, vp, i32, i32, i32]),
+        "vqhip_composite_reflections": (i32, [vp, vp, vp, vp, vp, i32, i32, i32]),
         "vqhip_ssr_environment_fallback": (i32, [vp, vp, vp, i32, i32, vp, i32, vp, i32, i32, i32, i32, C.POINTER(abi.SSSRConstants), C.POINTER(abi.EnvMap),
                                                  vp, i32, i32, vp]),
         "vqhip_rowtile": (i32, [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]),
@@ -115,7 +116,7 @@ EXPORTED_SYMBOLS = [
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_forward_lighting_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
     "vqhip_skydome", "vqhip_unlit_composite", "vqhip_set_fresnel_pow", "vqhip_set_arithmetic", "vqhip_set_option", "vqhip_hdr_parse_header", "vqhip_hdr_decode_rgba32f", "vqhip_hdr_downsize_rgba32f",
-    "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections", "vqhip_ssr_environment_fallback",
+    "vqhip_fsr_easu_con", "vqhip_fsr_rcas_con", "vqhip_fsr_easu", "vqhip_fsr_rcas", "vqhip_visualize", "vqhip_apply_reflections", "vqhip_composite_reflections", "vqhip_ssr_environment_fallback",
     "vqhip_rowtile", "vqhip_comm_unique_id", "vqhip_comm_create", "vqhip_comm_adopt", "vqhip_comm_destroy", "vqhip_comm_query", "vqhip_comm_abort", "vqhip_comm_loopback", "vqhip_exchange_blur_halos",
     "vqhip_composite_tiles",
 ]
@@ -535,6 +536,17 @@ class Context:
         self._ck(self.lib.vqhip_apply_reflections(self._h, self._stream(stream), _ptr(reflection), _ptr(scene_color), w, h, fmt))
         return scene_color
 
+    def composite_reflections(self, reflection, scene_color, fmt, bounding_volumes=None, stream=None):
+        """VQRenderer::CompositeReflections: apply_reflections, or — with the light-bounds image — the COMPOSITE_BOUNDING_VOLUMES permutation
+        (rgb = BV.rgb * BV.a + (scene + reflection) * (1 - BV.a), alpha = BV.a). In place on scene_color."""
+        _check_img(reflection, fmt, "reflection", scene_color.shape[:2])
+        _check_img(scene_color, fmt, "scene_color")
+        if bounding_volumes is not None:
+            _check_img(bounding_volumes, fmt, "bounding_volumes", scene_color.shape[:2])
+        h, w = scene_color.shape[0], scene_color.shape[1]
+        self._ck(self.lib.vqhip_composite_reflections(self._h, self._stream(stream), _ptr(reflection), _ptr(bounding_volumes), _ptr(scene_color), w, h, fmt))
+        return scene_color
+
     def ssr_environment_fallback(self, scene_color, scene_fmt, depth, normals, normal_fmt, cb, env, out_fmt=None, extract_roughness=False, out=None, stream=None):
         """ClassifyReflectionTiles.hlsl: the environment-map fallback of SSR's tile classification (SampleEnvironmentMap under the condition of
         ClassifyTiles :146-152). scene_color: [H,W,4] image whose alpha is the roughness; depth: float32 [H,W]; normals: uint32 [H,W]
@@ -556,9 +568,16 @@ class Context:
         return (out, rough) if extract_roughness else out
 
     def visualize(self, src, in_fmt, params, out_fmt=None, out=None, stream=None):
-        """Visualization.hlsl:CSMain (debug draw modes). params: abi.VizParams."""
-        _check_img(src, in_fmt, "src")
-        out_fmt = in_fmt if out_fmt is None else out_fmt
+        """Visualization.hlsl:CSMain (debug draw modes). params: abi.VizParams. src in the format of the target the mode shows: a colour image, the int32 [H,W]
+        words of scene_normals_from_materials (in_fmt R10G10B10A2_UNORM) or the RG16F / RG32F motion vectors of forward_lighting_mrt; out_fmt defaults to in_fmt
+        for colour inputs, RGBA16F otherwise."""
+        if in_fmt == abi.FMT_R10G10B10A2_UNORM:
+            if not (src.is_cuda and src.is_contiguous() and src.dtype == torch.int32 and src.dim() == 2):
+                raise ValueError("src: expected contiguous cuda int32 [H,W] (R10G10B10A2_UNORM words)")
+        else:
+            _check_img(src, in_fmt, "src")
+        if out_fmt is None:
+            out_fmt = in_fmt if in_fmt in (FMT_RGBA32F, FMT_RGBA16F, FMT_RGBA8_UNORM) else FMT_RGBA16F
         h, w = src.shape[0], src.shape[1]
         if out is None:
             out = empty_image(h, w, out_fmt, self.device)

@@ -881,21 +881,31 @@ int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void* out, int
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "visualize: ctx is NULL");
     CTX_GUARD(ctx, "visualize");
     if (!in || !out || !params || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "visualize: bad argument");
-    if (!isColorFmt(inFmt) || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "visualize: formats must be RGBA8_UNORM, RGBA16F or RGBA32F");
+    // inputs: whatever the draw mode's SRV holds (SceneRendering.cpp:2555-2566) — colour formats, Tex_SceneNormals (R10G10B10A2), Tex_SceneMotionVectors (RG16F | RG32F)
+    const bool inOk = isColorFmt(inFmt) || inFmt == VQHIP_FMT_R10G10B10A2_UNORM || inFmt == VQHIP_FMT_RG16F || inFmt == VQHIP_FMT_RG32F;
+    if (!inOk || !isColorFmt(outFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "visualize: inFmt must be RGBA8_UNORM, RGBA16F, RGBA32F, RG16F, RG32F or R10G10B10A2_UNORM; outFmt RGBA8_UNORM, RGBA16F or RGBA32F");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipError_t e = launch_visualize((hipStream_t)stream, in, out, width, height, *params, inFmt, outFmt);
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "visualize launch");
 }
 
 int vqhip_apply_reflections(vqhip_ctx* ctx, void* stream, const void* reflectionRadiance, void* sceneColor, int width, int height, vqhip_format fmt) {
-    vqk::Range range_("CompositeReflections");            // :2374
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "apply_reflections: ctx is NULL");
     CTX_GUARD(ctx, "apply_reflections");
-    if (!reflectionRadiance || !sceneColor || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "apply_reflections: bad argument");
-    if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "apply_reflections: fmt must be RGBA32F or RGBA16F");
+    return vqhip_composite_reflections(ctx, stream, reflectionRadiance, nullptr, sceneColor, width, height, fmt);
+}
+
+// VQRenderer::CompositeReflections (SceneRendering.cpp:2362-2403): ApplyReflectionsPass in the permutation its SRVBoundingVolumes selects (ApplyReflections.cpp:62-68)
+int vqhip_composite_reflections(vqhip_ctx* ctx, void* stream, const void* reflectionRadiance, const void* boundingVolumes, void* sceneColor, int width, int height, vqhip_format fmt) {
+    vqk::Range range_("CompositeReflections");            // :2374
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "composite_reflections: ctx is NULL");
+    CTX_GUARD(ctx, "composite_reflections");
+    if (!reflectionRadiance || !sceneColor || width <= 0 || height <= 0 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, VQHIP_ERR_INVALID_ARG, "composite_reflections: bad argument");
+    if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "composite_reflections: fmt must be RGBA32F or RGBA16F");
+    if (boundingVolumes == sceneColor || reflectionRadiance == sceneColor) return fail(ctx, VQHIP_ERR_INVALID_ARG, "composite_reflections: the inputs must not alias the scene colour");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = launch_apply_reflections((hipStream_t)stream, reflectionRadiance, sceneColor, width, height, fmt);
-    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "apply_reflections launch");
+    hipError_t e = launch_apply_reflections((hipStream_t)stream, reflectionRadiance, boundingVolumes, sceneColor, width, height, fmt);
+    return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "composite_reflections launch");
 }
 
 int vqhip_ssr_environment_fallback(vqhip_ctx* ctx, void* stream, const void* sceneColorRoughness, vqhip_format sceneFmt, int scenePitchPx,

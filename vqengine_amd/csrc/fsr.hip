@@ -169,6 +169,12 @@ __global__ __launch_bounds__(256) void k_visualize(const void* __restrict__ in, 
     float4 t;
     if (INFMT == VQHIP_FMT_RGBA32F) t = ((const float4*)in)[i];
     else if (INFMT == VQHIP_FMT_RGBA16F) t = load_rgba16f(in, i);
+    else if (INFMT == VQHIP_FMT_RG16F) { const h2 q = ((const h2*)in)[i]; t = make_float4((float)q.x, (float)q.y, 0.0f, 1.0f); }        // Tex_SceneMotionVectors: missing channels read (0, 1)
+    else if (INFMT == VQHIP_FMT_RG32F) { const float2 q = ((const float2*)in)[i]; t = make_float4(q.x, q.y, 0.0f, 1.0f); }
+    else if (INFMT == VQHIP_FMT_R10G10B10A2_UNORM) {                                                                                     // Tex_SceneNormals: c / (2^n - 1), correctly rounded
+        const uint32_t q = ((const uint32_t*)in)[i];
+        t = make_float4(fdiv_((float)(q & 1023u), 1023.0f), fdiv_((float)((q >> 10) & 1023u), 1023.0f), fdiv_((float)((q >> 20) & 1023u), 1023.0f), fdiv_((float)(q >> 30), 3.0f));
+    }
     else { const uint32_t q = ((const uint32_t*)in)[i]; const float s = 0.0039215688593685627f;
            t = make_float4((float)(q & 255u) * s, (float)((q >> 8) & 255u) * s, (float)((q >> 16) & 255u) * s, (float)(q >> 24) * s); }
     f3 o;
@@ -190,17 +196,31 @@ __global__ __launch_bounds__(256) void k_visualize(const void* __restrict__ in, 
     else store_rgba8(out, i, r);
 }
 // ---- ApplyReflections.hlsl:CSMain :30-50: scene.rgb += reflection.rgb, alpha kept; in place, HBM-bound (24 B/pixel RGBA16F) ----
-template <int FMT>
-__global__ __launch_bounds__(256) void k_apply_reflections(const void* __restrict__ refl, void* scene, uint32_t n) {
+// BV: the COMPOSITE_BOUNDING_VOLUMES permutation (:44-48; "[PSO] ApplyReflectionsAndBoundingVolumes", ApplyReflections.cpp:82-86): the light-bounds image is
+// blended over the sum by its alpha, which also replaces the scene's alpha; as written — two products and one sum per channel, each rounded (32 B/pixel).
+template <int FMT, bool BV>
+__global__ __launch_bounds__(256) void k_apply_reflections(const void* __restrict__ refl, const void* __restrict__ bv, void* scene, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 r = load_px<FMT>(refl, i), s = load_px<FMT>(scene, i);
-    store_px<FMT>(scene, i, make_float4(s.x + r.x, s.y + r.y, s.z + r.z, s.w));
+    float4 o = make_float4(s.x + r.x, s.y + r.y, s.z + r.z, s.w);
+    if (BV) {
+        const float4 b = load_px<FMT>(bv, i);
+        const float k = 1.0f - b.w;
+        o = make_float4(b.x * b.w + o.x * k, b.y * b.w + o.y * k, b.z * b.w + o.z * k, b.w);
+    }
+    store_px<FMT>(scene, i, o);
 }
-hipError_t launch_apply_reflections(hipStream_t s, const void* refl, void* scene, int W, int H, int fmt) {
+hipError_t launch_apply_reflections(hipStream_t s, const void* refl, const void* bv, void* scene, int W, int H, int fmt) {
     const uint32_t n = (uint32_t)W * (uint32_t)H;
-    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_apply_reflections<0>), dim3((n + 255) / 256), dim3(256), 0, s, refl, scene, n);
-    else                          hipLaunchKernelGGL((k_apply_reflections<1>), dim3((n + 255) / 256), dim3(256), 0, s, refl, scene, n);
+    const dim3 grid((n + 255) / 256);
+    if (bv) {
+        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_apply_reflections<0, true>), grid, dim3(256), 0, s, refl, bv, scene, n);
+        else                          hipLaunchKernelGGL((k_apply_reflections<1, true>), grid, dim3(256), 0, s, refl, bv, scene, n);
+    } else {
+        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_apply_reflections<0, false>), grid, dim3(256), 0, s, refl, bv, scene, n);
+        else                          hipLaunchKernelGGL((k_apply_reflections<1, false>), grid, dim3(256), 0, s, refl, bv, scene, n);
+    }
     return hipGetLastError();
 }
 
@@ -218,6 +238,9 @@ hipError_t launch_visualize(hipStream_t s, const void* in, void* out, int W, int
     switch (inFmt) {
         case VQHIP_FMT_RGBA32F: return viz_out<VQHIP_FMT_RGBA32F>(s, in, out, n, p, outFmt);
         case VQHIP_FMT_RGBA16F: return viz_out<VQHIP_FMT_RGBA16F>(s, in, out, n, p, outFmt);
+        case VQHIP_FMT_RG16F:   return viz_out<VQHIP_FMT_RG16F>(s, in, out, n, p, outFmt);
+        case VQHIP_FMT_RG32F:   return viz_out<VQHIP_FMT_RG32F>(s, in, out, n, p, outFmt);
+        case VQHIP_FMT_R10G10B10A2_UNORM: return viz_out<VQHIP_FMT_R10G10B10A2_UNORM>(s, in, out, n, p, outFmt);
         default:                return viz_out<VQHIP_FMT_RGBA8_UNORM>(s, in, out, n, p, outFmt);
     }
 }

@@ -110,7 +110,7 @@ hipError_t launch_downsize_box(hipStream_t s, const void* src, void* dst, int sw
 hipError_t launch_fsr_easu(hipStream_t s, const void* in, int inW, int inH, int inFmt, const uint32_t* con16, void* out, int outW, int outH, int outFmt);
 hipError_t launch_fsr_rcas(hipStream_t s, const void* in, void* out, int W, int H, const uint32_t* con4, int inFmt, int outFmt);
 hipError_t launch_visualize(hipStream_t s, const void* in, void* out, int W, int H, const VQ_VizParams& p, int inFmt, int outFmt);
-hipError_t launch_apply_reflections(hipStream_t s, const void* refl, void* scene, int W, int H, int fmt);
+hipError_t launch_apply_reflections(hipStream_t s, const void* refl, const void* boundingVolumes, void* scene, int W, int H, int fmt);   // boundingVolumes NULL: plain permutation
 
 // SSR environment fallback (§8f.4, ssr.hip): what the kernel reads of VQ_SSSRConstants + the resource descriptors, by value
 struct SsrArgs {
