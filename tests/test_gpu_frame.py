@@ -64,6 +64,62 @@ def test_full_frame_chain_matches_oracle(ctx):
     assert fin_o.shape == (OH, OW, 4) and fin_o[..., :3].std() > 5
 
 
+def test_ssr_frame_chain_matches_oracle(ctx):
+    """The frame with reflections on, in the engine's order (SceneRendering.cpp:563-755): Z pre-pass normals -> lit draws as ONE PSMain kernel with the extra render
+    targets bound (EnvironmentMapDiffuseOnlyIllumination = 1: the specular IBL comes from the reflections pass, :464) -> SSR's environment fallback -> CompositeReflections
+    (with a light-bounds image) -> blur -> tonemap; and the debug views of the intermediate targets. Product chain == oracle chain, every intermediate, bit for bit."""
+    W, H, NM = 192, 96, 5
+    F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
+    eq = synth.equirect(128, 64)
+    chain_o, n = O.mip_chain(eq)
+    chain_g, n_g = ctx.mip_chain(dev(eq))
+    pre_o = O.envmap_prefilter(chain_o, 128, 64, n, 16, 0.05, 32, abi.CONV_SEQUENTIAL)
+    pre_g = ctx.envmap_prefilter(chain_g, 128, 64, n_g, 16, 0.05, 32, abi.CONV_SEQUENTIAL)
+    lut_o, lut_g = O.brdf_lut(64, 128, abi.FMT_RG16F), ctx.brdf_lut(64, 128, abi.FMT_RG16F)
+    env_o = O.host_envmap(pre_o["diffuse_blurred"], pre_o["specular"], 32, pre_o["spec_mips"], lut_o)
+    env_g = capi.make_envmap(pre_g["diffuse_blurred"], pre_g["specular"], 32, pre_g["spec_mips"], lut_g)
+    ip = synth.interpolants(W, H, NM)
+    _, _, hmats, dmats, keep = build_materials(ctx, NM, max_dim=128)
+    ssao = synth.ssao_image(W, H)
+    cur, prev = synth.clip_positions(W, H)
+    pf, extra = synth.per_frame(points=synth.point_lights(9, seed=0xBEE), hdri_offset=0.3)
+    pv = synth.per_view(W, H, max_env_lod=pre_o["spec_mips"])
+    pv.EnvironmentMapDiffuseOnlyIllumination = 1
+    _, depth, _, _ = synth.ssr_surfaces(W, H, seed=5)
+    cb = synth.ssr_constants(W, H, pre_o["spec_mips"], hdri_yaw=0.3)
+    r = np.random.default_rng(2)
+    bv = np.zeros((H, W, 4), np.float16)                     # light bounds drawn over a corner of the frame (RenderLightBounds: rasterised, the caller's)
+    bv[10:40, 20:90] = (0.1, 0.8, 0.2, 0.35)
+    bv[..., 3] *= (r.random((H, W)) > 0.2)
+    # ---- oracle chain
+    nrm_o = O.scene_normals_from_materials(ip, hmats)
+    gb_o = O.gbuffer_from_materials([p.copy() for p in ip], hmats, pf.fAmbientLightingFactor, ssao)
+    col_o = O.forward_lighting(gb_o, pf, pv, F16, env=env_o)
+    alb_o, mv_o = O.psmain_extra_targets(gb_o, cur, prev)
+    rad_o = O.ssr_environment_fallback(col_o, F16, depth, nrm_o, abi.FMT_R10G10B10A2_UNORM, cb, env_o, F16)
+    comp_o = O.composite_reflections(rad_o, col_o, F16, bv)
+    sdr_o = O.tonemap(O.gaussian_blur(comp_o, F16), F16, R8)
+    # ---- product chain
+    ipd = [dev(p) for p in ip]
+    nrm_g = ctx.scene_normals_from_materials(ipd, dmats)
+    col_g, alb_g, mv_g = ctx.forward_lighting_from_materials_mrt(ipd, dmats, pf, pv, motion_fmt=abi.FMT_RG16F, sv_curr=dev(cur), sv_prev=dev(prev), ssao=dev(ssao), env=env_g)
+    rad_g = ctx.ssr_environment_fallback(col_g, F16, dev(depth), nrm_g, abi.FMT_R10G10B10A2_UNORM, cb, env_g, F16)
+    lit_g = col_g.clone()
+    comp_g = ctx.composite_reflections(rad_g, col_g, F16, dev(bv))
+    sdr_g = ctx.tonemap(ctx.gaussian_blur(comp_g, F16), F16, R8)
+    torch.cuda.synchronize()
+    for name, g, o in (("scene normals", nrm_g.cpu().numpy().view(np.uint32), nrm_o), ("scene colour", lit_g, col_o), ("albedo / metalness", alb_g, alb_o), ("motion vectors", mv_g, mv_o),
+                       ("reflection radiance", rad_g, rad_o), ("composite", comp_g, comp_o), ("sdr", sdr_g, sdr_o)):
+        n_bad, idx = O.bits_equal(g.cpu().numpy() if hasattr(g, "cpu") else g, o)
+        assert n_bad == 0, (name, n_bad, idx)
+    # the debug views read the targets as they are (SceneRendering.cpp:2555-2566)
+    for src_g, src_o, fmt, p in ((nrm_g, nrm_o, abi.FMT_R10G10B10A2_UNORM, abi.VizParams(2, 1, 1.0)), (mv_g, mv_o, abi.FMT_RG16F, abi.VizParams(8, 0, 30.0)),
+                                 (alb_g, alb_o, F16, abi.VizParams(6, 0, 1.0)), (rad_g, rad_o, F16, abi.VizParams(7, 0, 1.0)), (lit_g, col_o, F16, abi.VizParams(3, 0, 1.0))):
+        n_bad, idx = O.bits_equal(ctx.visualize(src_g, fmt, p, R8).cpu().numpy(), O.visualize(src_o, fmt, p, R8))
+        assert n_bad == 0, (fmt, p.iDrawMode, n_bad, idx)
+    assert (rad_o[..., :3].astype(np.float32).sum(-1) > 0).mean() > 0.3 and (comp_o != col_o).any()
+
+
 def test_hdri_downsize_matches_oracle_and_reports_unsupported(ctx):
     """vqhip_hdr_downsize_rgba32f: the engine's 8k -> 4k / 2k / 1k fallback shapes at 1/8 scale (1024x512 -> 512x256 / 256x128 / 128x64) bit for
     bit against the oracle; any non-integer or anisotropic ratio is VQHIP_ERR_UNSUPPORTED, not an approximation."""
