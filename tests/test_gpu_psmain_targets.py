@@ -150,3 +150,22 @@ def test_argument_checks(ctx):
     assert call(abi.PsmainTargets(None, 0, 0, buf.data_ptr(), abi.FMT_RG16F, 0, buf.data_ptr(), buf.data_ptr(), 63, 0)) == abi.VQHIP_ERR_INVALID_ARG
     assert call(abi.PsmainTargets(buf.data_ptr(), abi.FMT_RGBA16F, 0, buf.data_ptr(), abi.FMT_RG32F, 0, buf.data_ptr(), buf.data_ptr(), 0, 0)) == 0
     torch.cuda.synchronize()
+
+
+def test_full_4k_frame_properties(ctx):
+    """BASELINE cfg3's frame (3840 x 2160, 64 lights + the IBL-less path) with both extra targets bound: SV_TARGET1 is the gb2 plane rounded to halfs, the motion
+    vectors equal the oracle's on three row bands and are antisymmetric under swapping the two position planes, and the scene colour is the plain call's."""
+    W, H = 3840, 2160
+    gb, pf, pv, cur, prev = _frame(W, H, n_lights=64, seed=0x6400)
+    gbd = [dev(g) for g in gb]
+    dc, dp = dev(cur), dev(prev)
+    plain = ctx.forward_lighting(gbd, pf, pv)
+    out, alb, mv = ctx.forward_lighting_mrt(gbd, pf, pv, motion_fmt=abi.FMT_RG32F, sv_curr=dc, sv_prev=dp)
+    assert torch.equal(out.view(torch.int16), plain.view(torch.int16))
+    assert torch.equal(alb.view(torch.int16), gbd[2].to(torch.float16).view(torch.int16))
+    _, _, swapped = ctx.forward_lighting_mrt(gbd, pf, pv, albedo_fmt=None, motion_fmt=abi.FMT_RG32F, sv_curr=dp, sv_prev=dc)
+    assert torch.equal(mv, -swapped)                                                   # a - b == -(b - a) exactly in IEEE arithmetic
+    mvh = mv.cpu().numpy()
+    for r0 in (0, 1079, 2128):
+        g = [p[r0:r0 + 32] for p in gb]
+        assert_bits(mvh[r0:r0 + 32], O.psmain_extra_targets(g, cur[r0:r0 + 32], prev[r0:r0 + 32], None, abi.FMT_RG32F)[1], f"motion vectors rows {r0}..")

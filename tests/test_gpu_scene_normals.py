@@ -171,3 +171,24 @@ def test_pitched_output_and_argument_checks(ctx):
     assert call(out.data_ptr(), abi.FMT_R10G10B10A2_UNORM, P, n=0, mats=None) == 0
     torch.cuda.synchronize()
     assert (out[:, :W] == 0).all()
+
+
+def test_full_4k_frame_properties_and_bands(ctx):
+    """3840 x 2160, 12 materials: whole-frame properties (covered <=> valid material index; the stored word == the float4 output quantised; unit normals to UNORM10
+    precision) and three 32-row bands word for word against the oracle (bands start on even rows: the quad derivatives see the same neighbours)."""
+    W, H, NM, BAND = 3840, 2160, 12, 540
+    band = synth.interpolants(W, BAND, NM)
+    ip = [np.tile(p, (H // BAND, 1, 1)) for p in band]
+    _, _, hmats, dmats, keep = build_materials(ctx, NM, max_dim=512)
+    ipd = [dev(p) for p in ip]
+    w = words(ctx.scene_normals_from_materials(ipd, dmats))
+    f = ctx.scene_normals_from_materials(ipd, dmats, abi.FMT_RGBA32F).cpu().numpy()
+    idx = ip[2][..., 3].view(np.int32)
+    covered = (idx >= 0) & (idx < NM)
+    assert np.array_equal((w >> 30) == 3, covered) and (w[~covered] == 0).all()
+    assert np.array_equal(w, ref_cases.pack_r10g10b10a2(f))
+    n = unpack(w)[covered] * 2.0 - 1.0
+    assert np.abs(np.linalg.norm(n.astype(np.float64), axis=-1) - 1.0).max() < 4e-3
+    for r0 in (0, 1052, 2128):
+        sub = [p[r0:r0 + 32] for p in ip]
+        assert np.array_equal(w[r0:r0 + 32], O.scene_normals_from_materials(sub, hmats)), r0
