@@ -56,8 +56,8 @@ for key, tag in (("cfg3/product", "cfg3_product"), ("cfg3/exp2_log2", "cfg3_exp2
         e["quarter_rate_instr_per_wave"] = round(tr / waves, 1)
     else:   # the counter is not exposed on this pool: ISA count instead — 5 v_rsq/v_rcp per executed light (2 sqrt seeds, 3 reciprocals), ~12 per pixel
         lights = bench.CONFIGS[key.split("/")[0].split("_")[0]]["lights"]
-        e["quarter_rate_instr_per_wave"] = round(5 * lights * 0.82 + 12)
-        e["quarter_rate_source"] = "estimate: ISA count (5 per executed light + 12) x 0.82 wave-level executed-light fraction; SQ_INSTS_VALU_TRANS is not available"
+        e["quarter_rate_instr_per_wave"] = round(3 * lights * 0.82 + 8)
+        e["quarter_rate_source"] = "estimate: ISA count (3 per executed light: two v_rsq_f32 + one v_rcp_f32; + 8 per pixel) x 0.82 wave-level executed-light fraction; SQ_INSTS_VALU_TRANS is not available"
     f, w = med(tag + "_fetch", "FETCH_SIZE"), med(tag + "_write", "WRITE_SIZE")
     if f and w:
         e["fetch_size_kib"], e["write_size_kib"] = f, w

@@ -24,22 +24,27 @@ __global__ void k(uint32_t base, unsigned long long* bad) {
     const float ref = rcp_newton(D);
     const float yp = __uint_as_float(__float_as_uint(y) + 1u), ym = __uint_as_float(__float_as_uint(y) - 1u);
     const float e = __builtin_fmaf(-D, y, 1.0f);
-    float c[6];
+    float c[10];
     c[0] = newton(D, y);
     c[1] = newton(D, c[0]);
     c[2] = __builtin_fmaf(__builtin_fmaf(e, e, e), y, y);
     c[3] = newton(D, yp);
     c[4] = newton(D, ym);
     c[5] = __builtin_fmaf(e, yp, y);
-    for (int i = 0; i < 6; ++i) if (__float_as_uint(c[i]) != __float_as_uint(ref)) atomicAdd(&bad[i], 1ull);
-    atomicAdd(&bad[6], 1ull);
+    c[6] = __builtin_fmaf(e + 0x1p-47f, y, y);          // biased residual: Newton always underestimates (by y e^2); 2^-47 = 2^-24 ulp of the result
+    c[7] = __builtin_fmaf(e + 0x1.000002p-48f, y, y);
+    c[8] = __builtin_fmaf(e + 0x1.8p-48f, y, y);
+    c[9] = __builtin_fmaf(__builtin_fmaf(-D, y, 1.0f + 0x1p-23f) - 0x1p-23f, y, y);
+    for (int i = 0; i < 10; ++i) if (__float_as_uint(c[i]) != __float_as_uint(ref)) { if (atomicAdd(&bad[i], 1ull) == 0 && i == 6) { bad[11] = u; bad[12] = __float_as_uint(y); bad[13] = __float_as_uint(D); bad[14] = __float_as_uint(ref); bad[15] = __float_as_uint(c[6]); } }
+    atomicAdd(&bad[10], 1ull);
 }
 int main() {
-    unsigned long long* d; unsigned long long h[7] = {};
+    unsigned long long* d; unsigned long long h[16] = {};
     (void)hipMalloc(&d, sizeof(h)); (void)hipMemset(d, 0, sizeof(h));
     for (uint32_t hi = 0; hi < 128; ++hi) hipLaunchKernelGGL(k, dim3((1u << 24) / 256), dim3(256), 0, 0, hi << 24, d);
     (void)hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
-    printf("{\"inputs\": %llu, \"A_2fma\": %llu, \"B_4fma\": %llu, \"C_second_order\": %llu, \"P_seed_plus_1ulp\": %llu, \"M_seed_minus_1ulp\": %llu, \"Q2_mixed\": %llu}\n",
-           h[6], h[0], h[1], h[2], h[3], h[4], h[5]);
+    printf("{\"inputs\": %llu, \"A_2fma\": %llu, \"B_4fma\": %llu, \"C_second_order\": %llu, \"P_seed_plus_1ulp\": %llu, \"M_seed_minus_1ulp\": %llu, \"Q2_mixed\": %llu, \"bias_2^-47\": %llu, \"bias_just_above_2^-48\": %llu, \"bias_1.5x2^-48\": %llu, \"x9\": %llu}\n",
+           h[10], h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8], h[9]);
+    printf("first bad of bias_2^-47: x=%08llx y=%08llx D=%08llx ref=%08llx got=%08llx\n", h[11], h[12], h[13], h[14], h[15]);
     return 0;
 }

@@ -30,6 +30,7 @@ extern "C" __attribute__((visibility("default"))) int vqprobe_math(int fn, const
 
 // which: 0 rcp() vs 1.0f/x | 1 sqrt_() vs IEEE sqrtf | 2 saturate() vs the select form | 3/4 the unchecked fast paths
 // inside their validated domains (rcp_newton: normal result; sqrt_newton: x in [2^-100, FLT_MAX]) | 5 rsqrt_cr() vs (float)(1.0 / sqrt((double)x)) | 6 rsqrt_cr_fast in [2^-100, 2^100]
+// | 7 / 8 sqrt_rcp_newton: 1 / sqrtf(x) as two IEEE operations (the reciprocal OF THE ROUNDED ROOT) and the root, x in [2^-100, 2^100]
 __global__ void k_exhaust(int which, uint32_t base, unsigned long long* bad, uint32_t* first) {
     const uint32_t u = base + blockIdx.x * blockDim.x + threadIdx.x;
     const float x = __uint_as_float(u);
@@ -42,6 +43,8 @@ __global__ void k_exhaust(int which, uint32_t base, unsigned long long* bad, uin
         case 3:  ref = 1.0f / x; got = rcp_newton(x); inDomain = is_normal(got); break;
         case 5:  ref = (float)(1.0 / __builtin_sqrt((double)x)); got = rsqrt_cr(x); break;                       // the DXC reading's Rsqrt: definition vs product, all inputs
         case 6:  ref = (float)(1.0 / __builtin_sqrt((double)x)); got = rsqrt_cr_fast(x); inDomain = rsqrt_cr_fast_ok(x); break;   // the unchecked fast sequence inside its domain
+        case 7:  { float r; const float D = sqrt_rcp_newton(x, &r); ref = 1.0f / __builtin_sqrtf(x); got = r; inDomain = sqrt_rcp_fast_ok(x) && D == __builtin_sqrtf(x); } break;   // the reciprocal of the root from the root's own v_rsq seed
+        case 8:  { float r; ref = __builtin_sqrtf(x); got = sqrt_rcp_newton(x, &r); inDomain = sqrt_rcp_fast_ok(x); } break;                                                        // ... and the root it returns
         default: ref = __builtin_sqrtf(x); got = sqrt_newton(x); inDomain = sqrt_fast_ok(x); break;
     }
     if (inDomain && __float_as_uint(ref) != __float_as_uint(got) && !(ref != ref && got != got)) { if (atomicAdd(bad, 1ull) == 0) *first = u; }

@@ -96,7 +96,9 @@ def test_storage_conversions(probe):
                                         (3, "rcp_newton correct whenever its result is normal"),
                                         (4, "sqrt_newton correct on [2^-100, FLT_MAX]"),
                                         (5, "rsqrt_cr == (float)(1.0 / sqrt((double)x)), the DXC reading's correctly rounded Rsqrt"),
-                                        (6, "rsqrt_cr_fast (v_rsq_f32 seed + binary64 second-order correction) correct on [2^-100, 2^100]")])
+                                        (6, "rsqrt_cr_fast (v_rsq_f32 seed + binary64 second-order correction) correct on [2^-100, 2^100]"),
+                                        (7, "sqrt_rcp_newton: the reciprocal refined from the root's v_rsq_f32 seed == 1.0f / sqrtf(x) on [2^-100, 2^100]"),
+                                        (8, "sqrt_rcp_newton: the root == IEEE sqrtf on [2^-100, 2^100]")])
 def test_fast_paths_exhaustive(ctx, which, name):
     """The product's fast exact primitives against the plain IEEE forms for ALL 2^32 float bit patterns."""
     lib = C.CDLL(PROBE)

@@ -289,7 +289,7 @@ VQD void strip_pixel(int& x, int& y, int& lane) {
     y = blockIdx.y * 2 + ((lane >> 1) & 1);
 }
 
-__global__ __launch_bounds__(256) void k_gbuffer_from_materials(GbufArgs a) {
+__global__ __launch_bounds__(256, 4) void k_gbuffer_from_materials(GbufArgs a) {      // 4 waves per SIMD = 128 VGPRs (5 spilled): 17 % faster than the 137 the compiler takes uncapped (profiles/r4p_gbuffer_waves.jsonl)
     int x, y, lane;
     strip_pixel(x, y, lane);
     const bool inside = (x < a.width) & (y < a.height);

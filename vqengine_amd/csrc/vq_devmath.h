@@ -44,6 +44,21 @@ VQD float sqrt_newton(float x) {
     return __builtin_fmaf(r, h, s);
 }
 VQD bool sqrt_fast_ok(float x) { return (x >= 0x1p-100f) & (x <= 3.4028234663852886e38f); }
+// D = RN(sqrt(x)) AND r = RN(1/D) from ONE quarter-rate instruction: the reciprocal is refined from the v_rsq_f32 seed the root already fetched — one Markstein step on
+// y against D whose residual carries a bias just above 2^-48: a Newton step always underestimates (by y e^2), and for the one significand family where that lands exactly on a
+// rounding midpoint (D = 2^n (2 - 2^-23): 1/D = 2^-n-1 (1 + 2^-24 + 2^-48 + ...)) the bias turns e = 2^-24 into 2^-24 + 2^-47 and the tie into the right neighbour.
+// EXHAUSTIVELY equal to (sqrt_newton(x), rcp_newton(sqrt_newton(x))) — i.e. to the correctly rounded pair — for every x in [2^-100, 2^100] on gfx950
+// (tests/test_gpu_devmath.py; scripts/ubench/rcp_from_rsq.hip scans the alternatives: without the bias 200 inputs differ, with 1.5 x 2^-48 another 100). 3 full-rate VALU
+// replace v_rcp_f32 (4 issue slots) + 2 fma.
+VQD float sqrt_rcp_newton(float x, float* rD) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s = x * y, h = 0.5f * y;
+    const float D = __builtin_fmaf(__builtin_fmaf(-s, s, x), h, s);
+    const float e = __builtin_fmaf(-D, y, 1.0f) + 0x1.000002p-48f;
+    *rD = __builtin_fmaf(e, y, y);
+    return D;
+}
+VQD bool sqrt_rcp_fast_ok(float x) { return (x >= 0x1p-100f) & (x <= 0x1p100f); }
 VQD float sqrt_(float x) {
     float s = sqrt_newton(x);
     if (__builtin_expect(!sqrt_fast_ok(x), 0)) s = __builtin_sqrtf(x);
@@ -86,6 +101,7 @@ struct RcpFast {
     bool ok = true;
     VQD float operator()(float b) { const float r = rcp_newton(b); ok = ok & is_normal(r); return r; }
     VQD float sqrt(float x) { ok = ok & sqrt_fast_ok(x); return sqrt_newton(x); }
+    VQD float sqrt_rcp(float x, float* r) { ok = ok & sqrt_rcp_fast_ok(x); return sqrt_rcp_newton(x, r); }   // D = sqrt(x) and *r = 1/D, both correctly rounded
     VQD float div(float a, float b, float r) { ok = ok & fdiv_rcp_ok(a); return fdiv_rcp(a, b, r); }       // r = (*this)(b)
     VQD float rsqrt(float x) { ok = ok & rsqrt_cr_fast_ok(x); return rsqrt_cr_fast(x); }                  // DXC reading only
 };
@@ -93,6 +109,7 @@ struct RcpIEEE {
     static constexpr bool kGgxDenomAboveEps = false;
     VQD float operator()(float b) const { return 1.0f / b; }
     VQD float sqrt(float x) const { return __builtin_sqrtf(x); }
+    VQD float sqrt_rcp(float x, float* r) const { const float D = __builtin_sqrtf(x); *r = 1.0f / D; return D; }
     VQD float div(float a, float b, float) const { return a / b; }
     VQD float rsqrt(float x) const { return (float)(1.0 / __builtin_sqrt((double)x)); }
 };
@@ -125,7 +142,24 @@ VQD f3 reflect(f3 i, f3 n) { float t = 2.0f * dot(n, i); return mk3(i.x - n.x * 
 VQD float dot_lit(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 VQD float length_lit(f3 v) { return sqrt_(dot_lit(v, v)); }
 VQD f3 div_lit(f3 v, float l) { return mk3(fdiv_(v.x, l), fdiv_(v.y, l), fdiv_(v.z, l)); }
-VQD f3 normalize_lit(f3 v) { return div_lit(v, length_lit(v)); }
+// normalize(v) AS WRITTEN = one IEEE quotient per component by length(v). Fast form: the root and its reciprocal from one v_rsq_f32 (sqrt_rcp_newton), the three
+// quotients by fdiv_rcp (3 VALU each) — equal to the IEEE operations whenever dot(v,v) lies in [2^-100, 2^100] and no component is a non-zero number below 2^-78
+// (exhaustive proofs above); a zero component keeps its sign (0 * r would lose a -0). One test per vector (integer tricks: (bits << 1) - 1 maps +-0 to 0xffffffff and
+// orders the magnitudes); anything else — NaN, inf, denormal components, a zero vector — takes the plain IEEE operations. ~37 VALU instead of ~58.
+VQD f3 normalize_lit(f3 v) {
+    const float dd = dot_lit(v, v);
+    float r;
+    const float D = sqrt_rcp_newton(dd, &r);
+    const uint32_t bx = __float_as_uint(v.x), by = __float_as_uint(v.y), bz = __float_as_uint(v.z);
+    const uint32_t m = min((bx << 1) - 1u, min((by << 1) - 1u, (bz << 1) - 1u));                  // smallest magnitude, zeros excluded
+    const bool ok = (m >= ((0x18800000u << 1) - 1u)) & ((__float_as_uint(dd) - 0x0d800000u) <= (0x71800000u - 0x0d800000u));   // 2^-78; dd in [2^-100, 2^100] (NaN / negative: out)
+    f3 q;
+    q.x = __uint_as_float(__float_as_uint(fdiv_rcp(v.x, D, r)) | (bx & 0x80000000u));
+    q.y = __uint_as_float(__float_as_uint(fdiv_rcp(v.y, D, r)) | (by & 0x80000000u));
+    q.z = __uint_as_float(__float_as_uint(fdiv_rcp(v.z, D, r)) | (bz & 0x80000000u));
+    if (__builtin_expect(!ok, 0)) q = div_lit(v, sqrt_(dd));
+    return q;
+}
 VQD float lerp_lit(float a, float b, float t) { return a + t * (b - a); }
 VQD f3 reflect_lit(f3 i, f3 n) { const float t = 2.0f * dot_lit(n, i); return mk3(i.x - t * n.x, i.y - t * n.y, i.z - t * n.z); }
 

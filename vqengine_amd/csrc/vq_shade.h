@@ -95,8 +95,8 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     if (AR) {
         H = mul(Hs, rc.rsqrt(dot(Hs, Hs)));                  // DXC reading: one correctly rounded rsqrt, three products
     } else {
-        const float Hl = rc.sqrt(dot_lit(Hs, Hs));           // length(Wo + Wi)
-        const float rH = rc(Hl);
+        float rH;
+        const float Hl = rc.sqrt_rcp(dot_lit(Hs, Hs), &rH);  // length(Wo + Wi) and its reciprocal from one v_rsq_f32 (vq_devmath.h:sqrt_rcp_newton)
         H = mk3(rc.div(Hs.x, Hl, rH), rc.div(Hs.y, Hl, rH), rc.div(Hs.z, Hl, rH));
     }
     const float NdotH = saturate(dot_r<AR>(px.Nn, H));       // :169
@@ -137,9 +137,9 @@ template <int AR, class R>
 VQD f3 point_light_t(const Pixel& px, f3 lpos, float range, f3 cb, f3 acc, R& rc) {
     const f3 d = sub(lpos, px.P);
     const float dd = dot_r<AR>(d, d);
-    const float D = rc.sqrt(dd);                             // length(Lw - P) as written; the literal normalize() shares the sqrt
+    float rD;                                                // one reciprocal for the quotients of normalize(Lw - P) and for AttenuationBRDF :29-32
+    const float D = rc.sqrt_rcp(dd, &rD);                    // length(Lw - P) as written; the literal normalize() shares the sqrt
     if (D < range) {
-        const float rD = rc(D);                              // one reciprocal for the quotients of normalize(Lw - P) and for AttenuationBRDF :29-32
         const f3 Wi = AR ? mul(d, rc.rsqrt(dd)) : mk3(rc.div(d.x, D, rD), rc.div(d.y, D, rD), rc.div(d.z, D, rD));
         const float NdotL = saturate(dot(px.Nraw, Wi));
         const float w = (rD * rD) * NdotL;                   // 1/(D*D) as (1/D)*(1/D) (contract v3)
@@ -180,6 +180,7 @@ struct RcpTrust {
     static constexpr bool kGgxDenomAboveEps = true;
     VQD float operator()(float b) const { return rcp_newton(b); }
     VQD float sqrt(float x) const { return sqrt_newton(x); }
+    VQD float sqrt_rcp(float x, float* r) const { return sqrt_rcp_newton(x, r); }
     VQD float div(float a, float b, float r) const { return fdiv_rcp(a, b, r); }
     VQD float rsqrt(float x) const { return rsqrt_cr_fast(x); }      // DXC reading: dd and hh lie in [2^-80, 2^60], inside its validated domain [2^-100, 2^100]
 };
@@ -206,8 +207,8 @@ VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I, fl
     const float dd = dot_r<AR>(d, d);                        // as written: D decides the range cull
     if (dd < l.rangeSq) {                                    // == (length(Lw - P) < l.range), exactly (host-made threshold): culled lights
         RC rc;                                               // need no square root; wave-coherent (execz skip)
-        const float D = sqrt_newton(dd);
-        const float rD = rc(D);
+        float rD;
+        const float D = rc.sqrt_rcp(dd, &rD);                // dd in [2^-80, 2^60]: inside the proven domain of sqrt_rcp_newton
         const f3 Wi = AR ? mul(d, rc.rsqrt(dd)) : mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P) | (Lw - P) * rsqrt
         const f3 Hs = add(px.Wo, Wi);
         vmin = min3abs_acc(min3abs_acc(min3abs_acc(vmin, d.x, d.y), d.z, Hs.x), Hs.y, Hs.z);
