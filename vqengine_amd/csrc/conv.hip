@@ -102,7 +102,7 @@ VQD void lut_sample(const float4 hv, f3 V, float NdotV, float k, float omk, floa
     if (FAST) {
         const float t = 2.0f * fma_(H.z, -V.z, H.x * -V.x);     // reflect(-V, H): i - n * (2 dot(n, i)), i = -V
         const f3 Lr = mk3(-V.x - H.x * t, -(H.y * t), -V.z - H.z * t);
-        const float r = rcp_newton(sqrt_newton(dot(Lr, Lr)));
+        float r; (void)sqrt_rcp_newton(dot(Lr, Lr), &r);     // == rcp_newton(sqrt_newton(.)) bit for bit, from one quarter-rate instruction (vq_devmath.h)
         const float Lz = Lr.z * r;
         if (max_(Lz, 0.0f) > 0.0f) {
             const float VdotH = max_(fma_(V.z, H.z, V.x * H.x), 0.0f);
@@ -200,7 +200,7 @@ struct DiffuseLevel { const char* tex; int W, H, rowShift; float W256, H256; con
 struct TapTexels { float4 c00, c10, c01, c11; float wx, wy; };
 template <bool REC = false>
 VQD TapTexels diffuse_tap_fetch(f3 sv, const DiffuseLevel& lv, bool& special) {
-    sv = mul(sv, rcp_newton(sqrt_newton(dot(sv, sv))));                                                           // normalize
+    { float r; (void)sqrt_rcp_newton(dot(sv, sv), &r); sv = mul(sv, r); }                                         // normalize: v * rcp(sqrt(dot)), one quarter-rate instruction
     // atan2_(sv.z, sv.x)
     const float ay = sv.z, axx = sv.x;
     special |= !(abs_(axx) >= 0x1p-100f) | (ay == 0.0f);

@@ -113,7 +113,12 @@ struct RcpIEEE {
     VQD float div(float a, float b, float) const { return a / b; }
     VQD float rsqrt(float x) const { return (float)(1.0 / __builtin_sqrt((double)x)); }
 };
-VQD float rsqrt(float x) { return rcp(sqrt_(x)); }
+VQD float rsqrt(float x) {                                   // rcp(sqrt(x)), both correctly rounded: from one v_rsq_f32 inside sqrt_rcp_newton's proven domain
+    float r;
+    (void)sqrt_rcp_newton(x, &r);
+    if (__builtin_expect(!sqrt_rcp_fast_ok(x), 0)) r = rcp(sqrt_(x));
+    return r;
+}
 VQD float div_(float a, float b) { return a * rcp(b); }     // HLSL a / b
 VQD float max_(float a, float b) { return __builtin_fmaxf(a, b); }
 VQD float min_(float a, float b) { return __builtin_fminf(a, b); }
