@@ -64,14 +64,16 @@ VQD float sqrt_(float x) {
     if (__builtin_expect(!sqrt_fast_ok(x), 0)) s = __builtin_sqrtf(x);
     return s;
 }
-// RN(x^-1/2). Fast path: v_rsq_f32 seed (1 ulp), then the residual e = 1 - x y^2 and the second-order correction y (1 + e/2 + 3/8 e^2) in BINARY64 — a
-// binary32 correction term is only known to 2^-47 of the result, 2^-23 of an ulp, which mis-rounds a dozen significands; the double result is within
-// 2^-52 relative of the truth. Equal to (float)(1.0 / sqrt((double)x)) (the oracle's and the shim's definition) for EVERY x in [2^-100, 2^100] on gfx950:
-// tests/probe/devmath_probe.hip `rsqrt_cr`, tests/test_gpu_devmath.py::test_rsqrt_cr_exhaustive. Outside (0, denormal, inf, NaN, negative): the definition itself.
+// RN(x^-1/2) as the oracle and the shim define it, (float)(1.0 / sqrt((double)x)). Fast path in BINARY32: v_rsq_f32 seed y (1 ulp), the residual e = 1 - x y^2 to ~2^-47
+// (x*y = t + d exactly: d = fma(x, y, -t) recovers the product's rounding error) and the second-order correction y + y (e/2 + 3/8 e^2) in exactly this grouping.
+// EXHAUSTIVELY equal to the definition for every x in [2^-100, 2^100] on gfx950 (tests/probe/devmath_probe.hip `rsqrt_cr`, tests/test_gpu_devmath.py); the scan of the
+// alternatives (scripts/ubench/rsqrt_fp32.hip, profiles/r4r_rsqrt_fp32.md): a first-order step mis-rounds 100 inputs whatever its bias, other groupings of the second-order
+// term 100, dropping d 218 million. 8 full-rate VALU; rounds 3-4 used a binary64 tail (~15 issue slots). Outside the domain (0, denormal, inf, NaN, negative): the definition itself.
 VQD float rsqrt_cr_fast(float x) {
-    const double yd = (double)__builtin_amdgcn_rsqf(x), xd = (double)x;
-    const double e = __builtin_fma(-(xd * yd), yd, 1.0);                 // xd * yd is exact (48 bits)
-    return (float)__builtin_fma(yd * e, __builtin_fma(0.375, e, 0.5), yd);
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float t = x * y, d = __builtin_fmaf(x, y, -t);
+    const float e = __builtin_fmaf(-d, y, __builtin_fmaf(-t, y, 1.0f));
+    return __builtin_fmaf(__builtin_fmaf(0.375f * e, e, 0.5f * e), y, y);
 }
 VQD bool rsqrt_cr_fast_ok(float x) { return (x >= 0x1p-100f) & (x <= 0x1p100f); }
 VQD float rsqrt_cr(float x) {
