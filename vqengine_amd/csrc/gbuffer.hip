@@ -29,7 +29,8 @@
 
 #include <cstdlib>
 #ifndef VQ_PSMAIN_WAVES_DEFAULT
-#define VQ_PSMAIN_WAVES_DEFAULT 5      // measured at 4K, 12 materials + 64 lights + IBL (profiles/r3e_psmain.jsonl): 4 / 5 / 6 waves -> 1.532 / 1.529 / 1.552 ms
+#define VQ_PSMAIN_WAVES_DEFAULT 6      // measured at 4K, 12 materials + 64 lights + IBL: 4 / 5 / 6 / 7 waves -> 1.535 / 1.58 / 1.528 / 1.63 ms (profiles/r4t_psmain_waves.jsonl, after the round-4
+                                       // normalize_lit; round 3 measured 1.532 / 1.529 / 1.552 and kept 5)
 #endif
 namespace vqk {
 using namespace vqd;
