@@ -28,6 +28,18 @@ extern "C" __attribute__((visibility("default"))) int vqprobe_math(int fn, const
     return (int)hipGetLastError();
 }
 
+// normalize() of n float3 vectors in the reading `dxc` (0: as written = v / length(v), the guarded fast form of vq_devmath.h:normalize_lit; 1: v * rsqrt_cr(dot))
+__global__ void k_normalize(const float* v, float* out, size_t n, int dxc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 r = normalize_rt(mk3(v[3 * i], v[3 * i + 1], v[3 * i + 2]), dxc != 0);
+    out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+}
+extern "C" __attribute__((visibility("default"))) int vqprobe_normalize(const float* v, float* out, size_t n, int dxc, void* stream) {
+    hipLaunchKernelGGL(k_normalize, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, v, out, n, dxc);
+    return (int)hipGetLastError();
+}
+
 // which: 0 rcp() vs 1.0f/x | 1 sqrt_() vs IEEE sqrtf | 2 saturate() vs the select form | 3/4 the unchecked fast paths
 // inside their validated domains (rcp_newton: normal result; sqrt_newton: x in [2^-100, FLT_MAX]) | 5 rsqrt_cr() vs (float)(1.0 / sqrt((double)x)) | 6 rsqrt_cr_fast in [2^-100, 2^100]
 // | 7 / 8 sqrt_rcp_newton: 1 / sqrtf(x) as two IEEE operations (the reciprocal OF THE ROUNDED ROOT) and the root, x in [2^-100, 2^100]

@@ -118,3 +118,35 @@ def test_fdiv_rcp_exhaustive_significands(ctx):
     first = (C.c_uint32 * 2)()
     n = lib.vqprobe_fdiv_exhaustive(0, 1 << 23, 0, 1 << 23, first)
     assert n == 0, f"{n} mismatching significand pairs, e.g. a=1+{first[0]}*2^-23, b=1+{first[1]}*2^-23"
+
+
+@pytest.mark.parametrize("dxc", [0, 1])
+def test_normalize_fast_form_on_adversarial_vectors(ctx, dxc):
+    """vq_devmath.h:normalize_lit — root + reciprocal from one v_rsq_f32, three fdiv_rcp quotients, one integer guard — against the oracle's plain IEEE statement on
+    vectors built to sit on every edge of the guard: components at and around 2^-78 and 2^-102 (the underflow limit of the corrected quotient), +-0 (a zero keeps its sign),
+    denormals, dot products at and around 2^-100 / 2^100, all-ones significands (the hard case of the reciprocal), inf / NaN, the zero vector; and 2 M random vectors over
+    the whole exponent range. Bit for bit (NaN == NaN), both readings."""
+    lib = C.CDLL(PROBE)
+    lib.vqprobe_normalize.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    r = np.random.default_rng(123 + dxc)
+    mags = np.concatenate([np.float32(2.0) ** np.arange(-149, 128, dtype=np.float32), np.array([0.0, np.inf, np.nan], np.float32),
+                           np.nextafter(np.float32(2.0) ** np.arange(-110, -70), np.float32(0)), np.nextafter(np.float32(2.0) ** np.arange(-60, 60), np.float32(0))]).astype(np.float32)
+    a = mags[r.integers(0, mags.size, (400_000, 3))] * r.choice(np.array([1.0, -1.0], np.float32), (400_000, 3))
+    a[::7, 1] = 0.0; a[1::7, 2] = -0.0; a[2::7, 0] = a[2::7, 1]                       # zero components of either sign, equal components
+    u = r.integers(0, 2 ** 32, (2_000_000, 3), dtype=np.uint32).view(np.float32)        # arbitrary bit patterns
+    g = (r.standard_normal((600_000, 3)) * 10.0 ** r.uniform(-30, 30, (600_000, 1))).astype(np.float32)
+    v = np.ascontiguousarray(np.concatenate([a, u, g]), np.float32)
+    want = np.empty_like(v)
+    O.load().vqo_normalize_lit_array.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    O.load().vqo_set_arithmetic(dxc)
+    try:
+        with np.errstate(all="ignore"):
+            O.load().vqo_normalize_lit_array(v.ctypes.data, want.ctypes.data, v.shape[0])
+    finally:
+        O.load().vqo_set_arithmetic(0)
+    dv = torch.from_numpy(v).cuda()
+    out = torch.empty_like(dv)
+    assert lib.vqprobe_normalize(dv.data_ptr(), out.data_ptr(), v.shape[0], dxc, None) == 0
+    torch.cuda.synchronize()
+    n, idx = O.bits_equal(out.cpu().numpy(), want)
+    assert n == 0, (n, idx, v[idx[:, 0]][:3])
