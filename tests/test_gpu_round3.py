@@ -122,6 +122,51 @@ def test_forward_skip_keeps_signed_zero_and_nonfinite(ctx):
     assert (ref[..., :3] == 0).any()
 
 
+@pytest.mark.parametrize("arith_dxc", [False, True])
+def test_forward_light_loop_granularity_conditions(ctx, arith_dxc):
+    """The light loop proves its fast quotients from the granularity of the coordinates (vq_shade.h:add_point_light): light / pixel coordinates that are 0 or have magnitude
+    in [2^-40, 2^40], view components that are 0 or >= 2^-40, no (-0) - (+0), and per light only min(dd, hh) >= 2^-80. Everything on or across those edges must still
+    equal the oracle bit for bit: coordinates of 0, -0, 1e-13 (2^-43), 1e-20, 1e-38, denormals, 2^40, 1e13, 1e30; a light exactly AT a pixel (dd = 0), exactly behind the
+    view direction of a pixel (Wo + Wi = 0: hh = 0), on one of its axes (zero components of Lw - P); the camera exactly above / beside pixels (zero view components);
+    lights whose -0.0 coordinate meets a pixel's +0.0. Each variant makes a different subset of the conditions fail, frame-wide or per pixel."""
+    rng = np.random.default_rng(77)
+    W, H = 256, 16
+    cam = np.array([2.0, 10.0, -60.0], np.float32)
+    special = np.array([0.0, -0.0, 1e-13, -1e-13, 2.0 ** -40, 2.0 ** -41, 1e-20, -1e-30, 1e-38, 1e-42, 2.0 ** 40, 2.0 ** 41, 1e13, -1e30, 2.0, 10.0, -60.0], np.float32)
+    ctx.set_arithmetic(arith_dxc); O.load().vqo_set_arithmetic(1 if arith_dxc else 0)
+    try:
+        for variant in range(4):
+            gb = synth.gbuffer(W, H, seed=0x6A + variant, coherent=(variant % 2 == 1))
+            P = gb[0]
+            sel = rng.random((H, W, 3)) < 0.25
+            P[..., :3] = np.where(sel, special[rng.integers(0, special.size, (H, W, 3))], P[..., :3])     # special coordinates, one to three per pixel
+            P[0, :, 0] = cam[0]; P[1, :, 1] = cam[1]; P[2, :, 2] = cam[2]                                # zero view components along whole rows
+            P[3, ::2, :3] = cam                                                                            # the camera AT the pixel: V = 0 / 0
+            pts = synth.point_lights(12, seed=0x6A + variant)
+            for i in range(12):
+                pts[i].range = 1e6 if variant < 3 else 3e9                                               # variant 3: ranges beyond 2^30 as well
+            pts[0].position.set(tuple(P[5, 10, :3]))                                                       # a light exactly at a pixel
+            pts[1].position.set((0.0, 7.0, 3.0)); pts[2].position.set((4.0, 0.0, -2.0))                    # +0 coordinates: allowed
+            pts[3].position.set((1e-13, 5.0, 1.0)); pts[4].position.set((3.0, 1e-20, 1e-38))               # below 2^-40: the frame takes the IEEE loop (variants 1-3)
+            if variant == 0:
+                pts[3].position.set((2.0 ** -40, 5.0, 1.0)); pts[4].position.set((3.0, 2.0 ** 40, -(2.0 ** -40)))   # exactly on the edges: fast loop stays on
+            if variant == 2:
+                pts[5].position.set((-0.0, 3.0, -0.0)); pts[3].position.set((0.5, 5.0, 1.0)); pts[4].position.set((3.0, 2.0, 1.0))   # -0 lights, otherwise clean
+            # a light exactly behind the view direction of pixel (6, 20): Wi = -Wo as exactly as floats allow, hh = 0 or tiny
+            Pq = P[6, 20, :3].astype(np.float64)
+            pts[6].position.set(tuple((Pq - 3.0 * (cam - Pq) / np.linalg.norm(cam - Pq)).astype(np.float32)))
+            pts[7].position.set((float(P[7, 30, 0]), float(P[7, 30, 1]) + 4.0, float(P[7, 30, 2])))       # straight above a pixel: two zero components of Lw - P
+            pf, _ = synth.per_frame(points=pts)
+            pv = synth.per_view(W, H, camera=tuple(float(c) for c in cam))
+            with np.errstate(all="ignore"):
+                ref = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F)
+            got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=abi.FMT_RGBA32F)
+            assert_bits(got, ref, f"granularity conditions, variant {variant}, dxc {arith_dxc}")
+            assert np.isfinite(ref[8:, :, :3]).mean() > 0.5
+    finally:
+        ctx.set_arithmetic(False); O.load().vqo_set_arithmetic(0)
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------
 # post
 # ---------------------------------------------------------------------------------------------------------------------------------

@@ -321,17 +321,24 @@ static size_t fillFrameConstants(vqhip_ctx* ctx, int slot, const VQ_PerFrameData
     // pack the non-shadowing point lights for the hot loop: cbuffer array first, then the extension array, in index order
     DevPointLight* pts = (DevPointLight*)(fc + 1);
     const int nPts = L.numPointLights + numExtraPoint;
-    int32_t pointFastOK = 1, pointSkipOK = 1;
+    int32_t pointFastOK = 1, pointSkipOK = 1, negZeroAxes = 0;
+    auto coordOK = [](float c) { const float m = std::fabs(c); return c == 0.0f || (m >= 0x1p-40f && m <= 0x1p40f); };      // false for NaN / inf
     for (int i = 0; i < nPts; ++i) {
         const VQ_PointLight& l = i < L.numPointLights ? L.point_lights[i] : extraPoint[i - L.numPointLights];
         pts[i].px = l.position.x; pts[i].py = l.position.y; pts[i].pz = l.position.z; pts[i].range = l.range;
         pts[i].cbx = l.color.x * l.brightness; pts[i].cby = l.color.y * l.brightness; pts[i].cbz = l.color.z * l.brightness;   // l.color * l.brightness (Lighting.hlsl:317)
         pts[i].rangeSq = rangeCullThreshold(l.range);
         if (pts[i].rangeSq > 0x1p60f) pointFastOK = 0;                           // false for a NaN threshold (never lit)
+        // the light loop proves its fast quotients from the GRANULARITY of the coordinates (vq_shade.h:add_point_light): a non-zero Lw - P then has magnitude >= 2^-63
+        if (!(coordOK(l.position.x) && coordOK(l.position.y) && coordOK(l.position.z))) pointFastOK = 0;
+        if (l.position.x == 0.0f && std::signbit(l.position.x)) negZeroAxes |= 1;
+        if (l.position.y == 0.0f && std::signbit(l.position.y)) negZeroAxes |= 2;
+        if (l.position.z == 0.0f && std::signbit(l.position.z)) negZeroAxes |= 4;
         if (!(std::isfinite(pts[i].cbx) && std::isfinite(pts[i].cby) && std::isfinite(pts[i].cbz))) pointSkipOK = 0;
     }
     fc->pointFastOK = pointFastOK;
     fc->pointSkipOK = pointSkipOK;
+    fc->pointNegZeroAxes = negZeroAxes;
     fc->numPointAll = nPts;
     return sizeof(FrameConstants) + (size_t)nPts * sizeof(DevPointLight);
 }

@@ -41,10 +41,12 @@ struct alignas(16) FrameConstants {
     int32_t                hasEnv;
     int32_t                numPointAll;    // numPointLights + numExtraPoint
     int32_t                pow5ExpLog;     // vqhip_set_fresnel_pow: 0 = product (default), 1 = exp2(5*log2 x)
-    int32_t                pointFastOK;    // every point light's rangeSq <= 2^60 (or never lit): precondition of the unchecked light loop (shade.hip)
+    int32_t                pointFastOK;    // every point light's rangeSq <= 2^60 (or never lit) and every coordinate of its position is 0 or has magnitude in [2^-40, 2^40]:
+                                           // preconditions of the unchecked light loop (vq_shade.h)
     float                  hdriSin, hdriCos;   // sin / cos(-fHDRIOffsetInRadians): frame-uniform, taken CORRECTLY ROUNDED on the host (double libm
                                                // rounded to float, capi.hip; contract v5 — the oracle does the same), not the contract's polynomial
     int32_t                pointSkipOK;    // every point light's color*brightness is finite: precondition of the back-facing-light skip (shade.hip)
+    int32_t                pointNegZeroAxes;   // bit c: some point light has the coordinate -0.0 on axis c (then a pixel whose P has +0.0 there takes the IEEE loop: (-0) - (+0) = -0)
     // DevPointLight pts[numPointAll] follows
 };
 // Non-shadowing point lights as the hot loop reads them (one s_load_dwordx8 per light): point_lights[0..numPointLights)

@@ -46,11 +46,13 @@ struct Pixel {
 };
 
 VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
-VQD float min3abs_acc(float m, float a, float b) { return __builtin_fminf(__builtin_fminf(m, __builtin_fabsf(a)), __builtin_fabsf(b)); }   // m >= 0
 VQD float min3abs(f3 v) { return __builtin_fminf(__builtin_fminf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), __builtin_fabsf(v.z)); }   // one v_min3_f32 with |.| modifiers
 
+// (bits << 1) - 1: the magnitude of a float as an unsigned integer with +-0 mapped to 0xffffffff (a zero is always an acceptable operand below)
+VQD uint32_t mag_or_top(float v) { return (__float_as_uint(v) << 1) - 1u; }
+
 template <int AR>
-VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
+VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam, int negZeroAxes = 0) {
     px.P = mk3(g0.x, g0.y, g0.z);
     px.Nraw = mk3(g1.x, g1.y, g1.z);
     px.roughness = g1.w;
@@ -80,6 +82,22 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
     // EPSILON early-out may fire: such a wave takes the loop form that keeps the early-out as a select, RcpTrustEps) and a finite Wo (with a
     // finite Wi it makes Wo + Wi free of NaN, which the min3 test there cannot see)
     px.fastOK = (px.roughness >= 0.0f) & (px.roughness <= 1.0f) & (dot_r<AR>(px.Wo, px.Wo) <= 4.0f);       // the comparison is false for a NaN component
+    // ... and the GRANULARITY conditions that make every quotient of the light loop free of underflow without a test per light (add_point_light): each coordinate of P
+    // is 0 or has magnitude in [2^-40, 2^40] (the host checks the same for every light position: pointFastOK), each component of Wo is 0 or >= 2^-40; where some light
+    // has a -0.0 coordinate, P must not hold +0.0 on that axis ((-0) - (+0) is the one difference that yields -0, which the fast quotient would turn into +0)
+    {
+        const uint32_t lo = (0x2b800000u << 1) - 1u;                                                           // 2^-40
+        const uint32_t pm = min(mag_or_top(px.P.x), min(mag_or_top(px.P.y), mag_or_top(px.P.z)));
+        const uint32_t wm = min(mag_or_top(px.Wo.x), min(mag_or_top(px.Wo.y), mag_or_top(px.Wo.z)));
+        const float pmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(px.P.x), __builtin_fabsf(px.P.y)), __builtin_fabsf(px.P.z));
+        bool ok = (pm >= lo) & (wm >= lo) & (pmax <= 0x1p40f);                                                 // false for a NaN / inf coordinate (fmax drops a NaN: caught by the others below)
+        ok &= (px.P.x == px.P.x) & (px.P.y == px.P.y) & (px.P.z == px.P.z);
+        if (negZeroAxes) {                                                                                     // wave-uniform, almost never taken
+            const int z = (__float_as_uint(px.P.x) == 0u ? 1 : 0) | (__float_as_uint(px.P.y) == 0u ? 2 : 0) | (__float_as_uint(px.P.z) == 0u ? 4 : 0);
+            ok &= (z & negZeroAxes) == 0;
+        }
+        px.fastOK &= ok;
+    }
     // the skip of back-facing lights (add_point_light<.., true>) needs a finite BRDF whatever the light: finite F0 (hence 1 - F0) and kA
     px.skipOK = ((__builtin_fabsf(px.F0.x) + __builtin_fabsf(px.F0.y) + __builtin_fabsf(px.F0.z)) +
                  (__builtin_fabsf(px.kA.x) + __builtin_fabsf(px.kA.y) + __builtin_fabsf(px.kA.z))) < __builtin_inff();
@@ -88,15 +106,15 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam) {
 // BRDF(s, Wi, V), BRDF.hlsl:163-194. As written: H = normalize(Wo + Wi) (IEEE quotients through rc.div), NdotH, nh2*(a2-1)+1.
 // Regrouped (contract v2-v4): fma(F, sG - kA, kA) with sG = (D*G)*rcp(denom) and the per-pixel kA = ((1-metal)*albedo)*rcp(PI).
 // `rc` is the reciprocal / sqrt / quotient policy (vq_devmath.h).
+// hh = |Wo + Wi|^2 in the reading AR (dot / dot_lit): handed in by the hot loop, which also folds it into its validity minimum
 template <int AR, class R>
-VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
-    const f3 Hs = add(px.Wo, Wi);
+VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc, f3 Hs, float hh) {
     f3 H;                                                    // normalize(Wo + Wi) :168
     if (AR) {
-        H = mul(Hs, rc.rsqrt(dot(Hs, Hs)));                  // DXC reading: one correctly rounded rsqrt, three products
+        H = mul(Hs, rc.rsqrt(hh));                           // DXC reading: one correctly rounded rsqrt, three products
     } else {
         float rH;
-        const float Hl = rc.sqrt_rcp(dot_lit(Hs, Hs), &rH);  // length(Wo + Wi) and its reciprocal from one v_rsq_f32 (vq_devmath.h:sqrt_rcp_newton)
+        const float Hl = rc.sqrt_rcp(hh, &rH);               // length(Wo + Wi) and its reciprocal from one v_rsq_f32 (vq_devmath.h:sqrt_rcp_newton)
         H = mk3(rc.div(Hs.x, Hl, rH), rc.div(Hs.y, Hl, rH), rc.div(Hs.z, Hl, rH));
     }
     const float NdotH = saturate(dot_r<AR>(px.Nn, H));       // :169
@@ -126,6 +144,11 @@ VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
     }
     // Id + Is = (1-F)*kA + F*sG regrouped as kA + F*(sG - kA) (contract v3)
     return mk3(fma_(F.x, sG - px.kA.x, px.kA.x), fma_(F.y, sG - px.kA.y, px.kA.y), fma_(F.z, sG - px.kA.z, px.kA.z));
+}
+template <int AR, class R>
+VQD f3 brdf_t(const Pixel& px, f3 Wi, R& rc) {
+    const f3 Hs = add(px.Wo, Wi);
+    return brdf_t<AR>(px, Wi, rc, Hs, AR ? dot(Hs, Hs) : dot_lit(Hs, Hs));
 }
 
 // acc + b * (cb * w): cb = l.color * l.brightness, w = attenuation [* cone] * NdotL (one mad per channel)
@@ -165,12 +188,14 @@ VQD f3 point_light(const Pixel& px, const VQ_PointLight& l) {       // per-op va
 //              pi t^2 in [1.9e-11, pi] (t = nh2*(a2-1) + 1, product and sum each rounded — contract v5 — in [a2 - 2^-24, 1], nh2 saturated)
 //              denom = max(4 NdotV NdotL, 1e-4) in [1e-4, 4]
 //              => the merged reciprocal's operand (pi t^2 * gL) * denom in [2.4e-16, 17.6]: operand and result normal
-//   light  : every component of Lw-P has magnitude >= 2^-40 and dd = |Lw-P|^2 < rangeSq <= 2^60 (the host checks the thresholds of the whole
-//            light set: FrameConstants::pointFastOK; a NaN / inf dd fails the cull)
-//            => dd in [2^-80, 2^60], D in [2^-40, 2^30]: sqrt, 1/D normal ((1/D)^2 is a plain product), quotients d/D free of underflow
-//   light  : every component of Wo+Wi has magnitude >= 2^-40 (Wo, Wi finite => no NaN) => hh = |Wo+Wi|^2 in [2^-80, ~4]
-//   => the corrected quotients d/D, Hs/|Hs| (fdiv_rcp: exhaustively equal to IEEE division when nothing underflows) are the IEEE
-//      quotients; a zero or tiny component (a light exactly above the pixel on one axis) sends the pixel to the IEEE loop
+//   frame  : every coordinate of every light position is +0 or has magnitude in [2^-40, 2^40], every rangeSq <= 2^60 (host: FrameConstants::pointFastOK)
+//   pixel  : every coordinate of P is 0 or has magnitude in [2^-40, 2^40]; every component of Wo is 0 or >= 2^-40; no (-0) - (+0) on any axis (setup_pixel)
+//            => a component of Lw-P is +0 or has magnitude >= 2^-63 (the difference of two such floats is a multiple of the smaller one's ulp)
+//   light  : dd = |Lw-P|^2 in [2^-80, 2^60) (upper: the cull, a NaN / inf dd fails it; lower: vmin) => D in [2^-40, 2^30]: root and reciprocal inside sqrt_rcp_newton's
+//            proven domain; a quotient d.c / D is +0 or has magnitude >= 2^-93: normal, and its residual d.c - D q (a multiple of 2^-46 |d.c| >= 2^-109) is exact
+//   light  : a component of Wo+Wi is +0 (x + (-x), or 0 + 0: never -0 because d.c is never -0), or — with Wo.c >= 2^-40 — has magnitude >= 2^-64, or — with Wo.c = 0 —
+//            equals Wi.c (>= 2^-93); hh = |Wo+Wi|^2 in [2^-80, ~4] (vmin) => the quotients Hs.c / |Hs| are normal with exact residuals (>= 2^-139) as well
+//   => the corrected quotients d/D, Hs/|Hs| (fdiv_rcp: exhaustively equal to IEEE division when nothing underflows; +0 / D = +0 either way) are the IEEE quotients
 // all inside the exhaustively validated domains of rcp_newton / sqrt_newton (vq_devmath.h). A failed test (NaN inputs,
 // degenerate geometry, roughness outside [0,1], a range beyond 2^30) redoes the pixel's point-light loop with IEEE operations
 // (k_forward_lighting); where both are valid the two give identical bits, so the redo changes only what was invalid.
@@ -190,8 +215,8 @@ struct RcpTrust {
 // validity proof above carries over with roughness in [0, 1] (k in [1/8, 1/2] as before). Where the early-out cannot fire the select form
 // and RcpTrust give identical bits, so which of the two a wave runs is a pure speed choice (+3 VALU per light).
 struct RcpTrustEps : RcpTrust { static constexpr bool kGgxDenomAboveEps = false; };
-// `vmin` collects the smallest |component| of Lw-P and Wo+Wi over the lights that passed the range cull (three v_min3 with |.| modifiers);
-// the caller compares it with 2^-40 ONCE after the loop and, when the test fails, redoes the pixel's whole point-light loop with IEEE
+// `vmin` collects the smallest dd and hh over the lights that passed the range cull (ONE v_min3 per light; rounds 2-3 tracked the six components: three);
+// the caller compares it with 2^-80 ONCE after the loop and, when the test fails, redoes the pixel's whole point-light loop with IEEE
 // operations (k_forward_lighting) — the accumulator needs no copy per light and the loop carries no validity masks.
 // dd <= 2^60 follows from dd < rangeSq <= 2^60 (FrameConstants::pointFastOK, host); a NaN / inf dd fails the cull like the reference's D < range.
 // SKIP (wave-uniform choice of the caller): a light that faces away from every lane that passed the cull — NdotL = saturate(dot(N, Wi)) = +0 —
@@ -211,12 +236,13 @@ VQD void add_point_light(const Pixel& px, const vqk::DevPointLight& l, f3& I, fl
         const float D = rc.sqrt_rcp(dd, &rD);                // dd in [2^-80, 2^60]: inside the proven domain of sqrt_rcp_newton
         const f3 Wi = AR ? mul(d, rc.rsqrt(dd)) : mk3(fdiv_rcp(d.x, D, rD), fdiv_rcp(d.y, D, rD), fdiv_rcp(d.z, D, rD));    // (Lw - P) / length(Lw - P) | (Lw - P) * rsqrt
         const f3 Hs = add(px.Wo, Wi);
-        vmin = min3abs_acc(min3abs_acc(min3abs_acc(vmin, d.x, d.y), d.z, Hs.x), Hs.y, Hs.z);
         const float dNL = dot(px.Nraw, Wi);
+        const float hh = AR ? dot(Hs, Hs) : dot_lit(Hs, Hs);                 // the operand of brdf_t's root
+        vmin = __builtin_fminf(__builtin_fminf(vmin, dd), hh);               // one v_min3_f32, in front of the skip like the three it replaces (behind it the skip form ran 4 % slower)
         if (SKIP) { if (__builtin_amdgcn_ballot_w64((dNL > 0.0f) | !(izmin > 0.0f)) == 0) return; }
         const float NdotL = saturate(dNL);
         const float w = (rD * rD) * NdotL;
-        const f3 b = brdf_t<AR>(px, Wi, rc);
+        const f3 b = brdf_t<AR>(px, Wi, rc, Hs, hh);
         I = lit(I, b, cb, w);
         if (SKIP) izmin = min3abs(I);
     }
@@ -345,7 +371,7 @@ VQD float4 shade_pixel(const float4 g0, const float4 g1, const float4 g2, const 
     Pixel px;
     const f3 cam = ld3(fc->perView.CameraPosition);
     px.p5ExpLog = fc->pow5ExpLog != 0;
-    setup_pixel<AR>(px, g0, g1, g2, cam);
+    setup_pixel<AR>(px, g0, g1, g2, cam, fc->pointNegZeroAxes);
     const float ao = g0.w;
     // illumination accumulators, ForwardLighting.hlsl:290-293: diffuse*ao + emissive*intensity, as written
     f3 I = mk3(px.albedo.x * ao + g3.x * g3.w, px.albedo.y * ao + g3.y * g3.w, px.albedo.z * ao + g3.z * g3.w);
@@ -378,7 +404,7 @@ VQD float4 shade_pixel(const float4 g0, const float4 g1, const float4 g2, const 
         if (skip) { if (eps) point_light_loop<AR, RcpTrustEps, true>(px, pts, nP, I, vmin); else point_light_loop<AR, RcpTrust, true>(px, pts, nP, I, vmin); }
         else      { if (eps) point_light_loop<AR, RcpTrustEps, false>(px, pts, nP, I, vmin); else point_light_loop<AR, RcpTrust, false>(px, pts, nP, I, vmin); }
     }
-    if (__builtin_expect(!(vmin >= 0x1p-40f), 0)) {
+    if (__builtin_expect(!(vmin >= 0x1p-80f), 0)) {
         I = I0;
         RcpIEEE ieee;
         for (int p = 0; p < nP; ++p) I = point_light_t<AR>(px, mk3(pts[p].px, pts[p].py, pts[p].pz), pts[p].range, mk3(pts[p].cbx, pts[p].cby, pts[p].cbz), I, ieee);
