@@ -63,6 +63,11 @@ def test_quotients_of_the_light_loop_are_exact_at_the_allowed_scales():
         a = f32(rng, -93, -93 + rng.choice([0, 0, 1, 10, 60])) * rng.choice([1, -1])
         if abs(a) <= Hl * 2:
             assert fdiv_rcp(a, Hl) == rn32(a / Hl), (a, Hl)
+    for _ in range(3000):                                    # vq_devmath.h:normalize_lit: |a| >= 2^-78, |v| = sqrt(dd) in [2^-50, 2^48]
+        D = f32(rng, -50, 47)
+        a = f32(rng, -78, -78 + rng.choice([0, 0, 2, 30, 100])) * rng.choice([1, -1])
+        if abs(a) <= D * 2:
+            assert fdiv_rcp(a, D) == rn32(a / D), (a, D)
     assert fdiv_rcp(Fraction(0), f32(rng, -10, 10)) == 0     # a zero component stays zero
 
 

@@ -150,7 +150,7 @@ VQD float dot_lit(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 VQD float length_lit(f3 v) { return sqrt_(dot_lit(v, v)); }
 VQD f3 div_lit(f3 v, float l) { return mk3(fdiv_(v.x, l), fdiv_(v.y, l), fdiv_(v.z, l)); }
 // normalize(v) AS WRITTEN = one IEEE quotient per component by length(v). Fast form: the root and its reciprocal from one v_rsq_f32 (sqrt_rcp_newton), the three
-// quotients by fdiv_rcp (3 VALU each) — equal to the IEEE operations whenever dot(v,v) lies in [2^-100, 2^100] and no component is a non-zero number below 2^-78
+// quotients by fdiv_rcp (3 VALU each) — equal to the IEEE operations whenever dot(v,v) lies in [2^-100, 2^96] and no component is a non-zero number below 2^-78
 // (exhaustive proofs above); a zero component keeps its sign (0 * r would lose a -0). One test per vector (integer tricks: (bits << 1) - 1 maps +-0 to 0xffffffff and
 // orders the magnitudes); anything else — NaN, inf, denormal components, a zero vector — takes the plain IEEE operations. ~37 VALU instead of ~58.
 VQD f3 normalize_lit(f3 v) {
@@ -159,7 +159,8 @@ VQD f3 normalize_lit(f3 v) {
     const float D = sqrt_rcp_newton(dd, &r);
     const uint32_t bx = __float_as_uint(v.x), by = __float_as_uint(v.y), bz = __float_as_uint(v.z);
     const uint32_t m = min((bx << 1) - 1u, min((by << 1) - 1u, (bz << 1) - 1u));                  // smallest magnitude, zeros excluded
-    const bool ok = (m >= ((0x18800000u << 1) - 1u)) & ((__float_as_uint(dd) - 0x0d800000u) <= (0x71800000u - 0x0d800000u));   // 2^-78; dd in [2^-100, 2^100] (NaN / negative: out)
+    const bool ok = (m >= ((0x18800000u << 1) - 1u)) & ((__float_as_uint(dd) - 0x0d800000u) <= (0x6f800000u - 0x0d800000u));   // 2^-78; dd in [2^-100, 2^96] (NaN / negative: out):
+                                                                                                                                  // every quotient >= 2^-78 / 2^48 = 2^-126 is normal
     f3 q;
     q.x = __uint_as_float(__float_as_uint(fdiv_rcp(v.x, D, r)) | (bx & 0x80000000u));
     q.y = __uint_as_float(__float_as_uint(fdiv_rcp(v.y, D, r)) | (by & 0x80000000u));
