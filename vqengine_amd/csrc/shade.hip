@@ -1,5 +1,5 @@
 // shade.hip — forward-PBR lighting kernel for gfx950: ForwardLighting.hlsl:PSMain :289-380 evaluated per G-buffer pixel (SURVEY.md §8a rows
-// A1-A7). One lane per pixel, 256-lane workgroups (128 for frames under 4 Mpixel), float4 SoA plane loads (16 B/lane, fully coalesced); the per-pixel body is vq_shade.h.
+// A1-A7). One lane per pixel, 256-lane workgroups (64 for frames under 4 Mpixel), float4 SoA plane loads (16 B/lane, fully coalesced); the per-pixel body is vq_shade.h.
 #include "vq_shade.h"
 #include "vq_mrt.h"
 #include <cstdlib>
@@ -40,9 +40,10 @@ hipError_t launch_fmt(hipStream_t s, const vqk::ShadeArgs& a, int outFmt, dim3 g
 namespace vqk {
 hipError_t launch_forward_lighting(hipStream_t s, const ShadeArgs& a, bool hasEnv, bool hasCasters, int outFmt, const Options& opt) {
     // Workgroup = wg consecutive pixels of one row (grid.z carries wg to launch_fmt). 256 for large frames; frames under 4 Mpixel (1080p: 32 400 waves,
-    // 4.5 rounds of the chip at 7 waves per SIMD) run 7.5 % faster with 128-lane workgroups — finer-grained dispatch shortens the tail, and a width
-    // like 1920 is no multiple of 256 (profiles/r3t_shade_wg.jsonl: cfg2 0.0913 -> 0.0845 ms; cfg3 unchanged either way). Option "shade_wg" overrides.
-    int wg = (size_t)a.width * a.height < ((size_t)4 << 20) ? 128 : 256;
+    // ~4 rounds of the chip at 8 waves per SIMD) run faster with finer-grained dispatch, which shortens the fill and the tail, and a width like 1920 is no multiple of 256:
+    // cfg2 0.0778 / 0.0739 / 0.0730 ms at 256 / 128 / 64 lanes, cfg3 0.919 / 0.921 / 0.924 (profiles/r4z_shade_wg.jsonl; round 3 chose 128 on r3t_shade_wg.jsonl).
+    // Option "shade_wg" overrides.
+    int wg = (size_t)a.width * a.height < ((size_t)4 << 20) ? 64 : 256;
     if (opt.shadeWg == 64 || opt.shadeWg == 128 || opt.shadeWg == 256) wg = opt.shadeWg;
     dim3 grid((a.width + wg - 1) / wg, a.height, wg);
     if (hasEnv) return hasCasters ? launch_fmt<true, true>(s, a, outFmt, grid) : launch_fmt<true, false>(s, a, outFmt, grid);
