@@ -12,7 +12,10 @@ __global__ __launch_bounds__(256, VQ_SHADE_WAVES) void k_forward_lighting(vqk::S
     const int y = blockIdx.y;
     if (x >= a.width) return;
     const size_t i = (size_t)y * a.pitch + x;
-    const float4 g0 = a.gb0[i], g1 = a.gb1[i], g2 = a.gb2[i], g3 = a.gb3[i];
+    // the G-buffer record is read once and never again: non-temporal loads keep the 531 MB stream of a 4K frame from evicting the BRDF LUT and the cubes from the XCD's L2
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    auto ntload = [](const float4* p) { const v4f v = __builtin_nontemporal_load((const v4f*)p); return make_float4(v.x, v.y, v.z, v.w); };
+    const float4 g0 = ntload(&a.gb0[i]), g1 = ntload(&a.gb1[i]), g2 = ntload(&a.gb2[i]), g3 = ntload(&a.gb3[i]);
     if (MRT) vqk::write_extra_targets(a.mrt, x, y, g2);      // SV_TARGET1 / motion vectors of the same draw (vqhip_forward_lighting_mrt): its own instantiation,
                                                              // the kernel without them is instruction for instruction what it was
     const vqk::FrameConstants* fc = a.fc;
