@@ -169,7 +169,10 @@ VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane
     float4 i0 = make_float4(0, 0, 0, 0), i1 = i0, i2 = i0;
     int idx = -1;
     if (inside) {
-        i0 = *(const float4*)((const char*)a.ip0 + o); i1 = *(const float4*)((const char*)a.ip1 + o); i2 = *(const float4*)((const char*)a.ip2 + o);
+        // the interpolant planes are a stream (48 B per pixel, read once per kernel): non-temporal, so that they do not evict the material maps / LUT / cubes from the XCD L2s
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        auto nt = [](const void* p) { const v4f v = __builtin_nontemporal_load((const v4f*)p); return make_float4(v.x, v.y, v.z, v.w); };
+        i0 = nt((const char*)a.ip0 + o); i1 = nt((const char*)a.ip1 + o); i2 = nt((const char*)a.ip2 + o);
         idx = __float_as_int(i2.w);
         if (idx >= gc->numMaterials) idx = -1;
     }
