@@ -70,9 +70,21 @@ F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
 
 
 def kernel_source_hash():
+    """sha256 over the shade kernel's sources and over the lines of the Makefile that decide its code generation (the HIPFLAGS assignments and their
+    continuation lines) — a change of prerequisites or comments in the Makefile does not make the counters stale, a change of flags does."""
     h = hashlib.sha256()
     for f in PMC_SOURCES:
-        h.update(open(os.path.join(ROOT, f), "rb").read())
+        data = open(os.path.join(ROOT, f), "rb").read()
+        if f.endswith("Makefile"):
+            keep, cont = [], False
+            for ln in data.splitlines():
+                if cont or (b"HIPFLAGS" in ln and not ln.lstrip().startswith(b"#") and not ln.startswith(b"\t")):
+                    keep.append(ln.strip())
+                    cont = ln.rstrip().endswith(b"\\")
+                else:
+                    cont = False
+            data = b"\n".join(keep)
+        h.update(data)
     return h.hexdigest()[:16]
 
 
@@ -122,7 +134,9 @@ def build_ibl(ctx, timings=None):
             a, b = _ev(), _ev()
             a.record(); fn(); b.record(); b.synchronize()
             timings[name.replace("_ms", "_single_call_ms")] = round(a.elapsed_time(b), 4)      # one call, clocks as the set-up phase left them
-            timings[name] = round(_stage_ms(fn), 4)                  # back-to-back calls after a ~0.1 s spin-up, like every other per-stage figure of the line
+            st = _stage_stats(fn)                                    # >= 0.25 s spin-up, median of 7 batches: the timer of every per-stage figure of the line
+            timings[name] = round(st["ms"], 4)
+            timings[name.replace("_ms", "_ms_spread")] = [round(st["ms_min"], 4), round(st["ms_max"], 4)]
     return pre, lut
 
 
@@ -220,6 +234,27 @@ def cpu_reference_source(cfg, env_np, pf, extra, pv, frame_h, target_s=6.0):
             "sample": f"the reference's HLSL (PSMain {cfg['lights']} lights{' + IBL' if env is not None else ''}, CSMain_X/_Y, tonemapper CSMain) compiled to C++ through "
                       f"oracle/ref_src/hlsl_shim.h, {cores} threads (one private copy of the library each), {bands} bands of {W}x{rows_per} rows of the same frame "
                       f"({W * rows / 1e6:.2f} Mpix); {wall:.1f} s wall, {sum(b for _, b in res):.1f} thread-seconds"}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: bench.py starts its own N ranks (one per GPU) by replacing itself with
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>`;
+    rank 0 prints the one JSON line, the exit status is the launcher's. Refuses — non-zero, with a message — when the node has fewer than N GPUs
+    (VQ_BENCH_SHARE_GPU=1, the single-GPU debug aid, lifts that: the ranks then share the visible GPUs)."""
+    import socket
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("VQ_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"bench.py: --gpus {n} but this node shows {have} GPU(s); one rank per GPU is the only supported layout")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: no launcher in the environment (WORLD_SIZE unset): starting {n} ranks: {' '.join(cmd[1:9])} ...", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
 
 
 class Dist:
@@ -532,6 +567,10 @@ def main():
     cfg = CONFIGS[args.config]
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                              # does not return
     d = Dist(args)
     world, rank = d.world, d.rank
     ctx = capi.Context(d.device_ordinal)
@@ -575,15 +614,9 @@ def main():
         iso = {}
         for name, fn in (("blur_x", lambda: ctx.gaussian_blur_x(pipe.scene[0], F16, out=pipe.xblur)),
                          ("blur_y_tonemap", lambda: ctx.gaussian_blur_y_tonemap(pipe.xblur, F16, R8, out=pipe.sdr[0], halo_top=pipe.halo_top, halo_bottom=pipe.halo_bottom))):
-            for _ in range(5):
-                fn()
-            e0, e1 = _ev(), _ev()
-            e0.record(pipe.s_main)
-            for _ in range(20):
-                fn()
-            e1.record(pipe.s_main)
-            e1.synchronize()
-            iso[name] = e0.elapsed_time(e1) / 20 * 1e-3
+            st = _stage_stats(fn, spin_s=0.01)               # the frame loop has just spun the chip up
+            iso[name] = st["ms"] * 1e-3
+            iso[name + "_spread"] = [round(st["ms_min"], 4), round(st["ms_max"], 4)]
         pipe.drain()
         d.barrier()
     for i in range(args.warmup):
@@ -664,8 +697,8 @@ def main():
         dxc = {"arithmetic": "dxc", "fresnel_pow": "exp2_log2", "value": round(W * frame_h * args.steps / dt3 / 1e6, 2), "unit": "Mpix/s",
                "ms_per_step": round(dt3 / args.steps * 1e3, 4), "shade_ms": round(mean_ms(evs3, "t0", "shade"), 4),
                "note": "vqhip_set_arithmetic(VQHIP_ARITH_DXC) + VQHIP_FRESNEL_POW_EXP2_LOG2: within one RGBA16F ulp of the reference's HLSL in DXC's reading of dot / "
-                       "normalize / pow (tests/test_gpu_arith_modes.py); the headline runs the literal reading. The correctly rounded rsqrt costs a binary64 correction "
-                       "(v_rsq_f32 seed + 5 DP operations), which is why the mode is no faster than the literal quotients"}
+                       "normalize / pow (tests/test_gpu_arith_modes.py); the headline runs the literal reading. normalize = v * rsqrt(dot) with a correctly rounded rsqrt: a binary32 "
+                       "second-order sequence from the v_rsq_f32 seed (vq_devmath.h:rsqrt_cr_fast, validated on [2^-100, 2^100]; the binary64 definition is the out-of-range fallback)"}
 
     # 6. the other BASELINE configs, outside the headline's timed region (every rank takes part in the distributed ones)
     extras = {}
@@ -742,7 +775,8 @@ def main():
                                         "blur_y_tonemap_ms": round(iso["blur_y_tonemap"] * 1e3, 4),
                                         "blur_y_tonemap_GBps": round(px_tile * 12 / iso["blur_y_tonemap"] / 1e9, 1),
                                         "blur_y_tonemap_frac_of_hbm_peak": round(px_tile * 12 / iso["blur_y_tonemap"] / 1e9 / HBM_PEAK_GBPS, 4),
-                                        "note": "20 back-to-back launches of the one kernel between two events, after the spin-up and before the warm-up steps; "
+                                        "blur_x_ms_spread": iso["blur_x_spread"], "blur_y_tonemap_ms_spread": iso["blur_y_tonemap_spread"],
+                                        "note": "median of 7 batches of back-to-back launches of the one kernel (spread = fastest / slowest batch), after the spin-up and before the warm-up steps; "
                                                 "the figures above are taken inside the frame loop with an event record between the stages"}}),
                        **({"blur_x_includes": "halo exchange", "composite_ms": round(mean_ms(evd, "comp0", "comp1"), 4)} if world > 1 else {})},
             "frame_latency_ms": round(frame_latency * 1e3, 4),
@@ -808,15 +842,14 @@ def shade_only(ctx, d, comms, args, cfg, env, max_env_lod, coherent=False):
     p = Pipeline(ctx, d, comms, cfg, args, env=env, max_env_lod=max_env_lod, coherent=coherent)
     out_img = p.scene[0]
     fn = lambda i: ctx.forward_lighting(p.gb, p.pf, p.pv, out=out_img, out_fmt=F16, extra_point=p.extra, env=p.env)  # noqa: E731
-    probe = _time_loop(fn, 20, 20)                           # the spin-up is a TIME, like the headline's (~0.25 s of load to reach the clocks): short kernels get more launches
-    spin = int(min(5000, max(120, 0.25e3 / probe)))
-    n = int(min(2000, max(60, 0.05e3 / probe)))
-    ms = _time_loop(fn, n, spin)
+    st = _stage_stats(lambda: fn(0))
+    ms = st["ms"]
     px, L = p.W * p.rows, cfg["lights"]
-    res = {"workload": cfg["workload"] + (" [surface-coherent content]" if coherent else ""), "shade_ms": round(ms, 4), "shade_Mpix_s": round(px / ms / 1e3, 1),
+    res = {"workload": cfg["workload"] + (" [surface-coherent content]" if coherent else ""), "shade_ms": round(ms, 4), "shade_ms_min": round(st["ms_min"], 4),
+           "shade_ms_max": round(st["ms_max"], 4), "shade_Mpix_s": round(px / ms / 1e3, 1),
            "hbm_GBps": round(SHADE_BYTES_PER_PX * px / ms / 1e6, 1), "hbm_frac": round(SHADE_BYTES_PER_PX * px / ms / 1e6 / HBM_PEAK_GBPS, 4),
            "valu_frac_model": round((170 * L + 160) * px / ms / 1e9 / VALU_PEAK_TFLOPS, 4), "bytes_per_px": SHADE_BYTES_PER_PX, "flops_per_px_model": 170 * L + 160,
-           "note": f"shade kernel only, {n} back-to-back launches after a {spin}-launch spin-up (~0.25 s of load)"}
+           "note": f"shade kernel only: median of {st['batches']} batches of {st['launches_per_batch']} back-to-back launches after a {st['spinup_launches']}-launch spin-up (>= 0.25 s of load)"}
     if coherent:
         r = p.gb[1][..., 3]
         res["slow_path_pixel_fraction_round2"] = round(float((r < 0.04).float().mean().item()), 4)
@@ -833,12 +866,35 @@ def coherent_scene(ctx, d, comms, args, cfg, env, spec_mips):
     return res
 
 
-def _stage_ms(fn, budget_s=0.12):
-    """time of one call of fn in a back-to-back loop: a spin-up and a timed loop sized by TIME (the chip needs sustained load to hold its clocks)"""
-    probe = _time_loop(lambda i: fn(), 3, 2)
-    spin = int(min(2000, max(3, budget_s * 1e3 / probe)))
-    n = int(min(1000, max(5, 0.5 * budget_s * 1e3 / probe)))
-    return _time_loop(lambda i: fn(), n, spin)
+STAGE_SPIN_S = float(os.environ.get("VQ_BENCH_STAGE_SPIN_S", "0.25"))     # the chip needs ~0.25 s of sustained load to reach its clocks
+STAGE_BATCHES = 7
+STAGE_BATCH_S = 0.03
+
+
+def _stage_stats(fn, spin_s=None, batches=STAGE_BATCHES, batch_s=STAGE_BATCH_S):
+    """THE timer of every per-stage figure of the line (widened.*, ibl_load.*_warm_ms, cfg2, coherent_scene, stages.isolated): a spin-up sized by TIME
+    (>= STAGE_SPIN_S of back-to-back calls of the same fn), then `batches` back-to-back timed batches of ~batch_s each, every batch between its own
+    two HIP events with no host synchronisation in between (all events are recorded first, read afterwards). The figure is the MEDIAN batch; the
+    spread (min / max batch) is reported with it."""
+    spin_s = STAGE_SPIN_S if spin_s is None else spin_s
+    probe = _time_loop(lambda i: fn(), 3, 2)                                   # ms per call, cold: only sizes the loops
+    spin = int(min(20000, max(3, spin_s * 1e3 / probe)))
+    n = int(min(4000, max(2, batch_s * 1e3 / probe)))
+    for _ in range(spin):
+        fn()
+    ev = [_ev() for _ in range(batches + 1)]
+    ev[0].record()
+    for b in range(batches):
+        for _ in range(n):
+            fn()
+        ev[b + 1].record()
+    ev[-1].synchronize()
+    per = sorted(ev[b].elapsed_time(ev[b + 1]) / n for b in range(batches))
+    return {"ms": per[len(per) // 2], "ms_min": per[0], "ms_max": per[-1], "batches": batches, "launches_per_batch": n, "spinup_launches": spin}
+
+
+def _stage_ms(fn):
+    return _stage_stats(fn)["ms"]
 
 
 def widened_report(ctx, env, spec_mips):
@@ -848,11 +904,13 @@ def widened_report(ctx, env, spec_mips):
     px = W * H
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
     tile = lambda a: np.tile(a, (H // BAND,) + (1,) * (a.ndim - 1))   # noqa: E731
-    res = {"frame": [W, H], "note": "back-to-back launches of the one call after a ~0.1 s spin-up; *_hbm_frac = algorithmic bytes / time / 8 TB/s. producer / "
+    res = {"frame": [W, H], "note": "every figure: >= 0.25 s spin-up of the one call, then the median of 7 back-to-back batches of ~30 ms (ms_min / ms_max = the fastest / slowest batch); *_hbm_frac = algorithmic bytes / time / 8 TB/s. producer / "
                                     "skydome / RCAS / SSR fallback are HBM-shaped; the fused PSMain and EASU are VALU-bound (see their notes)"}
 
-    def entry(ms, bytes_px, **kw):
-        return dict(ms=round(ms, 4), Mpix_s=round(px / ms / 1e3, 1), bytes_per_px=bytes_px, GBps=round(px * bytes_px / ms / 1e6, 1),
+    def entry(st, bytes_px, **kw):
+        ms = st["ms"]
+        return dict(ms=round(ms, 4), ms_min=round(st["ms_min"], 4), ms_max=round(st["ms_max"], 4), batches=st["batches"], launches_per_batch=st["launches_per_batch"],
+                    Mpix_s=round(px / ms / 1e3, 1), bytes_per_px=bytes_px, GBps=round(px * bytes_px / ms / 1e6, 1),
                     hbm_frac=round(px * bytes_px / ms / 1e6 / HBM_PEAK_GBPS, 4), **kw)
     # ---- 8f.1: G-buffer producer, alone and fused with the lighting (PSMain as one kernel)
     ipd = [dev(tile(p_)) for p_ in synth.interpolants(W, BAND, NM)]
@@ -869,25 +927,28 @@ def widened_report(ctx, env, spec_mips):
             setattr(dmats[i], slot, abi.Texture2D(chain_g.data_ptr(), img.shape[1], img.shape[0], nm, 0))
             nmaps += 1
     gb = tuple(torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(4))
-    res["gbuffer_producer_textured"] = entry(_stage_ms(lambda: ctx.gbuffer_from_materials(ipd, dmats, 0.055, ssao, out=gb)), 113,
+    res["gbuffer_producer_textured"] = entry(_stage_stats(lambda: ctx.gbuffer_from_materials(ipd, dmats, 0.055, ssao, out=gb)), 113,
                                              what=f"vqhip_gbuffer_from_materials: 3 interpolant planes + SSAO -> 4 float4 planes, {NM} materials, {nmaps} RGBA8 mip-chained maps (cache resident)")
-    res["gbuffer_producer_textureless"] = entry(_stage_ms(lambda: ctx.gbuffer_from_materials(ipd, dm0, 0.055, None, out=gb)), 112,
+    res["gbuffer_producer_textureless"] = entry(_stage_stats(lambda: ctx.gbuffer_from_materials(ipd, dm0, 0.055, None, out=gb)), 112,
                                                 what="the same call with texture-less materials: the streaming floor of the kernel")
     pf, extra = synth.per_frame(points=synth.point_lights(64, seed=0x6400), hdri_offset=0.3)
     pv = synth.per_view(W, H, max_env_lod=spec_mips)
     scene = capi.empty_image(H, W, F16, ctx.device)
-    ms = _stage_ms(lambda: ctx.forward_lighting_from_materials(ipd, dmats, pf, pv, ssao=ssao, out=scene, out_fmt=F16, extra_point=extra, env=env))
-    res["psmain_fused"] = entry(ms, 57, valu_frac_model=round((170 * 64 + 160) * px / ms / 1e9 / VALU_PEAK_TFLOPS, 4),
+    st_f = _stage_stats(lambda: ctx.forward_lighting_from_materials(ipd, dmats, pf, pv, ssao=ssao, out=scene, out_fmt=F16, extra_point=extra, env=env))
+    ms = st_f["ms"]
+    res["psmain_fused"] = entry(st_f, 57, valu_frac_model=round((170 * 64 + 160) * px / ms / 1e9 / VALU_PEAK_TFLOPS, 4),
                                 what="vqhip_forward_lighting_from_materials: PSMain as ONE kernel (producer + 64 point lights + IBL), 48 + 1 B in, 8 B out; VALU-bound like the headline's shade kernel")
     # the same draw with its other render targets bound (OUTPUT_ALBEDO + OUTPUT_MOTION_VECTORS, ForwardLighting.hlsl:382-389), and the Z pre-pass's normals
     svc, svp = (dev(tile(a_)) for a_ in synth.clip_positions(W, BAND))
     tg, _alb, _mv = ctx._psmain_targets(H, W, F16, abi.FMT_RG16F, svc, svp)
-    ms_mrt = _stage_ms(lambda: ctx.forward_lighting_from_materials(ipd, dmats, pf, pv, ssao=ssao, out=scene, out_fmt=F16, extra_point=extra, env=env, _targets=tg))
-    res["psmain_fused_mrt"] = entry(ms_mrt, 101, extra_ms_over_psmain_fused=round(ms_mrt - ms, 4),
+    st_m = _stage_stats(lambda: ctx.forward_lighting_from_materials(ipd, dmats, pf, pv, ssao=ssao, out=scene, out_fmt=F16, extra_point=extra, env=env, _targets=tg))
+    ms_mrt = st_m["ms"]
+    res["psmain_fused_mrt"] = entry(st_m, 101, extra_ms_over_psmain_fused=round(ms_mrt - ms, 4),
+                                    extra_ms_spread=[round(st_m["ms_min"] - st_f["ms_max"], 4), round(st_m["ms_max"] - st_f["ms_min"], 4)],
                                     what="vqhip_forward_lighting_from_materials_mrt: the same kernel also writing SV_TARGET1 (albedo, metalness: RGBA16F) and the motion "
                                          "vectors (RG16F, from two float4 clip-position planes): + 32 B in, + 12 B out per pixel")
     nrm = torch.empty((H, W), dtype=torch.int32, device="cuda")
-    res["scene_normals_prepass"] = entry(_stage_ms(lambda: ctx.scene_normals_from_materials(ipd, dmats, out=nrm)), 52,
+    res["scene_normals_prepass"] = entry(_stage_stats(lambda: ctx.scene_normals_from_materials(ipd, dmats, out=nrm)), 52,
                                          what="vqhip_scene_normals_from_materials (DepthPrePass.hlsl:PSMain): 3 interpolant planes -> Tex_SceneNormals R10G10B10A2, normal maps "
                                               "(+ diffuse alpha of masked materials) cache resident: 48 B in, 4 B out")
     del gb, ipd, ssao, keep, svc, svp, _alb, _mv, nrm
@@ -896,7 +957,7 @@ def widened_report(ctx, env, spec_mips):
     from vqengine_amd import scene as scene_mod
     eq = dev(synth.equirect(2048, 2048))
     sp = scene_mod.skydome_params(0.9, -0.2, 0.5, 60.0 * math.pi / 180.0, W, H)
-    res["skydome_all_sky"] = entry(_stage_ms(lambda: ctx.skydome(eq, sp, scene, F16)), 8, what="vqhip_skydome over a frame without geometry: 8 B/px written, equirect taps cache resident")
+    res["skydome_all_sky"] = entry(_stage_stats(lambda: ctx.skydome(eq, sp, scene, F16)), 8, what="vqhip_skydome over a frame without geometry: 8 B/px written, equirect taps cache resident")
     # ---- 8f.3: Radiance .hdr ingest, 2048^2 (256 run-length coded rows, repeated): host header parse + run expansion, device RGBE -> RGBA32F
     rgbe = synth.float_to_rgbe(synth.equirect(2048, 256)[..., :3])
     part = synth.hdr_file_bytes(rgbe)
@@ -916,14 +977,14 @@ def widened_report(ctx, env, spec_mips):
     src = torch.randint(0, 256, (ih, iw, 4), dtype=torch.uint8, device="cuda")
     up, fin = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda"), torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
     econ, rcon = capi.fsr_easu_con(iw, ih, W, H), capi.fsr_rcas_con(0.2)
-    res["fsr_easu_1440p_to_4k"] = entry(_stage_ms(lambda: ctx.fsr_easu(src, R8, W, H, con=econ, out=up)), round(4 + iw * ih * 4 / px, 2),
+    res["fsr_easu_1440p_to_4k"] = entry(_stage_stats(lambda: ctx.fsr_easu(src, R8, W, H, con=econ, out=up)), round(4 + iw * ih * 4 / px, 2),
                                         what="vqhip_fsr_easu RGBA8 -> RGBA8; VALU-bound: ~700 VALU per output pixel (profiles/r3i_conv_kernels.md addendum)")
-    res["fsr_rcas_4k"] = entry(_stage_ms(lambda: ctx.fsr_rcas(up, R8, con=rcon, out=fin)), 8, what="vqhip_fsr_rcas RGBA8 -> RGBA8; VALU-bound: ~300 VALU per pixel")
+    res["fsr_rcas_4k"] = entry(_stage_stats(lambda: ctx.fsr_rcas(up, R8, con=rcon, out=fin)), 8, what="vqhip_fsr_rcas RGBA8 -> RGBA8; VALU-bound: ~300 VALU per pixel")
     sc, depth, packed, _ = synth.ssr_surfaces(W, BAND)
     scd, dpd, nmd = dev(tile(sc.astype(np.float16))), dev(tile(depth)), dev(tile(packed.view(np.int32)))
     cb = synth.ssr_constants(W, H, spec_mips)
     rad = capi.empty_image(H, W, F16, ctx.device)
-    res["ssr_env_fallback_4k"] = entry(_stage_ms(lambda: ctx.ssr_environment_fallback(scd, F16, dpd, nmd, abi.FMT_R10G10B10A2_UNORM, cb, env, F16, out=rad)), 24,
+    res["ssr_env_fallback_4k"] = entry(_stage_stats(lambda: ctx.ssr_environment_fallback(scd, F16, dpd, nmd, abi.FMT_R10G10B10A2_UNORM, cb, env, F16, out=rad)), 24,
                                        what="vqhip_ssr_environment_fallback on white-noise surfaces (72 % of the pixels take the fallback): 8 + 4 + 4 B in, 8 B out; "
                                             "fractional-LOD seamless cube fetch + LUT per pixel, cache resident")
     return res
@@ -942,7 +1003,7 @@ def ibl_load_report(t):
     out["workload"] = "BASELINE cfg4: 2048^2 RGBA32F equirect -> 12-level min-filter chain, diffuse irradiance 6x64^2 at step 0.010 (99 382 taps/texel) + blur, 7-mip GGX specular 128^2, BRDF LUT 1024^2 x 2048"
     out["note"] = ("mip_chain / prefilter (diffuse + face blur + specular) / brdf_lut are the product calls as build_ibl() issues them, first use of each kernel "
                    "(code load and cold clocks included: total_ms); conv_diffuse / conv_specular / brdf_lut_warm / mip_chain_warm / prefilter_warm are the stage on its "
-                   "own in back-to-back calls after a ~0.1 s spin-up, like the headline and every other per-stage figure (warm_total_ms = mip chain + prefilter + "
+                   "own in back-to-back calls after a >= 0.25 s spin-up (median of 7 batches, *_ms_spread = [min, max]), like every other per-stage figure (warm_total_ms = mip chain + prefilter + "
                    "LUT of those); *_single_call_ms = ONE call without a spin-up (what these keys meant in rounds 1-3). The convolutions run in the reference's "
                    "summation order (wave-parallel taps parked in LDS, added in order: profiles/r4a_conv_ordered.md); the diffuse one is bound by L1 tag lookups")
     return out

@@ -498,7 +498,9 @@ VQHIP_API int vqhip_forward_lighting_from_materials(vqhip_ctx* ctx, void* stream
         const VQ_PointLight* extraPoint, int numExtraPoint,
         const vqhip_envmap* env, const vqhip_shadowmaps* sm,
         void* out, int out_row_pitch_px, vqhip_format outFmt);
-/* the same with the extra render targets of the draw (vqhip_psmain_targets above); bit-identical to vqhip_gbuffer_from_materials + vqhip_forward_lighting_mrt */
+/* the same with the extra render targets of the draw (vqhip_psmain_targets above); bit-identical to vqhip_gbuffer_from_materials + vqhip_forward_lighting_mrt
+ * on every pixel a fragment covers. Pixels WITHOUT geometry and alpha-mask discards are not written in albedo_metallic / motion_vectors — they keep the
+ * values the caller cleared the targets to, as under the rasteriser (PSMain never runs there; the G-buffer form above cannot know and writes them all). */
 VQHIP_API int vqhip_forward_lighting_from_materials_mrt(vqhip_ctx* ctx, void* stream,
         const vqhip_interpolants* in, const vqhip_material* materials, int numMaterials, const vqhip_ssao* ssao,
         const VQ_PerFrameData* perFrame, const VQ_PerViewLightingData* perView,

@@ -119,14 +119,28 @@ def test_psmain_one_kernel_with_targets_equals_the_two_calls(ctx):
             setattr(dm[k], slot, abi.Texture2D(chain.data_ptr(), img.shape[1], img.shape[0], n, 0))
     env = ref_cases.dev_env(i["env"], keep)
     cur, prev, ssao = dev(i["sv_curr"]), dev(i["sv_prev"]), dev(i["ssao"])
+    nmat = len(i["datas"])
     for afmt, mfmt in ((abi.FMT_RGBA16F, abi.FMT_RG16F), (abi.FMT_RGBA32F, abi.FMT_RG32F)):
-        one = ctx.forward_lighting_from_materials_mrt([dev(p) for p in i["ip"]], dm, i["pf"], i["pv"], albedo_fmt=afmt, motion_fmt=mfmt, sv_curr=cur, sv_prev=prev,
-                                                      ssao=ssao, env=env)
-        gb = ctx.gbuffer_from_materials([dev(p) for p in i["ip"]], dm, i["pf"].fAmbientLightingFactor, ssao)
-        two = ctx.forward_lighting_mrt(gb, i["pf"], i["pv"], albedo_fmt=afmt, motion_fmt=mfmt, sv_curr=cur, sv_prev=prev, env=env)
-        for a, b, what in zip(one, two, ("scene colour", "albedo / metalness", "motion vectors")):
-            assert_bits(a, b.cpu().numpy(), f"one kernel vs two calls: {what}")
-        assert_bits(one[1], gb[2].cpu().numpy().astype(np.float16) if afmt == abi.FMT_RGBA16F else gb[2].cpu().numpy(), "SV_TARGET1 is the G-buffer's gb2")
+        for hole in (False, True):
+            ip = [p.copy() for p in i["ip"]]
+            if hole:                                         # a block without geometry: coverage index -1 (what a rasteriser leaves where nothing is drawn)
+                ip[2][H // 4:H // 2, W // 4:W // 2, 3] = np.int32(-1).view(np.float32)
+            ipd = [dev(p) for p in ip]
+            one = ctx.forward_lighting_from_materials_mrt(ipd, dm, i["pf"], i["pv"], albedo_fmt=afmt, motion_fmt=mfmt, sv_curr=cur, sv_prev=prev, ssao=ssao, env=env)
+            gb = ctx.gbuffer_from_materials([dev(p) for p in ip], dm, i["pf"].fAmbientLightingFactor, ssao)
+            two = ctx.forward_lighting_mrt(gb, i["pf"], i["pv"], albedo_fmt=afmt, motion_fmt=mfmt, sv_curr=cur, sv_prev=prev, env=env)
+            torch.cuda.synchronize()
+            idx = ipd[2][..., 3].contiguous().view(torch.int32).cpu().numpy()        # after the call: alpha-mask discards are marked -1 too
+            cov = (idx >= 0) & (idx < nmat)
+            assert hole == bool((~cov[H // 4:H // 2, W // 4:W // 2]).all()) and cov.mean() > 0.5
+            assert_bits(one[0], two[0].cpu().numpy(), "one kernel vs two calls: scene colour (every pixel, covered or not)")
+            for a, b, what in zip(one[1:], two[1:], ("albedo / metalness", "motion vectors")):
+                a, b = a.cpu().numpy(), b.cpu().numpy()
+                assert_bits(np.ascontiguousarray(a[cov]), np.ascontiguousarray(b[cov]), f"one kernel vs two calls, covered pixels: {what}")
+                assert not a[~cov].view(np.uint8).any(), f"{what}: a pixel without a fragment must keep the target's clear value (PSMain never runs there)"
+            g2 = gb[2].cpu().numpy()
+            assert_bits(np.ascontiguousarray(one[1].cpu().numpy()[cov]), np.ascontiguousarray((g2.astype(np.float16) if afmt == abi.FMT_RGBA16F else g2)[cov]),
+                        "SV_TARGET1 is the G-buffer's gb2")
 
 
 def test_argument_checks(ctx):

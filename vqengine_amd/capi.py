@@ -306,13 +306,13 @@ class Context:
         t = abi.PsmainTargets()
         albedo = motion = None
         if albedo_fmt is not None:
-            albedo = empty_image(h, w, albedo_fmt, self.device)
+            albedo = empty_image(h, w, albedo_fmt, self.device).zero_()          # the clear value: uncovered pixels of the one-kernel PSMain keep it
             t.albedo_metallic, t.albedo_fmt, t.albedo_pitch_px = albedo.data_ptr(), albedo_fmt, w
         if motion_fmt is not None:
             if sv_curr is None or sv_prev is None:
                 raise ValueError("motion vectors need sv_curr and sv_prev (float32 cuda [H,W,4])")
             _check_img(sv_curr, FMT_RGBA32F, "sv_curr", (h, w)); _check_img(sv_prev, FMT_RGBA32F, "sv_prev", (h, w))
-            motion = empty_image(h, w, motion_fmt, self.device)
+            motion = empty_image(h, w, motion_fmt, self.device).zero_()
             t.motion_vectors, t.motion_fmt, t.motion_pitch_px = motion.data_ptr(), motion_fmt, w
             t.svPositionCurr, t.svPositionPrev, t.sv_pitch_px = sv_curr.data_ptr(), sv_prev.data_ptr(), w
         return t, albedo, motion
@@ -555,7 +555,7 @@ class Context:
         h, w = scene_color.shape[0], scene_color.shape[1]
         assert depth.dtype == torch.float32 and tuple(depth.shape) == (h, w) and depth.is_contiguous()
         if normal_fmt == abi.FMT_R10G10B10A2_UNORM:
-            assert normals.dtype in (torch.int32, torch.uint32) and tuple(normals.shape) == (h, w) and normals.is_contiguous()
+            assert normals.dtype == torch.int32 and tuple(normals.shape) == (h, w) and normals.is_contiguous()
         else:
             _check_img(normals, normal_fmt, "normals", (h, w))
         out_fmt = FMT_RGBA16F if out_fmt is None else out_fmt

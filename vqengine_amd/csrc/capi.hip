@@ -41,7 +41,7 @@ struct vqhip_ctx {
     // that has been read from MORE THAN ONE stream (one event cannot cover readers on several streams) is replaced after a device-wide wait.
     static constexpr int kLuts = 4;
     struct TonemapLut { void* table = nullptr; VQ_TonemapperParams key{}; int outFmt = -1; bool valid = false;
-                        hipEvent_t built = nullptr, lastUse = nullptr; hipStream_t lastStream = nullptr; bool used = false, multiStream = false;
+                        hipEvent_t built = nullptr, lastUse = nullptr; hipStream_t lastStream = nullptr; bool used = false, multiStream = false, everBuilt = false;
                         uint64_t lastUseTick = 0; } lut[kLuts];
     uint64_t lutTick = 0;
     // one thread at a time per context: entry points detect a second thread inside the same context and refuse it
@@ -126,15 +126,19 @@ int acquireTonemapLut(vqhip_ctx* ctx, hipStream_t st, const VQ_TonemapperParams&
         else if (ctx->lut[victim].valid && L.lastUseTick < ctx->lut[victim].lastUseTick) victim = i;
     }
     auto& L = ctx->lut[victim];
-    if (L.valid && L.used) {
+    // Whatever state an earlier failure left the slot in (valid or not), the rebuild must queue behind every kernel that may still read the table and
+    // behind the last build that wrote it: `used` / `lastUse` / `built` survive an invalidation and are only reset once the NEW build is enqueued.
+    if (L.used) {
         if (L.multiStream) HIP_TRY(ctx, hipDeviceSynchronize());            // readers on several streams: one event does not cover them (documented in vqhip.h)
         else HIP_TRY(ctx, hipStreamWaitEvent(st, L.lastUse, 0));              // the rebuild queues behind the last kernel that read the table
+    } else if (L.everBuilt) {
+        HIP_TRY(ctx, hipStreamWaitEvent(st, L.built, 0));                     // built (possibly on another stream) and never read: write after write
     }
     L.valid = false;
     hipError_t e = launch_tonemap_lut_build(st, L.table, p, outFmt);
     if (e != hipSuccess) return failHip(ctx, e, "tonemap table build launch");
     HIP_TRY(ctx, hipEventRecord(L.built, st));
-    L.key = p; L.outFmt = outFmt; L.valid = true; L.used = false; L.multiStream = false; L.lastStream = nullptr; L.lastUseTick = ++ctx->lutTick;
+    L.key = p; L.outFmt = outFmt; L.valid = true; L.everBuilt = true; L.used = false; L.multiStream = false; L.lastStream = nullptr; L.lastUseTick = ++ctx->lutTick;
     *slotOut = victim;
     return VQHIP_OK;
 }

@@ -158,12 +158,13 @@ struct MaterialSampler {
 // PREPASS: the Z pre-pass's pixel shader instead (DepthPrePass.hlsl:PSMain :153-171): only g1 = float4((SurfaceN + 1) * 0.5, 1) is produced (0 = not covered);
 // the diffuse map is fetched for the alpha test of the "_AlphaMasked" permutation alone, the normal map WITHOUT normalMapMipBias (:164 is Sample), the
 // coverage plane is left as it is (the lighting pass repeats the discard itself, ForwardLighting.hlsl:237-240).
-struct Record { float4 g0, g1, g2, g3; };
+struct Record { float4 g0, g1, g2, g3; bool covered; };    // covered: a fragment of some material survived to the end of PSMain at this pixel
 template <bool PREPASS = false>
 VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane) {
     const GbufConstants* __restrict__ gc = a.gc;
     Record rec;
     rec.g0 = rec.g1 = rec.g2 = rec.g3 = make_float4(0, 0, 0, 0);
+    rec.covered = false;
     const uint32_t o = (__umul24(y, a.pitch) + (uint32_t)x) << 4;      // 32-bit byte offsets: planes are < 4 GB (checked by the C ABI)
 
     float4 i0 = make_float4(0, 0, 0, 0), i1 = i0, i2 = i0;
@@ -272,6 +273,7 @@ VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane
             }
             if (PREPASS) {                                                                // DepthPrePass.hlsl:168-169 (the rest of this body is dead code here)
                 rec.g1 = make_float4((SurfN.x + 1.0f) * 0.5f, (SurfN.y + 1.0f) * 0.5f, (SurfN.z + 1.0f) * 0.5f, 1.0f);
+                rec.covered = true;
                 todo = false;
                 continue;
             }
@@ -279,6 +281,7 @@ VQD Record produce_record(const GbufArgs& a, int x, int y, bool inside, int lane
             rec.g1 = make_float4(SurfN.x, SurfN.y, SurfN.z, roughness);
             rec.g2 = make_float4(diffuseColor.x, diffuseColor.y, diffuseColor.z, metalness);
             rec.g3 = make_float4(emissiveColor.x, emissiveColor.y, emissiveColor.z, m.emissiveIntensity);   // :251
+            rec.covered = true;
             todo = false;
         }
     }
@@ -328,7 +331,9 @@ __global__ __launch_bounds__(256, WAVES) void k_forward_from_materials(GbufArgs 
     const bool inside = (x < a.width) & (y < a.height);
     const Record r = produce_record<false>(a, x, y, inside, lane);
     if (!inside) return;
-    write_extra_targets(mrt, x, y, r.g2);
+    // SV_TARGET1 / the motion vectors exist only where a fragment reaches :382-389: pixels without geometry and alpha-mask discards keep the targets' clear
+    // values, as under the rasteriser (the colour target is still written for them: the all-zero record shaded, like the two calls do)
+    if (r.covered) write_extra_targets(mrt, x, y, r.g2);
     const float4 c = shade_pixel<HAS_ENV, HAS_CASTERS, AR>(r.g0, r.g1, r.g2, r.g3, fc);
     store_px<OUTFMT>(out, (size_t)y * outPitch + x, c);
 }
