@@ -104,6 +104,10 @@ def test_visualize_reads_the_targets_the_draw_modes_bind(ctx):
     nrm_o = O.scene_normals_from_materials(ip, hmats)
     gb_o = O.gbuffer_from_materials([p.copy() for p in ip], hmats, pf.fAmbientLightingFactor, None)
     alb_o, mv_o = O.psmain_extra_targets(gb_o, cur, prev)
+    idx = ipd[2][..., 3].contiguous().view(torch.int32).cpu().numpy()
+    holes = ~((idx >= 0) & (idx < NM))                       # no fragment there: the one-kernel PSMain leaves the targets at their clear value (0), like the rasteriser
+    alb_o[holes] = 0
+    mv_o[holes] = 0
     for src, src_o, fmt, modes in ((nrm, nrm_o, abi.FMT_R10G10B10A2_UNORM, ((2, 0, 1.0), (2, 1, 1.0))), (mv, mv_o, abi.FMT_RG16F, ((8, 0, 40.0),)),
                                    (alb, alb_o, abi.FMT_RGBA16F, ((6, 0, 1.0), (4, 0, 1.0)))):
         for mode, unpack, strength in modes:
