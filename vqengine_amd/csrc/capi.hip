@@ -532,6 +532,8 @@ int vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value) {
     if (k == "psmain_waves") return num(&o.psmainWaves, { 0, 4, 5, 6 });
     if (k == "blur_x_wgs") return num(&o.blurXWgs, {});
     if (k == "blur_y_wgs") return num(&o.blurYWgs, {});
+    if (k == "blur_y_form") { if (v == "roll") { o.blurYForm = 0; return VQHIP_OK; } return pick(&o.blurYForm, { "window" }); }
+    if (k == "blur_y_rows") return num(&o.blurYRows, {});
     if (k == "lut_form") return pick(&o.lutForm, { "general" });
     if (k == "diffuse_form") { if (v == "records") { o.diffuseForm = 0; return VQHIP_OK; } return pick(&o.diffuseForm, { "texels", "general" }); }
     if (k == "diffuse_seq_form") { if (v == "ordered") { o.diffuseSeqForm = 0; return VQHIP_OK; } return pick(&o.diffuseSeqForm, { "lane" }); }

@@ -385,6 +385,68 @@ __global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restri
     }
 }
 
+// ---- Y blur + tonemap through the table, ROLLING window (round 5) -----------------------------------------------------------------------
+// The same arithmetic and the same table as k_blur_y_tonemap_lut, another schedule. A wave owns a 64-column strip of S output rows and walks down
+// it one row at a time: the 21 rows the filter reaches live in a 32-row register ring in the STORAGE format (two dwords per row: the fp16 -> fp32
+// conversion is the operand conversion of v_fma_mix_f32, exact, so there is no convert instruction and the ring costs 64 VGPRs), and the 11 other
+// slots of the ring are loads IN FLIGHT: at step j the wave issues the load of row j + 21 into the slot row j - 11 has just left, then runs the
+// 63 mads of row j. Loads and mads of ONE wave overlap for the whole strip — the 36-row-window form loaded, waited, computed, stored, in phases that
+// all 4 096 resident waves went through together — and an input row is read (S + 20) / S times instead of 36 / 16 = 2.25 times.
+// Ring slot of input row (y0 - 10 + i) is i & 31; the step loop is unrolled 32-fold so that every ring index is a compile-time register.
+// acc = fma((float)half(lo / hi 16 bits of h), w, acc): ONE v_fma_mix_f32 — the fp16 operand is converted exactly inside the instruction, the product and the
+// sum are rounded once to fp32 like v_fma_f32 of the converted value (same MODE denormal fields as v_cvt_f32_f16 + v_fma_f32: identical bits). Written as asm
+// because the compiler, left alone, converts every ring row once and keeps an fp32 ring (96 VGPRs + 3 converts per row instead of 64 + 0).
+VQD float fma_mix_lo(uint32_t h, float w, float acc) { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h), "s"(w)); return acc; }
+VQD float fma_mix_hi(uint32_t h, float w, float acc) { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h), "s"(w)); return acc; }
+__global__ __launch_bounds__(512, 2) void k_blur_y_tonemap_roll(const void* __restrict__ in, void* __restrict__ out, const void* __restrict__ haloTop,
+                                                               const void* __restrict__ haloBottom, int haloRows, int W, int H,
+                                                               const void* __restrict__ table, int stripsX, int nStrips, int S) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = blockIdx.x * 8 + wv;
+    const bool valid = strip < nStrips;                     // wave-uniform; an idle wave still helps to fill the table and meets the barrier
+    const int sy = strip / stripsX, sx = strip - sy * stripsX;
+    const int x = sx * 64 + (threadIdx.x & 63);
+    const int xc = min(x, W - 1);
+    const int y0 = sy * S;
+    const int rows = min(S, H - y0);                        // output rows of this strip (> 0 when valid)
+    // wave-uniform row source of input row r: image / halo / clamp (GaussianBlur.hlsl:178); never outside the halo buffers
+    auto load_row = [&](int r) -> uint2 {
+        const uint2* rowp;
+        if (r < 0 && haloTop)              rowp = (const uint2*)haloTop + (size_t)(haloRows + max(r, -haloRows)) * W;
+        else if (r > H - 1 && haloBottom)  rowp = (const uint2*)haloBottom + (size_t)min(r - H, haloRows - 1) * W;
+        else                               rowp = (const uint2*)in + (size_t)min(max(r, 0), H - 1) * W;
+        return rowp[xc];
+    };
+    uint2 ring[32];
+    if (valid) {
+        #pragma unroll
+        for (int i = 0; i < 31; ++i) ring[i] = (i <= rows + 19) ? load_row(y0 - R + i) : make_uint2(0, 0);     // 31 loads in flight while the table arrives
+    }
+    for (int i = threadIdx.x * 16; i < 65536; i += 512 * 16) *(uint4*)(lds + i) = *(const uint4*)((const unsigned char*)table + i);
+    __syncthreads();
+    if (!valid) return;
+    uint32_t* __restrict__ dst = (uint32_t*)out + (size_t)y0 * W + x;
+    for (int jb = 0; jb < rows; jb += 32) {
+        #pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int j = jb + u;
+            if (j >= rows) return;                          // wave-uniform
+            if (j + 31 <= rows + 19) ring[(u + 31) & 31] = load_row(y0 - R + j + 31);      // row j + 21 into the slot of row j - 11
+            float ax = 0.0f, ay = 0.0f, az = 0.0f;
+            #pragma unroll
+            for (int it = 0; it < 21; ++it) {               // kernelIt = 0..20: the HLSL's order
+                const int off = it - R;
+                const float w = kW[off < 0 ? -off : off];
+                const uint2 v = ring[(u + it) & 31];
+                ax = fma_mix_lo(v.x, w, ax); ay = fma_mix_hi(v.x, w, ay); az = fma_mix_lo(v.y, w, az);
+            }
+            const uint32_t hx = float_to_half_bits(ax), hy = float_to_half_bits(ay), hz = float_to_half_bits(az);   // == the BlurOutput store
+            if (x < W) dst[(size_t)j * W] = (uint32_t)lds[hx] | ((uint32_t)lds[hy] << 8) | ((uint32_t)lds[hz] << 16) | (255u << 24);   // alpha 1 -> 255
+        }
+    }
+}
+
 
 } // namespace
 
@@ -475,6 +537,13 @@ hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
                                  const VQ_TonemapperParams& p, int fmt, int outFmt, const void* lutTable, const Options& opt) {
     if (lutTable && blur_y_tonemap_uses_lut(p, fmt, outFmt, (size_t)W * H)) {
+        if (opt.blurYForm != 1) {                             // rolling window (default); "blur_y_form" = "window" selects the 36-row-window kernel below
+            int S = opt.blurYRows > 0 ? opt.blurYRows : 64;
+            if (S < 12) S = 12;
+            const int stripsX = (W + 63) / 64, stripsY = (H + S - 1) / S, nStrips = stripsX * stripsY;
+            hipLaunchKernelGGL(k_blur_y_tonemap_roll, dim3((nStrips + 7) / 8), dim3(512), 0, s, in, out, haloTop, haloBottom, haloRows, W, H, lutTable, stripsX, nStrips, S);
+            return hipGetLastError();
+        }
         const int tilesX = (W + 63) / 64, tilesY = (H + 127) / 128, nTiles = tilesX * tilesY;
         int wgs = 512;                                        // two 64 KB tables per CU
         if (opt.blurYWgs > 0) wgs = opt.blurYWgs;             // tuning knob, like "blur_x_wgs"

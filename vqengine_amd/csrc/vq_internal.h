@@ -24,6 +24,8 @@ struct Options {
     int psmainWaves = 0;        // "psmain_waves"      : 4 | 5 | 6 waves per SIMD of the fused PSMain kernel
     int blurXWgs = 0;           // "blur_x_wgs"        : n > 0 = n persistent workgroups (k_blur_x4p)
     int blurYWgs = 0;           // "blur_y_wgs"        : workgroups of k_blur_y_tonemap_lut
+    int blurYForm = 0;          // "blur_y_form"       : 1 "window" = k_blur_y_tonemap_lut (36-row register window; round 2-4's default); default: k_blur_y_tonemap_roll
+    int blurYRows = 0;          // "blur_y_rows"       : output rows per wave-strip of k_blur_y_tonemap_roll (default 64)
     int lutForm = 0;            // "lut_form"          : 1 "general" (every range test left in)
     int diffuseForm = 0;        // "diffuse_form"      : 1 "texels", 2 "general" (default: footprint records)
     int diffuseSeqForm = 0;     // "diffuse_seq_form"  : 1 "lane" (default: k_conv_diffuse_ordered)
