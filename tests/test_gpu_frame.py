@@ -108,6 +108,10 @@ def test_ssr_frame_chain_matches_oracle(ctx):
     comp_g = ctx.composite_reflections(rad_g, col_g, F16, dev(bv))
     sdr_g = ctx.tonemap(ctx.gaussian_blur(comp_g, F16), F16, R8)
     torch.cuda.synchronize()
+    idx = ipd[2][..., 3].contiguous().view(torch.int32).cpu().numpy()
+    holes = ~((idx >= 0) & (idx < NM))                       # pixels no fragment reached: the one-kernel PSMain leaves SV_TARGET1 / the motion vectors at their clear value 0,
+    alb_o[holes] = 0                                         # like the rasteriser (the G-buffer form of the oracle chain writes every pixel)
+    mv_o[holes] = 0
     for name, g, o in (("scene normals", nrm_g.cpu().numpy().view(np.uint32), nrm_o), ("scene colour", lit_g, col_o), ("albedo / metalness", alb_g, alb_o), ("motion vectors", mv_g, mv_o),
                        ("reflection radiance", rad_g, rad_o), ("composite", comp_g, comp_o), ("sdr", sdr_g, sdr_o)):
         n_bad, idx = O.bits_equal(g.cpu().numpy() if hasattr(g, "cpu") else g, o)
