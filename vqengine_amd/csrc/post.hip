@@ -423,8 +423,10 @@ __global__ __launch_bounds__(512, 2) void k_blur_y_tonemap_roll(const void* __re
         const int rowIn = min(max(r, 0), H - 1), rowTop = haloRows + max(r, -haloRows), rowBot = min(r - H, haloRows - 1);
         const int row = rowIn + (mT & (rowTop - rowIn)) + (mB & (rowBot - rowIn));
         const uint64_t base = aIn + ((uint64_t)(int64_t)mT & dTop) + ((uint64_t)(int64_t)mB & dBot);
-        typedef const uint2 __attribute__((address_space(1))) * gptr;             // an address built from integers is a FLAT pointer unless it says otherwise
-        return *(gptr)(base + (((uint64_t)row * (uint64_t)W + (uint64_t)xc) << 3));
+        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+        typedef const u2v __attribute__((address_space(1))) * gptr;               // an address built from integers is a FLAT pointer unless it says otherwise
+        const u2v v = *(gptr)(base + (((uint64_t)row * (uint64_t)W + (uint64_t)xc) << 3));
+        return make_uint2(v.x, v.y);
     };
     // one memory round trip before the first row: the 31 ring loads and the wave's share of the table go out together, the table is parked in LDS, barrier
     uint2 ring[32];
