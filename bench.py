@@ -411,6 +411,19 @@ class Pipeline:
         ctx.forward_lighting(self.gb, self.pf, self.pv, out=self.scene[b], out_fmt=F16, extra_point=self.extra, env=self.env)
         if ev and "shade" in ev:
             rec("shade")
+        if self.args.post == "chain":
+            # X, Y and the tonemapper in ONE kernel (k_post_chain): neither BlurIntermediate nor BlurOutput exists. Row tiles exchange 10 rows of SCENE COLOUR
+            # right behind the shade kernel (the X pass is horizontal: the kernel filters the neighbour's rows like its own)
+            if ev and "x" in ev:
+                rec("x")
+            if world > 1:
+                self.comms.halo.exchange_blur_halos(self.scene[b], F16, self.halo_top, self.halo_bottom, stream=C.c_void_p(s_main.cuda_stream))
+            if ev and "halo" in ev:
+                rec("halo")
+            ctx.post_process_tile(self.scene[b], F16, R8, out=self.sdr[b], halo_top=self.halo_top, halo_bottom=self.halo_bottom)
+            if ev and "post" in ev:
+                rec("post")
+            return self._composite(b, ev, rec, s_main, s_comp, overlap, world)
         ctx.gaussian_blur_x(self.scene[b], F16, out=self.xblur)
         if ev and "x" in ev:
             rec("x")
@@ -428,6 +441,9 @@ class Pipeline:
             ctx.tonemap(self.yblur, F16, R8, out=self.sdr[b])
         if ev and "post" in ev:
             rec("post")
+        self._composite(b, ev, rec, s_main, s_comp, overlap, world)
+
+    def _composite(self, b, ev, rec, s_main, s_comp, overlap, world):
         if world > 1:
             if overlap:
                 self.e_post[b].record(s_main)
@@ -548,7 +564,7 @@ def main():
     ap.add_argument("--config", choices=["cfg3", "cfg5"], default="cfg3", help="the HEADLINE workload (the other BASELINE configs are reported as extra objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip cfg5_strong / cfg2 / ibl_load / coherent_scene / tile_curve")
-    ap.add_argument("--post", choices=["fused", "split"], default="fused",
+    ap.add_argument("--post", choices=["chain", "fused", "split"], default="fused",
                     help="post chain after the X blur: Y blur and tonemapper as two dispatches (split) or one kernel (fused); identical bits")
     ap.add_argument("--composite", choices=["root", "all"], default="root",
                     help="final composite of the RGBA8 tiles: on rank 0 only (the presenting GPU; it receives over its N-1 direct xGMI links) or on every rank")
@@ -610,6 +626,11 @@ def main():
     #     than after the timed region: after ~0.4 s of sustained shading a burst of X passes runs 2.5-3x slower — the chip's power limiter,
     #     profiles/r2k_frame_loop.md — which says nothing about the kernel.)
     iso = None
+    if args.post == "chain":
+        st = _stage_stats(lambda: ctx.post_process_tile(pipe.scene[0], F16, R8, out=pipe.sdr[0], halo_top=pipe.halo_top, halo_bottom=pipe.halo_bottom), spin_s=0.01)
+        iso = {"post_chain": st["ms"] * 1e-3, "post_chain_spread": [round(st["ms_min"], 4), round(st["ms_max"], 4)]}
+        pipe.drain()
+        d.barrier()
     if args.post == "fused":
         iso = {}
         for name, fn in (("blur_x", lambda: ctx.gaussian_blur_x(pipe.scene[0], F16, out=pipe.xblur)),
@@ -750,7 +771,8 @@ def main():
                                                        f"{'rank 0' if root == 0 else 'every rank'} through the C ABI"),
                        "name": args.config, "width": W, "frame_height": frame_h, "tile_rows": rows, "lights": L, "parallelism": f"rows{world}",
                        "composite_overlap": overlap, "untimed_spinup_steps": SPINUP_STEPS, "fresnel_pow": args.fresnel_pow,
-                       "post": "blur X, then blur Y + tonemap in one kernel (identical bits to three dispatches)" if args.post == "fused" else "blur X, blur Y, tonemap"},
+                       "post": {"chain": "blur X, blur Y and the tonemapper in ONE kernel (identical bits to three dispatches)",
+                                "fused": "blur X, then blur Y + tonemap in one kernel (identical bits to three dispatches)", "split": "blur X, blur Y, tonemap"}[args.post]},
             "roofline": {"bound": "hbm", "kernel": f"k_forward_lighting<{'env' if cfg['env'] else 'noenv'},nocasters,RGBA16F>", "achieved": round(ach, 2),
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 5),
                          "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "traffic_unit": "bytes/launch",
@@ -764,6 +786,15 @@ def main():
             "stages": {"shade_Mpix_s": round(px_tile / t_shade / 1e6, 1), "shade_ms": round(t_shade * 1e3, 4),
                        **({"blur_xy_ms": round(t_blur * 1e3, 4), "blur_xy_GBps": round(px_tile * 32 / t_blur / 1e9, 1),
                            "tonemap_ms": round(t_tm * 1e3, 4), "tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1)} if args.post == "split" else
+                          {"post_chain_ms": round(t_chain * 1e3, 4), "post_chain_bytes_per_px": 12, "post_chain_GBps": round(px_tile * 12 / t_chain / 1e9, 1),
+                           "post_chain_frac_of_hbm_peak": round(px_tile * 12 / t_chain / 1e9 / HBM_PEAK_GBPS, 4),
+                           "post_chain_frac_at_28_B_per_px": round(px_tile * 28 / t_chain / 1e9 / HBM_PEAK_GBPS, 4),
+                           "post_chain_note": "ONE kernel (k_post_chain: blur X, blur Y, tonemapper; 8 B read + 4 B written per pixel, no intermediate image), from the end of the shade "
+                                              "kernel to its end inside the frame loop. The kernel is bound by VALU issue (126 mads + 6 conversions + 3 table lookups per pixel), not by "
+                                              "HBM: *_frac_at_28_B_per_px prices the same time at the 28 B/px the two-kernel chain of rounds 1-4 moved, for comparison with their figures",
+                           "isolated": {"post_chain_ms": round(iso["post_chain"] * 1e3, 4), "post_chain_ms_spread": iso["post_chain_spread"],
+                                        "post_chain_frac_of_hbm_peak": round(px_tile * 12 / iso["post_chain"] / 1e9 / HBM_PEAK_GBPS, 4),
+                                        "note": "median of 7 batches of back-to-back launches of the one kernel, after the spin-up and before the warm-up steps"}} if args.post == "chain" else
                           {"blur_x_ms": round(t_blur * 1e3, 4), "blur_x_GBps": round(px_tile * 16 / t_blur / 1e9, 1),
                            "blur_y_tonemap_ms": round(t_tm * 1e3, 4), "blur_y_tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1),
                            "post_chain_ms": round(t_chain * 1e3, 4), "post_chain_GBps": round(px_tile * 28 / t_chain / 1e9, 1),

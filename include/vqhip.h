@@ -329,14 +329,17 @@ VQHIP_API int  vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode);
 /* Tuning / A-B options of a context, read by the launchers at call time (never from the process environment: getenv racing a host setenv is
  * undefined behaviour, and VQEngine records on many threads, SceneRendering.cpp:563-706). value NULL, "" or "default" restores the default. Every
  * form selected here gives the bits of the default form (tests/test_gpu_conv_forms.py, tests/test_gpu_round3.py); unknown keys / values: VQHIP_ERR_INVALID_ARG.
- *   shade_wg 64|128|256 · psmain_waves 4|5|6 · blur_x_wgs n · blur_y_wgs n · lut_form general · diffuse_form records|texels|general ·
- *   diffuse_seq_form ordered|lane
- * (the non-default values are the general / fallback forms of the same kernels; the measured-and-rejected kernel forms of rounds 2-3 — the one-kernel
- * post chain, the compact tonemap tables, the per-sample LUT and per-mip specular kernels — were removed in round 4: docs/HISTORY.md). */
+ *   shade_wg 64|128|256 · psmain_waves 4|5|6 · blur_y_wgs n · post_form two|chain · post_strips n · lut_form general ·
+ *   diffuse_form records|texels|general · diffuse_seq_form ordered|lane
+ * (the non-default values are the general / fallback forms of the same kernels; the measured-and-rejected kernel forms of rounds 2-5 — the compact tonemap
+ * tables, the per-sample LUT and per-mip specular kernels, the persistent X pass, the rolling-ring Y pass — are not in the library: docs/HISTORY.md).
+ * post_form: "two" = vqhip_post_process[_tile] always runs blur X, then blur Y + tonemap (two kernels); "chain" = the one-kernel chain whatever the frame size
+ * (default: the chain for RGBA16F -> RGBA8 frames of >= 2^20 pixels and a per-channel display curve, the two kernels otherwise). */
 VQHIP_API int  vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value);
 typedef enum vqhip_arithmetic { VQHIP_ARITH_LITERAL = 0, VQHIP_ARITH_DXC = 1 } vqhip_arithmetic;
 VQHIP_API int  vqhip_set_arithmetic(vqhip_ctx* ctx, vqhip_arithmetic mode);
-#define VQHIP_ABI_VERSION 2   /* 2 (round 4): + vqhip_set_arithmetic, vqhip_set_option, vqhip_ssr_environment_fallback, VQHIP_FMT_R10G10B10A2_UNORM; conv order default SEQUENTIAL;
+#define VQHIP_ABI_VERSION 3   /* 3 (round 5): + vqhip_post_process_tile; options blur_x_wgs / blur_y_form / blur_y_rows removed, post_form / post_strips added.
+                               * 2 (round 4): + vqhip_set_arithmetic, vqhip_set_option, vqhip_ssr_environment_fallback, VQHIP_FMT_R10G10B10A2_UNORM; conv order default SEQUENTIAL;
                                * later in round 4, additions only: vqhip_forward_lighting_mrt, vqhip_forward_lighting_from_materials_mrt, vqhip_scene_normals_from_materials,
                                * vqhip_composite_reflections; vqhip_visualize reads R10G10B10A2 / RG16F / RG32F inputs */
 
@@ -420,10 +423,19 @@ VQHIP_API int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* 
 /* Replaces the blur + tonemapper part of VQRenderer::RenderPostProcess as ONE call (SceneRendering.cpp:2579-2656: "BlurCS" { CSMain_X, CSMain_Y }
  * when bEnableGaussianBlur, then "TonemapperCS"): sceneColor -> out. BlurIntermediate lives in a scratch buffer of the context; for the
  * reference's formats (RGBA16F scene colour, RGBA8 SDR target) and a display curve that does not mix channels (sRGB, LINEAR, ST2084 on Rec.2020
- * content) the Y pass and the tonemapper are one kernel and BlurOutput never exists. Identical bits to vqhip_gaussian_blur_x -> _y ->
+ * content) the Y pass and the tonemapper are one kernel and BlurOutput never exists; for frames of >= 2^20 pixels the X pass joins them (k_post_chain: 8 B read +
+ * 4 B written per pixel, BlurIntermediate never exists either). Identical bits to vqhip_gaussian_blur_x -> _y ->
  * vqhip_tonemap (the intermediate roundings to the blur format are reproduced). enableGaussianBlur == 0: the tonemapper alone. */
 VQHIP_API int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, void* out, int width, int height,
         const VQ_TonemapperParams* tonemapParams, int enableGaussianBlur, vqhip_format inFmt, vqhip_format outFmt);
+/* The same chain (blur enabled) over ONE ROW TILE of a frame that is split between GPUs. halo_top = the `halo_rows` SCENE-COLOUR rows just above
+ * row 0 of `sceneColor` (row -halo_rows first), halo_bottom = the rows just below the tile, in `inFmt`; NULL => that side is the image border (clamp).
+ * halo_rows must be 0 (both NULL) or >= 10. The X pass is purely horizontal, so the neighbour's shaded rows are filtered in X here like the tile's own and the
+ * Y window reaches them: neighbours exchange 10 rows of scene colour (vqhip_exchange_blur_halos moves rows of any RGBA16F / RGBA32F image) right after the
+ * shade kernel instead of 10 X-blurred rows after the X pass — the same bytes, one dependency earlier. Identical bits to the untiled frame. */
+VQHIP_API int vqhip_post_process_tile(vqhip_ctx* ctx, void* stream, const void* sceneColor, void* out,
+        const void* halo_top, const void* halo_bottom, int halo_rows, int width, int height,
+        const VQ_TonemapperParams* tonemapParams, vqhip_format inFmt, vqhip_format outFmt);
 
 /* Replaces VQRenderer::ComputeBRDFIntegrationLUT (Renderer.cpp:871-909) == CubemapConvolution.hlsl:
  * CSMain_BRDFIntegration :225-240. Reference values: size 1024, samples 2048, RG16F. */

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the cfg3 shade kernel between two builds of libvqhip.so IN ONE PROCESS (same box, same clocks, interleaved rounds):
-usage: ab_shade.py <other.so> [noise|coherent]. Prints one JSON line with the per-round times of both libraries."""
+usage: ab_shade.py <other.so>[,<other2.so>...] [noise|coherent]. Prints one JSON line with the per-round times of all libraries."""
 import json
 import os
 import sys
@@ -14,13 +14,15 @@ from vqengine_amd import abi, capi, synth  # noqa: E402
 
 
 def main():
-    other = os.path.abspath(sys.argv[1])
+    others = [os.path.abspath(o) for o in sys.argv[1].split(",")]
     content = sys.argv[2] if len(sys.argv) > 2 else "noise"
     cfg = bench.CONFIGS["cfg3"]
     W, H, L = cfg["width"], cfg["height"], cfg["lights"]
     ctx_a = capi.Context(0)
-    capi._lib, capi._LIB_PATH = None, other                  # second binding: the other build (RTLD_LOCAL keeps the two apart)
-    ctx_b = capi.Context(0)
+    ctx_o = []
+    for other in others:
+        capi._lib, capi._LIB_PATH = None, other              # another binding: the other build (RTLD_LOCAL keeps them apart)
+        ctx_o.append(capi.Context(0))
     pre, lut = bench.build_ibl(ctx_a)
     env = capi.make_envmap(pre["diffuse_blurred"], pre["specular"], 128, pre["spec_mips"], lut)
     gb = bench.upload_tile(cfg, H, 0, H, coherent=(content == "coherent"))
@@ -36,11 +38,13 @@ def main():
         b.record(); b.synchronize()
         return a.elapsed_time(b) / n
     run(ctx_a, 300)
-    ta, tb = [], []
+    ta, tb = [], [[] for _ in others]
     for r in range(6):
-        ta.append(round(run(ctx_a, 100), 4)); tb.append(round(run(ctx_b, 100), 4))
-    print(json.dumps({"content": content, "current_ms": ta, "other_ms": tb, "current_median": float(np.median(ta)), "other_median": float(np.median(tb)),
-                      "other": os.path.basename(other)}), flush=True)
+        ta.append(round(run(ctx_a, 100), 4))
+        for k, c in enumerate(ctx_o):
+            tb[k].append(round(run(c, 100), 4))
+    print(json.dumps({"content": content, "current_ms": ta, "current_median": float(np.median(ta)),
+                      "others": {os.path.basename(o): {"ms": tb[k], "median": float(np.median(tb[k]))} for k, o in enumerate(others)}}), flush=True)
 
 
 if __name__ == "__main__":

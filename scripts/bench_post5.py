@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Round 5: forms of the post chain at 4K on one MI355X, one JSON line per form (bench.py's stage timer: >= 0.25 s spin-up, median of 7 batches).
-  * the X pass alone, the fused Y blur + tonemap alone (36-row window kernel vs the rolling-ring kernel at several strip heights), the pair X -> Y back to back
-  * every form's output is compared byte for byte with the window kernel's
+  * the X pass alone, the fused Y blur + tonemap alone, vqhip_post_process as two kernels, and as the one-kernel chain (k_post_chain) at several strip heights
+  * hbm_frac counts the 28 B/px of the two-kernel chain for every form (so that the column compares times); own_hbm_frac counts the form's own 12 B/px
+  * every form's output is compared byte for byte with the two-kernel path's
 usage: python scripts/bench_post5.py [W H]"""
 import json
 import os
@@ -31,20 +32,21 @@ def main():
                               TBps=round(px * bytes_px / st["ms"] / 1e9, 3), hbm_frac=round(px * bytes_px / st["ms"] / 1e9 / 8.0, 4), **kw)), flush=True)
 
     line("blur_x", bench._stage_stats(lambda: ctx.gaussian_blur_x(scene, F16, out=xb)), 16)
-    ctx.set_option("blur_y_form", "window")
-    ref = ctx.gaussian_blur_y_tonemap(xb, F16, R8).clone()
-    line("y_window_36", bench._stage_stats(lambda: ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=sdr)), 12)
-    line("pair_x_then_y_window", bench._stage_stats(lambda: (ctx.gaussian_blur_x(scene, F16, out=xb), ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=sdr))), 28)
-    ctx.set_option("blur_y_form", None)
-    for S in (24, 32, 48, 64, 96, 128, 192, 270):
-        ctx.set_option("blur_y_rows", S)
+    line("blur_y_tonemap (36-row window)", bench._stage_stats(lambda: ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=sdr)), 12)
+    ctx.set_option("post_form", "two")
+    ref = ctx.post_process(scene, F16, R8).clone()
+    line("post_process two kernels", bench._stage_stats(lambda: ctx.post_process(scene, F16, R8, out=sdr)), 28, own_bytes_px=28)
+    ctx.set_option("post_form", "chain")
+    strips = [int(a) for a in os.environ.get("VQ_POST_STRIPS", "0,4,6,7,8,9,12,16,17,24,34").split(",")]
+    for ny, mix in [(n, m) for m in (0, 1) for n in strips]:
+        ctx.set_option("post_strips", ny if ny else None)
+        ctx.set_option("post_mix", mix)
         sdr.zero_()
-        st = bench._stage_stats(lambda: ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=sdr))
+        st = bench._stage_stats(lambda: ctx.post_process(scene, F16, R8, out=sdr))
         torch.cuda.synchronize()
-        line(f"y_roll_S{S}", st, 12, mismatching_bytes=int((sdr != ref).sum().item()), wave_strips=((W + 63) // 64) * ((H + S - 1) // S))
-    for S in (48, 64, 96):
-        ctx.set_option("blur_y_rows", S)
-        line(f"pair_x_then_y_roll_S{S}", bench._stage_stats(lambda: (ctx.gaussian_blur_x(scene, F16, out=xb), ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=sdr))), 28)
+        us = st["ms"] * 1e3
+        line(f"post_process chain strips={ny or 'default'} {'cvt+fmac' if mix else 'v_fma_mix'}", st, 28, own_bytes_px=12, own_hbm_frac=round(px * 12 / st["ms"] / 1e9 / 8.0, 4),
+             mismatching_bytes=int((sdr != ref).sum().item()), workgroups=((W + 127) // 128) * (ny or max(1, 256 // ((W + 127) // 128))))
     ctx.close()
 
 

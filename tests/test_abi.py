@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load_library()                       # loud failure if the .so is missing
     for s in syms:
         assert hasattr(lib, s), f"libvqhip.so does not export {s}"
-    assert lib.vqhip_abi_version() == abi.ABI_VERSION == 2
+    assert lib.vqhip_abi_version() == abi.ABI_VERSION == 3
 
 
 def test_size_helpers_match_reference_mip_rules():

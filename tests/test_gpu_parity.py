@@ -358,27 +358,75 @@ def test_forward_cfg3_full_frame_with_ibl(ctx):
 # ---------------------------------------------------------------------------------------------------
 # post chain
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(2160, 3840), (97, 301), (64, 64), (33, 1000), (540, 257), (1440, 2560), (32, 64), (31, 700)])
-def test_post_process_one_call_equals_three_dispatches(ctx, shape):
-    """vqhip_post_process (blur X into the context's scratch, then blur Y + tonemap in one kernel) against the oracle's three passes, bit for bit: 4K,
-    sizes that are no multiple of the tiles, small images, negative and NaN inputs. (The experimental single-kernel chain of rounds 2-3 was measured
-    slower — 60 against 51 us at 4K, profiles/r3g_post_one_kernel.md — and removed in round 4.)"""
+POST_FORMS = [None, ("chain", 0), ("chain", 1), ("chain", 5), ("chain", 40), ("two", 0)]      # (post_form, post_strips): default / the one-kernel chain at any size, with
+                                                                                               # one / few / more row strips than fit / the two-kernel path
+
+
+@pytest.mark.parametrize("form", POST_FORMS)
+@pytest.mark.parametrize("shape", [(2160, 3840), (97, 301), (64, 64), (33, 1000), (540, 257), (1440, 2560), (32, 64), (31, 700), (1, 1), (53, 129), (300, 128)])
+def test_post_process_one_call_equals_three_dispatches(ctx, shape, form, set_opt):
+    """vqhip_post_process against the oracle's three passes, bit for bit: 4K, sizes that are no multiple of the tiles, small images, negative and NaN inputs.
+    Default = the one-kernel chain (k_post_chain: X, Y and the tonemapper; frames of >= 2^20 pixels) or blur X into the context's scratch, then blur Y + tonemap
+    in one kernel; both forms at every size through the option post_form, the chain with several strip heights (post_strips)."""
     h, w = shape
+    if form is not None:
+        set_opt("post_form", form[0])
+        if form[1]:
+            set_opt("post_strips", form[1])
+    if form is not None and form[1] and h * w > 3000 * 2000:
+        pytest.skip("strip sweeps on the smaller frames")
     img = synth.hdr_image(w, h, seed=h * 7 + w).astype(np.float16)
-    img[h // 3, w // 2, 0] = np.float16(-3.5)          # negative / NaN colours reach the half of the table that is not in LDS
+    img[h // 3, w // 2, 0] = np.float16(-3.5)          # negative / NaN colours
     img[h // 2, w // 3, 1] = np.float16(np.nan)
     img[0, 0, 2] = np.float16(-0.0)
-    want = O.tonemap(O.gaussian_blur(img, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
+    img[h - 1, w - 1, 0] = np.float16(6.0e4)
+    with np.errstate(all="ignore"):
+        want = O.tonemap(O.gaussian_blur(img, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
     got = ctx.post_process(dev(img), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM)
-    assert_bits(got, want, f"post_process {shape}")
+    assert_bits(got, want, f"post_process {shape} {form}")
     if h <= 100:
         for p in (abi.TonemapperParams(0, abi.DISPLAY_CURVE_SRGB, 200.0, 0), abi.TonemapperParams(1, abi.DISPLAY_CURVE_ST2084, 200.0, 1),
                   abi.TonemapperParams(0, abi.DISPLAY_CURVE_ST2084, 200.0, 1), abi.TonemapperParams(0, abi.DISPLAY_CURVE_LINEAR, 200.0, 1)):
-            want = O.tonemap(O.gaussian_blur(img, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, params=p)
+            with np.errstate(all="ignore"):
+                want = O.tonemap(O.gaussian_blur(img, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, params=p)
             assert_bits(ctx.post_process(dev(img), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, params=p), want, f"post_process {shape} curve {p.OutputDisplayCurveEnum}")
-        want16 = O.tonemap(O.gaussian_blur(img, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA16F)
+        with np.errstate(all="ignore"):
+            want16 = O.tonemap(O.gaussian_blur(img, abi.FMT_RGBA16F), abi.FMT_RGBA16F, abi.FMT_RGBA16F)
         assert_bits(ctx.post_process(dev(img), abi.FMT_RGBA16F, abi.FMT_RGBA16F), want16, "post_process HDR target (three dispatches)")
         assert_bits(ctx.post_process(dev(img), abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, blur=False), O.tonemap(img, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM), "no blur")
+
+
+@pytest.mark.parametrize("form", [None, ("chain", 0), ("chain", 3), ("two", 0)])
+@pytest.mark.parametrize("geom", [(192, 270, 10), (700, 135, 10), (130, 27, 12), (3840, 270, 10), (257, 64, 16)])
+def test_post_process_tile_with_scene_colour_halos(ctx, geom, form, set_opt):
+    """vqhip_post_process_tile: a row tile of a frame plus the neighbouring tiles' SCENE-COLOUR rows == the same rows of the untiled chain (oracle), bit for bit —
+    the one-kernel chain filters the halo rows in X itself, the two-kernel path filters them into the context's scratch. Each halo is the LAST `hr` rows of its own
+    exact-size allocation (no read may leave it); tiles at the top / bottom border of the frame (one halo NULL) and RGBA32F / HDR targets (two-kernel path) included."""
+    W, rows, hr = geom
+    if form is not None:
+        set_opt("post_form", form[0])
+        if form[1]:
+            set_opt("post_strips", form[1])
+    F16, F32, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA32F, abi.FMT_RGBA8_UNORM
+    img = synth.hdr_image(W, rows + 2 * hr, seed=0x7113 + W).astype(np.float16)
+    img[hr + rows // 2, W // 2, 1] = np.float16(-2.0)
+    with np.errstate(all="ignore"):
+        full = O.tonemap(O.gaussian_blur(img, F16), F16, R8)
+    top, mid, bottom = dev(img[:hr].copy()), dev(img[hr:hr + rows].copy()), dev(img[hr + rows:].copy())
+    assert_bits(ctx.post_process_tile(mid, F16, R8, halo_top=top, halo_bottom=bottom), full[hr:hr + rows], f"interior tile {geom} {form}")
+    # top tile of the frame: rows [0, rows) of img[hr:], the frame border above (clamp), the next tile's rows below
+    with np.errstate(all="ignore"):
+        full_t = O.tonemap(O.gaussian_blur(img[hr:], F16), F16, R8)
+        full_b = O.tonemap(O.gaussian_blur(img[:hr + rows], F16), F16, R8)
+    assert_bits(ctx.post_process_tile(mid, F16, R8, halo_bottom=bottom), full_t[:rows], f"top tile {geom} {form}")
+    assert_bits(ctx.post_process_tile(mid, F16, R8, halo_top=top), full_b[hr:], f"bottom tile {geom} {form}")
+    if W <= 300:
+        with np.errstate(all="ignore"):
+            hdr = O.tonemap(O.gaussian_blur(img, F16), F16, F16)
+            f32 = O.tonemap(O.gaussian_blur(img.astype(np.float32), F32), F32, R8)
+        assert_bits(ctx.post_process_tile(mid, F16, F16, halo_top=top, halo_bottom=bottom), hdr[hr:hr + rows], "HDR target")
+        assert_bits(ctx.post_process_tile(dev(img[hr:hr + rows].astype(np.float32)), F32, R8, halo_top=dev(img[:hr].astype(np.float32)),
+                                          halo_bottom=dev(img[hr + rows:].astype(np.float32))), f32[hr:hr + rows], "RGBA32F scene colour")
 
 
 @pytest.mark.parametrize("rows", [270, 135, 27])
@@ -400,12 +448,9 @@ def test_blur_y_halo_at_the_end_of_an_allocation(ctx, rows):
     assert_bits(hdr, O.tonemap(full[10:10 + rows], abi.FMT_RGBA16F, abi.FMT_RGBA16F), "fused blur Y + tonemap, LDS-tile kernel")
 
 
-@pytest.mark.parametrize("x_wgs", [None, "3", "2048"])             # the X pass's forms: one workgroup per segment (default) / persistent, pipelined
 @pytest.mark.parametrize("fmt", [abi.FMT_RGBA32F, abi.FMT_RGBA16F])
 @pytest.mark.parametrize("shape", [(97, 301), (1, 5), (64, 64), (40, 1), (7, 2051)])
-def test_blur(ctx, fmt, shape, x_wgs, set_opt):
-    if x_wgs is not None:
-        set_opt("blur_x_wgs", x_wgs)
+def test_blur(ctx, fmt, shape):
     h, w = shape
     img = synth.hdr_image(w, h).astype(O._NP[fmt][0])
     x_o = O.blur_pass(img, fmt, 0)

@@ -12,10 +12,7 @@ from vqengine_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
 
-# forms of the fused Y blur + tonemap kernel: the default (rolling 32-row register ring, 64-row strips), other strip heights (blur_y_rows: shorter than the
-# ring, no multiple of anything, longer than the 32-fold unrolled step loop), and round 2-4's 36-row-window kernel (blur_y_form=window) at its default /
-# fewer than tiles / more than tiles persistent workgroups (blur_y_wgs)
-Y_WGS = [None, ("rows", 12), ("rows", 37), ("rows", 128), ("rows", 700), ("window", 0), ("window", 96), ("window", 2048)]
+Y_WGS = [None, 96, 2048]        # workgroups of the persistent fused Y kernel (option blur_y_wgs): default 512 / fewer than tiles / more than tiles
 
 
 # ---------------------------------------------------------------------------------------------------------------------------------
@@ -178,12 +175,8 @@ def test_forward_light_loop_granularity_conditions(ctx, arith_dxc):
 def test_blur_y_tonemap_forms(ctx, form, shape, set_opt):
     """The fused Y blur + tonemap kernel (64 KB table in LDS, persistent workgroups) == oracle: whole images, odd widths, heights that are no multiple
     of the tile, a row tile with halos — at several workgroup counts (the compact-table forms of round 3 were removed: bit-identical, slower)."""
-    if form is not None and form[0] == "rows":
-        set_opt("blur_y_rows", form[1])
-    elif form is not None:
-        set_opt("blur_y_form", "window")
-        if form[1]:
-            set_opt("blur_y_wgs", form[1])
+    if form is not None:
+        set_opt("blur_y_wgs", form)
     h, w = shape
     F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
     img = synth.hdr_image(w, h, scale=30.0)

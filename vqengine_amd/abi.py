@@ -15,7 +15,7 @@ FMT_R10G10B10A2_UNORM = 5          # Tex_SceneNormals: input of ssr_environment_
 FMT_BPP = {FMT_RGBA32F: 16, FMT_RGBA16F: 8, FMT_RGBA8_UNORM: 4, FMT_RG16F: 4, FMT_RG32F: 8}
 CONV_SEQUENTIAL, CONV_WAVE64 = 0, 1
 ARITH_LITERAL, ARITH_DXC = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 COLOR_SPACE_REC_709, COLOR_SPACE_REC_2020 = 0, 1
 DISPLAY_CURVE_SRGB, DISPLAY_CURVE_ST2084, DISPLAY_CURVE_LINEAR = 0, 1, 2
 

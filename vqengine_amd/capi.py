@@ -50,6 +50,7 @@ def load_library():
         "vqhip_tonemap": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.TonemapperParams), i32, i32]),
         "vqhip_gaussian_blur_y_tonemap": (i32, [vp, vp, vp, vp, vp, vp, i32, C.POINTER(abi.BlurParams), C.POINTER(abi.TonemapperParams), i32, i32]),
         "vqhip_post_process": (i32, [vp, vp, vp, vp, i32, i32, C.POINTER(abi.TonemapperParams), i32, i32, i32]),
+        "vqhip_post_process_tile": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, C.POINTER(abi.TonemapperParams), i32, i32]),
         "vqhip_brdf_lut": (i32, [vp, vp, vp, i32, i32, i32]),
         "vqhip_mip_level_count": (i32, [i32, i32]),
         "vqhip_mip_chain_bytes": (sz, [i32, i32, i32]),
@@ -111,7 +112,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "vqhip_abi_version", "vqhip_create", "vqhip_destroy", "vqhip_last_error", "vqhip_forward_lighting", "vqhip_forward_lighting_mrt", "vqhip_forward_lighting_from_materials_mrt", "vqhip_scene_normals_from_materials",
-    "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_gaussian_blur_y_tonemap", "vqhip_tonemap", "vqhip_post_process", "vqhip_brdf_lut",
+    "vqhip_gaussian_blur", "vqhip_gaussian_blur_x", "vqhip_gaussian_blur_y", "vqhip_gaussian_blur_y_tonemap", "vqhip_tonemap", "vqhip_post_process", "vqhip_post_process_tile", "vqhip_brdf_lut",
     "vqhip_mip_level_count", "vqhip_mip_chain_bytes", "vqhip_mip_level_offset_bytes", "vqhip_mip_chain_min_rgba32f",
     "vqhip_specular_mip_count", "vqhip_cube_bytes", "vqhip_conv_diffuse", "vqhip_conv_specular", "vqhip_envmap_prefilter",
     "vqhip_max_materials", "vqhip_gbuffer_from_materials", "vqhip_forward_lighting_from_materials", "vqhip_mip_chain_bytes_rgba8", "vqhip_mip_chain_box_rgba8",
@@ -388,6 +389,18 @@ class Context:
                                                          C.byref(p), C.byref(params), fmt, out_fmt))
         return out
 
+    def post_process_tile(self, src, in_fmt, out_fmt=FMT_RGBA8_UNORM, params=None, out=None, halo_top=None, halo_bottom=None, stream=None):
+        """The blur + tonemapper chain over one row tile; halo_top / halo_bottom are the neighbouring tiles' SCENE-COLOUR rows (>= 10, in in_fmt)."""
+        _check_img(src, in_fmt, "src")
+        h, w = src.shape[0], src.shape[1]
+        out = out if out is not None else empty_image(h, w, out_fmt, self.device)
+        _check_img(out, out_fmt, "out", (h, w))
+        rows = _halo_rows(halo_top, halo_bottom, in_fmt, w)
+        params = params if params is not None else abi.TonemapperParams.default()
+        self._ck(self.lib.vqhip_post_process_tile(self._h, self._stream(stream), _ptr(src), _ptr(out), _ptr(halo_top), _ptr(halo_bottom), rows, w, h,
+                                                  C.byref(params), in_fmt, out_fmt))
+        return out
+
     def post_process(self, src, in_fmt, out_fmt=FMT_RGBA8_UNORM, params=None, blur=True, out=None, stream=None):
         """RenderPostProcess's blur + tonemapper as one call (one kernel for RGBA16F -> RGBA8 and a per-channel curve); same bits as
         gaussian_blur_x -> gaussian_blur_y -> tonemap."""
@@ -630,10 +643,10 @@ class Context:
 
     # the environment variables of rounds 1-3 map onto options (scripts that sweep forms): VQHIP_LUT_FORM -> "lut_form", ...
     ENV_OPTIONS = {"VQHIP_LUT_FORM": "lut_form", "VQHIP_DIFFUSE_FORM": "diffuse_form", "VQHIP_DIFFUSE_SEQ_FORM": "diffuse_seq_form",
-                   "VQHIP_BLUR_X_WGS": "blur_x_wgs", "VQHIP_BLUR_Y_WGS": "blur_y_wgs", "VQHIP_SHADE_WG": "shade_wg", "VQHIP_PSMAIN_WAVES": "psmain_waves"}
+                   "VQHIP_BLUR_Y_WGS": "blur_y_wgs", "VQHIP_SHADE_WG": "shade_wg", "VQHIP_PSMAIN_WAVES": "psmain_waves"}
 
     def set_option_env(self, env_name, value):
-        v = None if value in (None, "", "default", "0") and env_name != "VQHIP_BLUR_X_WGS" else value
+        v = None if value in (None, "", "default", "0") else value
         self.set_option(self.ENV_OPTIONS[env_name], v)
 
     def unlit_composite(self, coverage_ip, colors, color, fmt, stream=None):

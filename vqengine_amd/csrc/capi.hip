@@ -19,6 +19,7 @@ using namespace vqk;
 
 struct vqhip_ctx {
     int device = 0;
+    int nCUs = 256;
     static constexpr int kSlots = 32;
     char* hostRing = nullptr;      // pinned
     char* devRing = nullptr;
@@ -240,6 +241,7 @@ int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
     HIP_TRY(nullptr, hipSetDevice(device_ordinal));
     vqhip_ctx* ctx = new vqhip_ctx();
     ctx->device = device_ordinal;
+    ctx->nCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     ctx->generation = g_ctxGeneration.fetch_add(1, std::memory_order_relaxed);
     const size_t ringBytes = kConstSlotBytes * vqhip_ctx::kSlots;
     if ((e = hipHostMalloc((void**)&ctx->hostRing, ringBytes, hipHostMallocDefault)) != hipSuccess ||
@@ -487,24 +489,66 @@ int vqhip_tonemap(vqhip_ctx* ctx, void* stream, const void* in, void* out, int w
     return slot >= 0 ? releaseTonemapLut(ctx, (hipStream_t)stream, slot) : VQHIP_OK;
 }
 
+// sceneColor -> out for one row tile; halo_top / halo_bottom are SCENE-COLOUR rows (NULL: image border)
+static int postProcessTile(vqhip_ctx* ctx, void* stream, const void* sceneColor, void* out, const void* halo_top, const void* halo_bottom, int halo_rows,
+                           int width, int height, const VQ_TonemapperParams* tm, vqhip_format inFmt, vqhip_format outFmt) {
+    const hipStream_t st = (hipStream_t)stream;
+    if (post_chain_applies(*tm, inFmt, outFmt, width, height, ctx->opt)) {                      // X, Y and the tonemapper in one kernel: no intermediate at all
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        int slot = -1;
+        const int rc = acquireTonemapLut(ctx, st, *tm, outFmt, &slot);
+        if (rc) return rc;
+        hipError_t e = launch_post_chain(st, sceneColor, out, halo_top, halo_bottom, halo_rows, width, height, ctx->lut[slot].table, ctx->nCUs, ctx->opt);
+        if (e != hipSuccess) return failHip(ctx, e, "post chain launch");
+        return releaseTonemapLut(ctx, st, slot);
+    }
+    // blur X into a BlurIntermediate held in the context's scratch buffer (the tile, then the halo rows behind it), then blur Y + tonemap in one kernel
+    // (or on the LDS-tile kernel: HDR / RGBA32F targets)
+    const size_t bpp = inFmt == VQHIP_FMT_RGBA32F ? 16 : 8;
+    const size_t tileBytes = (size_t)width * height * bpp, haloBytes = (size_t)width * halo_rows * bpp;
+    const int rc0 = ensureScratch(ctx, tileBytes + 2 * haloBytes);
+    if (rc0) return rc0;
+    char* xt = (char*)ctx->scratch; char* xTop = xt + tileBytes; char* xBot = xTop + haloBytes;
+    const VQ_BlurParams bp = { width, height };
+    int rc = vqhip_gaussian_blur_x(ctx, stream, sceneColor, xt, &bp, inFmt);
+    if (rc) return rc;
+    const VQ_BlurParams hp = { width, halo_rows };
+    if (halo_top && (rc = vqhip_gaussian_blur_x(ctx, stream, halo_top, xTop, &hp, inFmt))) return rc;
+    if (halo_bottom && (rc = vqhip_gaussian_blur_x(ctx, stream, halo_bottom, xBot, &hp, inFmt))) return rc;
+    return vqhip_gaussian_blur_y_tonemap(ctx, stream, xt, out, halo_top ? xTop : nullptr, halo_bottom ? xBot : nullptr, halo_rows, &bp, tm, inFmt, outFmt);
+}
+
+static int postProcessCheck(vqhip_ctx* ctx, const char* who, const void* sceneColor, const void* out, int width, int height, const VQ_TonemapperParams* tm,
+                            vqhip_format inFmt, vqhip_format outFmt) {
+    const std::string w = who;
+    if (!sceneColor || !out || !tm || width <= 0 || height <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": bad argument");
+    if (!isImageFmt(inFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, w + ": inFmt must be RGBA32F or RGBA16F");
+    if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, w + ": outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
+    if (sceneColor == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": in-place is not supported");
+    return VQHIP_OK;
+}
+
 int vqhip_post_process(vqhip_ctx* ctx, void* stream, const void* sceneColor, void* out, int width, int height,
                        const VQ_TonemapperParams* tm, int enableGaussianBlur, vqhip_format inFmt, vqhip_format outFmt) {
     vqk::Range range_("RenderPostProcess");
     if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "post_process: ctx is NULL");
     CTX_GUARD(ctx, "post_process");
-    if (!sceneColor || !out || !tm || width <= 0 || height <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, "post_process: bad argument");
-    if (!isImageFmt(inFmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "post_process: inFmt must be RGBA32F or RGBA16F");
-    if (!isImageFmt(outFmt) && outFmt != VQHIP_FMT_RGBA8_UNORM) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "post_process: outFmt must be RGBA32F, RGBA16F or RGBA8_UNORM");
-    if (sceneColor == out) return fail(ctx, VQHIP_ERR_INVALID_ARG, "post_process: in-place is not supported");
-    if (!enableGaussianBlur) return vqhip_tonemap(ctx, stream, sceneColor, out, width, height, tm, inFmt, outFmt);
-    // blur X into a BlurIntermediate held in the context's scratch buffer, then blur Y + tonemap in one kernel (or two: HDR / RGBA32F targets)
-    const size_t bpp = inFmt == VQHIP_FMT_RGBA32F ? 16 : 8;
-    const int rc0 = ensureScratch(ctx, (size_t)width * height * bpp);
-    if (rc0) return rc0;
-    const VQ_BlurParams bp = { width, height };
-    int rc = vqhip_gaussian_blur_x(ctx, stream, sceneColor, ctx->scratch, &bp, inFmt);
+    const int rc = postProcessCheck(ctx, "post_process", sceneColor, out, width, height, tm, inFmt, outFmt);
     if (rc) return rc;
-    return vqhip_gaussian_blur_y_tonemap(ctx, stream, ctx->scratch, out, nullptr, nullptr, 0, &bp, tm, inFmt, outFmt);
+    if (!enableGaussianBlur) return vqhip_tonemap(ctx, stream, sceneColor, out, width, height, tm, inFmt, outFmt);
+    return postProcessTile(ctx, stream, sceneColor, out, nullptr, nullptr, 0, width, height, tm, inFmt, outFmt);
+}
+
+int vqhip_post_process_tile(vqhip_ctx* ctx, void* stream, const void* sceneColor, void* out, const void* halo_top, const void* halo_bottom, int halo_rows,
+                            int width, int height, const VQ_TonemapperParams* tm, vqhip_format inFmt, vqhip_format outFmt) {
+    vqk::Range range_("RenderPostProcess(tile)");
+    if (!ctx) return fail(nullptr, VQHIP_ERR_INVALID_ARG, "post_process_tile: ctx is NULL");
+    CTX_GUARD(ctx, "post_process_tile");
+    const int rc = postProcessCheck(ctx, "post_process_tile", sceneColor, out, width, height, tm, inFmt, outFmt);
+    if (rc) return rc;
+    if ((halo_top || halo_bottom) && halo_rows < 10) return fail(ctx, VQHIP_ERR_INVALID_ARG, "post_process_tile: halo_rows must be >= 10");
+    if (!halo_top && !halo_bottom) halo_rows = 0;
+    return postProcessTile(ctx, stream, sceneColor, out, halo_top, halo_bottom, halo_rows, width, height, tm, inFmt, outFmt);
 }
 
 int vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value) {
@@ -530,10 +574,10 @@ int vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value) {
     };
     if (k == "shade_wg") return num(&o.shadeWg, { 0, 64, 128, 256 });
     if (k == "psmain_waves") return num(&o.psmainWaves, { 0, 4, 5, 6 });
-    if (k == "blur_x_wgs") return num(&o.blurXWgs, {});
     if (k == "blur_y_wgs") return num(&o.blurYWgs, {});
-    if (k == "blur_y_form") { if (v == "roll") { o.blurYForm = 0; return VQHIP_OK; } return pick(&o.blurYForm, { "window" }); }
-    if (k == "blur_y_rows") return num(&o.blurYRows, {});
+    if (k == "post_form") return pick(&o.postForm, { "two", "chain" });
+    if (k == "post_strips") return num(&o.postStrips, {});
+    if (k == "post_mix") return num(&o.postMix, { 0, 1 });
     if (k == "lut_form") return pick(&o.lutForm, { "general" });
     if (k == "diffuse_form") { if (v == "records") { o.diffuseForm = 0; return VQHIP_OK; } return pick(&o.diffuseForm, { "texels", "general" }); }
     if (k == "diffuse_seq_form") { if (v == "ordered") { o.diffuseSeqForm = 0; return VQHIP_OK; } return pick(&o.diffuseSeqForm, { "lane" }); }

@@ -36,11 +36,11 @@ template <int FMT> VQD void store_px2(void* base, size_t idx, float4 a, float4 b
 // instead of 21). One padding pixel after every 4 puts lane i's window element k at 5i + k + k/4: the stride-5-pixel
 // (10-dword) ds_read_b64 pattern is conflict-free within each 32-lane group.
 template <int FMT>
-__global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, void* __restrict__ out, int W, int H) {
+__global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, void* __restrict__ out, int W, int H, int segsPerRow) {
     constexpr int PXB = (FMT == 0) ? 16 : 8;
     constexpr int NPX = 1024 + 2 * R;
     __shared__ __attribute__((aligned(16))) unsigned char tile[(NPX + NPX / 4 + 4) * PXB];
-    const int y = blockIdx.y, x0 = blockIdx.x * 1024, t = threadIdx.x;
+    const int y = blockIdx.x / segsPerRow, x0 = (blockIdx.x - y * segsPerRow) * 1024, t = threadIdx.x;      // one workgroup per (row, segment): a 1-D grid, so the height is not limited by grid.y
     const size_t row = (size_t)y * W;
     for (int i = t; i < NPX; i += 256) {
         const int sx = min(max(x0 - R + i, 0), W - 1);      // clamp(sampleCoord.x, 0, iImageSize.x - 1) :143
@@ -57,6 +57,10 @@ __global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, vo
         const int p = 4 * t + k;
         const float4 s = load_px<FMT>(tile, (size_t)(p + (p >> 2)));
         wx[k] = s.x; wy[k] = s.y; wz[k] = s.z;
+        // the converted texel as three fp32 registers: left alone, the compiler folds each conversion into the four mads that use it (v_fma_mix_f32, 252 per lane), and
+        // v_fma_mix_f32 issues no faster than v_cvt_f32_f16 on gfx950 while v_fmac_f32 with a literal weight issues faster (scripts/ubench/mix_rate.hip): 72 conversions +
+        // 252 v_fmac_f32 — 31.6 against 33.1 us at 4K on one box (profiles/r5g_post_forms.md)
+        if (FMT == 1) asm("" : "+v"(wx[k]), "+v"(wy[k]), "+v"(wz[k]));
     }
     float4 res[4];
     #pragma unroll
@@ -76,70 +80,6 @@ __global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, vo
     } else {
         #pragma unroll
         for (int j = 0; j < 4; ++j) if (xb + j < W) store_px<FMT>(out, row + xb + j, res[j]);
-    }
-}
-
-// Same arithmetic as k_blur_x4, software-pipelined: a persistent workgroup walks over 1024-pixel row segments and issues the
-// global loads of segment n+1 (5 pixels per lane, kept in registers) before it filters segment n out of LDS, so the HBM
-// latency of the next tile hides behind the 252 mads of the current one instead of adding to them.
-template <int FMT>
-__global__ __launch_bounds__(256) void k_blur_x4p(const void* __restrict__ in, void* __restrict__ out, int W, int H, int segsPerRow, int nSeg) {
-    constexpr int PXB = (FMT == 0) ? 16 : 8;
-    constexpr int NPX = 1024 + 2 * R;
-    using px_t = typename std::conditional<FMT == 0, float4, h4>::type;
-    __shared__ __attribute__((aligned(16))) unsigned char tile[(NPX + NPX / 4 + 4) * PXB];
-    const int t = threadIdx.x;
-    px_t pre[5];
-    auto fetch = [&](int seg) {
-        const int y = seg / segsPerRow, x0 = (seg - y * segsPerRow) * 1024;
-        const size_t row = (size_t)y * W;
-        #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int i = t + 256 * j;
-            if (i < NPX) pre[j] = ((const px_t*)in)[row + min(max(x0 - R + i, 0), W - 1)];      // clamp(sampleCoord.x, 0, iImageSize.x - 1) :143
-        }
-    };
-    int seg = blockIdx.x;
-    if (seg < nSeg) fetch(seg);
-    for (; seg < nSeg; seg += gridDim.x) {
-        #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int i = t + 256 * j;
-            if (i < NPX) ((px_t*)tile)[i + (i >> 2)] = pre[j];
-        }
-        __syncthreads();
-        if (seg + (int)gridDim.x < nSeg) fetch(seg + gridDim.x);
-        const int y = seg / segsPerRow, x0 = (seg - y * segsPerRow) * 1024;
-        const size_t row = (size_t)y * W;
-        const int xb = x0 + 4 * t;
-        if (xb < W) {                                       // early out :129
-            float wx[24], wy[24], wz[24];
-            #pragma unroll
-            for (int k = 0; k < 24; ++k) {
-                const float4 s = load_px<FMT>(tile, (size_t)(5 * t + k + (k >> 2)));     // slot of pixel 4t + k: constant offsets from one address
-                wx[k] = s.x; wy[k] = s.y; wz[k] = s.z;
-            }
-            float4 res[4];
-            #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float ax = 0.0f, ay = 0.0f, az = 0.0f;
-                #pragma unroll
-                for (int it = 0; it < 21; ++it) {
-                    const int off = it - R;
-                    const float w = kW[off < 0 ? -off : off];
-                    ax = fma_(wx[j + it], w, ax); ay = fma_(wy[j + it], w, ay); az = fma_(wz[j + it], w, az);
-                }
-                res[j] = make_float4(ax, ay, az, 1.0f);
-            }
-            if (xb + 3 < W && ((row + xb) & 1) == 0) {       // the lane's 4 pixels are 32 contiguous bytes (RGBA16F): two 16-byte stores instead of
-                #pragma unroll                               // four 8-byte ones (-2.4 us at 4K, profiles/r2e_post_chain.md)
-                for (int j = 0; j < 4; j += 2) store_px2<FMT>(out, row + xb + j, res[j], res[j + 1]);
-            } else {
-                #pragma unroll
-                for (int j = 0; j < 4; ++j) if (xb + j < W) store_px<FMT>(out, row + xb + j, res[j]);      // early out :129
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -248,7 +188,7 @@ __global__ __launch_bounds__(256) void k_tonemap(const void* __restrict__ in, vo
 // format (8 B/px for RGBA16F), then lane (column c, row group g) produces TR/4 consecutive outputs from a register window
 // read out of LDS (wave = 64 adjacent columns of one row: conflict-free ds_read_b64/b128). Compared with the pure
 // register-window Y pass this has 4x more lanes and 4x shorter serial chains, which the 3 pow() per pixel need.
-template <int FMT, int OUTFMT, int TR, bool TM = true>
+template <int FMT, int OUTFMT, int TR>
 __global__ __launch_bounds__(256) void k_blur_y_tonemap(const void* __restrict__ in, void* __restrict__ out,
                                                         const void* __restrict__ haloTop, const void* __restrict__ haloBottom, int haloRows,
                                                         int W, int H, VQ_TonemapperParams p) {
@@ -288,7 +228,6 @@ __global__ __launch_bounds__(256) void k_blur_y_tonemap(const void* __restrict__
             ax = fma_(wx[r + it], w, ax); ay = fma_(wy[r + it], w, ay); az = fma_(wz[r + it], w, az);
         }
         float4 b = make_float4(ax, ay, az, 1.0f);
-        if (!TM) { store_px<OUTFMT>(out, (size_t)(yBase + r) * W + x, b); continue; }                     // plain CSMain_Y (OUTFMT == FMT)
         if (FMT == 1) b = make_float4((float)to_f16(ax), (float)to_f16(ay), (float)to_f16(az), 1.0f);      // BlurOutput is RGBA16F
         store_px<OUTFMT>(out, (size_t)(yBase + r) * W + x, tonemap_px(b, p));
     }
@@ -385,121 +324,215 @@ __global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restri
     }
 }
 
-// ---- Y blur + tonemap through the table, ROLLING window (round 5) -----------------------------------------------------------------------
-// The same arithmetic and the same table as k_blur_y_tonemap_lut, another schedule. A wave owns a 64-column strip of S output rows and walks down
-// it one row at a time: the 21 rows the filter reaches live in a 32-row register ring in the STORAGE format (two dwords per row: the fp16 -> fp32
-// conversion is the operand conversion of v_fma_mix_f32, exact, so there is no convert instruction and the ring costs 64 VGPRs), and the 11 other
-// slots of the ring are loads IN FLIGHT: at step j the wave issues the load of row j + 21 into the slot row j - 11 has just left, then runs the
-// 63 mads of row j. Loads and mads of ONE wave overlap for the whole strip — the 36-row-window form loaded, waited, computed, stored, in phases that
-// all 4 096 resident waves went through together — and an input row is read (S + 20) / S times instead of 36 / 16 = 2.25 times.
-// Ring slot of input row (y0 - 10 + i) is i & 31; the step loop is unrolled 32-fold so that every ring index is a compile-time register.
-// acc = fma((float)half(lo / hi 16 bits of h), w, acc): ONE v_fma_mix_f32 — the fp16 operand is converted exactly inside the instruction, the product and the
-// sum are rounded once to fp32 like v_fma_f32 of the converted value (same MODE denormal fields as v_cvt_f32_f16 + v_fma_f32: identical bits). Written as asm
-// because the compiler, left alone, converts every ring row once and keeps an fp32 ring (96 VGPRs + 3 converts per row instead of 64 + 0).
+// ---- the whole chain in ONE kernel (round 5): CSMain_X -> CSMain_Y -> tonemapper, RGBA16F scene colour in, RGBA8 out ---------------------------------
+// BlurIntermediate never exists either: 8 B read + 4 B written per pixel instead of 28. The same arithmetic as k_blur_x4 -> k_blur_y_tonemap_lut (each
+// X-blurred texel is rounded to fp16 exactly like the store to BlurIntermediate, each Y-blurred one like the store to BlurOutput, whose 16 bits index the
+// 64 KB tonemap table), another schedule:
+//   * one 1 024-lane workgroup per CU owns a 64-column strip of S output rows and walks down it 32 rows per iteration. LDS = the tonemap table (64 KB) + a
+//     ring of 84 X-blurred rows of 64 texels in the storage format, 8 B each (140 800 bytes);
+//   * waves 0-7 are the X waves, waves 8-15 the Y waves (two of each per SIMD), and they work on DIFFERENT iterations: while the X waves filter the 32 input
+//     rows of iteration i into the ring, the Y waves filter the 32 output rows whose windows iteration i - 1 completed. The two halves meet at ONE barrier per
+//     iteration; in between, the LDS phases (window reads) of one half run under the mad phases of the other — with all 16 waves in the same stage
+//     (first form of this kernel: profiles/r5d_post_forms.md) the LDS and the VALU took turns and the kernel was no faster than the two it replaces;
+//   * X waves: a quarter-wave filters one 64-texel row, 4 adjacent texels per lane. The 84 input texels are parked raw in the row's ring slot (slot of texel
+//     p = p + p/4: the stride-5 ds_read_b64 pattern of k_blur_x4; the row stride of 112 slots puts the second row of a 32-lane group on the other half of the
+//     banks), every lane reads its 24-texel window (6 LDS reads per output), runs the 252 mads and writes its 4 results over the raw texels — the LDS
+//     operations of one wave complete in order. The global loads of iteration i + 1 are issued before the mads of iteration i;
+//   * Y waves: 64 columns x 4 rows per wave; a lane reads its 24-row column window out of the ring (6 LDS reads per output again), 252 mads, three table
+//     lookups and one 4-byte store per output. In iteration 0 they have no rows yet and fill the table.
+// All mads are v_fma_mix_f32 on the packed halfs (the fp16 -> fp32 conversion of the operand is exact and part of the instruction): no window is ever converted.
+// Halos (row-tiled frames): halo_top / halo_bottom are SCENE-COLOUR rows here — the X pass is purely horizontal, so the rows the neighbour tile shaded are filtered
+// in X like the tile's own and the Y window reaches them: 10 rows per side, the same byte count as the X-blurred halos of the two-kernel path.
 VQD float fma_mix_lo(uint32_t h, float w, float acc) { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h), "s"(w)); return acc; }
 VQD float fma_mix_hi(uint32_t h, float w, float acc) { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h), "s"(w)); return acc; }
-__global__ __launch_bounds__(512, 2) void k_blur_y_tonemap_roll(const void* __restrict__ in, void* __restrict__ out, const void* __restrict__ haloTop,
-                                                               const void* __restrict__ haloBottom, int haloRows, int W, int H,
-                                                               const void* __restrict__ table, int stripsX, int nStrips, int S) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[65536];
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int strip = blockIdx.x * 8 + wv;
-    const bool valid = strip < nStrips;                     // wave-uniform; an idle wave still helps to fill the table and meets the barrier
-    const int sy = strip / stripsX, sx = strip - sy * stripsX;
-    const int x = sx * 64 + (threadIdx.x & 63);
-    const int xc = min(x, W - 1);
-    const int y0 = sy * S;
-    const int rows = min(S, H - y0);                        // output rows of this strip (> 0 when valid)
-    // wave-uniform row source of input row r: image / halo / clamp (GaussianBlur.hlsl:178); never outside the halo buffers. Written as scalar selects and
-    // the step loop below kept free of branches (but the one wave-uniform exit): with control flow inside the unrolled body the compiler's wait-count
-    // insertion loses track of the loads in flight at every join and drains them all (s_waitcnt vmcnt(0)) — measured: 35 us instead of the window kernel's 27.
-    const int lastRow = y0 + rows - 1 + R;                  // the last input row any output of this strip reads
-    // (masks instead of selects: the compiler turns a chain of wave-uniform selects back into branches)
-    const uint64_t aIn = (uint64_t)in, dTop = haloTop ? (uint64_t)haloTop - aIn : 0, dBot = haloBottom ? (uint64_t)haloBottom - aIn : 0;
-    const int hasTop = haloTop ? -1 : 0, hasBot = haloBottom ? -1 : 0;
-    auto load_row = [&](int r) -> uint2 {
-        r = min(r, lastRow);                                // the ring runs 11 rows ahead: past the end of the strip it re-reads the last row instead of branching
-        const int mT = (r >> 31) & hasTop, mB = ((H - 1 - r) >> 31) & hasBot;          // all ones when the row comes from the top / bottom halo
-        const int rowIn = min(max(r, 0), H - 1), rowTop = haloRows + max(r, -haloRows), rowBot = min(r - H, haloRows - 1);
-        const int row = rowIn + (mT & (rowTop - rowIn)) + (mB & (rowBot - rowIn));
-        const uint64_t base = aIn + ((uint64_t)(int64_t)mT & dTop) + ((uint64_t)(int64_t)mB & dBot);
-        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-        typedef const u2v __attribute__((address_space(1))) * gptr;               // an address built from integers is a FLAT pointer unless it says otherwise
-        const u2v v = *(gptr)(base + (((uint64_t)row * (uint64_t)W + (uint64_t)xc) << 3));
-        return make_uint2(v.x, v.y);
-    };
-    // one memory round trip before the first row: the 31 ring loads and the wave's share of the table go out together, the table is parked in LDS, barrier
-    uint2 ring[32];
-    if (valid) {
-        #pragma unroll
-        for (int i = 0; i < 31; ++i) ring[i] = load_row(y0 - R + i);
+// An 8-byte LDS read that stays ONE ds_read_b64 (2 LDS cycles per wave): left to the compiler, two reads of adjacent slots become a 16-byte load with 8-byte
+// alignment = ds_read2_b64 (8 cycles). The compiler does not count these in its lgkmcnt bookkeeping: lds_wait() below is the wait, and it names every destination
+// so that no consumer can be scheduled above it. (The compiler's own waits can only over-wait: LDS operations of a wave complete in order.)
+template <int OFF> VQD void lds_read_b64(uint32_t& lo, uint32_t& hi, uint32_t addr) {
+    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+    u2v v;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    lo = v.x; hi = v.y;
+}
+#define PC_TIE6(a, i) "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]), "+v"(a[i + 4]), "+v"(a[i + 5])
+VQD void lds_wait(uint32_t (&lo)[24], uint32_t (&hi)[24]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : PC_TIE6(lo, 0), PC_TIE6(lo, 6), PC_TIE6(lo, 12), PC_TIE6(lo, 18));
+    asm volatile("" : PC_TIE6(hi, 0), PC_TIE6(hi, 6), PC_TIE6(hi, 12), PC_TIE6(hi, 18));
+}
+template <int T> struct XWindow {                             // window texel t of the X stage: slot 5 li + t + t / 4
+    static VQD void read(uint32_t (&lo)[24], uint32_t (&hi)[24], uint32_t base) {
+        XWindow<T - 1>::read(lo, hi, base);
+        lds_read_b64<(T + (T >> 2)) * 8>(lo[T], hi[T], base);
     }
-    for (int i = threadIdx.x * 16; i < 65536; i += 512 * 16) *(uint4*)(lds + i) = *(const uint4*)((const unsigned char*)table + i);
-    __syncthreads();
-    if (!valid) return;
-    // lanes beyond the image (x >= W) load column W - 1, compute the same value as lane W - 1 and store it to the same pixel: a benign duplicate instead of a predicate
-    uint32_t* __restrict__ dst = (uint32_t*)out + (size_t)y0 * W + xc;
-    for (int jb = 0; jb < rows; jb += 32) {
+};
+template <> struct XWindow<-1> { static VQD void read(uint32_t (&)[24], uint32_t (&)[24], uint32_t) {} };
+// the first 12 / the last 12 destinations of 24 reads issued in order: LDS operations of a wave complete in order
+VQD void lds_wait_first12(uint32_t (&lo)[24], uint32_t (&hi)[24]) {
+    asm volatile("s_waitcnt lgkmcnt(12)" : PC_TIE6(lo, 0), PC_TIE6(lo, 6), PC_TIE6(hi, 0), PC_TIE6(hi, 6));
+}
+VQD void lds_wait_last12(uint32_t (&lo)[24], uint32_t (&hi)[24]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : PC_TIE6(lo, 12), PC_TIE6(lo, 18), PC_TIE6(hi, 12), PC_TIE6(hi, 18));
+}
+// The window as fp32 registers (three v_cvt_f32_f16 per texel), then v_fmac_f32 with the weight as a literal: on gfx950 v_fma_mix_f32 and v_cvt issue at 4.4 cycles
+// per wave, v_fmac_f32 on VGPRs / literals at 2.45 (scripts/ubench/mix_rate.hip): 72 x 4.4 + 252 x 2.45 = 934 cycles per 4 outputs against 252 x 4.45 = 1 121.
+struct Window32 { float x[24], y[24], z[24]; };
+VQD void unpack12(const uint32_t (&wl)[24], const uint32_t (&wh)[24], Window32& f, int t0) {
+    #pragma unroll
+    for (int t = t0; t < t0 + 12; ++t) {
+        f.x[t] = half_bits_to_float(wl[t] & 0xffffu); f.y[t] = half_bits_to_float(wl[t] >> 16); f.z[t] = half_bits_to_float(wh[t] & 0xffffu);
+        asm("" : "+v"(f.x[t]), "+v"(f.y[t]), "+v"(f.z[t]));                  // three fp32 registers: the compiler must not fold the conversions back into v_fma_mix_f32
+    }
+}
+VQD void filter21(const Window32& f, int j, float& ax, float& ay, float& az) {
+    ax = 0.0f; ay = 0.0f; az = 0.0f;
+    #pragma unroll
+    for (int it = 0; it < 21; ++it) {
+        const int off = it - R;
+        const float wt = kW[off < 0 ? -off : off];
+        ax = fma_(f.x[j + it], wt, ax); ay = fma_(f.y[j + it], wt, ay); az = fma_(f.z[j + it], wt, az);
+    }
+}
+// the 63 mads of one output: kernelIt = 0..20, the HLSL's order (GaussianBlur.hlsl:138-150 / :173-185)
+VQD void filter21(const uint32_t (&wl)[24], const uint32_t (&wh)[24], int j, float& ax, float& ay, float& az) {
+    ax = 0.0f; ay = 0.0f; az = 0.0f;
+    #pragma unroll
+    for (int it = 0; it < 21; ++it) {
+        const int off = it - R;
+        const float wt = kW[off < 0 ? -off : off];
+        ax = fma_mix_lo(wl[j + it], wt, ax); ay = fma_mix_hi(wl[j + it], wt, ay); az = fma_mix_lo(wh[j + it], wt, az);
+    }
+}
+constexpr int PC_C = 64;                                      // columns of a strip
+constexpr int PC_RS = 32;                                     // rows per iteration
+constexpr int PC_RING = 2 * PC_RS + 2 * R;                    // 84 rows: the 32 the X waves write + the 52 the Y waves read
+constexpr int PC_NPX = PC_C + 2 * R;                          // 84 input texels per row
+constexpr int PC_ROWB = 112 * 8;                              // bytes per ring row: 84 texels + one pad after every 4 = 105 slots, rounded up to 16 mod 32 slots
+constexpr int PC_TABLE = 65536;
+constexpr int PC_LDS = PC_TABLE + PC_RING * PC_ROWB;          // 140 800
+static_assert(PC_NPX + PC_NPX / 4 <= PC_ROWB / 8 && (PC_ROWB / 8) % 32 == 16, "ring row");
+template <bool MIX>
+__global__ __launch_bounds__(1024) void k_post_chain(const void* __restrict__ in, void* __restrict__ out, const void* __restrict__ haloTop,
+                                                     const void* __restrict__ haloBottom, int haloRows, int W, int H,
+                                                     const void* __restrict__ table, int stripsX, int stripsY, int S, int xcdBands) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // strip (sx, sy) of workgroup b. Workgroup b runs on XCD b % 8 and every XCD has its own L2: with xcdBands = 8 / stripsY > 0 an XCD owns ONE band of rows
+    // and a contiguous range of its column strips, so that the 20 halo columns two neighbouring strips share are read through one L2.
+    int sx, sy;
+    if (xcdBands > 0) {
+        const int xcd = blockIdx.x & 7, m = blockIdx.x >> 3;
+        sy = xcd % stripsY;
+        sx = (xcd / stripsY) * (stripsX / xcdBands) + m;
+    } else { sx = blockIdx.x / stripsY; sy = blockIdx.x - sx * stripsY; }
+    const int x0 = sx * PC_C, y0 = sy * S;
+    const int rows = min(S, H - y0);                          // output rows of this strip (> 0)
+    const int nX = (rows + 2 * R + PC_RS - 1) / PC_RS;        // X iterations; the Y waves run one iteration behind
+    if (wv < 8) {
+        // ================= X waves: row rr of the iteration, texels 4 li .. 4 li + 3 of the strip; staging texels li + 16 j =================
+        const int li = lane & 15, rr = 4 * wv + (lane >> 4);
+        uint32_t colOff[6], slotOff[6];
         #pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int j = jb + u;
-            if (j >= rows) return;                          // wave-uniform exit
-            ring[(u + 31) & 31] = load_row(y0 - R + j + 31);                  // row j + 21 into the slot of row j - 11
-            float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        for (int j = 0; j < 6; ++j) {
+            const int p = li + 16 * j;
+            colOff[j] = (uint32_t)min(max(x0 - R + p, 0), W - 1) * 8u;         // clamp(sampleCoord.x, 0, iImageSize.x - 1) :143
+            slotOff[j] = (uint32_t)(p + (p >> 2)) * 8u;
+        }
+        const bool stage5 = li + 80 < PC_NPX;                                   // the sixth staging texel exists for li < 4
+        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+        u2v pre[6];
+        auto fetch = [&](int k) {
+            const int r = y0 - R + PC_RS * k + rr;                              // image row of this quarter-wave (clamp :178, or the neighbour tile's rows)
+            const unsigned char* rowp;
+            if (r < 0 && haloTop)             rowp = (const unsigned char*)haloTop + (size_t)(haloRows + max(r, -haloRows)) * W * 8;
+            else if (r > H - 1 && haloBottom) rowp = (const unsigned char*)haloBottom + (size_t)min(r - H, haloRows - 1) * W * 8;
+            else                              rowp = (const unsigned char*)in + (size_t)min(max(r, 0), H - 1) * W * 8;
             #pragma unroll
-            for (int it = 0; it < 21; ++it) {               // kernelIt = 0..20: the HLSL's order
-                const int off = it - R;
-                const float w = kW[off < 0 ? -off : off];
-                const uint2 v = ring[(u + it) & 31];
-                ax = fma_mix_lo(v.x, w, ax); ay = fma_mix_hi(v.x, w, ay); az = fma_mix_lo(v.y, w, az);
+            for (int j = 0; j < 6; ++j) if (j < 5 || stage5) pre[j] = *(const u2v*)(rowp + colOff[j]);
+        };
+        fetch(0);
+        int pb = 0;                                           // (32 k) mod 84: ring slot of the iteration's first row
+        for (int k = 0; k <= nX; ++k) {
+            if (k < nX) {
+                int phys = pb + rr; if (phys >= PC_RING) phys -= PC_RING;
+                const uint32_t rowB = PC_TABLE + (uint32_t)phys * PC_ROWB;
+                #pragma unroll
+                for (int j = 0; j < 6; ++j) if (j < 5 || stage5) *(u2v*)(lds + rowB + slotOff[j]) = pre[j];
+                __builtin_amdgcn_wave_barrier();
+                uint32_t wl[24], wh[24];                      // the 24-texel window: x | y << 16, z | a << 16
+                XWindow<23>::read(wl, wh, rowB + (uint32_t)(5 * li) * 8u);
+                if (k + 1 < nX) fetch(k + 1);                 // in flight during the mads below
+                Window32 f;
+                if (MIX) lds_wait(wl, wh);
+                else { lds_wait_first12(wl, wh); unpack12(wl, wh, f, 0); lds_wait_last12(wl, wh); unpack12(wl, wh, f, 12); }
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float ax, ay, az;
+                    if (MIX) filter21(wl, wh, j, ax, ay, az); else filter21(f, j, ax, ay, az);
+                    u2v o;                                    // == the store to BlurIntermediate (RGBA16F, alpha 1)
+                    o.x = float_to_half_bits(ax) | (float_to_half_bits(ay) << 16); o.y = float_to_half_bits(az) | 0x3C000000u;
+                    *(u2v*)(lds + rowB + (uint32_t)(5 * li + j) * 8u) = o;
+                }
+                pb += PC_RS; if (pb >= PC_RING) pb -= PC_RING;
             }
-            const uint32_t hx = float_to_half_bits(ax), hy = float_to_half_bits(ay), hz = float_to_half_bits(az);   // == the BlurOutput store
-            dst[(size_t)j * W] = (uint32_t)lds[hx] | ((uint32_t)lds[hy] << 8) | ((uint32_t)lds[hz] << 16) | (255u << 24);   // alpha 1 -> 255
+            __syncthreads();
+        }
+    } else {
+        // ================= Y waves: column `lane` of the strip, rows 4 g .. 4 g + 3 of the iteration's 32 outputs =================
+        const int g = wv - 8;
+        const uint32_t colB = PC_TABLE + (uint32_t)(lane + (lane >> 2)) * 8u;
+        const bool xOk = x0 + lane < W;
+        uint32_t* __restrict__ dstCol = (uint32_t*)out + (size_t)y0 * W + (xOk ? x0 + lane : 0);
+        for (int i = (tid - 512) * 16; i < PC_TABLE; i += 512 * 16) *(uint4*)(lds + i) = *(const uint4*)((const unsigned char*)table + i);
+        __syncthreads();                                      // iteration 0: no rows yet
+        int pb = PC_RING - 2 * R;                             // (32 (k - 1) - 20) mod 84 for k = 1: ring slot of the first row the iteration's first output reads
+        for (int k = 1; k <= nX; ++k) {
+            const int oRel = PC_RS * (k - 1) - 2 * R + 4 * g;     // first output row of this wave, relative to y0 (a multiple of 4; negative in the first iteration)
+            if (oRel >= 0 && oRel < rows) {
+                int q = pb + 4 * g; if (q >= PC_RING) q -= PC_RING;
+                uint32_t wl[24], wh[24];
+                #pragma unroll
+                for (int t = 0; t < 24; ++t) {
+                    int ph = q + t; if (ph >= PC_RING) ph -= PC_RING;
+                    lds_read_b64<0>(wl[t], wh[t], colB + (uint32_t)ph * PC_ROWB);
+                }
+                Window32 f;
+                if (MIX) lds_wait(wl, wh);
+                else { lds_wait_first12(wl, wh); unpack12(wl, wh, f, 0); lds_wait_last12(wl, wh); unpack12(wl, wh, f, 12); }
+                #pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (oRel + j >= rows) break;              // wave-uniform
+                    float ax, ay, az;
+                    if (MIX) filter21(wl, wh, j, ax, ay, az); else filter21(f, j, ax, ay, az);
+                    const uint32_t hx = float_to_half_bits(ax), hy = float_to_half_bits(ay), hz = float_to_half_bits(az);   // == the BlurOutput store
+                    const uint32_t px = (uint32_t)lds[hx] | ((uint32_t)lds[hy] << 8) | ((uint32_t)lds[hz] << 16) | (255u << 24);   // alpha 1 -> 255
+                    if (xOk) dstCol[(size_t)(oRel + j) * W] = px;
+                }
+            }
+            pb += PC_RS; if (pb >= PC_RING) pb -= PC_RING;
+            __syncthreads();
         }
     }
 }
-
 
 } // namespace
 
 namespace vqk {
 
-// Which form of the X pass runs is chosen for the FRAME, not for the kernel alone (profiles/r2k_frame_loop.md): the software-pipelined persistent
-// form is the fastest kernel in isolation (25.9 us at 4K with 1 024 workgroups, 27.3 with 2 048), but with many workgroups in flight on real image
-// data it makes the chip throttle, and the shade kernel that follows it runs 2-13 % slower. Option "blur_x_wgs" overrides the default for tuning:
-// 0 = one workgroup per 1024-pixel segment (k_blur_x4), n > 0 = n persistent workgroups (k_blur_x4p).
 hipError_t launch_blur_x(hipStream_t s, const void* in, void* out, int W, int H, int fmt, const Options& opt) {
-    const int segsPerRow = (W + 1023) / 1024, nSeg = segsPerRow * H;
-    int want = opt.blurXWgs;
-    if (want <= 0 && H > 65535) want = 1024;               // grid.y is limited to 65 535: taller images take the persistent form
-    if (want > 0) {
-        const int wgs = nSeg < want ? nSeg : want;
-        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4p<0>), dim3(wgs), dim3(256), 0, s, in, out, W, H, segsPerRow, nSeg);
-        else                          hipLaunchKernelGGL((k_blur_x4p<1>), dim3(wgs), dim3(256), 0, s, in, out, W, H, segsPerRow, nSeg);
-    } else {
-        dim3 grid(segsPerRow, H);
-        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4<0>), grid, dim3(256), 0, s, in, out, W, H);
-        else                          hipLaunchKernelGGL((k_blur_x4<1>), grid, dim3(256), 0, s, in, out, W, H);
-    }
+    const int segsPerRow = (W + 1023) / 1024;
+    if ((long long)segsPerRow * H > 0x7fffffffLL) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(segsPerRow * H));
+    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_x4<0>), grid, dim3(256), 0, s, in, out, W, H, segsPerRow);
+    else                          hipLaunchKernelGGL((k_blur_x4<1>), grid, dim3(256), 0, s, in, out, W, H, segsPerRow);
     return hipGetLastError();
 }
 
 hipError_t launch_blur_y(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H, int fmt) {
-#ifndef VQ_BLUR_Y_TR
-#define VQ_BLUR_Y_TR 0      // A/B at 4K RGBA16F (scripts/bench_variants.sh): register window 31 us, LDS tile TR=16/32/64: 41/36/49 us
-#endif
-#if VQ_BLUR_Y_TR
-    constexpr int TR = VQ_BLUR_Y_TR;                          // LDS-tiled: (TR+20) rows x 64 px staged once, TR/4 outputs per lane
-    dim3 grid((W + 63) / 64, (H + TR - 1) / TR);
-    const VQ_TonemapperParams none = {};
-    if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_y_tonemap<0, 0, TR, false>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H, none);
-    else                          hipLaunchKernelGGL((k_blur_y_tonemap<1, 1, TR, false>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H, none);
-#else
     constexpr int ROWS = 16;                                  // register-window variant
     dim3 grid((W + 63) / 64, (H + 4 * ROWS - 1) / (4 * ROWS));
     if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_blur_y<0, ROWS>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H);
     else                          hipLaunchKernelGGL((k_blur_y<1, ROWS>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H);
-#endif
     return hipGetLastError();
 }
 
@@ -549,13 +582,6 @@ hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
                                  const VQ_TonemapperParams& p, int fmt, int outFmt, const void* lutTable, const Options& opt) {
     if (lutTable && blur_y_tonemap_uses_lut(p, fmt, outFmt, (size_t)W * H)) {
-        if (opt.blurYForm != 1) {                             // rolling window (default); "blur_y_form" = "window" selects the 36-row-window kernel below
-            int S = opt.blurYRows > 0 ? opt.blurYRows : 64;
-            if (S < 12) S = 12;
-            const int stripsX = (W + 63) / 64, stripsY = (H + S - 1) / S, nStrips = stripsX * stripsY;
-            hipLaunchKernelGGL(k_blur_y_tonemap_roll, dim3((nStrips + 7) / 8), dim3(512), 0, s, in, out, haloTop, haloBottom, haloRows, W, H, lutTable, stripsX, nStrips, S);
-            return hipGetLastError();
-        }
         const int tilesX = (W + 63) / 64, tilesY = (H + 127) / 128, nTiles = tilesX * tilesY;
         int wgs = 512;                                        // two 64 KB tables per CU
         if (opt.blurYWgs > 0) wgs = opt.blurYWgs;             // tuning knob, like "blur_x_wgs"
@@ -563,10 +589,7 @@ hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const
                            lutTable, tilesX, nTiles);
         return hipGetLastError();
     }
-#ifndef VQ_FUSED_TR
-#define VQ_FUSED_TR 16
-#endif
-    constexpr int TR = VQ_FUSED_TR;                           // output rows per workgroup (TR/4 per lane); LDS (TR+20) rows x 64 px
+    constexpr int TR = 16;                                    // output rows per workgroup (TR/4 per lane); LDS (TR+20) rows x 64 px
     dim3 grid((W + 63) / 64, (H + TR - 1) / TR);
 #define BT(F, O) hipLaunchKernelGGL((k_blur_y_tonemap<F, O, TR>), grid, dim3(256), 0, s, in, out, haloTop, haloBottom, haloRows, W, H, p)
     if (fmt == VQHIP_FMT_RGBA32F) {
@@ -575,6 +598,37 @@ hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const
         if (outFmt == VQHIP_FMT_RGBA32F) BT(1, 0); else if (outFmt == VQHIP_FMT_RGBA16F) BT(1, 1); else BT(1, 2);
     }
 #undef BT
+    return hipGetLastError();
+}
+
+// The chain kernel applies: RGBA16F scene colour, RGBA8 target, a display curve that does not mix channels, and a frame large enough to give every CU a strip
+bool post_chain_applies(const VQ_TonemapperParams& p, int inFmt, int outFmt, int W, int H, const Options& opt) {
+    if (opt.postForm == 1 || !perChannelCurve(p) || inFmt != VQHIP_FMT_RGBA16F || outFmt != VQHIP_FMT_RGBA8_UNORM) return false;
+    return opt.postForm == 2 || (long long)W * H >= (1 << 20);
+}
+// haloTop / haloBottom: SCENE-COLOUR rows of the neighbouring tiles (NULL: image border)
+hipError_t launch_post_chain(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
+                             const void* lutTable, int nCUs, const Options& opt) {
+    const int stripsX = (W + PC_C - 1) / PC_C;
+    int stripsY = opt.postStrips > 0 ? opt.postStrips : (nCUs > stripsX ? nCUs / stripsX : 1);      // one workgroup per CU, in ONE round
+    const int maxY = (H + 43) / 44;                           // strips shorter than 44 rows filter more halo rows than rows of their own
+    if (stripsY > maxY) stripsY = maxY;
+    if (stripsY < 1) stripsY = 1;
+    const int S = (H + stripsY - 1) / stripsY;
+    stripsY = (H + S - 1) / S;
+    const int xcdBands = (8 % stripsY == 0 && stripsX % (8 / stripsY) == 0) ? 8 / stripsY : 0;     // XCD-aware strip order (see the kernel) when the strips divide evenly
+    hipError_t e;
+    if (opt.postMix != 1) {                                   // default: v_fma_mix_f32 on the packed window (58.9 against 61.7 us at 4K for the converted window, profiles/r5g_post_forms.md)
+        e = hipFuncSetAttribute((const void*)k_post_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);      // > 64 KB of LDS needs the opt-in
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_post_chain<true>, dim3((unsigned)(stripsX * stripsY)), dim3(1024), PC_LDS, s, in, out, haloTop, haloBottom, haloRows, W, H, lutTable,
+                           stripsX, stripsY, S, xcdBands);
+    } else {
+        e = hipFuncSetAttribute((const void*)k_post_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_post_chain<false>, dim3((unsigned)(stripsX * stripsY)), dim3(1024), PC_LDS, s, in, out, haloTop, haloBottom, haloRows, W, H, lutTable,
+                           stripsX, stripsY, S, xcdBands);
+    }
     return hipGetLastError();
 }
 

@@ -22,10 +22,11 @@ struct Range {
 struct Options {
     int shadeWg = 0;            // "shade_wg"          : 64 | 128 | 256 lanes per workgroup of the shade kernel (default: by frame size)
     int psmainWaves = 0;        // "psmain_waves"      : 4 | 5 | 6 waves per SIMD of the fused PSMain kernel
-    int blurXWgs = 0;           // "blur_x_wgs"        : n > 0 = n persistent workgroups (k_blur_x4p)
     int blurYWgs = 0;           // "blur_y_wgs"        : workgroups of k_blur_y_tonemap_lut
-    int blurYForm = 0;          // "blur_y_form"       : 1 "window" = k_blur_y_tonemap_lut (36-row register window; round 2-4's default); default: k_blur_y_tonemap_roll
-    int blurYRows = 0;          // "blur_y_rows"       : output rows per wave-strip of k_blur_y_tonemap_roll (default 64)
+    int postForm = 0;           // "post_form"         : 1 "two" = blur X, then blur Y + tonemap (two kernels) whatever the frame; 2 "chain" = k_post_chain whatever the size
+                                //                       (default: k_post_chain for RGBA16F -> RGBA8 frames of >= 2^20 pixels with a per-channel display curve, else two kernels)
+    int postMix = 0;            // "post_mix"          : 1 = k_post_chain converts its windows to fp32 and filters with v_fmac_f32 (default: v_fma_mix_f32 on the packed window)
+    int postStrips = 0;         // "post_strips"       : row strips per column strip of k_post_chain (default: CUs / column strips — one workgroup per CU)
     int lutForm = 0;            // "lut_form"          : 1 "general" (every range test left in)
     int diffuseForm = 0;        // "diffuse_form"      : 1 "texels", 2 "general" (default: footprint records)
     int diffuseSeqForm = 0;     // "diffuse_seq_form"  : 1 "lane" (default: k_conv_diffuse_ordered)
@@ -138,6 +139,9 @@ hipError_t launch_tonemap_lut_build(hipStream_t s, void* table, const VQ_Tonemap
 hipError_t launch_tonemap(hipStream_t s, const void* in, void* out, int W, int H, const VQ_TonemapperParams& p, int inFmt, int outFmt, const void* lutTable, const Options& opt);
 hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
                                  const VQ_TonemapperParams& p, int fmt, int outFmt, const void* lutTable, const Options& opt);
+bool post_chain_applies(const VQ_TonemapperParams& p, int inFmt, int outFmt, int W, int H, const Options& opt);
+hipError_t launch_post_chain(hipStream_t s, const void* in, void* out, const void* haloTop, const void* haloBottom, int haloRows, int W, int H,
+                             const void* lutTable, int nCUs, const Options& opt);
 hipError_t launch_brdf_lut(hipStream_t s, void* out, int size, int samples, int fmt, int pow5ExpLog, const Options& opt);
 hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw, int sh, int dw, int dh);
 size_t conv_diffuse_record_bytes(int w0, int h0, int nMips);
