@@ -989,7 +989,7 @@ def widened_report(ctx, env, spec_mips):
     eq = dev(synth.equirect(2048, 2048))
     sp = scene_mod.skydome_params(0.9, -0.2, 0.5, 60.0 * math.pi / 180.0, W, H)
     res["skydome_all_sky"] = entry(_stage_stats(lambda: ctx.skydome(eq, sp, scene, F16)), 8, what="vqhip_skydome over a frame without geometry: 8 B/px written, equirect taps cache resident")
-    # ---- 8f.3: Radiance .hdr ingest, 2048^2 (256 run-length coded rows, repeated): host header parse + run expansion, device RGBE -> RGBA32F
+    # ---- 8f.3: Radiance .hdr ingest, 2048^2 (256 run-length coded rows, repeated): host header parse + walk of the run headers, device run expansion + RGBE -> RGBA32F
     rgbe = synth.float_to_rgbe(synth.equirect(2048, 256)[..., :3])
     part = synth.hdr_file_bytes(rgbe)
     body = part[part.index(b"+X 2048\n") + 8:]
@@ -1002,7 +1002,9 @@ def widened_report(ctx, env, spec_mips):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 3 * 1e3
     res["hdr_decode_2048"] = {"ms": round(ms, 3), "file_bytes": len(data), "Mpix_s": round(2048 * 2048 / ms / 1e3, 1),
-                              "what": "vqhip_hdr_decode_rgba32f, wall time of the call + stream sync: the run expansion is host code (one thread), the conversion a 20 B/px kernel"}
+                              "kernel_ms": None,
+                              "what": "vqhip_hdr_decode_rgba32f, wall time of the call + stream sync: host walk of the run headers (count bytes only), upload of the encoded file from "
+                                      "pageable memory, ONE kernel that expands the runs (a workgroup per scanline, a wave per byte plane, through LDS) and converts RGBE -> RGBA32F"}
     # ---- 8f.4: FSR 1.0 (2560x1440 -> 3840x2160, RGBA8), SSR environment fallback
     iw, ih = 2560, 1440
     src = torch.randint(0, 256, (ih, iw, 4), dtype=torch.uint8, device="cuda")

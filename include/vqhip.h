@@ -329,11 +329,12 @@ VQHIP_API int  vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode);
 /* Tuning / A-B options of a context, read by the launchers at call time (never from the process environment: getenv racing a host setenv is
  * undefined behaviour, and VQEngine records on many threads, SceneRendering.cpp:563-706). value NULL, "" or "default" restores the default. Every
  * form selected here gives the bits of the default form (tests/test_gpu_conv_forms.py, tests/test_gpu_round3.py); unknown keys / values: VQHIP_ERR_INVALID_ARG.
- *   shade_wg 64|128|256 · psmain_waves 4|5|6 · blur_y_wgs n · post_form two|chain · post_strips n · lut_form general ·
+ *   shade_wg 64|128|256 · psmain_waves 4|5|6 · blur_y_wgs n · post_form two|chain · post_strips n · post_mix 0|1 · lut_form general ·
  *   diffuse_form records|texels|general · diffuse_seq_form ordered|lane
  * (the non-default values are the general / fallback forms of the same kernels; the measured-and-rejected kernel forms of rounds 2-5 — the compact tonemap
  * tables, the per-sample LUT and per-mip specular kernels, the persistent X pass, the rolling-ring Y pass — are not in the library: docs/HISTORY.md).
- * post_form: "two" = vqhip_post_process[_tile] always runs blur X, then blur Y + tonemap (two kernels); "chain" = the one-kernel chain whatever the frame size
+ * psmain_waves applies to the literal reading only (the DXC-reading instantiation of the fused PSMain kernel has one register cap). post_mix 1: the chain kernel converts its
+ * windows to fp32 first (A/B form, slower). post_form: "two" = vqhip_post_process[_tile] always runs blur X, then blur Y + tonemap (two kernels); "chain" = the one-kernel chain whatever the frame size
  * (default: the chain for RGBA16F -> RGBA8 frames of >= 2^20 pixels and a per-channel display curve, the two kernels otherwise). */
 VQHIP_API int  vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value);
 typedef enum vqhip_arithmetic { VQHIP_ARITH_LITERAL = 0, VQHIP_ARITH_DXC = 1 } vqhip_arithmetic;
@@ -580,8 +581,9 @@ VQHIP_API int vqhip_unlit_composite(vqhip_ctx* ctx, void* stream, const vqhip_in
  * "FORMAT=32-bit_rle_rgbe" line, blank line, "-Y <height> +X <width>", then per scanline either new-style RLE
  * (02 02 hi lo + four run-length coded byte planes) or flat RGBE quadruples (width < 8, width >= 32768, or no
  * 02 02 marker); pixel = (r,g,b) * 2^(e-136), (0,0,0) when e == 0, alpha := 1.
- * The header parse and the byte-serial run expansion stay on the host; the RGBE -> RGBA32F conversion (4 B in,
- * 16 B out per pixel) runs on the GPU straight into level 0 of the chain that vqhip_mip_chain_min_rgba32f completes.
+ * The host parses the header and walks the run headers (count bytes only: where every byte plane of every scanline starts, and whether the file is sound); the
+ * encoded bytes go to the GPU as they are, and one kernel expands the runs (a workgroup per scanline, a wave per byte plane, through LDS) and converts RGBE -> RGBA32F
+ * straight into level 0 of the chain that vqhip_mip_chain_min_rgba32f completes. Flat files and scanlines wider than ~19 000 pixels: expansion on the host.
  *   file / bytes : HOST memory holding the whole .hdr file
  * Truncated or corrupt run data returns VQHIP_ERR_INVALID_ARG (stb_image reads zeros past the end of the file). */
 VQHIP_API int vqhip_hdr_parse_header(const void* file, size_t bytes, int* width, int* height, size_t* data_offset);

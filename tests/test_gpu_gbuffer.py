@@ -169,6 +169,83 @@ def test_hdr_ingest_matches_oracle(ctx, rle):
     assert n == 0, (n, idx)
 
 
+def _hdr_with_groups(rgbe, r, style):
+    """A run-length coded .hdr whose byte planes are cut into groups the way `style` says (every coding stb_image accepts, not only the tidy one of synth._rle_plane):
+    'ones' = literal groups of one byte; 'max' = runs of 127 / literal groups of 128 wherever the data allows; 'mixed' = random group lengths, equal bytes coded as
+    runs OR literals at random (a run of length 1 and 2 included)."""
+    h, w = rgbe.shape[:2]
+    head = b"#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)
+    body = bytearray()
+    for y in range(h):
+        body += bytes((2, 2, w >> 8, w & 255))
+        for k in range(4):
+            row, i = rgbe[y, :, k], 0
+            while i < w:
+                same = 1
+                while i + same < w and same < 127 and row[i + same] == row[i]:
+                    same += 1
+                if style == "ones":
+                    n, run = 1, False
+                elif style == "max":
+                    run = same >= 2
+                    n = same if run else min(128, w - i)
+                else:
+                    run = bool(r.integers(0, 2))
+                    n = int(r.integers(1, same + 1)) if run else int(r.integers(1, min(128, w - i) + 1))
+                if run:
+                    body += bytes((128 + n, int(row[i])))
+                else:
+                    body += bytes((n,)) + row[i:i + n].tobytes()
+                i += n
+    return head + bytes(body)
+
+
+@pytest.mark.parametrize("style", ["ones", "max", "mixed"])
+@pytest.mark.parametrize("shape", [(3, 8), (5, 9), (2, 255), (7, 300), (3, 2048), (2, 4097), (1, 19000)])
+def test_hdr_run_expansion_on_the_gpu(ctx, shape, style):
+    """The GPU run expansion (hdri.hip:k_hdr_expand: a workgroup per scanline, a wave per byte plane) against the oracle for every group structure stb_image accepts,
+    widths from the smallest run-length coded one to the widest the LDS path takes, long constant stretches (runs of 127) and noise (literal groups of 128)."""
+    h, w = shape
+    r = np.random.default_rng(h * 1000 + w)
+    rgbe = r.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    rgbe[:, w // 3: w // 3 + min(w // 2, 700)] = (7, 7, 9, 130)          # constant stretch: runs
+    rgbe[0, :, 3] = 0                                                   # zero exponents
+    data = _hdr_with_groups(rgbe, r, style)
+    ref = O.hdr_decode(data)
+    got = ctx.load_hdr(data)
+    n, idx = O.bits_equal(got.cpu().numpy(), ref)
+    assert n == 0, (n, idx)
+
+
+def test_hdr_corrupt_files_get_the_oracles_verdict(ctx):
+    """Truncation at every byte of a small run-length coded file and single corrupted count bytes: the C ABI accepts / refuses exactly the files the oracle
+    accepts / refuses (the host walk of the run headers validates what the host expansion of round 4 validated), and what it accepts decodes to the same bits."""
+    r = np.random.default_rng(5)
+    rgbe = r.integers(0, 256, (3, 40, 4), dtype=np.uint8)
+    rgbe[1, 5:30] = (1, 2, 3, 140)
+    good = synth.hdr_file_bytes(rgbe)
+    w, h, off = capi.hdr_parse_header(good)
+    cases = [good[:n] for n in range(off, len(good))]
+    for pos in range(off, len(good), 3):
+        for v in (0, 129, 255, 128, 2):
+            cases.append(good[:pos] + bytes((v,)) + good[pos + 1:])
+    n_ok = 0
+    for data in cases:
+        try:
+            ref = O.hdr_decode(data)
+        except ValueError:
+            ref = None
+        try:
+            got = ctx.load_hdr(data).cpu().numpy()
+        except Exception:
+            got = None
+        assert (ref is None) == (got is None), (len(data), ref is None, got is None)
+        if ref is not None:
+            n_ok += 1
+            assert O.bits_equal(got, ref)[0] == 0
+    assert n_ok > 10
+
+
 def test_hdr_ingest_errors(ctx):
     rgbe = synth.float_to_rgbe(synth.equirect(32, 4)[..., :3])
     good = synth.hdr_file_bytes(rgbe)

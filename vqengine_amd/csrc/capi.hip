@@ -849,10 +849,29 @@ int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, siz
     if (hdr_parse_header((const uint8_t*)file, bytes, &w, &h, &off, &err)) return fail(ctx, VQHIP_ERR_INVALID_ARG, err);
     if (w != width || h != height) return fail(ctx, VQHIP_ERR_INVALID_ARG, "hdr_decode: width/height do not match the file header");
     const size_t px = (size_t)w * h;
-    std::vector<uint8_t> rgbe(px * 4);
-    if (hdr_expand_rgbe((const uint8_t*)file, bytes, off, w, h, rgbe.data(), &err)) return fail(ctx, VQHIP_ERR_INVALID_ARG, err);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
+    // run-length coded files: the host walks the run headers (offsets of every byte plane, validation), the GPU expands the runs and converts (hdri.hip:k_hdr_expand)
+    {
+        std::vector<uint32_t> planeOff(4 * (size_t)h + 1);
+        const int wr = hdr_walk_runs((const uint8_t*)file, bytes, off, w, h, planeOff.data(), &err);
+        if (wr < 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, err);
+        int encCap = 0, pitch = 0, ldsBytes = 0;
+        if (wr == 0 && hdr_expand_fits(planeOff.data(), w, h, &encCap, &pitch, &ldsBytes)) {
+            const size_t used = planeOff[4 * (size_t)h], fileDev = (used + 4 + 255) & ~(size_t)255, tabBytes = planeOff.size() * 4;
+            const int rc = ensureScratch(ctx, fileDev + tabBytes);
+            if (rc) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch, file, used, hipMemcpyHostToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->scratch + fileDev, planeOff.data(), tabBytes, hipMemcpyHostToDevice, st));
+            hipError_t e = launch_hdr_expand(st, ctx->scratch, (char*)ctx->scratch + fileDev, out_rgba32f, w, h, encCap, pitch, ldsBytes);
+            if (e != hipSuccess) return failHip(ctx, e, "hdr_expand launch");
+            HIP_TRY(ctx, hipStreamSynchronize(st));  // load-time call: the offset table and the scratch buffer are free again on return
+            return VQHIP_OK;
+        }
+    }
+    // flat files, scanlines too wide for the LDS: expansion on the host, conversion on the GPU
+    std::vector<uint8_t> rgbe(px * 4);
+    if (hdr_expand_rgbe((const uint8_t*)file, bytes, off, w, h, rgbe.data(), &err)) return fail(ctx, VQHIP_ERR_INVALID_ARG, err);
     int rc = ensureScratch(ctx, px * 4);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch, rgbe.data(), px * 4, hipMemcpyHostToDevice, st));

@@ -9,8 +9,12 @@
 //     followed by four run-length coded byte planes (count > 128: run of count-128 copies; else count literals; a count of
 //     0 or one overrunning the scanline is corrupt); a first scanline without the 02 02 marker means the whole image is flat;
 //   * pixel = (r,g,b) * 2^(e - 136) (ldexp(1, e-(128+8))), (0,0,0) for e == 0, alpha = 1.
-// Split: header parse + byte-serial run expansion on the host (each scanline's length is only known by walking its runs),
-// RGBE -> RGBA32F on the GPU (k_rgbe_to_rgba32f: 4 B in + 16 B out per pixel, HBM-bound), straight into level 0 of the mip chain.
+// Split (round 5): the host parses the header and WALKS the run headers of every scanline — count bytes only, no pixel is touched: that finds where every byte
+// plane of every scanline starts (a scanline's length is only known by walking its runs) and validates the file; the encoded bytes go to the GPU as they are and
+// k_hdr_expand expands them: one workgroup per scanline parks the scanline's encoded bytes in LDS, one wave per byte plane expands its runs (a run or literal group per
+// iteration, its up to 128 bytes written by the lanes in parallel) into four plane rows in LDS, then every lane converts whole pixels (RGBE -> RGBA32F, 16-byte coalesced
+// stores) straight into level 0 of the mip chain. Scanlines too wide for the LDS (> 19 000 pixels) and flat (not run-length coded) files take the round-4 path:
+// expansion on the host, k_rgbe_to_rgba32f on the GPU.
 #include <cstdlib>
 #include <cstring>
 #include "vq_internal.h"
@@ -111,17 +115,107 @@ int hdr_expand_rgbe(const uint8_t* f, size_t n, size_t off, int w, int h, uint8_
     return 0;
 }
 
-// stbi__hdr_convert, req_comp == 4: rgb * ldexp(1, e - 136), zero when e == 0, alpha 1
+// The run headers of a run-length coded image, walked without expanding anything: planeOff[4 j + k] = offset (from the start of the file) of byte plane k of
+// scanline j, planeOff[4 h] = the end of the data. Validates exactly what hdr_expand_rgbe validates. Returns 1 when the image is not (entirely) run-length coded
+// (flat data: the caller expands on the host), 0 on success, -1 on a corrupt file.
+int hdr_walk_runs(const uint8_t* f, size_t n, size_t off, int w, int h, uint32_t* planeOff, const char** err) {
+    if (w < 8 || w >= 32768 || n > 0xfffffff0u) return 1;
+    size_t i = off;
+    for (int j = 0; j < h; ++j) {
+        if (i > n || n - i < 3) { *err = "hdr: truncated pixel data"; return -1; }
+        if (f[i] != 2 || f[i + 1] != 2 || (f[i + 2] & 0x80)) {
+            if (j != 0) { *err = "hdr: scanline without run-length marker after the first"; return -1; }
+            return 1;                                          // flat data: hdr_expand_rgbe
+        }
+        if (n - i < 4) { *err = "hdr: truncated pixel data"; return -1; }
+        if (((f[i + 2] << 8) | f[i + 3]) != w) { *err = "hdr: invalid decoded scanline length"; return -1; }
+        i += 4;
+        for (int k = 0; k < 4; ++k) {
+            planeOff[4 * (size_t)j + k] = (uint32_t)i;
+            int left = w;
+            while (left > 0) {
+                if (i >= n) { *err = "hdr: truncated pixel data"; return -1; }
+                int count = f[i++];
+                if (count > 128) {
+                    if (i >= n) { *err = "hdr: truncated pixel data"; return -1; }
+                    count -= 128;
+                    if (count > left) { *err = "hdr: corrupt run"; return -1; }
+                    i += 1;
+                } else {
+                    if (count == 0 || count > left) { *err = "hdr: corrupt run"; return -1; }
+                    if (n - i < (size_t)count) { *err = "hdr: truncated pixel data"; return -1; }
+                    i += (size_t)count;
+                }
+                left -= count;
+            }
+        }
+    }
+    planeOff[4 * (size_t)h] = (uint32_t)i;
+    return 0;
+}
+
+__device__ __forceinline__ float4 rgbe_to_float4(uint32_t q) {                       // stbi__hdr_convert, req_comp == 4: rgb * ldexp(1, e - 136), zero when e == 0, alpha 1
+    const int e = (int)(q >> 24);
+    float4 c = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    if (e != 0) {
+        const float f1 = __builtin_ldexpf(1.0f, e - 136);       // exact, denormal below e = 10
+        c.x = (float)(q & 255u) * f1; c.y = (float)((q >> 8) & 255u) * f1; c.z = (float)((q >> 16) & 255u) * f1;
+    }
+    return c;
+}
+
+// One workgroup per scanline, 256 lanes = one wave per byte plane. LDS: the scanline's encoded bytes (from the 4-byte aligned address below its first plane), then
+// four plane rows of `pitch` bytes. file: the whole .hdr file on the device, 4-byte aligned; planeOff: hdr_walk_runs' table.
+__global__ __launch_bounds__(256) void k_hdr_expand(const uint8_t* __restrict__ file, const uint32_t* __restrict__ planeOff, float4* __restrict__ out, int w, int encCap, int pitch) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int j = blockIdx.x, t = threadIdx.x;
+    const uint32_t o0 = planeOff[4 * (size_t)j], o4 = planeOff[4 * (size_t)j + 4];
+    const uint32_t a0 = o0 & ~3u;                             // the copy starts at an aligned dword
+    const int nDw = (int)((o4 - a0 + 3) >> 2);
+    for (int i = t; i < nDw; i += 256) ((uint32_t*)lds)[i] = ((const uint32_t*)(file + a0))[i];
+    __syncthreads();
+    unsigned char* planes = lds + encCap;
+    {
+        const int k = __builtin_amdgcn_readfirstlane(t >> 6), lane = t & 63;
+        unsigned char* dst = planes + k * pitch;
+        int src = (int)(planeOff[4 * (size_t)j + k] - a0);    // wave-uniform
+        int done = 0;
+        while (done < w) {                                    // one run or literal group per iteration: validated by the host walk
+            int count = lds[src];
+            const bool run = count > 128;
+            if (run) count -= 128;
+            if (lane < count) dst[done + lane] = lds[run ? src + 1 : src + 1 + lane];
+            if (lane + 64 < count) dst[done + lane + 64] = lds[run ? src + 1 : src + 65 + lane];
+            src += run ? 2 : 1 + count;
+            done += count;
+        }
+    }
+    __syncthreads();
+    for (int x = t; x < w; x += 256) {
+        const uint32_t q = (uint32_t)planes[x] | ((uint32_t)planes[pitch + x] << 8) | ((uint32_t)planes[2 * pitch + x] << 16) | ((uint32_t)planes[3 * pitch + x] << 24);
+        out[(size_t)j * w + x] = rgbe_to_float4(q);
+    }
+}
+// encoded bytes of the longest scanline (+ alignment slack) and the LDS the kernel needs for it; false when it does not fit
+bool hdr_expand_fits(const uint32_t* planeOff, int w, int h, int* encCap, int* pitch, int* ldsBytes) {
+    uint32_t longest = 0;
+    for (int j = 0; j < h; ++j) { const uint32_t len = planeOff[4 * (size_t)j + 4] - (planeOff[4 * (size_t)j] & ~3u); if (len > longest) longest = len; }
+    *encCap = (int)((longest + 3 + 15) & ~15u);
+    *pitch = (w + 15) & ~15;
+    *ldsBytes = *encCap + 4 * *pitch;
+    return *ldsBytes <= 160 * 1024;
+}
+hipError_t launch_hdr_expand(hipStream_t s, const void* file, const void* planeOff, void* out, int w, int h, int encCap, int pitch, int ldsBytes) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_hdr_expand, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_hdr_expand, dim3((unsigned)h), dim3(256), ldsBytes, s, (const uint8_t*)file, (const uint32_t*)planeOff, (float4*)out, w, encCap, pitch);
+    return hipGetLastError();
+}
+
+// stbi__hdr_convert over expanded RGBE quadruples (the host-expansion path)
 __global__ __launch_bounds__(256) void k_rgbe_to_rgba32f(const uint32_t* __restrict__ rgbe, float4* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t q = rgbe[i];
-        const int e = (int)(q >> 24);
-        float4 c = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
-        if (e != 0) {
-            const float f1 = __builtin_ldexpf(1.0f, e - 136);       // exact, denormal below e = 10
-            c.x = (float)(q & 255u) * f1; c.y = (float)((q >> 8) & 255u) * f1; c.z = (float)((q >> 16) & 255u) * f1;
-        }
-        out[i] = c;
+        out[i] = rgbe_to_float4(rgbe[i]);
     }
 }
 

@@ -584,7 +584,7 @@ hipError_t launch_blur_y_tonemap(hipStream_t s, const void* in, void* out, const
     if (lutTable && blur_y_tonemap_uses_lut(p, fmt, outFmt, (size_t)W * H)) {
         const int tilesX = (W + 63) / 64, tilesY = (H + 127) / 128, nTiles = tilesX * tilesY;
         int wgs = 512;                                        // two 64 KB tables per CU
-        if (opt.blurYWgs > 0) wgs = opt.blurYWgs;             // tuning knob, like "blur_x_wgs"
+        if (opt.blurYWgs > 0) wgs = opt.blurYWgs;             // tuning knob
         hipLaunchKernelGGL((k_blur_y_tonemap_lut<16>), dim3(nTiles < wgs ? nTiles : wgs), dim3(512), 0, s, in, out, haloTop, haloBottom, haloRows, W, H,
                            lutTable, tilesX, nTiles);
         return hipGetLastError();

@@ -178,14 +178,9 @@ VQD float4 sample_cube_rgba16f(const void* cube, int N, f3 dir) {
     // One branch-free tap path for interior and edge footprints alike: on the 64^2 / <=128^2 cubes of the reference nearly
     // every wave holds a lane whose footprint crosses a face edge, so a separate interior fast path only ever ran IN ADDITION
     // to the general one. A tap outside through ONE edge comes from the adjacent face (table lookup, selected by predicate);
-    // a tap outside through a corner is "missing" (rare: handled in the only divergent branch).
+    // a tap outside through a corner is "missing" (rare: handled in the only divergent branch). (An interior fast path in front of it was measured:
+    // +1.6 % on coherent content, -0.8 % on the BASELINE frame, profiles/r4*; not in the source.)
     float4 c[4];
-#if VQ_CUBE_TWO_PATH                                                  // A/B switch (scripts/bench_variants.sh): interior fast path in front
-    if (ix >= 0 && iy >= 0 && ix + 1 < N && iy + 1 < N) {
-        const size_t base = ((size_t)f * N + iy) * N + ix;
-        return blend4(load_rgba16f(cube, base), load_rgba16f(cube, base + 1), load_rgba16f(cube, base + N), load_rgba16f(cube, base + N + 1), wx, wy);
-    }
-#endif
     int missing = -1;
     // the two columns of a footprint can only leave the face on the same side (ix < 0: left, else right), likewise the rows:
     // two table entries per sample serve all four taps
