@@ -391,6 +391,9 @@ class Pipeline:
         self.s_comp = torch.cuda.Stream(dev) if world > 1 else self.s_main       # used only while comms.overlap
         self.e_post = [torch.cuda.Event(), torch.cuda.Event()]
         self.e_comp = [None, None]
+        # fault injection for tests/test_gpu_bench_flow.py ("drop_post_wait"): leave out the wait that orders the composite behind the post kernel; against an
+        # asynchronous transport the frame must come out wrong
+        self.fault = os.environ.get("VQ_BENCH_FAULT", "")
 
     def free(self):
         self.gb = self.scene = self.sdr = self.frame = self.xblur = self.yblur = None
@@ -447,7 +450,8 @@ class Pipeline:
         if world > 1:
             if overlap:
                 self.e_post[b].record(s_main)
-                s_comp.wait_event(self.e_post[b])
+                if self.fault != "drop_post_wait":
+                    s_comp.wait_event(self.e_post[b])
             if ev and "comp0" in ev:
                 rec("comp0", s_comp)
             self.comms.comp.composite_tiles(self.sdr[b], R8, self.frame_h, self.root, self.frame[b], stream=C.c_void_p(s_comp.cuda_stream))
@@ -460,6 +464,24 @@ class Pipeline:
     def drain(self):
         if self.comms.overlap:
             self.s_main.wait_stream(self.s_comp)
+
+    def verify_step(self, i):
+        """One step whose output buffers were zeroed first (and the device drained): what the composite delivers can only be this step's pixels if every wait
+        between the streams is in place."""
+        b = i & 1
+        self.drain()
+        torch.cuda.synchronize()
+        self.sdr[b].zero_()
+        if self.frame[b] is not None:
+            self.frame[b].zero_()
+        torch.cuda.synchronize()
+        self.d.barrier()
+        self.e_comp[b] = None
+        self.step(i)
+        self.drain()
+        torch.cuda.synchronize()
+        self.d.barrier()
+        return b
 
     def timed(self, n_steps, evs=None, first=0):
         self.d.barrier()
@@ -680,7 +702,7 @@ def main():
         # debug aid: rank 0 recomputes the WHOLE frame on its own GPU (no tiles, no halos) and compares it byte for byte with the
         # composite of the last step — the row tiling + halo exchange + composite on real kernels (tests/test_gpu_bench_flow.py)
         torch.cuda.synchronize()
-        last = 4 & 1
+        last = pipe.verify_step(4)
         if rank == 0:
             gb_full = upload_tile(cfg, frame_h, 0, frame_h)
             sc = ctx.forward_lighting(gb_full, pipe.pf, pipe.pv, out_fmt=F16, extra_point=pipe.extra, env=pipe.env)

@@ -78,6 +78,19 @@ def test_overlap_watchdog_falls_back_to_one_stream_order():
     assert d["config"]["composite_overlap"] is False and d["rccl"]["composite_overlap_mode"] == "off" and d["rccl"]["fallback"], d["rccl"]
 
 
+def test_a_missing_stream_wait_corrupts_the_frame_under_the_asynchronous_transport():
+    """The stand-in for RCCL is asynchronous like RCCL (tests/cpp/mock_rccl.cpp: the transfers of a group run on the communicator's worker thread behind an event of
+    the caller's stream, later work on that stream waits on a signal word, ncclGroupEnd returns at once), so the orderings between the main stream and the composite's
+    stream are real orderings, not only control flow. The verified step starts from zeroed output buffers on a drained device: leaving out the wait that puts the
+    composite behind the post kernel (VQ_BENCH_FAULT) must deliver a wrong frame. The synchronous form of the stand-in ($VQMOCK_RCCL_SYNC=1, rounds 1-4) still runs
+    the unbroken flow to the right frame."""
+    args = ["--config", "cfg3", "--composite-overlap", "on", "--no-extras"]
+    d = _run(2, args, VQ_BENCH_FAULT="drop_post_wait")
+    assert d["verify"]["mismatching_bytes"] > 0, d["verify"]
+    d = _run(2, args, VQMOCK_RCCL_SYNC="1")
+    assert d["verify"]["mismatching_bytes"] == 0, d["verify"]
+
+
 def test_gpus_n_without_a_launcher_starts_its_own_ranks():
     """`python bench.py --gpus 2` — the shape of the driver's N = 1 command, no torchrun around it: bench.py starts the two ranks itself and rank 0
     prints one line with n_gpus 2 (VERDICT r4 #2). Without the share-one-GPU debug aid and with fewer GPUs than ranks it must refuse loudly."""
