@@ -60,7 +60,9 @@ VALU_PEAK_TFLOPS = 157.3        # :40
 SHADE_BYTES_PER_PX = 64 + 8     # 4 float4 G-buffer planes in + RGBA16F out
 SPINUP_STEPS = int(os.environ.get("VQ_BENCH_SPINUP", "200"))     # untimed steady-state spin-up before the W warm-up steps (~0.25 s of GPU work)
 COLD_STEPS = 20                 # the first steps after the idle set-up phase, timed on their own ("cold_start")
-VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s = 133 TFLOP/s of dependent-free v_fma_f32 at steady-state clocks (scripts/ubench/valu_ceiling.hip)
+VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s: the FAST issue rate of the chip at steady-state clocks — plain fp32 add / mul / fma on registers, or v_pk_fma_f32 counted as two
+                                # (scripts/ubench/valu_ceiling.hip is the packed form; scripts/ubench/mix_rate.hip, profiles/r5f_issue_classes.md: instructions with an SGPR source,
+                                # conversions, compares, min / max and integer operations issue at 35 T, v_rcp / v_rsq at 17 T)
 XGMI_LINK_GBPS = 153.0          # per direct GPU-GPU link, peak; the tile-curve model also quotes half of it
 WATCHDOG_S = float(os.environ.get("VQ_BENCH_WATCHDOG_S", "30"))
 SUSTAINED_S = float(os.environ.get("VQ_BENCH_SUSTAINED_S", "2.0"))   # length of the `sustained` companion run (0: off)
@@ -697,6 +699,26 @@ def main():
                      "value": round(W * frame_h * n_sus / dt_sus / 1e6, 2), "unit": "Mpix/s",
                      "note": "same step, same buffers, one barrier + synchronize bracket around all of it; after the timed region (power limiter and clocks in their long-run state)"}
 
+    # 4c. the post chain as ONE kernel (k_post_chain), same frame loop, same clocks: a companion figure next to the two-kernel chain the headline times by default
+    chain_alt = None
+    if args.post == "fused" and not args.no_extras:
+        args.post = "chain"
+        for i in range(10):
+            pipe.step(i)
+        pipe.drain()
+        n_alt = max(20, min(args.steps, 100)); n_alt += n_alt & 1
+        dt_alt = pipe.timed(n_alt)
+        evc2 = [{"shade": _ev(), "post": _ev()} for _ in range(10)]
+        for i in range(10):
+            pipe.step(n_alt + i, evc2[i])
+        pipe.drain()
+        d.barrier()
+        args.post = "fused"
+        chain_alt = {"steps": n_alt, "ms_per_step": round(dt_alt / n_alt * 1e3, 4), "value": round(W * frame_h * n_alt / dt_alt / 1e6, 2), "unit": "Mpix/s",
+                     "post_chain_ms": round(mean_ms(evc2, "shade", "post"), 4), "bytes_per_px": 12,
+                     "note": "bench.py --post chain: blur X, blur Y and the tonemapper in one kernel (8 B read + 4 B written per pixel; row tiles exchange scene-colour halos); "
+                             "identical bits; the default of vqhip_post_process for frames of >= 2^20 pixels (profiles/r5g_post_forms.md)"}
+
     verify = None
     if world > 1 and os.environ.get("VQ_BENCH_VERIFY") == "1":
         # debug aid: rank 0 recomputes the WHOLE frame on its own GPU (no tiles, no halos) and compares it byte for byte with the
@@ -765,7 +787,7 @@ def main():
                 extras["cfg2"]["valu_issue"] = {"valu_instr_per_wave": c2["valu_instr_per_wave"], "achieved_T_lane_instr_s": round(c2["valu_instr_per_wave"] * 64 * waves2 / t2 / 1e12, 2),
                                                 "ceiling": VALU_ISSUE_CEILING_TLIS, "frac": round(c2["valu_instr_per_wave"] * 64 * waves2 / t2 / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
                                                 "traffic": c2.get("hbm_bytes_per_launch"),
-                                                "note": "SQ_INSTS_VALU / SQ_WAVES of the cfg2 launch (profiles/pmc_constants.json) x live kernel time against the measured v_fma_f32 issue ceiling"}
+                                                "note": "SQ_INSTS_VALU / SQ_WAVES of the cfg2 launch (profiles/pmc_constants.json) x live kernel time against the fast issue rate (see valu_issue.note)"}
             extras["ibl_load"] = ibl_load_report(ibl_t)
             extras["widened"] = widened_report(ctx, env, pre["spec_mips"])
             if args.config == "cfg3":
@@ -834,6 +856,7 @@ def main():
                        **({"blur_x_includes": "halo exchange", "composite_ms": round(mean_ms(evd, "comp0", "comp1"), 4)} if world > 1 else {})},
             "frame_latency_ms": round(frame_latency * 1e3, 4),
             **({"sustained": sustained} if sustained else {}),
+            **({"one_kernel_post_chain": chain_alt} if chain_alt else {}),
             "cold_start": {"steps": COLD_STEPS, "ms_per_step": round(dt_cold / COLD_STEPS * 1e3, 4), "value": round(px_frame * COLD_STEPS / dt_cold / 1e6, 2),
                            "note": "the first steps after the idle set-up phase, before the clocks ramp; `value` is the steady-state figure"},
         }
@@ -844,8 +867,11 @@ def main():
                                  "frac": round(vw * 64 * waves / t_shade / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
                                  "frac_slot_weighted": round((vw + 3 * tw) * 64 * waves / t_shade / 1e12 / VALU_ISSUE_CEILING_TLIS, 4),
                                  "valu_instr_per_wave": vw, "quarter_rate_instr_per_wave": tw,
-                                 "note": "the binding roof: VALU instructions issued per second (PMC count x live kernel time) vs the steady-state v_fma_f32 "
-                                         "issue rate of the chip (scripts/ubench/valu_ceiling.hip); slot-weighted counts each quarter-rate v_rcp/v_rsq as 4 slots"}
+                                 "ceiling_slow_class": 35.4,
+                                 "note": "the binding roof: VALU instructions issued per second (PMC count x live kernel time) vs the FAST issue rate of the chip (plain fp32 "
+                                         "add / mul / fma on registers; scripts/ubench/valu_ceiling.hip, mix_rate.hip). Instructions with an SGPR source, conversions, compares, min / max "
+                                         "issue at ceiling_slow_class, v_rcp / v_rsq at a quarter of the fast rate (profiles/r5f_issue_classes.md): the light loop's mix (91 fast, 18 slow, "
+                                         "3 transcendental of 112) cannot reach frac 1 whatever its schedule; slot-weighted counts each v_rcp / v_rsq as 4 slots"}
         if second is not None:
             out["engine_lowering" if second["fresnel_pow"] == "exp2_log2" else "product_lowering"] = second
         if dxc is not None:

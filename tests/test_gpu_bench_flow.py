@@ -48,6 +48,15 @@ def test_cfg3_weak_scaling_flow_matches_the_untiled_frame(ranks, composite, over
     assert "cfg5_strong" not in d
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_one_kernel_post_chain_flow_matches_the_untiled_frame(ranks):
+    """bench.py --post chain: every rank runs blur X + blur Y + tonemap as ONE kernel over its tile (vqhip_post_process_tile) and the neighbours exchange 10 rows of SCENE
+    COLOUR right behind the shade kernel; the composited frame equals the untiled frame of the two-kernel chain byte for byte (3 ranks: the middle tile has two halos)."""
+    d = _run(ranks, ["--config", "cfg3", "--post", "chain", "--no-extras"])
+    assert d["n_gpus"] == ranks and d["verify"]["mismatching_bytes"] == 0, d["verify"]
+    assert "ONE kernel" in d["config"]["post"] and d["stages"]["post_chain_bytes_per_px"] == 12
+
+
 def test_every_run_also_times_cfg5_strong_scaling():
     """The standard invocation at N = 3: the cfg3 headline (weak) AND the cfg5 strong-scaling object the >= 6x target is defined on
     (one 7680x4320 frame, 256 lights, 1440 rows per rank), with its stage figures and the communicator's own report."""
@@ -121,8 +130,10 @@ def test_single_gpu_line_carries_the_contract_fields():
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline", "stages", "engine_lowering", "dxc_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants", "rccl",
-              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained", "widened"):
+              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained", "widened", "one_kernel_post_chain"):
         assert k in d, k
+    oc = d["one_kernel_post_chain"]
+    assert oc["bytes_per_px"] == 12 and oc["ms_per_step"] > 0 and abs(oc["value"] - 3840 * 2160 / (oc["ms_per_step"] * 1e-3) / 1e6) < 0.01 * oc["value"]
     su = d["sustained"]                                      # ~0.5 s of the headline's step here (VQ_BENCH_SUSTAINED_S), same order as `value`
     assert su["steps"] >= 200 and su["steps"] % 2 == 0 and su["value"] > 0
     assert abs(su["value"] - 3840 * 2160 * su["steps"] / su["seconds"] / 1e6) < 0.01 * su["value"]
