@@ -687,8 +687,9 @@ VQHIP_API int vqhip_visualize(vqhip_ctx* ctx, void* stream, const void* in, void
  * G-buffer, lights / env maps / LUT are replicated. vqhip_forward_lighting, vqhip_gaussian_blur_x and the tonemapper need
  * no communication; the two exchanges below are the whole multi-GPU data path:
  *
- *   vqhip_gaussian_blur_x(tile) -> vqhip_exchange_blur_halos -> vqhip_gaussian_blur_y[_tonemap](tile, halo_top, halo_bottom)
- *                                                            -> vqhip_composite_tiles
+ *   vqhip_forward_lighting(tile) -> vqhip_exchange_blur_halos(scene colour) -> vqhip_post_process_tile(tile, halo_top, halo_bottom) -> vqhip_composite_tiles
+ *   or, pass by pass:
+ *   vqhip_gaussian_blur_x(tile) -> vqhip_exchange_blur_halos(X-blurred) -> vqhip_gaussian_blur_y[_tonemap](tile, halo_top, halo_bottom) -> vqhip_composite_tiles
  *
  * A vqhip_comm wraps an RCCL communicator (one rank per GPU, xGMI point-to-point). RCCL is loaded at run time
  * (librccl.so.1, or the library named by $VQHIP_RCCL_LIBRARY): single-GPU hosts never touch it. Like every other entry point

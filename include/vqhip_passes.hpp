@@ -205,11 +205,21 @@ public:
             if (mStatus == VQHIP_OK && (p->CompositeRoot == VQHIP_ALL_RANKS || p->CompositeRoot == rank) && !p->pCompositeFrame) mStatus = VQHIP_ERR_INVALID_ARG;
             if (mStatus != VQHIP_OK) return;
         }
-        if (p->bEnableGaussianBlur) {
-            // CSMain_X -> BlurIntermediate, then CSMain_Y + Tonemapper in one kernel (SceneRendering.cpp:2582-2656): identical bits to
-            // the separate dispatches through BlurOutput, which never touches HBM. On the SDR path the Y pass stores through the
-            // 64 KB tonemap table in LDS (34 us vs 26 + 23 us at 4K); the HDR path (RGBA16F out) uses the LDS-tiled fused kernel,
-            // which is slower than two dispatches there, so it keeps them.
+        if (p->bEnableGaussianBlur && !p->bHDR) {
+            // SDR: CSMain_X, CSMain_Y and the tonemapper (SceneRendering.cpp:2582-2656) are ONE call — one kernel for frames of >= 2^20 pixels (neither BlurIntermediate
+            // nor BlurOutput touches HBM), identical bits to the separate dispatches. Row-tiled mode: exchange 1 moves the 10 boundary rows of SCENE COLOUR right behind
+            // the shade kernel (the X pass is horizontal: the neighbour's rows are filtered here like the tile's own).
+            const void* top = nullptr; const void* bottom = nullptr; int haloRows = 0;
+            if (p->pComm) {
+                mStatus = vqhip_exchange_blur_halos(p->pComm, p->Stream, p->pSceneColor, (int)mWidth, (int)mHeight, (int)mWidth, VQHIP_FMT_RGBA16F, mHaloTop, mHaloBottom);
+                if (mStatus != VQHIP_OK) return;
+                top = rank > 0 ? mHaloTop : nullptr; bottom = rank < world - 1 ? mHaloBottom : nullptr; haloRows = (top || bottom) ? VQHIP_HALO_ROWS : 0;
+            }
+            mStatus = vqhip_post_process_tile(mCtx, p->Stream, p->pSceneColor, mTonemapperOut, top, bottom, haloRows, (int)mWidth, (int)mHeight, &p->TonemapperParams,
+                                              VQHIP_FMT_RGBA16F, mOutFormat);
+        } else if (p->bEnableGaussianBlur) {
+            // HDR (RGBA16F out): CSMain_X -> BlurIntermediate, CSMain_Y -> BlurOutput, tonemapper — the fused Y + tonemap kernel on the LDS tile is slower than two
+            // dispatches there, so it keeps them.
             const VQ_BlurParams bp = { (int32_t)mWidth, (int32_t)mHeight };                                      // FBlurParams, PostProcess.h:92-96
             mStatus = vqhip_gaussian_blur_x(mCtx, p->Stream, p->pSceneColor, mBlurIntermediate, &bp, VQHIP_FMT_RGBA16F);
             if (mStatus != VQHIP_OK) return;
@@ -219,14 +229,9 @@ public:
                 if (mStatus != VQHIP_OK) return;
                 top = rank > 0 ? mHaloTop : nullptr; bottom = rank < world - 1 ? mHaloBottom : nullptr; haloRows = (top || bottom) ? VQHIP_HALO_ROWS : 0;
             }
-            if (!p->bHDR) {
-                mStatus = vqhip_gaussian_blur_y_tonemap(mCtx, p->Stream, mBlurIntermediate, mTonemapperOut, top, bottom, haloRows, &bp, &p->TonemapperParams,
-                                                        VQHIP_FMT_RGBA16F, mOutFormat);
-            } else {
-                mStatus = vqhip_gaussian_blur_y(mCtx, p->Stream, mBlurIntermediate, mBlurOutput, top, bottom, haloRows, &bp, VQHIP_FMT_RGBA16F);
-                if (mStatus != VQHIP_OK) return;
-                mStatus = vqhip_tonemap(mCtx, p->Stream, mBlurOutput, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
-            }
+            mStatus = vqhip_gaussian_blur_y(mCtx, p->Stream, mBlurIntermediate, mBlurOutput, top, bottom, haloRows, &bp, VQHIP_FMT_RGBA16F);
+            if (mStatus != VQHIP_OK) return;
+            mStatus = vqhip_tonemap(mCtx, p->Stream, mBlurOutput, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
         } else {
             mStatus = vqhip_tonemap(mCtx, p->Stream, p->pSceneColor, mTonemapperOut, (int)mWidth, (int)mHeight, &p->TonemapperParams, VQHIP_FMT_RGBA16F, mOutFormat);
         }
