@@ -3,10 +3,11 @@
 
 A "step" is one pass of the hot path over one synthetic frame (tile) that is already resident in HBM:
     forward lighting (point lights [+ IBL sample])   -> RGBA16F scene colour   [vqhip_forward_lighting]
-    21-tap Gaussian blur X                            -> RGBA16F                 [vqhip_gaussian_blur_x]
-    (N > 1) 10-row halo exchange with the neighbours                             [vqhip_exchange_blur_halos, RCCL send/recv]
-    blur Y + tonemap (Reinhard + sRGB OETF)           -> RGBA8_UNORM             [vqhip_gaussian_blur_y_tonemap]
+    (N > 1) 10-row halo exchange of scene colour with the neighbours            [vqhip_exchange_blur_halos, RCCL send/recv]
+    21-tap Gaussian blur X, blur Y, tonemap (Reinhard + sRGB OETF), ONE kernel -> RGBA8_UNORM   [vqhip_post_process_tile]
     (N > 1) composite of the RGBA8 tiles on rank 0                               [vqhip_composite_tiles, RCCL send/recv]
+(--post fused: blur X [vqhip_gaussian_blur_x], exchange of X-blurred rows, blur Y + tonemap in one kernel [vqhip_gaussian_blur_y_tonemap] — rounds 1-4's chain, reported
+as `other_post_form`; --post split: three dispatches.)
 
 The HEADLINE (`metric`, `value`, `ms_per_step`, `roofline`) is --config cfg3, BASELINE config 3, the configuration the metric is quoted on:
 a 3840x2160 tile per GPU, 64 point lights + the full-size cfg4 IBL; N > 1 is WEAK scaling (frame 3840 x 2160*N). K timed steps, exactly.
@@ -569,9 +570,10 @@ def measure_strong(pipe, steps, warmup):
     out = {"value": round(px * steps / dt / 1e6, 2), "unit": "Mpix/s", "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
            "frame": [pipe.W, pipe.frame_h], "tile_rows": pipe.rows, "lights": pipe.cfg["lights"], "scaling": pipe.cfg["scaling"],
            "shade_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "t0", "shade")), 4),
-           "blur_x_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "shade", "x")), 4),
+           **({"post_chain_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "halo", "post")), 4)} if pipe.args.post == "chain" else
+              {"blur_x_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "shade", "x")), 4),
+               "blur_y_tonemap_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "halo", "post")), 4)}),
            "halo_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "x", "halo")), 4) if pipe.d.world > 1 else 0.0,
-           "blur_y_tonemap_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "halo", "post")), 4),
            "composite_ms": round(pipe.d.max_over_ranks(mean_ms(evd, "comp0", "comp1")), 4) if pipe.d.world > 1 else 0.0,
            "composite_overlapped": pipe.comms.overlap,
            "frame_latency_ms": round(pipe.latency() * 1e3, 4),
@@ -588,8 +590,9 @@ def main():
     ap.add_argument("--config", choices=["cfg3", "cfg5"], default="cfg3", help="the HEADLINE workload (the other BASELINE configs are reported as extra objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip cfg5_strong / cfg2 / ibl_load / coherent_scene / tile_curve")
-    ap.add_argument("--post", choices=["chain", "fused", "split"], default="fused",
-                    help="post chain after the X blur: Y blur and tonemapper as two dispatches (split) or one kernel (fused); identical bits")
+    ap.add_argument("--post", choices=["chain", "fused", "split"], default="chain",
+                    help="post chain: blur X + blur Y + tonemapper in ONE kernel (chain: vqhip_post_process_tile, the library's default for frames of >= 2^20 pixels), "
+                         "blur X then Y blur + tonemapper in one kernel (fused), or three dispatches (split); identical bits")
     ap.add_argument("--composite", choices=["root", "all"], default="root",
                     help="final composite of the RGBA8 tiles: on rank 0 only (the presenting GPU; it receives over its N-1 direct xGMI links) or on every rank")
     ap.add_argument("--composite-overlap", choices=["auto", "on", "off", "two-comms"], default="auto",
@@ -650,13 +653,11 @@ def main():
     #     than after the timed region: after ~0.4 s of sustained shading a burst of X passes runs 2.5-3x slower — the chip's power limiter,
     #     profiles/r2k_frame_loop.md — which says nothing about the kernel.)
     iso = None
-    if args.post == "chain":
-        st = _stage_stats(lambda: ctx.post_process_tile(pipe.scene[0], F16, R8, out=pipe.sdr[0], halo_top=pipe.halo_top, halo_bottom=pipe.halo_bottom), spin_s=0.01)
-        iso = {"post_chain": st["ms"] * 1e-3, "post_chain_spread": [round(st["ms_min"], 4), round(st["ms_max"], 4)]}
-        pipe.drain()
-        d.barrier()
-    if args.post == "fused":
+    if args.post in ("chain", "fused"):
         iso = {}
+        if args.post == "chain":
+            st = _stage_stats(lambda: ctx.post_process_tile(pipe.scene[0], F16, R8, out=pipe.sdr[0], halo_top=pipe.halo_top, halo_bottom=pipe.halo_bottom), spin_s=0.01)
+            iso.update({"post_chain": st["ms"] * 1e-3, "post_chain_spread": [round(st["ms_min"], 4), round(st["ms_max"], 4)]})
         for name, fn in (("blur_x", lambda: ctx.gaussian_blur_x(pipe.scene[0], F16, out=pipe.xblur)),
                          ("blur_y_tonemap", lambda: ctx.gaussian_blur_y_tonemap(pipe.xblur, F16, R8, out=pipe.sdr[0], halo_top=pipe.halo_top, halo_bottom=pipe.halo_bottom))):
             st = _stage_stats(fn, spin_s=0.01)               # the frame loop has just spun the chip up
@@ -664,6 +665,11 @@ def main():
             iso[name + "_spread"] = [round(st["ms_min"], 4), round(st["ms_max"], 4)]
         pipe.drain()
         d.barrier()
+        # the isolated passes above are ~0.5 s of light post-kernel load: the chip leaves the clock / power state the frame loop had reached, and the W warm-up steps
+        # (5 for the driver) are too few to bring it back (measured: `value` 6 % under `sustained` without this). Half a spin-up of the frame loop again, untimed.
+        for i in range(SPINUP_STEPS // 2):
+            pipe.step(i)
+        pipe.drain()
     for i in range(args.warmup):
         pipe.step(i)
     pipe.drain()
@@ -699,10 +705,11 @@ def main():
                      "value": round(W * frame_h * n_sus / dt_sus / 1e6, 2), "unit": "Mpix/s",
                      "note": "same step, same buffers, one barrier + synchronize bracket around all of it; after the timed region (power limiter and clocks in their long-run state)"}
 
-    # 4c. the post chain as ONE kernel (k_post_chain), same frame loop, same clocks: a companion figure next to the two-kernel chain the headline times by default
+    # 4c. the OTHER form of the post chain (two kernels when the headline runs the one-kernel chain, and vice versa), same frame loop, same clocks: a companion figure
     chain_alt = None
-    if args.post == "fused" and not args.no_extras:
-        args.post = "chain"
+    if args.post in ("chain", "fused") and not args.no_extras:
+        mine, other = args.post, ("fused" if args.post == "chain" else "chain")
+        args.post = other
         for i in range(10):
             pipe.step(i)
         pipe.drain()
@@ -713,11 +720,12 @@ def main():
             pipe.step(n_alt + i, evc2[i])
         pipe.drain()
         d.barrier()
-        args.post = "fused"
-        chain_alt = {"steps": n_alt, "ms_per_step": round(dt_alt / n_alt * 1e3, 4), "value": round(W * frame_h * n_alt / dt_alt / 1e6, 2), "unit": "Mpix/s",
-                     "post_chain_ms": round(mean_ms(evc2, "shade", "post"), 4), "bytes_per_px": 12,
-                     "note": "bench.py --post chain: blur X, blur Y and the tonemapper in one kernel (8 B read + 4 B written per pixel; row tiles exchange scene-colour halos); "
-                             "identical bits; the default of vqhip_post_process for frames of >= 2^20 pixels (profiles/r5g_post_forms.md)"}
+        args.post = mine
+        chain_alt = {"form": other, "steps": n_alt, "ms_per_step": round(dt_alt / n_alt * 1e3, 4), "value": round(W * frame_h * n_alt / dt_alt / 1e6, 2), "unit": "Mpix/s",
+                     "post_chain_ms": round(mean_ms(evc2, "shade", "post"), 4), "bytes_per_px": 12 if other == "chain" else 28,
+                     "note": "bench.py --post " + other + ": " + ("blur X, blur Y and the tonemapper in one kernel (8 B read + 4 B written per pixel; row tiles exchange scene-colour halos)"
+                                                                 if other == "chain" else "blur X (16 B/px), then blur Y + tonemapper in one kernel (12 B/px); row tiles exchange X-blurred halos") +
+                             "; identical bits; measured right after the sustained run (compare with sustained.ms_per_step, not with ms_per_step: profiles/r5g_post_forms.md)"}
 
     verify = None
     if world > 1 and os.environ.get("VQ_BENCH_VERIFY") == "1":
@@ -814,7 +822,7 @@ def main():
             "config": {"workload": cfg["workload"] + ("" if world == 1 else f"; frame {W}x{frame_h} row-tiled {rows} rows per GPU, RCCL p2p halo exchange + composite on "
                                                        f"{'rank 0' if root == 0 else 'every rank'} through the C ABI"),
                        "name": args.config, "width": W, "frame_height": frame_h, "tile_rows": rows, "lights": L, "parallelism": f"rows{world}",
-                       "composite_overlap": overlap, "untimed_spinup_steps": SPINUP_STEPS, "fresnel_pow": args.fresnel_pow,
+                       "composite_overlap": overlap, "untimed_spinup_steps": SPINUP_STEPS + (SPINUP_STEPS // 2 if args.post in ("chain", "fused") else 0), "fresnel_pow": args.fresnel_pow,
                        "post": {"chain": "blur X, blur Y and the tonemapper in ONE kernel (identical bits to three dispatches)",
                                 "fused": "blur X, then blur Y + tonemap in one kernel (identical bits to three dispatches)", "split": "blur X, blur Y, tonemap"}[args.post]},
             "roofline": {"bound": "hbm", "kernel": f"k_forward_lighting<{'env' if cfg['env'] else 'noenv'},nocasters,RGBA16F>", "achieved": round(ach, 2),
@@ -838,6 +846,10 @@ def main():
                                               "HBM: *_frac_at_28_B_per_px prices the same time at the 28 B/px the two-kernel chain of rounds 1-4 moved, for comparison with their figures",
                            "isolated": {"post_chain_ms": round(iso["post_chain"] * 1e3, 4), "post_chain_ms_spread": iso["post_chain_spread"],
                                         "post_chain_frac_of_hbm_peak": round(px_tile * 12 / iso["post_chain"] / 1e9 / HBM_PEAK_GBPS, 4),
+                                        "two_kernels": {"blur_x_ms": round(iso["blur_x"] * 1e3, 4), "blur_x_frac_of_hbm_peak": round(px_tile * 16 / iso["blur_x"] / 1e9 / HBM_PEAK_GBPS, 4),
+                                                        "blur_y_tonemap_ms": round(iso["blur_y_tonemap"] * 1e3, 4),
+                                                        "blur_y_tonemap_frac_of_hbm_peak": round(px_tile * 12 / iso["blur_y_tonemap"] / 1e9 / HBM_PEAK_GBPS, 4),
+                                                        "note": "the kernels of --post fused alone (halos of the tiled path here: whatever the buffers hold)"},
                                         "note": "median of 7 batches of back-to-back launches of the one kernel, after the spin-up and before the warm-up steps"}} if args.post == "chain" else
                           {"blur_x_ms": round(t_blur * 1e3, 4), "blur_x_GBps": round(px_tile * 16 / t_blur / 1e9, 1),
                            "blur_y_tonemap_ms": round(t_tm * 1e3, 4), "blur_y_tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1),
@@ -856,7 +868,7 @@ def main():
                        **({"blur_x_includes": "halo exchange", "composite_ms": round(mean_ms(evd, "comp0", "comp1"), 4)} if world > 1 else {})},
             "frame_latency_ms": round(frame_latency * 1e3, 4),
             **({"sustained": sustained} if sustained else {}),
-            **({"one_kernel_post_chain": chain_alt} if chain_alt else {}),
+            **({"other_post_form": chain_alt} if chain_alt else {}),
             "cold_start": {"steps": COLD_STEPS, "ms_per_step": round(dt_cold / COLD_STEPS * 1e3, 4), "value": round(px_frame * COLD_STEPS / dt_cold / 1e6, 2),
                            "note": "the first steps after the idle set-up phase, before the clocks ramp; `value` is the steady-state figure"},
         }
