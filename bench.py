@@ -394,6 +394,9 @@ class Pipeline:
         self.s_comp = torch.cuda.Stream(dev) if world > 1 else self.s_main       # used only while comms.overlap
         self.e_post = [torch.cuda.Event(), torch.cuda.Event()]
         self.e_comp = [None, None]
+        self.s_post = torch.cuda.Stream(dev) if world == 1 else None
+        self.e_shade = [torch.cuda.Event(), torch.cuda.Event()]
+        self.e_pdone = [None, None]
         # fault injection for tests/test_gpu_bench_flow.py ("drop_post_wait"): leave out the wait that orders the composite behind the post kernel; against an
         # asynchronous transport the frame must come out wrong
         self.fault = os.environ.get("VQ_BENCH_FAULT", "")
@@ -412,11 +415,28 @@ class Pipeline:
         rec = (lambda k, s=s_main: ev[k].record(s)) if ev else (lambda k, s=None: None)
         if overlap and self.e_comp[b] is not None:   # sdr[b] / frame[b] were last touched by the composite of step i-2
             s_main.wait_event(self.e_comp[b])
+        if self.e_pdone[b] is not None:             # --post-stream own: shade(i) overwrites scene[b], which post(i - 2) reads on the other stream
+            s_main.wait_event(self.e_pdone[b])
+            self.e_pdone[b] = None
         if ev and "t0" in ev:
             rec("t0")
         ctx.forward_lighting(self.gb, self.pf, self.pv, out=self.scene[b], out_fmt=F16, extra_point=self.extra, env=self.env)
         if ev and "shade" in ev:
             rec("shade")
+        if self.args.post == "chain" and world == 1 and getattr(self.args, "post_stream", "main") == "own":
+            # N = 1 experiment: the post chain of frame i on its own stream, so that it runs next to the shade kernel of frame i + 1 (double-buffered scene colour)
+            if ev and "x" in ev:
+                rec("x")
+            if ev and "halo" in ev:
+                rec("halo")
+            self.e_shade[b].record(s_main)
+            self.s_post.wait_event(self.e_shade[b])
+            ctx.post_process_tile(self.scene[b], F16, R8, out=self.sdr[b], stream=self.s_post)
+            self.e_pdone[b] = torch.cuda.Event()
+            self.e_pdone[b].record(self.s_post)
+            if ev and "post" in ev:
+                ev["post"].record(self.s_post)
+            return
         if self.args.post == "chain":
             # X, Y and the tonemapper in ONE kernel (k_post_chain): neither BlurIntermediate nor BlurOutput exists. Row tiles exchange 10 rows of SCENE COLOUR
             # right behind the shade kernel (the X pass is horizontal: the kernel filters the neighbour's rows like its own)
@@ -467,6 +487,8 @@ class Pipeline:
     def drain(self):
         if self.comms.overlap:
             self.s_main.wait_stream(self.s_comp)
+        if self.s_post is not None:
+            self.s_main.wait_stream(self.s_post)
 
     def verify_step(self, i):
         """One step whose output buffers were zeroed first (and the device drained): what the composite delivers can only be this step's pixels if every wait
@@ -593,6 +615,9 @@ def main():
     ap.add_argument("--post", choices=["chain", "fused", "split"], default="chain",
                     help="post chain: blur X + blur Y + tonemapper in ONE kernel (chain: vqhip_post_process_tile, the library's default for frames of >= 2^20 pixels), "
                          "blur X then Y blur + tonemapper in one kernel (fused), or three dispatches (split); identical bits")
+    ap.add_argument("--post-stream", choices=["main", "own"], default="own",
+                    help="N = 1 with --post chain: the post chain of frame i on a stream of its own, next to the shade kernel of frame i + 1 (double-buffered scene colour; + 1.5 %: "
+                         "profiles/r5y_post_stream_ab.txt), or on the main stream (main). N > 1 keeps the main stream (the composite is what overlaps the next frame there)")
     ap.add_argument("--composite", choices=["root", "all"], default="root",
                     help="final composite of the RGBA8 tiles: on rank 0 only (the presenting GPU; it receives over its N-1 direct xGMI links) or on every rank")
     ap.add_argument("--composite-overlap", choices=["auto", "on", "off", "two-comms"], default="auto",
@@ -715,14 +740,14 @@ def main():
         pipe.drain()
         n_alt = max(20, min(args.steps, 100)); n_alt += n_alt & 1
         dt_alt = pipe.timed(n_alt)
-        evc2 = [{"shade": _ev(), "post": _ev()} for _ in range(10)]
+        evc2 = [{"t0": _ev(), "shade": _ev(), "post": _ev()} for _ in range(10)]
         for i in range(10):
             pipe.step(n_alt + i, evc2[i])
         pipe.drain()
         d.barrier()
         args.post = mine
         chain_alt = {"form": other, "steps": n_alt, "ms_per_step": round(dt_alt / n_alt * 1e3, 4), "value": round(W * frame_h * n_alt / dt_alt / 1e6, 2), "unit": "Mpix/s",
-                     "post_chain_ms": round(mean_ms(evc2, "shade", "post"), 4), "bytes_per_px": 12 if other == "chain" else 28,
+                     "shade_ms": round(mean_ms(evc2, "t0", "shade"), 4), "post_chain_ms": round(mean_ms(evc2, "shade", "post"), 4), "bytes_per_px": 12 if other == "chain" else 28,
                      "note": "bench.py --post " + other + ": " + ("blur X, blur Y and the tonemapper in one kernel (8 B read + 4 B written per pixel; row tiles exchange scene-colour halos)"
                                                                  if other == "chain" else "blur X (16 B/px), then blur Y + tonemapper in one kernel (12 B/px); row tiles exchange X-blurred halos") +
                              "; identical bits; measured right after the sustained run (compare with sustained.ms_per_step, not with ms_per_step: profiles/r5g_post_forms.md)"}
@@ -742,6 +767,23 @@ def main():
             verify = {"mismatching_bytes": int((want != pipe.frame[last]).sum().item()), "frame": [W, frame_h]}
             del gb_full, sc, xb, want
         d.barrier()
+    if world == 1 and os.environ.get("VQ_BENCH_VERIFY") == "1":
+        # N = 1: the frame loop's own double buffering (and, with --post-stream own, the ordering between the two streams): both buffer pairs zeroed on a drained
+        # device, four steps, then each SDR image against the two-kernel chain computed in stream order — a step that read scene colour before its shade kernel had
+        # written it, or a shade kernel that overwrote what a post chain was still reading, leaves other bytes
+        pipe.drain(); torch.cuda.synchronize()
+        for t in pipe.scene + pipe.sdr:
+            t.zero_()
+        pipe.e_pdone = [None, None]
+        torch.cuda.synchronize()
+        for i in range(4):
+            pipe.step(i)
+        pipe.drain(); torch.cuda.synchronize()
+        sc = ctx.forward_lighting(pipe.gb, pipe.pf, pipe.pv, out_fmt=F16, extra_point=pipe.extra, env=pipe.env)
+        want = ctx.gaussian_blur_y_tonemap(ctx.gaussian_blur_x(sc, F16), F16, R8)
+        torch.cuda.synchronize()
+        verify = {"mismatching_bytes": int((want != pipe.sdr[0]).sum().item()) + int((want != pipe.sdr[1]).sum().item()), "frame": [W, frame_h], "buffers": 2}
+        del sc, want
 
     # 5. the other Fresnel-pow lowering, same invocation, same clocks: `engine_lowering` is the engine-faithful exp2(5*log2 x) form
     second = None
@@ -809,6 +851,8 @@ def main():
         else:
             t_blur, t_tm = mean_ms(evd, "shade", "halo") * 1e-3, mean_ms(evd, "halo", "post") * 1e-3
         t_chain = mean_ms(evc, "shade", "post") * 1e-3
+        own_stream = args.post == "chain" and world == 1 and args.post_stream == "own"
+        t_chain_alone = iso["post_chain"] if (own_stream and iso and "post_chain" in iso) else t_chain
         ach = SHADE_BYTES_PER_PX * px_tile / t_shade / 1e9
         flops_px = 170 * L + 160
         pmc, pmc_meta = load_pmc_constants(args.config + ("_coherent" if args.content == "coherent" else ""), args.fresnel_pow)
@@ -823,6 +867,8 @@ def main():
                                                        f"{'rank 0' if root == 0 else 'every rank'} through the C ABI"),
                        "name": args.config, "width": W, "frame_height": frame_h, "tile_rows": rows, "lights": L, "parallelism": f"rows{world}",
                        "composite_overlap": overlap, "untimed_spinup_steps": SPINUP_STEPS + (SPINUP_STEPS // 2 if args.post in ("chain", "fused") else 0), "fresnel_pow": args.fresnel_pow,
+                       "post_stream": ("own: the post chain of frame i runs on a second stream next to the shade kernel of frame i + 1 (double-buffered); frame_latency_ms is one frame alone"
+                                       if (args.post == "chain" and world == 1 and args.post_stream == "own") else "main"),
                        "post": {"chain": "blur X, blur Y and the tonemapper in ONE kernel (identical bits to three dispatches)",
                                 "fused": "blur X, then blur Y + tonemap in one kernel (identical bits to three dispatches)", "split": "blur X, blur Y, tonemap"}[args.post]},
             "roofline": {"bound": "hbm", "kernel": f"k_forward_lighting<{'env' if cfg['env'] else 'noenv'},nocasters,RGBA16F>", "achieved": round(ach, 2),
@@ -830,7 +876,9 @@ def main():
                          "traffic": pmc["hbm_bytes_per_launch"] if pmc else None, "traffic_unit": "bytes/launch",
                          "traffic_source": "rocprofv3 PMC, separate passes, 2*FETCH_SIZE + WRITE_SIZE (profiles/pmc_constants.json); algorithmic = %d" % (SHADE_BYTES_PER_PX * px_tile),
                          "bytes_per_px": SHADE_BYTES_PER_PX, "ms": round(t_shade * 1e3, 4),
-                         "note": f"{L}-light shading is VALU-bound by construction (SURVEY.md 8d): see valu / valu_issue; the HBM-bound kernels are under stages and cfg2"},
+                         "note": f"{L}-light shading is VALU-bound by construction (SURVEY.md 8d): see valu / valu_issue; the post kernels are under stages, cfg2 is its own object" +
+                                 ("; --post-stream own: this kernel shares the chip with the previous frame's post chain, its launch lasts ~2-3 % longer than alone "
+                                  "(other_post_form.shade_ms: alone, main stream)" if own_stream else "")},
             "valu": {"achieved_tflops_model": round(flops_px * px_tile / t_shade / 1e12, 2), "peak": VALU_PEAK_TFLOPS,
                      "frac": round(flops_px * px_tile / t_shade / 1e12 / VALU_PEAK_TFLOPS, 4), "flops_per_px_model": flops_px},
             "pmc_constants": pmc_meta,
@@ -838,9 +886,12 @@ def main():
             "stages": {"shade_Mpix_s": round(px_tile / t_shade / 1e6, 1), "shade_ms": round(t_shade * 1e3, 4),
                        **({"blur_xy_ms": round(t_blur * 1e3, 4), "blur_xy_GBps": round(px_tile * 32 / t_blur / 1e9, 1),
                            "tonemap_ms": round(t_tm * 1e3, 4), "tonemap_GBps": round(px_tile * 12 / t_tm / 1e9, 1)} if args.post == "split" else
-                          {"post_chain_ms": round(t_chain * 1e3, 4), "post_chain_bytes_per_px": 12, "post_chain_GBps": round(px_tile * 12 / t_chain / 1e9, 1),
-                           "post_chain_frac_of_hbm_peak": round(px_tile * 12 / t_chain / 1e9 / HBM_PEAK_GBPS, 4),
-                           "post_chain_frac_at_28_B_per_px": round(px_tile * 28 / t_chain / 1e9 / HBM_PEAK_GBPS, 4),
+                          {"post_chain_ms": round(t_chain * 1e3, 4), "post_chain_bytes_per_px": 12,
+                           **({"post_chain_co_runs_with": "the shade kernel of the next frame (--post-stream own): post_chain_ms is the stretched interval on the second stream, the *_frac "
+                                                          "figures below price the kernel ALONE (stages.isolated.post_chain_ms)"} if own_stream else {}),
+                           "post_chain_GBps": round(px_tile * 12 / t_chain_alone / 1e9, 1),
+                           "post_chain_frac_of_hbm_peak": round(px_tile * 12 / t_chain_alone / 1e9 / HBM_PEAK_GBPS, 4),
+                           "post_chain_frac_at_28_B_per_px": round(px_tile * 28 / t_chain_alone / 1e9 / HBM_PEAK_GBPS, 4),
                            "post_chain_note": "ONE kernel (k_post_chain: blur X, blur Y, tonemapper; 8 B read + 4 B written per pixel, no intermediate image), from the end of the shade "
                                               "kernel to its end inside the frame loop. The kernel is bound by VALU issue (126 mads + 6 conversions + 3 table lookups per pixel), not by "
                                               "HBM: *_frac_at_28_B_per_px prices the same time at the 28 B/px the two-kernel chain of rounds 1-4 moved, for comparison with their figures",

@@ -128,7 +128,7 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks():
 def test_single_gpu_line_carries_the_contract_fields():
     """`python bench.py` (N = 1, defaults shortened): one JSON line with the driver's contract fields, the roofline and cpu_baseline objects,
     counter constants that belong to the current kernel sources, and the self-audit extras (engine lowering, cold start, isolated post kernels)."""
-    env = dict(os.environ, VQ_BENCH_SPINUP="30", VQ_BENCH_SUSTAINED_S="0.5")
+    env = dict(os.environ, VQ_BENCH_SPINUP="30", VQ_BENCH_SUSTAINED_S="0.5", VQ_BENCH_VERIFY="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
@@ -138,6 +138,8 @@ def test_single_gpu_line_carries_the_contract_fields():
               "roofline", "cpu_baseline", "stages", "engine_lowering", "dxc_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants", "rccl",
               "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained", "widened", "other_post_form"):
         assert k in d, k
+    assert d["verify"]["mismatching_bytes"] == 0 and d["verify"]["buffers"] == 2, d["verify"]      # the frame loop's two streams / two buffer pairs deliver the two-kernel chain's bytes
+    assert d["config"]["post_stream"].startswith("own")
     oc = d["other_post_form"]                                # the headline runs the one-kernel chain; the companion is the two-kernel path
     assert oc["form"] == "fused" and oc["bytes_per_px"] == 28 and oc["ms_per_step"] > 0 and abs(oc["value"] - 3840 * 2160 / (oc["ms_per_step"] * 1e-3) / 1e6) < 0.01 * oc["value"]
     su = d["sustained"]                                      # ~0.5 s of the headline's step here (VQ_BENCH_SUSTAINED_S), same order as `value`
