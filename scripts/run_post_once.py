@@ -17,7 +17,7 @@ band = synth.hdr_image(W, 270, scale=8.0).astype(np.float16)
 scene = torch.from_numpy(np.tile(band, (H // 270, 1, 1)).copy()).cuda()
 xb = capi.empty_image(H, W, F16, ctx.device)
 sdr = capi.empty_image(H, W, R8, ctx.device)
-for _ in range(200):                                         # spin-up
+for _ in range(int(os.environ.get("VQ_SPIN", "200"))):     # spin-up
     ctx.gaussian_blur_x(scene, F16, out=xb)
 for _ in range(int(os.environ.get("VQ_REPS", "5"))):
     ctx.gaussian_blur_x(scene, F16, out=xb)
