@@ -329,12 +329,11 @@ VQHIP_API int  vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode);
 /* Tuning / A-B options of a context, read by the launchers at call time (never from the process environment: getenv racing a host setenv is
  * undefined behaviour, and VQEngine records on many threads, SceneRendering.cpp:563-706). value NULL, "" or "default" restores the default. Every
  * form selected here gives the bits of the default form (tests/test_gpu_conv_forms.py, tests/test_gpu_round3.py); unknown keys / values: VQHIP_ERR_INVALID_ARG.
- *   shade_wg 64|128|256 · psmain_waves 4|5|6 · blur_y_wgs n · post_form two|chain · post_strips n · post_mix 0|1 · lut_form general ·
+ *   shade_wg 64|128|256 · psmain_waves 4|5|6 · blur_y_wgs n · post_form two|chain · post_strips n · lut_form general ·
  *   diffuse_form records|texels|general · diffuse_seq_form ordered|lane
  * (the non-default values are the general / fallback forms of the same kernels; the measured-and-rejected kernel forms of rounds 2-5 — the compact tonemap
  * tables, the per-sample LUT and per-mip specular kernels, the persistent X pass, the rolling-ring Y pass — are not in the library: docs/HISTORY.md).
- * psmain_waves applies to the literal reading only (the DXC-reading instantiation of the fused PSMain kernel has one register cap). post_mix 1: the chain kernel converts its
- * windows to fp32 first (A/B form, slower). post_form: "two" = vqhip_post_process[_tile] always runs blur X, then blur Y + tonemap (two kernels); "chain" = the one-kernel chain whatever the frame size
+ * psmain_waves applies to the literal reading only (the DXC-reading instantiation of the fused PSMain kernel has one register cap). post_form: "two" = vqhip_post_process[_tile] always runs blur X, then blur Y + tonemap (two kernels); "chain" = the one-kernel chain whatever the frame size
  * (default: the chain for RGBA16F -> RGBA8 frames of >= 2^20 pixels and a per-channel display curve, the two kernels otherwise). */
 VQHIP_API int  vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value);
 typedef enum vqhip_arithmetic { VQHIP_ARITH_LITERAL = 0, VQHIP_ARITH_DXC = 1 } vqhip_arithmetic;

@@ -577,7 +577,6 @@ int vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value) {
     if (k == "blur_y_wgs") return num(&o.blurYWgs, {});
     if (k == "post_form") return pick(&o.postForm, { "two", "chain" });
     if (k == "post_strips") return num(&o.postStrips, {});
-    if (k == "post_mix") return num(&o.postMix, { 0, 1 });
     if (k == "lut_form") return pick(&o.lutForm, { "general" });
     if (k == "diffuse_form") { if (v == "records") { o.diffuseForm = 0; return VQHIP_OK; } return pick(&o.diffuseForm, { "texels", "general" }); }
     if (k == "diffuse_seq_form") { if (v == "ordered") { o.diffuseSeqForm = 0; return VQHIP_OK; } return pick(&o.diffuseSeqForm, { "lane" }); }

@@ -1,10 +1,11 @@
 // post.hip — post-process kernels for gfx950:
 //   separable 21-tap Gaussian blur == Shaders/GaussianBlur.hlsl:CSMain_X :120-151 / CSMain_Y :155-187
 //   tonemapper                     == Shaders/Tonemapper.hlsl:CSMain :110-151 (+ HDR.hlsl:76-80,88-97,110-119)
-// Both are HBM-bound: one read + one write of the image per pass. The reference's
-// "naive" blur re-reads 21 texels per output from the texture cache (PipelineStateObjects.cpp:1321);
-// here the X pass stages a row segment + halo in LDS once, and the Y pass keeps a 36-row register
-// window per column (16 outputs per lane) so each input row is fetched 36/16 times from L2, once from HBM.
+// SURVEY.md §8d expected both to be HBM-bound (one read + one write of the image per pass); on gfx950 they are bound by VALU issue (63 mads per pixel and
+// pass on fp16 operands: profiles/r5g_post_forms.md). The reference's "naive" blur re-reads 21 texels per output from the texture cache
+// (PipelineStateObjects.cpp:1321); here the X pass stages a row segment + halo in LDS once, the Y pass keeps a 36-row register window per column
+// (16 outputs per lane) so each input row is fetched 36/16 times from L2, once from HBM, and k_post_chain (round 5) runs both passes and the tonemapper in
+// one kernel over an LDS ring of X-blurred rows: 8 B read + 4 B written per pixel.
 // Accumulation order is the HLSL's: kernelIt = 0..20 i.e. offset -10..+10; each `OutRGB += rgb * w` is one mad,
 // acc = fma(rgb, w, acc) (arithmetic contract v2: halves the VALU work of the two HBM-bound passes).
 #include <cstring>
@@ -340,7 +341,8 @@ __global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restri
 //     operations of one wave complete in order. The global loads of iteration i + 1 are issued before the mads of iteration i;
 //   * Y waves: 64 columns x 4 rows per wave; a lane reads its 24-row column window out of the ring (6 LDS reads per output again), 252 mads, three table
 //     lookups and one 4-byte store per output. In iteration 0 they have no rows yet and fill the table.
-// All mads are v_fma_mix_f32 on the packed halfs (the fp16 -> fp32 conversion of the operand is exact and part of the instruction): no window is ever converted.
+// All mads are v_fma_mix_f32 on the packed halfs (the fp16 -> fp32 conversion of the operand is exact and part of the instruction): no window is ever converted. (The form
+// that converts the windows first and filters with v_fmac_f32 was measured slower, 61.7 against 58.9 us: profiles/r5g_post_forms.md.)
 // Halos (row-tiled frames): halo_top / halo_bottom are SCENE-COLOUR rows here — the X pass is purely horizontal, so the rows the neighbour tile shaded are filtered
 // in X like the tile's own and the Y window reaches them: 10 rows per side, the same byte count as the X-blurred halos of the two-kernel path.
 VQD float fma_mix_lo(uint32_t h, float w, float acc) { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h), "s"(w)); return acc; }
@@ -366,32 +368,6 @@ template <int T> struct XWindow {                             // window texel t 
     }
 };
 template <> struct XWindow<-1> { static VQD void read(uint32_t (&)[24], uint32_t (&)[24], uint32_t) {} };
-// the first 12 / the last 12 destinations of 24 reads issued in order: LDS operations of a wave complete in order
-VQD void lds_wait_first12(uint32_t (&lo)[24], uint32_t (&hi)[24]) {
-    asm volatile("s_waitcnt lgkmcnt(12)" : PC_TIE6(lo, 0), PC_TIE6(lo, 6), PC_TIE6(hi, 0), PC_TIE6(hi, 6));
-}
-VQD void lds_wait_last12(uint32_t (&lo)[24], uint32_t (&hi)[24]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : PC_TIE6(lo, 12), PC_TIE6(lo, 18), PC_TIE6(hi, 12), PC_TIE6(hi, 18));
-}
-// The window as fp32 registers (three v_cvt_f32_f16 per texel), then v_fmac_f32 with the weight as a literal: on gfx950 v_fma_mix_f32 and v_cvt issue at 4.4 cycles
-// per wave, v_fmac_f32 on VGPRs / literals at 2.45 (scripts/ubench/mix_rate.hip): 72 x 4.4 + 252 x 2.45 = 934 cycles per 4 outputs against 252 x 4.45 = 1 121.
-struct Window32 { float x[24], y[24], z[24]; };
-VQD void unpack12(const uint32_t (&wl)[24], const uint32_t (&wh)[24], Window32& f, int t0) {
-    #pragma unroll
-    for (int t = t0; t < t0 + 12; ++t) {
-        f.x[t] = half_bits_to_float(wl[t] & 0xffffu); f.y[t] = half_bits_to_float(wl[t] >> 16); f.z[t] = half_bits_to_float(wh[t] & 0xffffu);
-        asm("" : "+v"(f.x[t]), "+v"(f.y[t]), "+v"(f.z[t]));                  // three fp32 registers: the compiler must not fold the conversions back into v_fma_mix_f32
-    }
-}
-VQD void filter21(const Window32& f, int j, float& ax, float& ay, float& az) {
-    ax = 0.0f; ay = 0.0f; az = 0.0f;
-    #pragma unroll
-    for (int it = 0; it < 21; ++it) {
-        const int off = it - R;
-        const float wt = kW[off < 0 ? -off : off];
-        ax = fma_(f.x[j + it], wt, ax); ay = fma_(f.y[j + it], wt, ay); az = fma_(f.z[j + it], wt, az);
-    }
-}
 // the 63 mads of one output: kernelIt = 0..20, the HLSL's order (GaussianBlur.hlsl:138-150 / :173-185)
 VQD void filter21(const uint32_t (&wl)[24], const uint32_t (&wh)[24], int j, float& ax, float& ay, float& az) {
     ax = 0.0f; ay = 0.0f; az = 0.0f;
@@ -410,7 +386,6 @@ constexpr int PC_ROWB = 112 * 8;                              // bytes per ring 
 constexpr int PC_TABLE = 65536;
 constexpr int PC_LDS = PC_TABLE + PC_RING * PC_ROWB;          // 140 800
 static_assert(PC_NPX + PC_NPX / 4 <= PC_ROWB / 8 && (PC_ROWB / 8) % 32 == 16, "ring row");
-template <bool MIX>
 __global__ __launch_bounds__(1024) void k_post_chain(const void* __restrict__ in, void* __restrict__ out, const void* __restrict__ haloTop,
                                                      const void* __restrict__ haloBottom, int haloRows, int W, int H,
                                                      const void* __restrict__ table, int stripsX, int stripsY, int S, int xcdBands) {
@@ -462,13 +437,11 @@ __global__ __launch_bounds__(1024) void k_post_chain(const void* __restrict__ in
                 uint32_t wl[24], wh[24];                      // the 24-texel window: x | y << 16, z | a << 16
                 XWindow<23>::read(wl, wh, rowB + (uint32_t)(5 * li) * 8u);
                 if (k + 1 < nX) fetch(k + 1);                 // in flight during the mads below
-                Window32 f;
-                if (MIX) lds_wait(wl, wh);
-                else { lds_wait_first12(wl, wh); unpack12(wl, wh, f, 0); lds_wait_last12(wl, wh); unpack12(wl, wh, f, 12); }
+                lds_wait(wl, wh);
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float ax, ay, az;
-                    if (MIX) filter21(wl, wh, j, ax, ay, az); else filter21(f, j, ax, ay, az);
+                    filter21(wl, wh, j, ax, ay, az);
                     u2v o;                                    // == the store to BlurIntermediate (RGBA16F, alpha 1)
                     o.x = float_to_half_bits(ax) | (float_to_half_bits(ay) << 16); o.y = float_to_half_bits(az) | 0x3C000000u;
                     *(u2v*)(lds + rowB + (uint32_t)(5 * li + j) * 8u) = o;
@@ -496,14 +469,12 @@ __global__ __launch_bounds__(1024) void k_post_chain(const void* __restrict__ in
                     int ph = q + t; if (ph >= PC_RING) ph -= PC_RING;
                     lds_read_b64<0>(wl[t], wh[t], colB + (uint32_t)ph * PC_ROWB);
                 }
-                Window32 f;
-                if (MIX) lds_wait(wl, wh);
-                else { lds_wait_first12(wl, wh); unpack12(wl, wh, f, 0); lds_wait_last12(wl, wh); unpack12(wl, wh, f, 12); }
+                lds_wait(wl, wh);
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (oRel + j >= rows) break;              // wave-uniform
                     float ax, ay, az;
-                    if (MIX) filter21(wl, wh, j, ax, ay, az); else filter21(f, j, ax, ay, az);
+                    filter21(wl, wh, j, ax, ay, az);
                     const uint32_t hx = float_to_half_bits(ax), hy = float_to_half_bits(ay), hz = float_to_half_bits(az);   // == the BlurOutput store
                     const uint32_t px = (uint32_t)lds[hx] | ((uint32_t)lds[hy] << 8) | ((uint32_t)lds[hz] << 16) | (255u << 24);   // alpha 1 -> 255
                     if (xOk) dstCol[(size_t)(oRel + j) * W] = px;
@@ -617,18 +588,10 @@ hipError_t launch_post_chain(hipStream_t s, const void* in, void* out, const voi
     const int S = (H + stripsY - 1) / stripsY;
     stripsY = (H + S - 1) / S;
     const int xcdBands = (8 % stripsY == 0 && stripsX % (8 / stripsY) == 0) ? 8 / stripsY : 0;     // XCD-aware strip order (see the kernel) when the strips divide evenly
-    hipError_t e;
-    if (opt.postMix != 1) {                                   // default: v_fma_mix_f32 on the packed window (58.9 against 61.7 us at 4K for the converted window, profiles/r5g_post_forms.md)
-        e = hipFuncSetAttribute((const void*)k_post_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);      // > 64 KB of LDS needs the opt-in
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_post_chain<true>, dim3((unsigned)(stripsX * stripsY)), dim3(1024), PC_LDS, s, in, out, haloTop, haloBottom, haloRows, W, H, lutTable,
-                           stripsX, stripsY, S, xcdBands);
-    } else {
-        e = hipFuncSetAttribute((const void*)k_post_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_post_chain<false>, dim3((unsigned)(stripsX * stripsY)), dim3(1024), PC_LDS, s, in, out, haloTop, haloBottom, haloRows, W, H, lutTable,
-                           stripsX, stripsY, S, xcdBands);
-    }
+    hipError_t e = hipFuncSetAttribute((const void*)k_post_chain, hipFuncAttributeMaxDynamicSharedMemorySize, PC_LDS);      // > 64 KB of LDS needs the opt-in
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_post_chain, dim3((unsigned)(stripsX * stripsY)), dim3(1024), PC_LDS, s, in, out, haloTop, haloBottom, haloRows, W, H, lutTable,
+                       stripsX, stripsY, S, xcdBands);
     return hipGetLastError();
 }
 

@@ -25,7 +25,6 @@ struct Options {
     int blurYWgs = 0;           // "blur_y_wgs"        : workgroups of k_blur_y_tonemap_lut
     int postForm = 0;           // "post_form"         : 1 "two" = blur X, then blur Y + tonemap (two kernels) whatever the frame; 2 "chain" = k_post_chain whatever the size
                                 //                       (default: k_post_chain for RGBA16F -> RGBA8 frames of >= 2^20 pixels with a per-channel display curve, else two kernels)
-    int postMix = 0;            // "post_mix"          : 1 = k_post_chain converts its windows to fp32 and filters with v_fmac_f32 (default: v_fma_mix_f32 on the packed window)
     int postStrips = 0;         // "post_strips"       : row strips per column strip of k_post_chain (default: CUs / column strips — one workgroup per CU)
     int lutForm = 0;            // "lut_form"          : 1 "general" (every range test left in)
     int diffuseForm = 0;        // "diffuse_form"      : 1 "texels", 2 "general" (default: footprint records)
