@@ -395,6 +395,7 @@ class Pipeline:
         self.e_post = [torch.cuda.Event(), torch.cuda.Event()]
         self.e_comp = [None, None]
         self.s_post = torch.cuda.Stream(dev) if world == 1 else None
+        self.s_frame = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if world == 1 else None
         self.e_shade = [torch.cuda.Event(), torch.cuda.Event()]
         self.e_pdone = [None, None]
         # fault injection for tests/test_gpu_bench_flow.py ("drop_post_wait"): leave out the wait that orders the composite behind the post kernel; against an
@@ -415,6 +416,20 @@ class Pipeline:
         rec = (lambda k, s=s_main: ev[k].record(s)) if ev else (lambda k, s=None: None)
         if overlap and self.e_comp[b] is not None:   # sdr[b] / frame[b] were last touched by the composite of step i-2
             s_main.wait_event(self.e_comp[b])
+        if self.args.post == "chain" and world == 1 and getattr(self.args, "post_stream", "main") == "frames":
+            # TWO FRAMES IN FLIGHT — frame i runs shade + post chain on stream i & 1 with its own buffer pair: no event between the streams at all, the tail of one
+            # frame's shade kernel runs under the head of the next frame's
+            st = self.s_frame[b]
+            if ev and "t0" in ev:
+                ev["t0"].record(st)
+            ctx.forward_lighting(self.gb, self.pf, self.pv, out=self.scene[b], out_fmt=F16, extra_point=self.extra, env=self.env, stream=st)
+            for k in ("shade", "x", "halo"):
+                if ev and k in ev:
+                    ev[k].record(st)
+            ctx.post_process_tile(self.scene[b], F16, R8, out=self.sdr[b], stream=st)
+            if ev and "post" in ev:
+                ev["post"].record(st)
+            return
         if self.e_pdone[b] is not None:             # --post-stream own: shade(i) overwrites scene[b], which post(i - 2) reads on the other stream
             s_main.wait_event(self.e_pdone[b])
             self.e_pdone[b] = None
@@ -423,6 +438,8 @@ class Pipeline:
         ctx.forward_lighting(self.gb, self.pf, self.pv, out=self.scene[b], out_fmt=F16, extra_point=self.extra, env=self.env)
         if ev and "shade" in ev:
             rec("shade")
+        if self.args.post == "chain" and world == 1 and getattr(self.args, "post_stream", "main") == "frames":
+            return                                           # handled above (two frames in flight)
         if self.args.post == "chain" and world == 1 and getattr(self.args, "post_stream", "main") == "own":
             # N = 1 experiment: the post chain of frame i on its own stream, so that it runs next to the shade kernel of frame i + 1 (double-buffered scene colour)
             if ev and "x" in ev:
@@ -489,6 +506,8 @@ class Pipeline:
             self.s_main.wait_stream(self.s_comp)
         if self.s_post is not None:
             self.s_main.wait_stream(self.s_post)
+            for st in self.s_frame:
+                self.s_main.wait_stream(st)
 
     def verify_step(self, i):
         """One step whose output buffers were zeroed first (and the device drained): what the composite delivers can only be this step's pixels if every wait
@@ -615,7 +634,7 @@ def main():
     ap.add_argument("--post", choices=["chain", "fused", "split"], default="chain",
                     help="post chain: blur X + blur Y + tonemapper in ONE kernel (chain: vqhip_post_process_tile, the library's default for frames of >= 2^20 pixels), "
                          "blur X then Y blur + tonemapper in one kernel (fused), or three dispatches (split); identical bits")
-    ap.add_argument("--post-stream", choices=["main", "own"], default="own",
+    ap.add_argument("--post-stream", choices=["main", "own", "frames"], default="own",
                     help="N = 1 with --post chain: the post chain of frame i on a stream of its own, next to the shade kernel of frame i + 1 (double-buffered scene colour; + 1.5 %: "
                          "profiles/r5y_post_stream_ab.txt), or on the main stream (main). N > 1 keeps the main stream (the composite is what overlaps the next frame there)")
     ap.add_argument("--composite", choices=["root", "all"], default="root",
@@ -751,6 +770,29 @@ def main():
                      "note": "bench.py --post " + other + ": " + ("blur X, blur Y and the tonemapper in one kernel (8 B read + 4 B written per pixel; row tiles exchange scene-colour halos)"
                                                                  if other == "chain" else "blur X (16 B/px), then blur Y + tonemapper in one kernel (12 B/px); row tiles exchange X-blurred halos") +
                              "; identical bits; measured right after the sustained run (compare with sustained.ms_per_step, not with ms_per_step: profiles/r5g_post_forms.md)"}
+
+    # 4d. N = 1: TWO FRAMES IN FLIGHT (--post-stream frames): frame i on stream i & 1 with its own buffer pair, so that the tail of one frame's shade kernel runs under the head of
+    #     the next frame's — the reference's own habit (three back buffers, SwapChain.h). A companion figure, not the headline: with two shade kernels on the chip at once a launch
+    #     lasts twice as long, and the per-kernel roofline / rocprofv3 figures of the line would stop describing the kernel
+    frames2 = None
+    if world == 1 and args.post == "chain" and args.post_stream != "frames" and not args.no_extras:
+        mine = args.post_stream
+        args.post_stream = "frames"
+        for i in range(10):
+            pipe.step(i)
+        pipe.drain()
+        n2 = max(20, min(args.steps, 100)); n2 += n2 & 1
+        dt2f = pipe.timed(n2)
+        ev2f = [{"t0": _ev(), "post": _ev()} for _ in range(10)]
+        for i in range(10):
+            pipe.step(n2 + i, ev2f[i])
+        pipe.drain()
+        args.post_stream = mine
+        frames2 = {"steps": n2, "ms_per_step": round(dt2f / n2 * 1e3, 4), "value": round(W * frame_h * n2 / dt2f / 1e6, 2), "unit": "Mpix/s", "frames_in_flight": 2,
+                   "frame_interval_ms": round(mean_ms(ev2f, "t0", "post"), 4),
+                   "note": "bench.py --post-stream frames: frame i runs shade + post chain on stream i & 1 with its own scene-colour / SDR buffers (no event between the streams); "
+                           "frame_interval_ms = first kernel's start to last kernel's end of ONE frame while the other is in flight; identical bytes (VQ_BENCH_VERIFY); measured "
+                           "right after other_post_form (compare with sustained.ms_per_step)"}
 
     verify = None
     if world > 1 and os.environ.get("VQ_BENCH_VERIFY") == "1":
@@ -920,6 +962,7 @@ def main():
             "frame_latency_ms": round(frame_latency * 1e3, 4),
             **({"sustained": sustained} if sustained else {}),
             **({"other_post_form": chain_alt} if chain_alt else {}),
+            **({"two_frames_in_flight": frames2} if frames2 else {}),
             "cold_start": {"steps": COLD_STEPS, "ms_per_step": round(dt_cold / COLD_STEPS * 1e3, 4), "value": round(px_frame * COLD_STEPS / dt_cold / 1e6, 2),
                            "note": "the first steps after the idle set-up phase, before the clocks ramp; `value` is the steady-state figure"},
         }

@@ -136,8 +136,9 @@ def test_single_gpu_line_carries_the_contract_fields():
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline", "stages", "engine_lowering", "dxc_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants", "rccl",
-              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained", "widened", "other_post_form"):
+              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained", "widened", "other_post_form", "two_frames_in_flight"):
         assert k in d, k
+    assert d["two_frames_in_flight"]["frames_in_flight"] == 2 and d["two_frames_in_flight"]["ms_per_step"] > 0
     assert d["verify"]["mismatching_bytes"] == 0 and d["verify"]["buffers"] == 2, d["verify"]      # the frame loop's two streams / two buffer pairs deliver the two-kernel chain's bytes
     assert d["config"]["post_stream"].startswith("own")
     oc = d["other_post_form"]                                # the headline runs the one-kernel chain; the companion is the two-kernel path
