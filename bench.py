@@ -787,6 +787,7 @@ def main():
         for i in range(10):
             pipe.step(n2 + i, ev2f[i])
         pipe.drain()
+        d.barrier()                                          # device idle: the events of both frame streams have completed
         args.post_stream = mine
         frames2 = {"steps": n2, "ms_per_step": round(dt2f / n2 * 1e3, 4), "value": round(W * frame_h * n2 / dt2f / 1e6, 2), "unit": "Mpix/s", "frames_in_flight": 2,
                    "frame_interval_ms": round(mean_ms(ev2f, "t0", "post"), 4),
