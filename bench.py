@@ -395,7 +395,8 @@ class Pipeline:
         self.e_post = [torch.cuda.Event(), torch.cuda.Event()]
         self.e_comp = [None, None]
         self.s_post = torch.cuda.Stream(dev) if world == 1 else None
-        self.s_frame = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if world == 1 else None
+        self.s_frame = [self.s_main, self.s_post] if world == 1 else None     # two frames in flight reuse the two streams of the default mode: HIP multiplexes streams onto 4
+                                                                               # hardware queues, and two more streams may land on ONE queue (then nothing overlaps)
         self.e_shade = [torch.cuda.Event(), torch.cuda.Event()]
         self.e_pdone = [None, None]
         # fault injection for tests/test_gpu_bench_flow.py ("drop_post_wait"): leave out the wait that orders the composite behind the post kernel; against an
@@ -506,8 +507,6 @@ class Pipeline:
             self.s_main.wait_stream(self.s_comp)
         if self.s_post is not None:
             self.s_main.wait_stream(self.s_post)
-            for st in self.s_frame:
-                self.s_main.wait_stream(st)
 
     def verify_step(self, i):
         """One step whose output buffers were zeroed first (and the device drained): what the composite delivers can only be this step's pixels if every wait
