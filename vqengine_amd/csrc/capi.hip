@@ -342,6 +342,37 @@ static size_t fillFrameConstants(vqhip_ctx* ctx, int slot, const VQ_PerFrameData
         if (l.position.z == 0.0f && std::signbit(l.position.z)) negZeroAxes |= 4;
         if (!(std::isfinite(pts[i].cbx) && std::isfinite(pts[i].cby) && std::isfinite(pts[i].cbz))) pointSkipOK = 0;
     }
+    // spot / directional lights: the wave-uniform parts of SpotlightIntensity / CalculateDirectionalLightIllumination, with the shader's own operations
+    // (this translation unit is built with -ffp-contract=off: every product and sum below is rounded on its own)
+    const bool dxc = ctx->arithDxc != 0;
+    auto normalizeAsShader = [dxc](const VQ_float3& v, float* o) {
+        if (dxc) {                                                               // DXC reading: v * rsqrt(dot(v, v)), FMA-chain dot, correctly rounded rsqrt (vq_devmath.h:rsqrt_cr)
+            const float dd = std::fma(v.z, v.z, std::fma(v.y, v.y, v.x * v.x));
+            const float r = (float)(1.0 / std::sqrt((double)dd));
+            o[0] = v.x * r; o[1] = v.y * r; o[2] = v.z * r;
+        } else {                                                                 // literal reading: one IEEE quotient per component by length(v)
+            const float dd = (v.x * v.x + v.y * v.y) + v.z * v.z;
+            const float D = std::sqrt(dd);
+            o[0] = v.x / D; o[1] = v.y / D; o[2] = v.z / D;
+        }
+    };
+    for (int i = 0; i < VQ_NUM_LIGHTS__SPOT + VQ_NUM_SHADOWING_LIGHTS__SPOT; ++i) {
+        const bool caster = i >= VQ_NUM_LIGHTS__SPOT;
+        if (i >= (caster ? VQ_NUM_LIGHTS__SPOT + L.numSpotCasters : L.numSpotLights)) continue;
+        const VQ_SpotLight& l = caster ? L.spot_casters[i - VQ_NUM_LIGHTS__SPOT] : L.spot_lights[i];
+        DevSpotLight& ds = fc->spot[i];
+        float sd[3];
+        normalizeAsShader(l.spotDir, sd);
+        ds.sdx = sd[0]; ds.sdy = sd[1]; ds.sdz = sd[2];
+        const float den = l.outerConeAngle - l.innerConeAngle;
+        ds.rConeDen = 1.0f / den;
+        ds.cbx = l.color.x * l.brightness; ds.cby = l.color.y * l.brightness; ds.cbz = l.color.z * l.brightness;
+        ds.flags = ((std::isnormal(den) && std::isnormal(ds.rConeDen)) ? 1 : 0) | ((std::isfinite(ds.cbx) && std::isfinite(ds.cby) && std::isfinite(ds.cbz)) ? 2 : 0);
+    }
+    {
+        const VQ_float3 nd = { -L.directional.lightDirection.x, -L.directional.lightDirection.y, -L.directional.lightDirection.z };
+        normalizeAsShader(nd, fc->dirWi);
+    }
     fc->pointFastOK = pointFastOK;
     fc->pointSkipOK = pointSkipOK;
     fc->pointNegZeroAxes = negZeroAxes;

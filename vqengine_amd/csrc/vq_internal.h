@@ -49,8 +49,20 @@ struct alignas(16) FrameConstants {
                                                // rounded to float, capi.hip; contract v5 — the oracle does the same), not the contract's polynomial
     int32_t                pointSkipOK;    // every point light's color*brightness is finite: precondition of the back-facing-light skip (shade.hip)
     int32_t                pointNegZeroAxes;   // bit c: some point light has the coordinate -0.0 on axis c (then a pixel whose P has +0.0 there takes the IEEE loop: (-0) - (+0) = -0)
+    // What the spot / directional lights hand to every pixel alike, formed once on the host with the operations the shader would use (round 6):
+    // spot[0..20) belong to Lights.spot_lights, spot[20..25) to Lights.spot_casters
+    struct alignas(16) DevSpotLight {
+        float sdx, sdy, sdz;       // normalize(l.spotDir) in the context's reading (Lighting.hlsl:60): IEEE quotients by the length | v * correctly rounded rsqrt
+        float rConeDen;            // RN(1 / (outerConeAngle - innerConeAngle)), the divisor of the penumbra quotient (:71)
+        float cbx, cby, cbz;       // l.color * l.brightness (:330)
+        int32_t flags;             // bit 0: outer - inner and its reciprocal are normal numbers (the penumbra quotient may use the corrected product);
+                                   // bit 1: color * brightness is finite (a light that adds w = +0 times a finite BRDF may be skipped)
+    } spot[VQ_NUM_LIGHTS__SPOT + VQ_NUM_SHADOWING_LIGHTS__SPOT];
+    float                  dirWi[3];           // normalize(-directional.lightDirection) in the context's reading (Lighting.hlsl:337)
+    int32_t                pad6[1];
     // DevPointLight pts[numPointAll] follows
 };
+using DevSpotLight = FrameConstants::DevSpotLight;
 // Non-shadowing point lights as the hot loop reads them (one s_load_dwordx8 per light): point_lights[0..numPointLights)
 // followed by the extension array, with the loop-invariant product color*brightness formed once on the host (IEEE
 // multiply, identical to the in-shader product).

@@ -253,33 +253,67 @@ VQD void point_light_loop(const Pixel& px, const vqk::DevPointLight* pts, int nP
     for (int p = 0; p < nP; ++p) add_point_light<AR, RC, SKIP>(px, pts[p], I, vmin, izmin);
 }
 
-// SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333 (no range cull)
-template <int AR>
-VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, f3 acc) {
+// SpotlightIntensity :57-73 + CalculateSpotLightIllumination :323-333 (no range cull), round 6.
+// What the HLSL writes three times is evaluated once:
+//   * pd = normalize(P - l.position) is -Wi BIT FOR BIT (a - b = -(b - a) in round-to-nearest, x / D and x * r are odd in x, and the dot product of a negated
+//     vector is the negated dot product in either reading), so dot(pd, sd) = -dot(Wi, sd): one normalize instead of two;
+//   * sd = normalize(l.spotDir), l.color * l.brightness and 1 / (outer - inner) do not depend on the pixel: formed on the host with the shader's operations
+//     (FrameConstants::spot, capi.hip);
+//   * length(Lw - P), its reciprocal and the quotients of the two normalizes come from the exactly rounded fast sequences (policy R, vq_devmath.h) with one validity flag
+//     per light (RcpFast), redone with IEEE operations when the flag drops — identical bits where both are valid.
+// spot_geometry: Wi and w = (cone / D^2) * NdotL, the light's scalar weight (:330-332).
+template <int AR, class R>
+VQD void spot_geometry(const Pixel& px, const VQ_SpotLight& l, const vqk::DevSpotLight& ds, R& rc, f3& Wi, float& w) {
     const f3 d = sub(ld3(l.position), px.P);
-    const float D = length_r<AR>(d);
-    const f3 Wi = AR ? normalize_r<AR>(d) : div_lit(d, D);   // normalize(l.position - P) as written
-    const float rD = rcp(D);
-    const f3 pd = normalize_r<AR>(sub(px.P, ld3(l.position))); // SpotlightIntensity as written: acos near 1 amplifies every ulp
-    const f3 sd = normalize_r<AR>(ld3(l.spotDir));
-    const float theta = acos_(dot_r<AR>(pd, sd));
-    float cone;
-    if (theta > l.outerConeAngle) cone = 0.0f;
-    else if (theta <= l.innerConeAngle) cone = 1.0f;
-    else cone = 1.0f - fdiv_(theta - l.innerConeAngle, l.outerConeAngle - l.innerConeAngle);
+    const float dd = dot_r<AR>(d, d);
+    float rD;
+    const float D = rc.sqrt_rcp(dd, &rD);                    // length(l.position - P) and 1 / it
+    Wi = AR ? mul(d, rc.rsqrt(dd)) : mk3(rc.div(d.x, D, rD), rc.div(d.y, D, rD), rc.div(d.z, D, rD));
+    const float theta = acos_(-dot_r<AR>(Wi, mk3(ds.sdx, ds.sdy, ds.sdz)));      // acos(dot(normalize(P - l.position), normalize(l.spotDir))) :60-61
+    const float a = theta - l.innerConeAngle, den = l.outerConeAngle - l.innerConeAngle;
+    const float q = (ds.flags & 1) ? rc.div(a, den, ds.rConeDen) : fdiv_(a, den);  // wave-uniform choice; the IEEE quotient either way
+    float cone = 1.0f - q;                                   // :71
+    cone = (theta <= l.innerConeAngle) ? 1.0f : cone;        // :67
+    cone = (theta > l.outerConeAngle) ? 0.0f : cone;         // :63
     const float NdotL = saturate(dot(px.Nraw, Wi));
-    const float w = (cone * (rD * rD)) * NdotL;
+    w = (cone * (rD * rD)) * NdotL;
+}
+// the light's contribution added to acc, IEEE operations throughout (the redo path, and the reading of the oracle)
+template <int AR>
+VQD f3 spot_light_ieee(const Pixel& px, const VQ_SpotLight& l, const vqk::DevSpotLight& ds, f3 acc) {
     RcpIEEE rc;
-    return lit(acc, brdf_t<AR>(px, Wi, rc), light_cb(l.color, l.brightness), w);
+    f3 Wi; float w;
+    spot_geometry<AR>(px, l, ds, rc, Wi, w);
+    return lit(acc, brdf_t<AR>(px, Wi, rc), mk3(ds.cbx, ds.cby, ds.cbz), w);
+}
+// Fast form. `mayContribute` (out): false when the WAVE skipped the BRDF because no lane can change its accumulator — every lane has w == +0 (outside the cone or
+// facing away; rD is finite: the flag), a BRDF that is finite whatever the light (px.skipOK, px.fastOK: roughness in [0, 1], finite F0 / kA / Wo, hh in the proven domain — the
+// reasoning of add_point_light<.., SKIP>), finite color * brightness (ds.flags bit 1) and — `accNoZero` — an accumulator without a zero component, the one value that
+// adding b * (cb * +0) = +-0 could change (-0 + +0 = +0). A spot light covers a few per cent of a frame: most waves take this exit, at the cost of the geometry alone.
+template <int AR>
+VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, const vqk::DevSpotLight& ds, f3 acc, bool laneSkipOK, bool* mayContribute) {
+    RcpFast fast;
+    f3 Wi; float w;
+    spot_geometry<AR>(px, l, ds, fast, Wi, w);
+    const f3 Hs = add(px.Wo, Wi);
+    const float hh = AR ? dot(Hs, Hs) : dot_lit(Hs, Hs);
+    const bool idle = laneSkipOK & fast.ok & sqrt_rcp_fast_ok(hh) & (w == 0.0f);
+    if (((ds.flags & 2) != 0) & !px.p5ExpLog & (__builtin_amdgcn_ballot_w64(!idle) == 0)) { *mayContribute = false; return acc; }
+    *mayContribute = true;
+    f3 r = lit(acc, brdf_t<AR>(px, Wi, fast, Hs, hh), mk3(ds.cbx, ds.cby, ds.cbz), w);
+    if (__builtin_expect(!fast.ok, 0)) r = spot_light_ieee<AR>(px, l, ds, acc);
+    return r;
 }
 
-// CalculateDirectionalLightIllumination :334-345
+// CalculateDirectionalLightIllumination :334-345; Wi = normalize(-l.lightDirection) comes from the host (FrameConstants::dirWi)
 template <int AR>
-VQD f3 directional_light(const Pixel& px, const VQ_DirectionalLight& l) {
-    const f3 Wi = normalize_r<AR>(neg(ld3(l.lightDirection)));
+VQD f3 directional_light(const Pixel& px, const VQ_DirectionalLight& l, f3 Wi) {
     const float NdotL = saturate(dot(px.Nraw, Wi));
-    RcpIEEE rc;
-    return lit(mk3(0.0f, 0.0f, 0.0f), brdf_t<AR>(px, Wi, rc), light_cb(l.color, l.brightness), NdotL);
+    const f3 cb = light_cb(l.color, l.brightness), zero = mk3(0.0f, 0.0f, 0.0f);
+    RcpFast fast;
+    f3 r = lit(zero, brdf_t<AR>(px, Wi, fast), cb, NdotL);
+    if (__builtin_expect(!fast.ok, 0)) { RcpIEEE rc; r = lit(zero, brdf_t<AR>(px, Wi, rc), cb, NdotL); }
+    return r;
 }
 
 VQD f3 mul_v_m3(f3 v, float c, float s) {     // mul(v, GetHDRIRotationMatrix) with m = {c,0,s; 0,1,0; -s,0,c}, as written (zero terms kept)
@@ -348,20 +382,36 @@ VQD float omni_pcf(const float* cubeArr, int dim, int index, f3 Lw, float farPla
     }
     return 1.0f - fdiv_(shadow, 20.0f);
 }
-// ShadowTestPCF :177-218 (useTanBias) / ShadowTestPCF_Directional :222-272 (raw bias)
+// ShadowTestPCF :177-218 (useTanBias) / ShadowTestPCF_Directional :222-272 (raw bias). Round 6: the 25 taps of the 5 x 5 kernel share 5 column and 5 row
+// coordinates — tap (x, y) samples (u + x * tx, v + y * ty), each coordinate a function of x or of y alone — so the POINT_WRAP address arithmetic
+// (floor(coord * dim), wrap) runs 10 times instead of 50 and a tap is one add + one load + one compare; a power-of-two map wraps with an AND instead of
+// two integer divisions. The sum of 25 zeros and ones is exact in any order: counted in an integer. shadow / 25 through the corrected product with RN(1 / 25)
+// (fdiv_rcp: equal to the IEEE quotient for every normal operand pair, +0 / 25 = +0).
 VQD float pcf_2d(const float* slice, int dim, float2 smDims, float4 lsp, float bias) {
     const f3 p = mk3(fdiv_(lsp.x, lsp.w), fdiv_(lsp.y, lsp.w), fdiv_(lsp.z, lsp.w));
     if (p.x < -1.0f || p.x > 1.0f || p.y < -1.0f || p.y > 1.0f || p.z < 0.0f || p.z > 1.0f) return 0.0f;
     const float tx = rcp(smDims.x), ty = rcp(smDims.y);
     const float u = 0.5f + p.x * 0.5f, v = 0.5f + p.y * -0.5f;
     const float ref = p.z - bias;
-    float shadow = 0.0f;
-    for (int x = -2; x <= 2; ++x)
-        for (int y = -2; y <= 2; ++y) {
-            const float closest = fetch_point_wrap(slice, dim, u + (float)x * tx, v + (float)y * ty);
-            shadow += (ref > closest) ? 1.0f : 0.0f;
+    const float fdim = (float)dim;
+    const bool pot = (dim & (dim - 1)) == 0;                 // wave-uniform
+    uint32_t col[5], row[5];                                 // byte offsets of the five columns / rows
+    #pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int ix = f2i_floor((u + (float)(k - 2) * tx) * fdim), iy = f2i_floor((v + (float)(k - 2) * ty) * fdim);
+        const int wx = pot ? (ix & (dim - 1)) : wrapi(ix, dim), wy = pot ? (iy & (dim - 1)) : wrapi(iy, dim);
+        col[k] = (uint32_t)wx * 4u;
+        row[k] = (uint32_t)wy * (uint32_t)dim * 4u;          // a slice is at most 2^32 bytes (dim <= 32768)
+    }
+    int count = 0;
+    #pragma unroll
+    for (int x = 0; x < 5; ++x)
+        #pragma unroll
+        for (int y = 0; y < 5; ++y) {
+            const float closest = *(const float*)((const char*)slice + (row[y] + col[x]));
+            count += (ref > closest) ? 1 : 0;
         }
-    return 1.0f - fdiv_(shadow, 25.0f);
+    return 1.0f - fdiv_rcp((float)count, 25.0f, 0.04f);
 }
 
 // PSMain :289-380 for ONE pixel whose G-buffer record is (g0, g1, g2, g3): returns float4(I_total, roughness) (:380).
@@ -411,32 +461,47 @@ VQD float4 shade_pixel(const float4 g0, const float4 g1, const float4 g2, const 
     }
     const VQ_SceneLighting& L = fc->perFrame.Lights;
     const int nS = L.numSpotLights;
-    for (int s = 0; s < nS; ++s) I = spot_light<AR>(px, L.spot_lights[s], I);                     // :314-317
+    // the wave-level skip of spot lights that cannot change the accumulator (spot_light) needs a lane whose BRDF is finite whatever the light, and an accumulator without zeros
+    const bool spotLaneOK = px.skipOK & px.fastOK;
+    float izmin = min3abs(I);
+    for (int s = 0; s < nS; ++s) {                                                                // :314-317
+        bool hit;
+        I = spot_light<AR>(px, L.spot_lights[s], fc->spot[s], I, spotLaneOK & (izmin > 0.0f), &hit);
+        if (hit) izmin = min3abs(I);
+    }
 
     if (HAS_CASTERS) {
         const int nPC = L.numPointCasters;
-        for (int pc = 0; pc < nPC; ++pc) {                                                    // :321-339
-            const VQ_PointLight& l = L.point_casters[pc];
-            const f3 Lw = sub(ld3(l.position), px.P);
-            const float D = length_r<AR>(Lw);
-            if (D < l.range) {
-                const float viewDist = length_r<AR>(sub(px.P, cam));
-                const f3 c = point_light<AR>(px, l);
-                const float sh = omni_pcf<AR>(fc->sm.point, fc->sm.point_dim, pc, Lw, l.range, l.depthBias, viewDist);
-                I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
+        if (nPC > 0) {
+            const float viewDist = length_r<AR>(sub(px.P, cam));                              // :325 (pcfData.viewDistanceOfPixel): the same for every caster
+            for (int pc = 0; pc < nPC; ++pc) {                                                // :321-339
+                const VQ_PointLight& l = L.point_casters[pc];
+                const f3 Lw = sub(ld3(l.position), px.P);
+                const float D = length_r<AR>(Lw);
+                if (D < l.range) {
+                    const f3 c = point_light<AR>(px, l);
+                    const float sh = omni_pcf<AR>(fc->sm.point, fc->sm.point_dim, pc, Lw, l.range, l.depthBias, viewDist);
+                    I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
+                }
             }
+            izmin = min3abs(I);
         }
         const int nSC = L.numSpotCasters;
         for (int sc = 0; sc < nSC; ++sc) {                                                    // :342-356
             const VQ_SpotLight& l = L.spot_casters[sc];
+            // illumination of the light from a zero accumulator, then * shadow factor. When no lane of the wave is lit (spot_light's exit: every lane w == +0, finite BRDF)
+            // the illumination is (+0, +0, +0) in every lane and I + 0 * sh = I for the finite sh of pcf_2d unless I holds a zero (izmin): the PCF is skipped with it
+            bool hit;
+            const f3 c = spot_light<AR>(px, l, fc->spot[VQ_NUM_LIGHTS__SPOT + sc], mk3(0.0f, 0.0f, 0.0f), spotLaneOK & (izmin > 0.0f), &hit);
+            if (!hit) continue;
             const f3 Ln = normalize_r<AR>(sub(ld3(l.position), px.P));
             const float NdotL = saturate(dot_r<AR>(px.Nraw, Ln));
             const float4 lsp = mul_M_v(L.shadowViews[sc], px.P);
-            const f3 c = spot_light<AR>(px, l, mk3(0.0f, 0.0f, 0.0f));
             const float bias = l.depthBias * tan_(acos_(NdotL));
             const float sh = pcf_2d(fc->sm.spot + (size_t)sc * fc->sm.spot_dim * fc->sm.spot_dim, fc->sm.spot_dim,
                                     make_float2(fc->perFrame.f2SpotLightShadowMapDimensions.x, fc->perFrame.f2SpotLightShadowMapDimensions.y), lsp, bias);
             I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
+            izmin = min3abs(I);
         }
     }
     {                                                                                         // :360-377
@@ -448,7 +513,7 @@ VQD float4 shade_pixel(const float4 g0, const float4 g1, const float4 g2, const 
                 sh = pcf_2d(fc->sm.directional, fc->sm.dir_dim,
                             make_float2(fc->perFrame.f2DirectionalLightShadowMapDimensions.x, fc->perFrame.f2DirectionalLightShadowMapDimensions.y), lsp, l.depthBias);
             }
-            const f3 c = directional_light<AR>(px, l);
+            const f3 c = directional_light<AR>(px, l, mk3(fc->dirWi[0], fc->dirWi[1], fc->dirWi[2]));
             I = mk3(fma_(c.x, sh, I.x), fma_(c.y, sh, I.y), fma_(c.z, sh, I.z));
         }
     }

@@ -313,3 +313,126 @@ def find_environment_map_to_downsize_from(files_in_folder, env_map_name, target_
             if len(tok) >= 2 and tok[-2].isalnum() and tok[0].isalnum() and tok[-1] == "k":
                 return path
     return ""
+
+
+# ---- shadow views of the lights (Light.cpp:133-233) and the two caster workloads the bench times ----------------------------------
+def _quat_to_matrix(q):
+    """Rotation matrix (row-vector convention, like DirectXMath) of the unit quaternion (w, x, y, z): rows are the images of the axes."""
+    return np.stack([_quat_rotate(q, e) for e in ((1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0))])
+
+
+def orthographic_lh(view_w, view_h, zn, zf):
+    """DirectX::XMMatrixOrthographicLH (float64)."""
+    m = np.zeros((4, 4))
+    m[0, 0], m[1, 1], m[2, 2], m[3, 2], m[3, 3] = 2.0 / view_w, 2.0 / view_h, 1.0 / (zf - zn), -zn / (zf - zn), 1.0
+    return m
+
+
+def light_view_projection(light, near_plane, far_plane, viewport=(2048, 2048), distance_from_origin=500.0):
+    """Light::GetViewProjectionMatrix for a spot or directional light (Light.cpp:133-233): spot = LookAtLH(pos, pos + rotated forward, rotated up) x
+    PerspectiveFovLH(pi/2, 1, near, far); directional = LookAtLH(-direction * distance, origin, up) x OrthographicLH(ViewportX, ViewportY, near, far).
+    float64 here, rounded to binary32 when stored in the cbuffer (the engine computes in binary32 SIMD: these are INPUTS of the path, not results)."""
+    from . import synth
+    if light.Type == Light.SPOT:
+        rot = _quat_to_matrix(light.RotationQuaternion)
+        pos = np.asarray(light.Position, np.float64)
+        view = synth._look_at_lh(pos, pos + rot[2], rot[1])
+        return view @ synth._perspective_fov_lh(math.pi / 2.0, 1.0, near_plane, far_plane)
+    if light.Type == Light.DIRECTIONAL:
+        direction = _quat_rotate(light.RotationQuaternion, (0.0, -1.0, 0.0))
+        pos = -direction * distance_from_origin
+        up = np.array([0.0, 1.0, 0.0])
+        ldu = float((-pos / np.linalg.norm(pos)) @ up)
+        if ldu in (1.0, -1.0):                                # Light.cpp:199-205: nudge the up vector when it is parallel to the light
+            up = up + np.array([0.001, 0.0, 0.0]); up /= np.linalg.norm(up)
+        view = synth._look_at_lh(pos, (0.0, 0.0, 0.0), up)
+        return view @ orthographic_lh(float(viewport[0]), float(viewport[1]), near_plane, far_plane)
+    raise ValueError("point lights render six faces: CubemapUtility::CalculateViewMatrix")
+
+
+def _quat_look_down(tilt_x_deg, tilt_z_deg):
+    return rotation_from_xml_euler_degrees(90.0 + tilt_x_deg, 0.0, tilt_z_deg)
+
+
+def synthetic_shadow_maps(dims=(2048, 1024, 1024), n_spot=5, n_point=5, seed=0x5AD0):
+    """Depth maps at the engine's sizes (SceneRendering.cpp:439-441: 2048^2 directional, n x 1024^2 spot, n x 6 x 1024^2 point faces): a lit half (depth 1) with a wavy
+    border and structured occluders + grain in the other, so the PCF kernels see lit, shadowed and penumbra taps. Content does not change the kernel's work (every tap is
+    fetched and compared), only the fetch addresses' locality, which comes from the pixels' positions."""
+    rng = np.random.Generator(np.random.Philox(key=[int(seed), 0x55]))
+
+    def depth(shape, lo, hi, fx, fy):
+        h, w = shape[-2:]
+        yy, xx = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+        base = (lo + (hi - lo) * (0.5 + 0.5 * np.sin(xx * fx) * np.cos(yy * fy))).astype(np.float32)
+        out = np.empty(shape, np.float32)
+        for n, idx in enumerate(np.ndindex(*shape[:-2])):
+            k = np.float32(1.0 + 0.13 * n)
+            out[idx] = base * np.float32((k % 1.0) * 0.2 + 0.9) + rng.random((h, w), dtype=np.float32) * np.float32(0.02)
+            out[idx][xx > w * 0.5 + 0.1 * w * np.sin(yy * 0.01 * k)] = 1.0
+        return out
+    return {"dir": depth((dims[0], dims[0]), 0.4, 0.6, 0.011, 0.017), "spot": depth((n_spot, dims[1], dims[1]), 0.35, 0.65, 0.02, 0.013),
+            "point": depth((n_point, 6, dims[2], dims[2]), 0.05, 0.55, 0.015, 0.019), "dims": tuple(dims)}
+
+
+def _set_shadow_dims(pf, dims):
+    pf.f2DirectionalLightShadowMapDimensions = abi.float2(float(dims[0]), float(dims[0]))
+    pf.f2SpotLightShadowMapDimensions = abi.float2(float(dims[1]), float(dims[1]))
+    pf.f2PointLightShadowMapDimensions = abi.float2(float(dims[2]), float(dims[2]))
+
+
+def default_scene_frame(map_dims=(2048, 1024, 1024)):
+    """BASELINE config 1's light set as the engine would hand it to PSMain: Data/Levels/Default.xml:202-308 through the parser (default_scene_lights) and
+    Scene::GatherSceneLightData, every caster with ITS OWN view-projection matrix (Light::GetViewProjectionMatrix: the directional light's 256 x 256 orthographic
+    volume at distance 120, the two spots' 90-degree perspective frusta, near / far planes of the file) and shadow maps of the engine's sizes.
+    Returns (PerFrameData, maps) with maps = {"dir", "spot", "point", "dims"} (host float32 arrays)."""
+    lights = default_scene_lights()
+    shadows = {0: (0.1, 15000.0), 3: (0.001, 1500.0), 4: (0.001, 1500.0)}           # <NearPlane>, <FarPlane> of the three enabled casters
+    for i, (zn, zf) in shadows.items():
+        lights[i].ViewProjection = light_view_projection(lights[i], zn, zf, viewport=(256, 256), distance_from_origin=120.0)
+    pf = abi.PerFrameData()
+    pf.Lights = gather_scene_light_data(lights)
+    pf.fAmbientLightingFactor = 0.055
+    _set_shadow_dims(pf, map_dims)
+    return pf, synthetic_shadow_maps(map_dims, n_spot=abi.NUM_SHADOWING_LIGHTS__SPOT, n_point=1)
+
+
+def engine_max_frame(map_dims=(2048, 1024, 1024)):
+    """The most lights the engine's cbuffer holds (LightingConstantBufferData.h:39-44): 100 point + 20 spot lights, the directional light shadowing, 5 spot casters and
+    5 point casters, shadow maps at the engine's sizes. Lights come from the same distributions as the BASELINE configs (synth.point_lights / spot_lights), the casters get
+    real view-projection matrices. Returns (PerFrameData, maps)."""
+    from . import synth
+    pf, _ = synth.per_frame(points=synth.point_lights(abi.NUM_LIGHTS__POINT, seed=0xE7A0), spots=synth.spot_lights(abi.NUM_LIGHTS__SPOT, seed=0xE7A1))
+    lights = [Light(Type=Light.DIRECTIONAL, Mobility=Light.STATIONARY, Brightness=0.9, DepthBias=0.00045, RotationQuaternion=rotation_from_xml_euler_degrees(0, 0, 40),
+                    bCastingShadows=True)]
+    lights[0].ViewProjection = light_view_projection(lights[0], 0.1, 15000.0, viewport=(256, 256), distance_from_origin=120.0)
+    r = np.random.Generator(np.random.Philox(key=[0xE7A2, 0x66]))
+    for i in range(abi.NUM_SHADOWING_LIGHTS__SPOT):
+        u = r.random(8)
+        l = Light(Type=Light.SPOT, Mobility=Light.STATIC, Position=(-35.0 + 70.0 * u[0], 18.0 + 12.0 * u[1], -35.0 + 70.0 * u[2]),
+                  Color=(0.3 + 0.7 * u[3], 0.3 + 0.7 * u[4], 0.3 + 0.7 * u[5]), Brightness=1000.0 + 1000.0 * u[6], DepthBias=0.000009,
+                  RotationQuaternion=_quat_look_down(0.0, -20.0 + 40.0 * u[7]), SpotOuterConeAngleDegrees=30.0 + 2.0 * i, SpotInnerConeAngleDegrees=24.0 + 2.0 * i,
+                  bCastingShadows=True)
+        l.ViewProjection = light_view_projection(l, 0.001, 1500.0)
+        lights.append(l)
+    pc = synth.point_lights(abi.NUM_SHADOWING_LIGHTS__POINT, seed=0xE7A3)
+    for i in range(abi.NUM_SHADOWING_LIGHTS__POINT):
+        p = pc[i].position
+        lights.append(Light(Type=Light.POINT, Mobility=Light.DYNAMIC, Position=(p.x, p.y, p.z), Range=float(np.float32(120.0 + 30.0 * i)),
+                            Color=(pc[i].color.x, pc[i].color.y, pc[i].color.z), Brightness=pc[i].brightness, DepthBias=0.00005, bCastingShadows=True))
+    g = gather_scene_light_data(lights)
+    L = pf.Lights
+    L.directional, L.shadowViewDirectional = g.directional, g.shadowViewDirectional
+    L.numSpotCasters, L.numPointCasters = g.numSpotCasters, g.numPointCasters
+    for i in range(g.numSpotCasters):
+        L.spot_casters[i] = g.spot_casters[i]
+        L.shadowViews[i] = g.shadowViews[i]
+    for i in range(g.numPointCasters):
+        L.point_casters[i] = g.point_casters[i]
+    _set_shadow_dims(pf, map_dims)
+    return pf, synthetic_shadow_maps(map_dims, n_spot=abi.NUM_SHADOWING_LIGHTS__SPOT, n_point=abi.NUM_SHADOWING_LIGHTS__POINT, seed=0x5AD1)
+
+
+def shadow_maps_struct(maps, to_ptr):
+    """abi.ShadowMaps over the three arrays of `maps` (to_ptr: array -> address; the caller keeps the arrays alive)."""
+    d = maps["dims"]
+    return abi.ShadowMaps(to_ptr(maps["dir"]), d[0], to_ptr(maps["spot"]), d[1], to_ptr(maps["point"]), d[2])
