@@ -30,7 +30,7 @@ def light_counts(pf):
             "directional": int(L.directional.enabled), "directional_shadowing": int(L.directional.shadowing)}
 
 
-def device_inputs(name, gb=None):
+def device_inputs(name, gb=None, coherent=False):
     """(gb planes on the device, PerFrameData, PerViewLightingData, abi.ShadowMaps, keep-alive list, host maps)"""
     w = WORKLOADS[name]
     W, H = w["width"], w["height"]
@@ -40,7 +40,7 @@ def device_inputs(name, gb=None):
     if gb is None:
         gb = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
         for r in range(0, H, 240):
-            part = synth.gbuffer_rows(W, H, r, min(r + 240, H), seed=w["seed"])
+            part = (synth.gbuffer_rows_coherent if coherent else synth.gbuffer_rows)(W, H, r, min(r + 240, H), seed=w["seed"])
             for k in range(4):
                 gb[k][r:r + part[k].shape[0]].copy_(torch.from_numpy(part[k]))
     return gb, pf, synth.per_view(W, H), sm, keep, maps

@@ -280,10 +280,11 @@ VQD void spot_geometry(const Pixel& px, const VQ_SpotLight& l, const vqk::DevSpo
 }
 // the light's contribution added to acc, IEEE operations throughout (the redo path, and the reading of the oracle)
 template <int AR>
-VQD f3 spot_light_ieee(const Pixel& px, const VQ_SpotLight& l, const vqk::DevSpotLight& ds, f3 acc) {
+VQD f3 spot_light_ieee(const Pixel& px, const VQ_SpotLight& l, const vqk::DevSpotLight& ds, f3 acc, f3* WiOut) {
     RcpIEEE rc;
     f3 Wi; float w;
     spot_geometry<AR>(px, l, ds, rc, Wi, w);
+    if (WiOut) *WiOut = Wi;
     return lit(acc, brdf_t<AR>(px, Wi, rc), mk3(ds.cbx, ds.cby, ds.cbz), w);
 }
 // Fast form. `mayContribute` (out): false when the WAVE skipped the BRDF because no lane can change its accumulator — every lane has w == +0 (outside the cone or
@@ -291,17 +292,18 @@ VQD f3 spot_light_ieee(const Pixel& px, const VQ_SpotLight& l, const vqk::DevSpo
 // reasoning of add_point_light<.., SKIP>), finite color * brightness (ds.flags bit 1) and — `accNoZero` — an accumulator without a zero component, the one value that
 // adding b * (cb * +0) = +-0 could change (-0 + +0 = +0). A spot light covers a few per cent of a frame: most waves take this exit, at the cost of the geometry alone.
 template <int AR>
-VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, const vqk::DevSpotLight& ds, f3 acc, bool laneSkipOK, bool* mayContribute) {
+VQD f3 spot_light(const Pixel& px, const VQ_SpotLight& l, const vqk::DevSpotLight& ds, f3 acc, bool laneSkipOK, bool* mayContribute, f3* WiOut = nullptr) {
     RcpFast fast;
     f3 Wi; float w;
     spot_geometry<AR>(px, l, ds, fast, Wi, w);
+    if (WiOut) *WiOut = Wi;
     const f3 Hs = add(px.Wo, Wi);
     const float hh = AR ? dot(Hs, Hs) : dot_lit(Hs, Hs);
     const bool idle = laneSkipOK & fast.ok & sqrt_rcp_fast_ok(hh) & (w == 0.0f);
     if (((ds.flags & 2) != 0) & !px.p5ExpLog & (__builtin_amdgcn_ballot_w64(!idle) == 0)) { *mayContribute = false; return acc; }
     *mayContribute = true;
     f3 r = lit(acc, brdf_t<AR>(px, Wi, fast, Hs, hh), mk3(ds.cbx, ds.cby, ds.cbz), w);
-    if (__builtin_expect(!fast.ok, 0)) r = spot_light_ieee<AR>(px, l, ds, acc);
+    if (__builtin_expect(!fast.ok, 0)) r = spot_light_ieee<AR>(px, l, ds, acc, WiOut);
     return r;
 }
 
@@ -360,28 +362,67 @@ VQD float4 mul_M_v(const VQ_matrix& M, f3 P) {     // HLSL mul(M, float4(P,1)) =
     return make_float4(o[0], o[1], o[2], o[3]);
 }
 
-// SAMPLE_OFFSET_DIRS_NORMALIZED, Lighting.hlsl:123-131
+// OmnidirectionalShadowTestPCF, Lighting.hlsl:110-174; SAMPLE_OFFSET_DIRS_NORMALIZED :123-131.
+// Round 6: the 20 taps are unrolled with their offsets as literals and fetched TOGETHER — all addresses first, then the loads, then the comparisons — where the rolled
+// loop waited for each texel before it formed the next address (three scalar loads of the offset tables, eight branches and one full memory latency per tap). The point
+// fetch of a cube texel is branch-free: the reciprocal of the major axis from the unchecked Markstein sequence with ONE validity flag for the 20 taps (a denormal / zero /
+// non-finite major axis redoes them with the checked operations — identical bits where both are valid), the texel index as (int)med3(floor(c), 0, dim - 1) (== the clamp of
+// the saturating truncation for every float, NaN -> 0 included). The count of lit taps is an integer, / 20 the corrected product with RN(1 / 20).
+VQD int texel_index(float c, float fdimm1) { return (int)__builtin_amdgcn_fmed3f(__builtin_floorf(c), 0.0f, fdimm1); }
+template <bool CHECKED>
+VQD uint32_t cube_point_offset(int dim, float fdim, float fdimm1, f3 d, bool& ok) {          // dword index of the texel fetch_cube_point reads
+    const float ax = abs_(d.x), ay = abs_(d.y), az = abs_(d.z);
+    const bool isZ = (az >= ax) & (az >= ay);
+    const bool isY = !isZ & (ay >= ax);
+    const bool isX = !(isZ | isY);
+    const float major = isZ ? d.z : (isY ? d.y : d.x);
+    const float ma = isZ ? az : (isY ? ay : ax);
+    const bool neg = major < 0.0f;
+    const float sc0 = isX ? -d.z : d.x;
+    const float tc0 = isY ? d.z : -d.y;
+    const float sc = (neg & !isY) ? -sc0 : sc0;
+    const float tc = (neg & isY) ? -tc0 : tc0;
+    const int face = (isZ ? 4 : (isY ? 2 : 0)) + (neg ? 1 : 0);
+    float r;
+    if (CHECKED) r = rcp(ma); else { r = rcp_newton(ma); ok = ok & is_normal(r); }
+    const float su = (sc * r) * 0.5f + 0.5f, sv = (tc * r) * 0.5f + 0.5f;
+    const int x = texel_index(su * fdim, fdimm1), y = texel_index(sv * fdim, fdimm1);
+    return (uint32_t)((face * dim + y) * dim + x);
+}
 #define PA 0.5773502691896258f
 #define PB 0.7071067811865475f
-__device__ const float DX[20] = {  PA,  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PB,  PB, -PB, -PB,  PB, -PB,  PB, -PB,  0,  0,  0,  0 };
-__device__ const float DY[20] = {  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PA,  PB, -PB, -PB,  PB,  0,  0,  0,  0,  PB, -PB, -PB,  PB };
-__device__ const float DZ[20] = {  PA,  PA,  PA,  PA, -PA, -PA, -PA, -PA,  0,  0,  0,  0,  PB,  PB, -PB, -PB,  PB,  PB, -PB, -PB };
-#undef PA
-#undef PB
-// OmnidirectionalShadowTestPCF, Lighting.hlsl:110-174
+__device__ const float kOmniDX[20] = {  PA,  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PB,  PB, -PB, -PB,  PB, -PB,  PB, -PB,  0,  0,  0,  0 };     // the rare checked redo indexes these
+__device__ const float kOmniDY[20] = {  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PA,  PB, -PB, -PB,  PB,  0,  0,  0,  0,  PB, -PB, -PB,  PB };
+__device__ const float kOmniDZ[20] = {  PA,  PA,  PA,  PA, -PA, -PA, -PA, -PA,  0,  0,  0,  0,  PB,  PB, -PB, -PB,  PB,  PB, -PB, -PB };
 template <int AR>
 VQD float omni_pcf(const float* cubeArr, int dim, int index, f3 Lw, float farPlane, float depthBias, float viewDist) {
+    constexpr float DX[20] = {  PA,  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PB,  PB, -PB, -PB,  PB, -PB,  PB, -PB,  0,  0,  0,  0 };
+    constexpr float DY[20] = {  PA, -PA, -PA,  PA,  PA, -PA, -PA,  PA,  PB, -PB, -PB,  PB,  0,  0,  0,  0,  PB, -PB, -PB,  PB };
+    constexpr float DZ[20] = {  PA,  PA,  PA,  PA, -PA, -PA, -PA, -PA,  0,  0,  0,  0,  PB,  PB, -PB, -PB,  PB,  PB, -PB, -PB };
     const float diskRadius = (1.0f + fdiv_(viewDist, farPlane)) * 0.125f;
     const float* cube = cubeArr + (size_t)index * 6 * dim * dim;
     const float lenLw = length_r<AR>(Lw);
-    float shadow = 0.0f;
-    for (int i = 0; i < 20; ++i) {
-        const f3 sv = mk3(-(Lw.x + DX[i] * diskRadius), -(Lw.y + DY[i] * diskRadius), -(Lw.z + DZ[i] * diskRadius));
-        const float closest = fetch_cube_point(cube, dim, sv) * farPlane;
-        shadow += (lenLw > (closest + depthBias) + 0.001f) ? 1.0f : 0.0f;
+    const float fdim = (float)dim, fdimm1 = (float)(dim - 1);
+    uint32_t off[20];
+    bool ok = true;
+    #pragma unroll
+    for (int i = 0; i < 20; ++i)
+        off[i] = cube_point_offset<false>(dim, fdim, fdimm1, mk3(-(Lw.x + DX[i] * diskRadius), -(Lw.y + DY[i] * diskRadius), -(Lw.z + DZ[i] * diskRadius)), ok);
+    if (__builtin_expect(!ok, 0)) {
+        #pragma unroll 1
+        for (int i = 0; i < 20; ++i)
+            off[i] = cube_point_offset<true>(dim, fdim, fdimm1, mk3(-(Lw.x + kOmniDX[i] * diskRadius), -(Lw.y + kOmniDY[i] * diskRadius), -(Lw.z + kOmniDZ[i] * diskRadius)), ok);
     }
-    return 1.0f - fdiv_(shadow, 20.0f);
+    float closest[20];
+    #pragma unroll
+    for (int i = 0; i < 20; ++i) closest[i] = cube[off[i]];
+    int count = 0;
+    #pragma unroll
+    for (int i = 0; i < 20; ++i) count += (lenLw > (closest[i] * farPlane + depthBias) + 0.001f) ? 1 : 0;
+    return 1.0f - fdiv_rcp((float)count, 20.0f, 0.05f);
 }
+#undef PA
+#undef PB
 // ShadowTestPCF :177-218 (useTanBias) / ShadowTestPCF_Directional :222-272 (raw bias). Round 6: the 25 taps of the 5 x 5 kernel share 5 column and 5 row
 // coordinates — tap (x, y) samples (u + x * tx, v + y * ty), each coordinate a function of x or of y alone — so the POINT_WRAP address arithmetic
 // (floor(coord * dim), wrap) runs 10 times instead of 50 and a tap is one add + one load + one compare; a power-of-two map wraps with an AND instead of
@@ -492,9 +533,9 @@ VQD float4 shade_pixel(const float4 g0, const float4 g1, const float4 g2, const 
             // illumination of the light from a zero accumulator, then * shadow factor. When no lane of the wave is lit (spot_light's exit: every lane w == +0, finite BRDF)
             // the illumination is (+0, +0, +0) in every lane and I + 0 * sh = I for the finite sh of pcf_2d unless I holds a zero (izmin): the PCF is skipped with it
             bool hit;
-            const f3 c = spot_light<AR>(px, l, fc->spot[VQ_NUM_LIGHTS__SPOT + sc], mk3(0.0f, 0.0f, 0.0f), spotLaneOK & (izmin > 0.0f), &hit);
+            f3 Ln;                                                                            // normalize(l.position - P) :348 == the Wi of the light's illumination
+            const f3 c = spot_light<AR>(px, l, fc->spot[VQ_NUM_LIGHTS__SPOT + sc], mk3(0.0f, 0.0f, 0.0f), spotLaneOK & (izmin > 0.0f), &hit, &Ln);
             if (!hit) continue;
-            const f3 Ln = normalize_r<AR>(sub(ld3(l.position), px.P));
             const float NdotL = saturate(dot_r<AR>(px.Nraw, Ln));
             const float4 lsp = mul_M_v(L.shadowViews[sc], px.P);
             const float bias = l.depthBias * tan_(acos_(NdotL));
