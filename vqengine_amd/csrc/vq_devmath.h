@@ -186,11 +186,11 @@ VQD f3 normalize_rt(f3 v, bool dxc) { return dxc ? mul(v, rsqrt_cr(dot(v, v))) :
 VQD f3 reflect_rt(f3 i, f3 n, bool dxc) { const float t = 2.0f * dot_rt(n, i, dxc); return mk3(i.x - t * n.x, i.y - t * n.y, i.z - t * n.z); }
 
 // float -> int: truncation, NaN -> 0, saturating
+// Branch-free (round 6; the if-ladder compiled to three nested exec-mask branches per conversion): the median clamps to the two largest binary32 integers that fit
+// (a NaN comes out as the minimum and is replaced below), the conversion of the clamped value is exact truncation. Same result for every float.
 VQD int f2i_trunc(float x) {
-    if (!(x == x)) return 0;
-    if (x >=  2147483520.0f) return  2147483520;
-    if (x <= -2147483520.0f) return -2147483520;
-    return (int)x;
+    const int r = (int)__builtin_amdgcn_fmed3f(x, -2147483520.0f, 2147483520.0f);
+    return (x == x) ? r : 0;
 }
 VQD int f2i_floor(float x) { return f2i_trunc(__builtin_floorf(x)); }
 
