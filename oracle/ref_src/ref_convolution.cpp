@@ -64,6 +64,26 @@ int vqref_conv_specular(const float* chain, int w0, int h0, int nMips, int res, 
     return 0;
 }
 
+// the same pass for n texels (face, x, y) of ONE mip: out [n][4]
+int vqref_conv_specular_texels(const float* chain, int w0, int h0, int nMips, int res, float roughness, float dimX, float dimY, int mip,
+                               const int* faces, const int* xs, const int* ys, int n, float* out) {
+    if (!chain || !out) return -1;
+    g_chain = { chain, w0, h0, nMips };
+    texEquirectEnvironmentMap.res = &g_chain; texEquirectEnvironmentMap.kind = kTexEquirect;
+    Roughness = roughness; TextureDimensionsLOD0 = float2(dimX, dimY); MIP = mip;
+    for (int k = 0; k < n; ++k) {
+        if (faces[k] < 0 || faces[k] > 5 || xs[k] < 0 || ys[k] < 0 || xs[k] >= res || ys[k] >= res) return -1;
+        const vqo::f3 d = vqo::cube_texel_dir(faces[k], xs[k], ys[k], res);
+        GSOut In;
+        In.CubemapLookDirection = float3(d.x, d.y, d.z);
+        In.layer = (uint)faces[k];
+        const float4 c = PSMain_SpecularIrradiance(In);
+        float* p = out + (size_t)k * 4;
+        p[0] = c.x; p[1] = c.y; p[2] = c.z; p[3] = c.w;
+    }
+    return 0;
+}
+
 // CSMain_BRDFIntegration for n texels (xs[i], ys[i]) of ITS 1024 x 1024 image with ITS 2048 samples: out [n][2]
 int vqref_brdf_lut_texels(const int* xs, const int* ys, int n, float* out) {
     static std::vector<float2> img(1024 * 1024);

@@ -806,6 +806,28 @@ int vqo_conv_specular(const float* chain, int w0, int h0, int nMips, int specRes
     return 0;
 }
 
+// The same pass for a LIST of texels of the mip-major cube (flat indices into [mip][face][y][x]): lets the tests sample a 512^2 x 9-mip cube (the engine's default size,
+// Data/EngineSettings.ini:11) without evaluating its 2.1 M texels on the CPU. out: n pixels in `fmt`.
+int vqo_conv_specular_texels(const float* chain, int w0, int h0, int nMips, int specRes0, int order, const int64_t* texels, int n, void* out, int fmt, int nthreads) {
+    if (fmt != VQHIP_FMT_RGBA32F && fmt != VQHIP_FMT_RGBA16F) return -3;
+    const int MIPS = mip_level_count(specRes0, specRes0) - 1;
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    int bad = 0;
+    #pragma omp parallel for schedule(dynamic, 8) num_threads(nthreads)
+    for (int k = 0; k < n; ++k) {
+        int64_t t = texels[k];
+        int mip = 0;
+        while (mip < MIPS && t >= 6LL * (specRes0 >> mip) * (specRes0 >> mip)) { t -= 6LL * (specRes0 >> mip) * (specRes0 >> mip); ++mip; }
+        if (mip >= MIPS || t < 0) { bad = 1; continue; }
+        const int r = specRes0 >> mip;
+        const float Roughness = div_((float)mip, (float)(MIPS - 1));                 // :432
+        const int f = (int)(t / ((int64_t)r * r)), y = (int)((t / r) % r), x = (int)(t % r);
+        const f3 c = specular_irradiance_texel(cube_texel_dir(f, x, y, r), Roughness, (float)w0, (float)h0, chain, w0, h0, nMips, order);
+        store_px(out, (size_t)k, fmt, { c.x, c.y, c.z, 1.0f });
+    }
+    return bad ? -1 : 0;
+}
+
 // VQRenderer::PreFilterEnvironmentMap, EnvironmentMapRendering.cpp:139-486: diffuse -> blur X,Y per face -> specular.
 int vqo_envmap_prefilter(const float* chain, int w0, int h0, int nMips, int diffuseRes, float diffuseStep, int specRes0, int order,
                          void* diffuse_unblurred, void* diffuse_blurred, void* specular, int nthreads) {

@@ -50,6 +50,7 @@ def load():
     lib.vqo_loop_count.argtypes = [f32, f32]
     lib.vqo_conv_diffuse.argtypes = [vp, i32, i32, i32, i32, f32, i32, vp, i32, lg, lg, i32]
     lib.vqo_conv_specular.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, i32]
+    lib.vqo_conv_specular_texels.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32]
     lib.vqo_envmap_prefilter.argtypes = [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32]
     lib.vqo_gbuffer_from_materials.argtypes = [C.POINTER(abi.Interpolants), C.POINTER(abi.MaterialDesc), i32, f32,
                                                C.POINTER(abi.SSAO), C.POINTER(abi.GBuffer), i32]
@@ -213,6 +214,17 @@ def conv_specular(chain, w0, h0, n_mips, res0, order, fmt=abi.FMT_RGBA16F, nthre
     rc = lib.vqo_conv_specular(_p(chain), w0, h0, n_mips, res0, order, _p(out), fmt, nthreads)
     assert rc == 0, rc
     return out, mips
+
+
+def conv_specular_texels(chain, w0, h0, n_mips, res0, order, texels, fmt=abi.FMT_RGBA16F, nthreads=0):
+    """PSMain_SpecularIrradiance at the flat texel indices `texels` of the mip-major cube: [n, 4]"""
+    lib = load()
+    dt, ch = _NP[fmt]
+    tx = np.ascontiguousarray(texels, np.int64)
+    out = np.empty((len(tx), ch), dt)
+    rc = lib.vqo_conv_specular_texels(_p(chain), w0, h0, n_mips, res0, order, _p(tx), len(tx), _p(out), fmt, nthreads)
+    assert rc == 0, rc
+    return out
 
 
 def envmap_prefilter(chain, w0, h0, n_mips, diffuse_res, diffuse_step, spec_res0, order, nthreads=0):

@@ -71,6 +71,7 @@ def load(name="shaders"):
             lib.vqref_unpack_normal.argtypes = [vp, vp, vp, vp]
             lib.vqref_conv_diffuse.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32]
             lib.vqref_conv_specular.argtypes = [vp, i32, i32, i32, i32, f32, f32, f32, i32, vp]
+            lib.vqref_conv_specular_texels.argtypes = [vp, i32, i32, i32, i32, f32, f32, f32, i32, vp, vp, vp, i32, vp]
             lib.vqref_brdf_lut_texels.argtypes = [vp, vp, i32, vp]
             lib.vqref_blur_pass.argtypes = [vp, i32, i32, i32, vp]
             lib.vqref_tonemap.argtypes = [vp, i32, i32, vp, vp]
@@ -181,6 +182,16 @@ def conv_specular_mip(chain, w0, h0, n_mips, res, roughness, mip):
     chain = np.ascontiguousarray(chain, np.float32)
     out = np.zeros((6, res, res, 4), np.float32)
     assert load().vqref_conv_specular(chain.ctypes.data, w0, h0, n_mips, res, roughness, float(w0), float(h0), mip, out.ctypes.data) == 0
+    return out
+
+
+def conv_specular_texels(chain, w0, h0, n_mips, res, roughness, mip, faces, xs, ys):
+    """PSMain_SpecularIrradiance of mip `mip` (res^2 faces) at the texels (faces[k], xs[k], ys[k]): float32 [n, 4]"""
+    chain = np.ascontiguousarray(chain, np.float32)
+    faces, xs, ys = (np.ascontiguousarray(a, np.int32) for a in (faces, xs, ys))
+    out = np.zeros((len(xs), 4), np.float32)
+    assert load().vqref_conv_specular_texels(chain.ctypes.data, w0, h0, n_mips, res, roughness, float(w0), float(h0), mip,
+                                             faces.ctypes.data, xs.ctypes.data, ys.ctypes.data, len(xs), out.ctypes.data) == 0
     return out
 
 
