@@ -330,67 +330,90 @@ __global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restri
 // X-blurred texel is rounded to fp16 exactly like the store to BlurIntermediate, each Y-blurred one like the store to BlurOutput, whose 16 bits index the
 // 64 KB tonemap table), another schedule:
 //   * one 1 024-lane workgroup per CU owns a 64-column strip of S output rows and walks down it 32 rows per iteration. LDS = the tonemap table (64 KB) + a
-//     ring of 84 X-blurred rows of 64 texels in the storage format, 8 B each (140 800 bytes);
+//     ring of 84 X-blurred rows of 64 texels — since round 6 as the fp32 VALUES of the stored halfs, (x, y) pairs of 8 B in the padded slots + a z plane of 4 B
+//     (162 640 of the CU's 163 840 bytes): the Y waves filter what they read without converting it (18 conversions per pixel less; 6 more in the X waves);
 //   * waves 0-7 are the X waves, waves 8-15 the Y waves (two of each per SIMD), and they work on DIFFERENT iterations: while the X waves filter the 32 input
 //     rows of iteration i into the ring, the Y waves filter the 32 output rows whose windows iteration i - 1 completed. The two halves meet at ONE barrier per
 //     iteration; in between, the LDS phases (window reads) of one half run under the mad phases of the other — with all 16 waves in the same stage
 //     (first form of this kernel: profiles/r5d_post_forms.md) the LDS and the VALU took turns and the kernel was no faster than the two it replaces;
 //   * X waves: a quarter-wave filters one 64-texel row, 4 adjacent texels per lane. The 84 input texels are parked raw in the row's ring slot (slot of texel
 //     p = p + p/4: the stride-5 ds_read_b64 pattern of k_blur_x4; the row stride of 112 slots puts the second row of a 32-lane group on the other half of the
-//     banks), every lane reads its 24-texel window (6 LDS reads per output), runs the 252 mads and writes its 4 results over the raw texels — the LDS
-//     operations of one wave complete in order. The global loads of iteration i + 1 are issued before the mads of iteration i;
-//   * Y waves: 64 columns x 4 rows per wave; a lane reads its 24-row column window out of the ring (6 LDS reads per output again), 252 mads, three table
-//     lookups and one 4-byte store per output. In iteration 0 they have no rows yet and fill the table.
-// All mads are v_fma_mix_f32 on the packed halfs (the fp16 -> fp32 conversion of the operand is exact and part of the instruction): no window is ever converted. (The form
-// that converts the windows first and filters with v_fmac_f32 was measured slower, 61.7 against 58.9 us: profiles/r5g_post_forms.md.)
+//     banks), every lane reads its 24-texel window (6 LDS reads per output), converts it, runs the 252 mads and writes its 4 results (rounded to fp16, kept as fp32)
+//     over the raw texels — the LDS operations of one wave complete in order. The global loads of iteration i + 1 are issued before the mads of iteration i;
+//   * Y waves: 64 columns x 4 rows per wave; a lane reads its 24-row column window out of the ring (an 8-byte and a 4-byte read per row; six group bases per plane,
+//     the rows of a group at immediate offsets: the ring's wrap never falls inside a group of 4), 252 mads, three table lookups and one 4-byte store per output.
+//     In iteration 0 they have no rows yet and fill the table.
+// The mads: Window4 below (round 6: converted window, v_pk_fma_f32 on (x, y) + v_fmac_f32 on z; round 5: 252 v_fma_mix_f32 on the packed halfs).
 // Halos (row-tiled frames): halo_top / halo_bottom are SCENE-COLOUR rows here — the X pass is purely horizontal, so the rows the neighbour tile shaded are filtered
 // in X like the tile's own and the Y window reaches them: 10 rows per side, the same byte count as the X-blurred halos of the two-kernel path.
-VQD float fma_mix_lo(uint32_t h, float w, float acc) { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h), "s"(w)); return acc; }
-VQD float fma_mix_hi(uint32_t h, float w, float acc) { asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h), "s"(w)); return acc; }
-// An 8-byte LDS read that stays ONE ds_read_b64 (2 LDS cycles per wave): left to the compiler, two reads of adjacent slots become a 16-byte load with 8-byte
-// alignment = ds_read2_b64 (8 cycles). The compiler does not count these in its lgkmcnt bookkeeping: lds_wait() below is the wait, and it names every destination
-// so that no consumer can be scheduled above it. (The compiler's own waits can only over-wait: LDS operations of a wave complete in order.)
-template <int OFF> VQD void lds_read_b64(uint32_t& lo, uint32_t& hi, uint32_t addr) {
-    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-    u2v v;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    lo = v.x; hi = v.y;
+// An 8-byte LDS read that stays ONE ds_read_b64 (2 LDS cycles per wave): left alone, the compiler merges two reads at nearby offsets of one base into ds_read2_b64
+// (8 cycles). Round 6: an ordinary load from an address-space-3 pointer whose integer BASE is laundered in place through an empty asm before every load — the compiler
+// cannot prove two such loads related, so it does not merge them, keeps the row / slot offsets in the instruction's immediate field (no address arithmetic per read: 158
+// v_add_u32 per window pair before), and tracks their completion itself (s_waitcnt lgkmcnt(n) as the data is needed). Round 5 issued the reads from inline asm whose
+// results the compiler believed ready at once and waited in a separate asm: correct only as long as the register allocator moved none of them in between.
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define LDS_AS __attribute__((address_space(3)))
+// `a` is a byte address in the LDS aperture (lds_addr() of a __shared__ pointer + offsets); it is laundered IN PLACE, so consecutive reads from one base register cost no copy
+template <class T, int OFF> VQD T lds_load(uint32_t& a) {
+    asm volatile("" : "+v"(a));
+    return *(const LDS_AS T*)(uintptr_t)(a + OFF);
 }
-#define PC_TIE6(a, i) "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]), "+v"(a[i + 4]), "+v"(a[i + 5])
-VQD void lds_wait(uint32_t (&lo)[24], uint32_t (&hi)[24]) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : PC_TIE6(lo, 0), PC_TIE6(lo, 6), PC_TIE6(lo, 12), PC_TIE6(lo, 18));
-    asm volatile("" : PC_TIE6(hi, 0), PC_TIE6(hi, 6), PC_TIE6(hi, 12), PC_TIE6(hi, 18));
-}
+VQD uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const LDS_AS void*)p; }
 template <int T> struct XWindow {                             // window texel t of the X stage: slot 5 li + t + t / 4
-    static VQD void read(uint32_t (&lo)[24], uint32_t (&hi)[24], uint32_t base) {
+    static VQD void read(uint32_t (&lo)[24], uint32_t (&hi)[24], uint32_t& base) {
         XWindow<T - 1>::read(lo, hi, base);
-        lds_read_b64<(T + (T >> 2)) * 8>(lo[T], hi[T], base);
+        const u2v v = lds_load<u2v, (T + (T >> 2)) * 8>(base);
+        lo[T] = v.x; hi[T] = v.y;
     }
 };
-template <> struct XWindow<-1> { static VQD void read(uint32_t (&)[24], uint32_t (&)[24], uint32_t) {} };
-// the 63 mads of one output: kernelIt = 0..20, the HLSL's order (GaussianBlur.hlsl:138-150 / :173-185)
-VQD void filter21(const uint32_t (&wl)[24], const uint32_t (&wh)[24], int j, float& ax, float& ay, float& az) {
-    ax = 0.0f; ay = 0.0f; az = 0.0f;
-    #pragma unroll
-    for (int it = 0; it < 21; ++it) {
-        const int off = it - R;
-        const float wt = kW[off < 0 ? -off : off];
-        ax = fma_mix_lo(wl[j + it], wt, ax); ay = fma_mix_hi(wl[j + it], wt, ay); az = fma_mix_lo(wh[j + it], wt, az);
+template <> struct XWindow<-1> { static VQD void read(uint32_t (&)[24], uint32_t (&)[24], uint32_t&) {} };
+// The 63 mads of each of a lane's 4 outputs: kernelIt = 0..20, the HLSL's order (GaussianBlur.hlsl:138-150 / :173-185). Round 6: the 24-texel window is converted ONCE
+// (72 v_cvt_f32_f16), then every tap is ONE v_pk_fma_f32 on the (x, y) register pair (weights in SGPR pairs: VOP3P takes no literal; VGPR weight pairs cost 12 registers and
+// spilled) and ONE v_fmac_f32 with a literal weight on z — 72 + 84 + 84 instructions where round 5 issued 252 v_fma_mix_f32 on the packed halfs (fp16 -> fp32 inside the
+// instruction): 60.4 -> 52.6 us at 4K on one box, identical bits (profiles/r6h_post_chain_forms.md). The same IEEE operations in the same order either way.
+VQD float half_lo(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu)); }
+VQD float half_hi(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
+struct Window4 {
+    uint32_t wl[24], wh[24];                                  // as read: x | y << 16, z | a << 16
+    v2f xy[24]; float z[24];
+    VQD void convert() {
+        #pragma unroll
+        for (int t = 0; t < 24; ++t) {
+            xy[t] = v2f{ half_lo(wl[t]), half_hi(wl[t]) }; z[t] = half_lo(wh[t]);
+            asm("" : "+v"(xy[t]), "+v"(z[t]));                // keep the conversion apart: left alone the compiler folds it back into v_fma_mix_f32
+        }
     }
-}
+    VQD void filter(int j, float& ax, float& ay, float& az) const {
+        v2f a = { 0.0f, 0.0f };
+        az = 0.0f;
+        #pragma unroll
+        for (int it = 0; it < 21; ++it) {
+            const int off = it - R;
+            const float wt = kW[off < 0 ? -off : off];
+            a = __builtin_elementwise_fma(xy[j + it], v2f{ wt, wt }, a);
+            az = fma_(z[j + it], wt, az);
+        }
+        ax = a.x; ay = a.y;
+    }
+};
 constexpr int PC_C = 64;                                      // columns of a strip
 constexpr int PC_RS = 32;                                     // rows per iteration
 constexpr int PC_RING = 2 * PC_RS + 2 * R;                    // 84 rows: the 32 the X waves write + the 52 the Y waves read
 constexpr int PC_NPX = PC_C + 2 * R;                          // 84 input texels per row
 constexpr int PC_ROWB = 112 * 8;                              // bytes per ring row: 84 texels + one pad after every 4 = 105 slots, rounded up to 16 mod 32 slots
 constexpr int PC_TABLE = 65536;
-constexpr int PC_LDS = PC_TABLE + PC_RING * PC_ROWB;          // 140 800
+constexpr int PC_ZROWB = 65 * 4;                              // bytes per row of the ring's z plane: 64 floats + 1 (the four rows a wave writes at once land on different banks)
+constexpr int PC_ZBASE = PC_TABLE + PC_RING * PC_ROWB;
+constexpr int PC_LDS = PC_ZBASE + PC_RING * PC_ZROWB;         // 162 640 of the CU's 163 840 bytes
 static_assert(PC_NPX + PC_NPX / 4 <= PC_ROWB / 8 && (PC_ROWB / 8) % 32 == 16, "ring row");
+static_assert(PC_LDS <= 160 * 1024, "LDS of one CU");
 __global__ __launch_bounds__(1024) void k_post_chain(const void* __restrict__ in, void* __restrict__ out, const void* __restrict__ haloTop,
                                                      const void* __restrict__ haloBottom, int haloRows, int W, int H,
                                                      const void* __restrict__ table, int stripsX, int stripsY, int S, int xcdBands) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
+    const uint32_t ldsA = lds_addr(lds);
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     // strip (sx, sy) of workgroup b. Workgroup b runs on XCD b % 8 and every XCD has its own L2: with xcdBands = 8 / stripsY > 0 an XCD owns ONE band of rows
     // and a contiguous range of its column strips, so that the 20 halo columns two neighbouring strips share are read through one L2.
@@ -414,7 +437,6 @@ __global__ __launch_bounds__(1024) void k_post_chain(const void* __restrict__ in
             slotOff[j] = (uint32_t)(p + (p >> 2)) * 8u;
         }
         const bool stage5 = li + 80 < PC_NPX;                                   // the sixth staging texel exists for li < 4
-        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
         u2v pre[6];
         auto fetch = [&](int k) {
             const int r = y0 - R + PC_RS * k + rr;                              // image row of this quarter-wave (clamp :178, or the neighbour tile's rows)
@@ -430,21 +452,22 @@ __global__ __launch_bounds__(1024) void k_post_chain(const void* __restrict__ in
         for (int k = 0; k <= nX; ++k) {
             if (k < nX) {
                 int phys = pb + rr; if (phys >= PC_RING) phys -= PC_RING;
-                const uint32_t rowB = PC_TABLE + (uint32_t)phys * PC_ROWB;
+                const uint32_t rowB = PC_TABLE + (uint32_t)phys * PC_ROWB, zRowB = PC_ZBASE + (uint32_t)phys * PC_ZROWB;
                 #pragma unroll
                 for (int j = 0; j < 6; ++j) if (j < 5 || stage5) *(u2v*)(lds + rowB + slotOff[j]) = pre[j];
                 __builtin_amdgcn_wave_barrier();
-                uint32_t wl[24], wh[24];                      // the 24-texel window: x | y << 16, z | a << 16
-                XWindow<23>::read(wl, wh, rowB + (uint32_t)(5 * li) * 8u);
+                Window4 w;                              // the 24-texel window: x | y << 16, z | a << 16
+                uint32_t wbase = ldsA + rowB + (uint32_t)(5 * li) * 8u;
+                XWindow<23>::read(w.wl, w.wh, wbase);
                 if (k + 1 < nX) fetch(k + 1);                 // in flight during the mads below
-                lds_wait(wl, wh);
+                w.convert();
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float ax, ay, az;
-                    filter21(wl, wh, j, ax, ay, az);
-                    u2v o;                                    // == the store to BlurIntermediate (RGBA16F, alpha 1)
-                    o.x = float_to_half_bits(ax) | (float_to_half_bits(ay) << 16); o.y = float_to_half_bits(az) | 0x3C000000u;
-                    *(u2v*)(lds + rowB + (uint32_t)(5 * li + j) * 8u) = o;
+                    w.filter(j, ax, ay, az);
+                    // == the store to BlurIntermediate (RGBA16F): rounded to fp16, and kept as the fp32 value of that half — the Y waves filter without converting
+                    *(v2f*)(lds + rowB + (uint32_t)(5 * li + j) * 8u) = v2f{ (float)to_f16(ax), (float)to_f16(ay) };
+                    *(float*)(lds + zRowB + (uint32_t)(4 * li + j) * 4u) = (float)to_f16(az);
                 }
                 pb += PC_RS; if (pb >= PC_RING) pb -= PC_RING;
             }
@@ -453,7 +476,7 @@ __global__ __launch_bounds__(1024) void k_post_chain(const void* __restrict__ in
     } else {
         // ================= Y waves: column `lane` of the strip, rows 4 g .. 4 g + 3 of the iteration's 32 outputs =================
         const int g = wv - 8;
-        const uint32_t colB = PC_TABLE + (uint32_t)(lane + (lane >> 2)) * 8u;
+        const uint32_t colB = PC_TABLE + (uint32_t)(lane + (lane >> 2)) * 8u, zColB = PC_ZBASE + (uint32_t)lane * 4u;
         const bool xOk = x0 + lane < W;
         uint32_t* __restrict__ dstCol = (uint32_t*)out + (size_t)y0 * W + (xOk ? x0 + lane : 0);
         for (int i = (tid - 512) * 16; i < PC_TABLE; i += 512 * 16) *(uint4*)(lds + i) = *(const uint4*)((const unsigned char*)table + i);
@@ -463,18 +486,21 @@ __global__ __launch_bounds__(1024) void k_post_chain(const void* __restrict__ in
             const int oRel = PC_RS * (k - 1) - 2 * R + 4 * g;     // first output row of this wave, relative to y0 (a multiple of 4; negative in the first iteration)
             if (oRel >= 0 && oRel < rows) {
                 int q = pb + 4 * g; if (q >= PC_RING) q -= PC_RING;
-                uint32_t wl[24], wh[24];
+                Window4 w;                                    // the ring holds fp32 values: nothing to convert
                 #pragma unroll
-                for (int t = 0; t < 24; ++t) {
-                    int ph = q + t; if (ph >= PC_RING) ph -= PC_RING;
-                    lds_read_b64<0>(wl[t], wh[t], colB + (uint32_t)ph * PC_ROWB);
+                for (int g4 = 0; g4 < 6; ++g4) {              // q and the ring length are multiples of 4: four consecutive window rows never straddle the ring's wrap
+                    int ph = q + 4 * g4; if (ph >= PC_RING) ph -= PC_RING;
+                    uint32_t axy = ldsA + colB + (uint32_t)ph * PC_ROWB, az_ = ldsA + zColB + (uint32_t)ph * PC_ZROWB;
+                    w.xy[4 * g4 + 0] = lds_load<v2f, 0>(axy);            w.z[4 * g4 + 0] = lds_load<float, 0>(az_);
+                    w.xy[4 * g4 + 1] = lds_load<v2f, PC_ROWB>(axy);      w.z[4 * g4 + 1] = lds_load<float, PC_ZROWB>(az_);
+                    w.xy[4 * g4 + 2] = lds_load<v2f, 2 * PC_ROWB>(axy);  w.z[4 * g4 + 2] = lds_load<float, 2 * PC_ZROWB>(az_);
+                    w.xy[4 * g4 + 3] = lds_load<v2f, 3 * PC_ROWB>(axy);  w.z[4 * g4 + 3] = lds_load<float, 3 * PC_ZROWB>(az_);
                 }
-                lds_wait(wl, wh);
                 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (oRel + j >= rows) break;              // wave-uniform
                     float ax, ay, az;
-                    filter21(wl, wh, j, ax, ay, az);
+                    w.filter(j, ax, ay, az);
                     const uint32_t hx = float_to_half_bits(ax), hy = float_to_half_bits(ay), hz = float_to_half_bits(az);   // == the BlurOutput store
                     const uint32_t px = (uint32_t)lds[hx] | ((uint32_t)lds[hy] << 8) | ((uint32_t)lds[hz] << 16) | (255u << 24);   // alpha 1 -> 255
                     if (xOk) dstCol[(size_t)(oRel + j) * W] = px;
