@@ -30,20 +30,26 @@ def light_counts(pf):
             "directional": int(L.directional.enabled), "directional_shadowing": int(L.directional.shadowing)}
 
 
+def device_gbuffer(name, coherent=False):
+    w = WORKLOADS[name]
+    W, H = w["width"], w["height"]
+    gb = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
+    for r in range(0, H, 240):
+        part = (synth.gbuffer_rows_coherent if coherent else synth.gbuffer_rows)(W, H, r, min(r + 240, H), seed=w["seed"])
+        for k in range(4):
+            gb[k][r:r + part[k].shape[0]].copy_(torch.from_numpy(part[k]))
+    return gb
+
+
 def device_inputs(name, gb=None, coherent=False):
     """(gb planes on the device, PerFrameData, PerViewLightingData, abi.ShadowMaps, keep-alive list, host maps)"""
     w = WORKLOADS[name]
-    W, H = w["width"], w["height"]
     pf, maps = w["frame"]()
     keep = [torch.from_numpy(maps[k]).cuda() for k in ("dir", "spot", "point")]
     sm = abi.ShadowMaps(keep[0].data_ptr(), maps["dims"][0], keep[1].data_ptr(), maps["dims"][1], keep[2].data_ptr(), maps["dims"][2])
     if gb is None:
-        gb = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(4)]
-        for r in range(0, H, 240):
-            part = (synth.gbuffer_rows_coherent if coherent else synth.gbuffer_rows)(W, H, r, min(r + 240, H), seed=w["seed"])
-            for k in range(4):
-                gb[k][r:r + part[k].shape[0]].copy_(torch.from_numpy(part[k]))
-    return gb, pf, synth.per_view(W, H), sm, keep, maps
+        gb = device_gbuffer(name, coherent)
+    return gb, pf, synth.per_view(w["width"], w["height"]), sm, keep, maps
 
 
 def cpu_baseline_cfg1(cores, target_s=8.0):
@@ -85,6 +91,12 @@ def casters_report(ctx, stage_stats, hbm_peak_gbps, gb_4k=None, cores=None):
                      "shade_Mpix_s": round(px / ms / 1e3, 1), "bytes_per_px": BYTES_PER_PX, "hbm_GBps": round(BYTES_PER_PX * px / ms / 1e6, 1),
                      "hbm_frac": round(BYTES_PER_PX * px / ms / 1e6 / hbm_peak_gbps, 4),
                      "kernel": "k_forward_lighting<noenv,casters,RGBA16F>"}
+        if name == "engine_max":                         # the same lights on surface-coherent positions / normals: whole waves skip spots and back-facing casters
+            gbc = device_gbuffer(name, coherent=True)
+            stc = stage_stats(lambda: ctx.forward_lighting(gbc, pf, pv, out=img, out_fmt=F16, shadow=sm))
+            out[name]["coherent_content"] = {"shade_ms": round(stc["ms"], 4), "shade_Mpix_s": round(px / stc["ms"] / 1e3, 1),
+                                             "note": "synth.gbuffer_rows_coherent instead of the white-noise G-buffer; the shadow maps' fetch addresses follow the positions"}
+            del gbc
         del gb, keep, img
         torch.cuda.empty_cache()
     if cores:

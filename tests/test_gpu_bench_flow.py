@@ -22,9 +22,12 @@ def _free_port():
 
 
 def _run(ranks, extra_args, **more_env):
-    env = dict(os.environ, VQ_BENCH_SHARE_GPU="1", VQ_BENCH_VERIFY="1", VQ_BENCH_SPINUP="4", VQ_BENCH_SUSTAINED_S="0.05", MASTER_ADDR="127.0.0.1", **more_env)
+    env = dict(os.environ, VQ_BENCH_SHARE_GPU="1", VQ_BENCH_VERIFY="1", VQ_BENCH_SPINUP="4", VQ_BENCH_SUSTAINED_S="0.05", MASTER_ADDR="127.0.0.1")
+    env.update(more_env)
+    # a fault is injected by running bench.main() with a Pipeline subclass (tests/bench_fault_harness.py): nothing of it lives in bench.py
+    script = os.path.join(ROOT, "tests", "bench_fault_harness.py") if "VQ_TEST_FAULT" in more_env else os.path.join(ROOT, "bench.py")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "4", "--warmup", "1",
+           "--master-port", str(_free_port()), script, "--gpus", str(ranks), "--steps", "4", "--warmup", "1",
            "--no-cpu-baseline", "--no-second-mode"] + extra_args
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
@@ -86,7 +89,7 @@ def test_cfg5_strong_scaling_flow_matches_the_untiled_frame():
 def test_overlap_watchdog_falls_back_to_one_stream_order():
     """--composite-overlap auto: when the first overlapped steps do not complete in time (forced here), every rank aborts its communicator,
     builds a new one and runs the composite in stream order; the frame is still the untiled one."""
-    d = _run(2, ["--config", "cfg3", "--no-extras"], VQ_BENCH_FAKE_OVERLAP_TIMEOUT="1")
+    d = _run(2, ["--config", "cfg3", "--no-extras"], VQ_TEST_FAULT="overlap_timeout")
     assert d["verify"]["mismatching_bytes"] == 0, d["verify"]
     assert d["config"]["composite_overlap"] is False and d["rccl"]["composite_overlap_mode"] == "off" and d["rccl"]["fallback"], d["rccl"]
 
@@ -95,15 +98,20 @@ def test_a_missing_stream_wait_corrupts_the_frame_under_the_asynchronous_transpo
     """The stand-in for RCCL is asynchronous like RCCL (tests/cpp/mock_rccl.cpp: the transfers of a group run on the communicator's worker thread behind an event of
     the caller's stream, later work on that stream waits on a signal word, ncclGroupEnd returns at once), so the orderings between the main stream and the composite's
     stream are real orderings, not only control flow. The verified step starts from zeroed output buffers on a drained device: leaving out the wait that puts the
-    composite behind the post kernel (VQ_BENCH_FAULT) must deliver a wrong frame. The synchronous form of the stand-in ($VQMOCK_RCCL_SYNC=1, rounds 1-4) still runs
+    composite behind the post kernel (tests/bench_fault_harness.py, VQ_TEST_FAULT) must deliver a wrong frame. The synchronous form of the stand-in ($VQMOCK_RCCL_SYNC=1, rounds 1-4) still runs
     the unbroken flow to the right frame."""
     args = ["--config", "cfg3", "--composite-overlap", "two-comms", "--no-extras"]       # the composite's communicator has its own worker: it starts as soon as its stream lets it
     d = _run(2, args, VQMOCK_RCCL_SYNC="1")
     assert d["verify"]["mismatching_bytes"] == 0, d["verify"]
-    d = _run(2, args, VQ_BENCH_FAULT="drop_post_wait")
-    if d["verify"]["mismatching_bytes"] == 0:                 # a race lost is not a defect of the product: report it without failing the suite
-        pytest.skip("the unordered composite happened to run after the post kernel on this box: the fault was not observable this time")
-    assert d["verify"]["mismatching_bytes"] > 1000, d["verify"]
+    worst = 0
+    for attempt, spin in enumerate(("4", "12", "40")):        # a race can be lost: three attempts with different amounts of work queued in front of the verified step
+        d = _run(2, args, VQ_TEST_FAULT="drop_post_wait", VQ_BENCH_SPINUP=spin)
+        worst = max(worst, d["verify"]["mismatching_bytes"])
+        if worst > 1000:
+            break
+    if worst == 0:                                            # lost three times: not a defect of the product — report it without failing the suite
+        pytest.skip("the unordered composite ran after the post kernel in all three attempts on this box: the fault was not observable")
+    assert worst > 1000, d["verify"]
 
 
 def test_gpus_n_without_a_launcher_starts_its_own_ranks():
@@ -136,7 +144,8 @@ def test_single_gpu_line_carries_the_contract_fields():
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline", "stages", "engine_lowering", "dxc_lowering", "cold_start", "frame_latency_ms", "valu_issue", "pmc_constants", "rccl",
-              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained", "widened", "other_post_form", "two_frames_in_flight"):
+              "cfg5_strong", "cfg2", "ibl_load", "coherent_scene", "tile_curve", "sustained", "widened", "other_post_form", "two_frames_in_flight", "cfg1", "engine_max",
+              "notes", "digest"):
         assert k in d, k
     assert d["two_frames_in_flight"]["frames_in_flight"] == 2 and d["two_frames_in_flight"]["ms_per_step"] > 0
     assert d["verify"]["mismatching_bytes"] == 0 and d["verify"]["buffers"] == 2, d["verify"]      # the frame loop's two streams / two buffer pairs deliver the two-kernel chain's bytes
@@ -154,11 +163,30 @@ def test_single_gpu_line_carries_the_contract_fields():
     assert isinstance(r["traffic"], int) and r["traffic"] > 597196800 // 2
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "Mpix/s" and c["sample"]
-    assert "stale" in d["pmc_constants"]                     # that the constants belong to the current kernel sources is a CPU test: test_abi.py::test_pmc_constants_are_current
+    assert "stale" in d["pmc_constants"]                     # that the constants belong to the current kernel sources is a CPU test: tests/test_bench_meta.py::test_pmc_constants_are_current
     assert d["engine_lowering"]["fresnel_pow"] == "exp2_log2" and d["engine_lowering"]["value"] > 0
     assert d["dxc_lowering"]["arithmetic"] == "dxc" and d["dxc_lowering"]["value"] > 0
     iso = d["stages"]["isolated"]
     assert iso["post_chain_ms"] > 0 and d["stages"]["post_chain_bytes_per_px"] == 12 and d["stages"]["shade_ms"] > 0
+    # loose upper bounds (no inequality BETWEEN measured times — boxes differ — but a 10x regression of a stage must still fail): round-6 figures 0.95 / 0.048 / 0.075 / 0.071 / 2.5 ms
+    assert d["stages"]["shade_ms"] < 9.5 and iso["post_chain_ms"] < 0.48 and d["cfg2"]["shade_ms"] < 0.75 and d["cfg1"]["shade_ms"] < 0.71 and d["engine_max"]["shade_ms"] < 25.0
+    assert d["stages"]["post_chain_in_loop_ms"] > 0 and abs(d["stages"]["post_chain_alone_ms"] - iso["post_chain_ms"]) < 1e-6      # two timing bases, two keys
+    # the spot-light + PCF caster path is timed in every run: BASELINE cfg1 with its own CPU baseline, and the cbuffer's limits at 4K
+    c1, em = d["cfg1"], d["engine_max"]
+    assert c1["lights"] == {"point": 0, "spot": 0, "point_casters": 0, "spot_casters": 2, "directional": 1, "directional_shadowing": 1} and c1["cpu_baseline"]["value"] > 0
+    assert em["lights"]["point"] == 100 and em["lights"]["spot"] == 20 and em["lights"]["point_casters"] == 5 and em["lights"]["spot_casters"] == 5 and em["coherent_content"]["shade_ms"] > 0
+    ed = d["ibl_load"]["engine_default"]                     # the engine's default IBL sizes
+    assert ed["spec_mips"] == 9 and ed["source_mips"] == 13 and ed["conv_specular_ms"] > 0 and ed["prefilter_ms"] > ed["conv_specular_ms"]
+    # the driver's record keeps `roofline` whole and the last ~2 000 characters of the line: the second-tier figures must sit there
+    kernels = [o["kernel"] for o in r["others"]]
+    assert any("k_post_chain" in k for k in kernels) and any("cfg2" in k for k in kernels) and any("k_conv_diffuse_ordered" in k for k in kernels) and any("cfg1" in k for k in kernels)
+    pc = next(o for o in r["others"] if "k_post_chain" in o["kernel"])
+    assert abs(pc["frac"] - pc["bytes"] / (pc["ms"] * 1e-3) / 8e12) < 0.02 * pc["frac"]
+    assert r["valu"]["frac_spec"] > 0 and r["valu"]["frac_issue"] is not None
+    assert list(d)[-1] == "digest" and list(d)[-4:-1] == ["valu_issue", "cfg5_strong", "stages"]
+    tail = lines[0][-2000:]
+    assert '"digest"' in tail and '"post_chain_alone_ms"' in tail and '"cfg2_hbm_frac"' in tail and '"cfg1_shade_ms"' in tail, "the digest must fit the last 2 000 characters of the line"
+    assert not any(isinstance(v, str) and len(v) > 80 for v in d["stages"].values()), "the prose of `stages` belongs in `notes`"
     # the other BASELINE configs ride in the same line
     c5 = d["cfg5_strong"]
     assert c5["frame"] == [7680, 4320] and c5["tile_rows"] == 4320 and c5["lights"] == 256 and c5["shade_ms"] > 0 and c5["ms_per_step"] > 0 and c5["halo_ms"] == 0
