@@ -164,8 +164,9 @@ public:
         bool bEnableGaussianBlur = false;                        // FPostProcessParameters::bEnableGaussianBlur (PostProcess.h:166); compiled out in the reference (:2526)
         bool bHDR = false;                                       // selects the RGBA16F tonemapper target
         // Row-tiled multi-GPU frame (no reference analogue): this pass was sized for ONE ROW TILE of the frame
-        // (vqhip_rowtile) and pSceneColor is that tile. With pComm set the pass exchanges the 10 X-blurred halo rows with the tiles
-        // above / below before the Y blur, and afterwards composites the finished tiles into pCompositeFrame on CompositeRoot
+        // (vqhip_rowtile) and pSceneColor is that tile. With pComm set the pass exchanges 10 halo rows with the tiles above / below — rows of SCENE COLOUR right
+        // behind the shade kernel on the SDR path (one call filters X, Y and tonemaps), X-blurred rows before the Y blur on the HDR path — and afterwards
+        // composites the finished tiles into pCompositeFrame on CompositeRoot
         // (VQHIP_ALL_RANKS: on every rank). pCompositeFrame: FrameHeight x Width texels of the output format, or nullptr on ranks that
         // do not receive the frame.
         vqhip_comm* pComm = nullptr;                             // its size and this process's rank are read from it (vqhip_comm_query)
@@ -181,11 +182,15 @@ public:
         OnDestroyWindowSizeDependentResources();
         mWidth = Width; mHeight = Height;
         const size_t px = (size_t)Width * Height;
-        mBlurIntermediate = Alloc(px * 8); mBlurOutput = Alloc(px * 8); mTonemapperOut = Alloc(px * 8);
+        mTonemapperOut = Alloc(px * 8);                          // BlurIntermediate / BlurOutput (16 B/px) are allocated on first use of the HDR path only: the SDR path
+                                                                 // never touches them (one kernel for frames of >= 2^20 pixels; below that, or for a curve that mixes channels,
+                                                                 // vqhip_post_process_tile blurs into the CONTEXT's scratch buffer — one more reason why a context
+                                                                 // serves one thread and one stream at a time)
         mHaloTop = Alloc((size_t)VQHIP_HALO_ROWS * Width * 8); mHaloBottom = Alloc((size_t)VQHIP_HALO_ROWS * Width * 8);   // row-tiled mode only
     }
     void OnDestroyWindowSizeDependentResources() override {
         Free(mBlurIntermediate); Free(mBlurOutput); Free(mTonemapperOut); Free(mHaloTop); Free(mHaloBottom); mWidth = mHeight = 0;
+        mBlurIntermediate = mBlurOutput = mTonemapperOut = mHaloTop = mHaloBottom = nullptr;
     }
     void RecordCommands(const IRenderPassDrawParameters* pDrawParameters = nullptr) override {
         const FDrawParameters* p = static_cast<const FDrawParameters*>(pDrawParameters);
@@ -221,6 +226,8 @@ public:
             // HDR (RGBA16F out): CSMain_X -> BlurIntermediate, CSMain_Y -> BlurOutput, tonemapper — the fused Y + tonemap kernel on the LDS tile is slower than two
             // dispatches there, so it keeps them.
             const VQ_BlurParams bp = { (int32_t)mWidth, (int32_t)mHeight };                                      // FBlurParams, PostProcess.h:92-96
+            if (!mBlurIntermediate) { const size_t px = (size_t)mWidth * mHeight; mBlurIntermediate = Alloc(px * 8); mBlurOutput = Alloc(px * 8); }
+            if (!mBlurIntermediate || !mBlurOutput) { mStatus = VQHIP_ERR_HIP; return; }
             mStatus = vqhip_gaussian_blur_x(mCtx, p->Stream, p->pSceneColor, mBlurIntermediate, &bp, VQHIP_FMT_RGBA16F);
             if (mStatus != VQHIP_OK) return;
             const void* top = nullptr; const void* bottom = nullptr; int haloRows = 0;

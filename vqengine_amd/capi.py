@@ -302,8 +302,13 @@ class Context:
             raise VQHipError(rc, (self.lib.vqhip_last_error(self._h) or b"").decode())
 
     # ---- forward lighting (RenderSceneColor, SceneRendering.cpp:1619) --------------------------------------
-    def _psmain_targets(self, h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev):
-        """vqhip_psmain_targets + the tensors it points at: (struct, albedo_metallic | None, motion_vectors | None)"""
+    def _psmain_targets(self, h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev, stream=None):
+        """vqhip_psmain_targets + the tensors it points at: (struct, albedo_metallic | None, motion_vectors | None). The clears run on `stream` — the stream the
+        kernel is launched on: the kernel skips uncovered pixels, so a clear that is not ordered in front of it on the same stream could wipe written pixels."""
+        with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream(self.device)):
+            return self._psmain_targets_on_current_stream(h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev)
+
+    def _psmain_targets_on_current_stream(self, h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev):
         t = abi.PsmainTargets()
         albedo = motion = None
         if albedo_fmt is not None:
@@ -323,7 +328,7 @@ class Context:
         """forward_lighting + the draw's other render targets (ForwardLighting.hlsl:382-389) from the same kernel: returns (out, albedo_metallic, motion_vectors);
         albedo_fmt / motion_fmt None = that target not bound (-> None)."""
         h, w = gb[0].shape[0], gb[0].shape[1]
-        t, albedo, motion = self._psmain_targets(h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev)
+        t, albedo, motion = self._psmain_targets(h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev, stream=stream)
         out = self.forward_lighting(gb, per_frame, per_view, out=out, out_fmt=out_fmt, extra_point=extra_point, env=env, shadow=shadow, stream=stream, _targets=t)
         return out, albedo, motion
 
@@ -488,7 +493,7 @@ class Context:
                                             **kw):
         """forward_lighting_from_materials + the draw's other render targets: returns (out, albedo_metallic, motion_vectors)"""
         h, w = ip[0].shape[0], ip[0].shape[1]
-        t, albedo, motion = self._psmain_targets(h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev)
+        t, albedo, motion = self._psmain_targets(h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev, stream=stream)
         return self.forward_lighting_from_materials(ip, materials, per_frame, per_view, _targets=t, **kw), albedo, motion
 
     def forward_lighting_from_materials(self, ip, materials, per_frame, per_view, ssao=None, out=None, out_fmt=FMT_RGBA16F, extra_point=None,

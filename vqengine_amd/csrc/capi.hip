@@ -20,6 +20,7 @@ using namespace vqk;
 struct vqhip_ctx {
     int device = 0;
     int nCUs = 256;
+    int ldsPerBlock = 64 * 1024;   // hipDeviceAttributeMaxSharedMemoryPerBlock (163 840 on gfx950): what a kernel may opt into, queried once in vqhip_create
     static constexpr int kSlots = 32;
     char* hostRing = nullptr;      // pinned
     char* devRing = nullptr;
@@ -242,6 +243,10 @@ int vqhip_create(int device_ordinal, vqhip_ctx** out_ctx) {
     vqhip_ctx* ctx = new vqhip_ctx();
     ctx->device = device_ordinal;
     ctx->nCUs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        int lds = 0;
+        if (hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, device_ordinal) == hipSuccess && lds > 0) ctx->ldsPerBlock = lds;
+    }
     ctx->generation = g_ctxGeneration.fetch_add(1, std::memory_order_relaxed);
     const size_t ringBytes = kConstSlotBytes * vqhip_ctx::kSlots;
     if ((e = hipHostMalloc((void**)&ctx->hostRing, ringBytes, hipHostMallocDefault)) != hipSuccess ||
@@ -887,16 +892,20 @@ int vqhip_hdr_decode_rgba32f(vqhip_ctx* ctx, void* stream, const void* file, siz
         const int wr = hdr_walk_runs((const uint8_t*)file, bytes, off, w, h, planeOff.data(), &err);
         if (wr < 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, err);
         int encCap = 0, pitch = 0, ldsBytes = 0;
-        if (wr == 0 && hdr_expand_fits(planeOff.data(), w, h, &encCap, &pitch, &ldsBytes)) {
+        if (wr == 0 && hdr_expand_fits(planeOff.data(), w, h, ctx->ldsPerBlock, &encCap, &pitch, &ldsBytes)) {
             const size_t used = planeOff[4 * (size_t)h], fileDev = (used + 4 + 255) & ~(size_t)255, tabBytes = planeOff.size() * 4;
             const int rc = ensureScratch(ctx, fileDev + tabBytes);
             if (rc) return rc;
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->scratch, file, used, hipMemcpyHostToDevice, st));
-            HIP_TRY(ctx, hipMemcpyAsync((char*)ctx->scratch + fileDev, planeOff.data(), tabBytes, hipMemcpyHostToDevice, st));
-            hipError_t e = launch_hdr_expand(st, ctx->scratch, (char*)ctx->scratch + fileDev, out_rgba32f, w, h, encCap, pitch, ldsBytes);
-            if (e != hipSuccess) return failHip(ctx, e, "hdr_expand launch");
-            HIP_TRY(ctx, hipStreamSynchronize(st));  // load-time call: the offset table and the scratch buffer are free again on return
-            return VQHIP_OK;
+            // the offset table is a pageable host vector: whatever happens below, the stream is drained before this scope (and the vector) ends
+            hipError_t e = hipMemcpyAsync(ctx->scratch, file, used, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync((char*)ctx->scratch + fileDev, planeOff.data(), tabBytes, hipMemcpyHostToDevice, st);
+            const bool copied = e == hipSuccess;
+            if (copied) e = launch_hdr_expand(st, ctx->scratch, (char*)ctx->scratch + fileDev, out_rgba32f, w, h, encCap, pitch, ldsBytes);
+            const hipError_t es = hipStreamSynchronize(st);  // load-time call: the offset table and the scratch buffer are free again on return
+            if (!copied) return failHip(ctx, e, "hdr_decode upload");
+            if (e == hipSuccess && es == hipSuccess) return VQHIP_OK;
+            if (es != hipSuccess) return failHip(ctx, es, "hdr_expand");
+            (void)hipGetLastError();                         // the launch was refused (e.g. the LDS opt-in on a part with less LDS): the host expansion below still decodes the file
         }
     }
     // flat files, scanlines too wide for the LDS: expansion on the host, conversion on the GPU

@@ -197,13 +197,13 @@ __global__ __launch_bounds__(256) void k_hdr_expand(const uint8_t* __restrict__ 
     }
 }
 // encoded bytes of the longest scanline (+ alignment slack) and the LDS the kernel needs for it; false when it does not fit
-bool hdr_expand_fits(const uint32_t* planeOff, int w, int h, int* encCap, int* pitch, int* ldsBytes) {
+bool hdr_expand_fits(const uint32_t* planeOff, int w, int h, int ldsLimit, int* encCap, int* pitch, int* ldsBytes) {
     uint32_t longest = 0;
     for (int j = 0; j < h; ++j) { const uint32_t len = planeOff[4 * (size_t)j + 4] - (planeOff[4 * (size_t)j] & ~3u); if (len > longest) longest = len; }
     *encCap = (int)((longest + 3 + 15) & ~15u);
     *pitch = (w + 15) & ~15;
     *ldsBytes = *encCap + 4 * *pitch;
-    return *ldsBytes <= 160 * 1024;
+    return *ldsBytes <= ldsLimit;                            // the device's own limit (hipDeviceAttributeMaxSharedMemoryPerBlock), not a constant of gfx950
 }
 hipError_t launch_hdr_expand(hipStream_t s, const void* file, const void* planeOff, void* out, int w, int h, int encCap, int pitch, int ldsBytes) {
     hipError_t e = hipFuncSetAttribute((const void*)k_hdr_expand, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes);

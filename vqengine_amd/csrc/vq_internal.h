@@ -121,7 +121,7 @@ int hdr_parse_header(const uint8_t* f, size_t n, int* w, int* h, size_t* off, co
 int hdr_expand_rgbe(const uint8_t* f, size_t n, size_t off, int w, int h, uint8_t* rgbe, const char** err);
 hipError_t launch_rgbe_to_rgba32f(hipStream_t s, const void* rgbe, void* out, size_t n);
 int hdr_walk_runs(const uint8_t* f, size_t n, size_t off, int w, int h, uint32_t* planeOff, const char** err);
-bool hdr_expand_fits(const uint32_t* planeOff, int w, int h, int* encCap, int* pitch, int* ldsBytes);
+bool hdr_expand_fits(const uint32_t* planeOff, int w, int h, int ldsLimit, int* encCap, int* pitch, int* ldsBytes);
 hipError_t launch_hdr_expand(hipStream_t s, const void* file, const void* planeOff, void* out, int w, int h, int encCap, int pitch, int ldsBytes);
 hipError_t launch_downsize_box(hipStream_t s, const void* src, void* dst, int sw, int sh, int k);
 
