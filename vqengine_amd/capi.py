@@ -493,7 +493,7 @@ class Context:
                                             **kw):
         """forward_lighting_from_materials + the draw's other render targets: returns (out, albedo_metallic, motion_vectors)"""
         h, w = ip[0].shape[0], ip[0].shape[1]
-        t, albedo, motion = self._psmain_targets(h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev, stream=stream)
+        t, albedo, motion = self._psmain_targets(h, w, albedo_fmt, motion_fmt, sv_curr, sv_prev, stream=kw.get("stream"))
         return self.forward_lighting_from_materials(ip, materials, per_frame, per_view, _targets=t, **kw), albedo, motion
 
     def forward_lighting_from_materials(self, ip, materials, per_frame, per_view, ssao=None, out=None, out_fmt=FMT_RGBA16F, extra_point=None,
