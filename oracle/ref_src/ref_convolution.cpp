@@ -84,6 +84,17 @@ int vqref_conv_specular_texels(const float* chain, int w0, int h0, int nMips, in
     return 0;
 }
 
+// the equirect fetches of ONE texel of the specular pass as the reference's code forms them: taps[k] = (uv.x, uv.y, lod) of the k-th SampleLevel call (samples with
+// NdotL <= 0 make none); returns the number of calls (<= 512), out4 = the texel's result
+int vqref_conv_specular_taps(const float* chain, int w0, int h0, int nMips, int res, float roughness, float dimX, float dimY, int mip, int face, int x, int y,
+                             float* taps, int cap, float* out4) {
+    vqref::TapRecorder rec = { taps, cap, 0 };
+    vqref::g_tapRecorder = &rec;
+    const int rc = vqref_conv_specular_texels(chain, w0, h0, nMips, res, roughness, dimX, dimY, mip, &face, &x, &y, 1, out4);
+    vqref::g_tapRecorder = nullptr;
+    return rc ? rc : rec.n;
+}
+
 // CSMain_BRDFIntegration for n texels (xs[i], ys[i]) of ITS 1024 x 1024 image with ITS 2048 samples: out [n][2]
 int vqref_brdf_lut_texels(const int* xs, const int* ys, int n, float* out) {
     static std::vector<float2> img(1024 * 1024);

@@ -1,7 +1,8 @@
 // ref_hooks.cpp — texture fetch hooks of the CPU-run reference shaders (see ref_hooks.h). TEST INFRASTRUCTURE.
 #include "ref_hooks.h"
 
-namespace vqref { Ctx g_ctx; }
+namespace vqref { Ctx g_ctx;
+TapRecorder* g_tapRecorder = nullptr; }
 
 namespace hlsl {
 using namespace vqref;
@@ -35,6 +36,11 @@ float4 vqref_sample_2d(const Texture2D& t, const SamplerState&, float2 uv, int m
     }
     case kTexEquirect: {
         const EquirectChain* c = (const EquirectChain*)t.res;
+        if (g_tapRecorder) {
+            TapRecorder* r = g_tapRecorder;
+            if (r->n < r->cap) { float* o = r->out + 3 * (size_t)r->n; o[0] = uv.x; o[1] = uv.y; o[2] = mode == kSampleLevel ? arg : 0.0f; }
+            ++r->n;
+        }
         const vqo::f4 r = vqo::sample_equirect_lod(c->chain, c->w0, c->h0, c->nMips, uv.x, uv.y, mode == kSampleLevel ? arg : 0.0f);
         return float4(r.x, r.y, r.z, r.w);
     }

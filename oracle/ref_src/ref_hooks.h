@@ -22,6 +22,9 @@ enum TexKind {
     kCubeDiffuse, kCubeSpecular, kArrSpot, kArrPoint
 };
 struct EquirectChain { const float* chain; int w0, h0, nMips; };
+// optional recorder of the equirect fetches (uv.x, uv.y, lod per SampleLevel call, in call order): tests list the taps of a texel as the REFERENCE'S code formed them
+struct TapRecorder { float* out; int cap, n; };
+extern TapRecorder* g_tapRecorder;
 struct Image { const float* rgba; int width, height; };       // RGBA32F row-major; out-of-range loads return 0 (D3D)
 
 struct Ctx {

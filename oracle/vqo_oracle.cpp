@@ -750,6 +750,9 @@ int vqo_conv_diffuse(const float* chain, int w0, int h0, int nMips, int res, flo
 // PSMain_SpecularIrradiance, CubemapConvolution.hlsl:168-223 for one texel.
 // order 1 (WAVE64): sample i goes to lane i % 64 (8 samples per lane, increasing i); prefilteredColor and
 // totalWeight partial sums are combined by the same butterfly as the diffuse pass.
+// optional recorder (per thread) of the equirect fetches of one texel: (uv.x, uv.y, lod) per executed sample, in sample order — tests/golden/make_filterstep_tail.py
+struct SpecTapRecorder { float* out; int cap, n; };
+static thread_local SpecTapRecorder* t_specTaps = nullptr;
 static f3 specular_irradiance_texel(f3 dirIn, float Roughness, float dimX, float dimY, const float* chain, int w0, int h0, int nMips, int order) {
     const f3 N = normalize(dirIn);
     const f3 V = N;
@@ -770,6 +773,7 @@ static f3 specular_irradiance_texel(f3 dirIn, float Roughness, float dimX, float
             const float fOmegaP = div_(4.0f * PI_, (6.0f * dimX) * dimY);
             const float fMipLevel = (Roughness == 0.0f) ? 0.0f : max_(0.5f * log2_(div_(fOmegaS, fOmegaP)) + -1.0f, 0.0f);
             const f2 uv = DirectionToEquirectUV(L);
+            if (t_specTaps) { SpecTapRecorder* r = t_specTaps; if (r->n < r->cap) { float* o = r->out + 3 * (size_t)r->n; o[0] = uv.x; o[1] = uv.y; o[2] = fMipLevel; } ++r->n; }
             const f4 c = sample_equirect_lod(chain, w0, h0, nMips, uv.x, uv.y, fMipLevel);
             f4& a = acc[i % nLanes];
             a = { a.x + c.x * NdotL, a.y + c.y * NdotL, a.z + c.z * NdotL, a.w + NdotL };
@@ -826,6 +830,23 @@ int vqo_conv_specular_texels(const float* chain, int w0, int h0, int nMips, int 
         store_px(out, (size_t)k, fmt, { c.x, c.y, c.z, 1.0f });
     }
     return bad ? -1 : 0;
+}
+
+// the equirect fetches of ONE texel (flat index into the mip-major cube), sequential order: taps[k] = (uv.x, uv.y, lod); returns their number, out3 = the texel's rgb (fp32)
+int vqo_conv_specular_taps(const float* chain, int w0, int h0, int nMips, int specRes0, int64_t texel, float* taps, int cap, float* out3) {
+    const int MIPS = mip_level_count(specRes0, specRes0) - 1;
+    int mip = 0;
+    int64_t t = texel;
+    while (mip < MIPS && t >= 6LL * (specRes0 >> mip) * (specRes0 >> mip)) { t -= 6LL * (specRes0 >> mip) * (specRes0 >> mip); ++mip; }
+    if (mip >= MIPS || t < 0) return -1;
+    const int r = specRes0 >> mip;
+    const int f = (int)(t / ((int64_t)r * r)), y = (int)((t / r) % r), x = (int)(t % r);
+    SpecTapRecorder rec = { taps, cap, 0 };
+    t_specTaps = &rec;
+    const f3 c = specular_irradiance_texel(cube_texel_dir(f, x, y, r), div_((float)mip, (float)(MIPS - 1)), (float)w0, (float)h0, chain, w0, h0, nMips, 0);
+    t_specTaps = nullptr;
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z;
+    return rec.n;
 }
 
 // VQRenderer::PreFilterEnvironmentMap, EnvironmentMapRendering.cpp:139-486: diffuse -> blur X,Y per face -> specular.

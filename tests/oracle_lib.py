@@ -51,6 +51,7 @@ def load():
     lib.vqo_conv_diffuse.argtypes = [vp, i32, i32, i32, i32, f32, i32, vp, i32, lg, lg, i32]
     lib.vqo_conv_specular.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, i32]
     lib.vqo_conv_specular_texels.argtypes = [vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, i32]
+    lib.vqo_conv_specular_taps.argtypes = [vp, i32, i32, i32, i32, C.c_int64, vp, i32, vp]
     lib.vqo_envmap_prefilter.argtypes = [vp, i32, i32, i32, i32, f32, i32, i32, vp, vp, vp, i32]
     lib.vqo_gbuffer_from_materials.argtypes = [C.POINTER(abi.Interpolants), C.POINTER(abi.MaterialDesc), i32, f32,
                                                C.POINTER(abi.SSAO), C.POINTER(abi.GBuffer), i32]
@@ -225,6 +226,15 @@ def conv_specular_texels(chain, w0, h0, n_mips, res0, order, texels, fmt=abi.FMT
     rc = lib.vqo_conv_specular_texels(_p(chain), w0, h0, n_mips, res0, order, _p(tx), len(tx), _p(out), fmt, nthreads)
     assert rc == 0, rc
     return out
+
+
+def conv_specular_taps(chain, w0, h0, n_mips, res0, texel):
+    """(taps float32 [n, 3] = (uv.x, uv.y, lod) of every executed sample of the texel, rgb float32 [3])"""
+    taps = np.zeros((512, 3), np.float32)
+    rgb = np.zeros(3, np.float32)
+    n = load().vqo_conv_specular_taps(_p(chain), w0, h0, n_mips, res0, int(texel), _p(taps), 512, _p(rgb))
+    assert 0 <= n <= 512, n
+    return taps[:n], rgb
 
 
 def envmap_prefilter(chain, w0, h0, n_mips, diffuse_res, diffuse_step, spec_res0, order, nthreads=0):

@@ -72,6 +72,7 @@ def load(name="shaders"):
             lib.vqref_conv_diffuse.argtypes = [vp, i32, i32, i32, i32, vp, i32, i32]
             lib.vqref_conv_specular.argtypes = [vp, i32, i32, i32, i32, f32, f32, f32, i32, vp]
             lib.vqref_conv_specular_texels.argtypes = [vp, i32, i32, i32, i32, f32, f32, f32, i32, vp, vp, vp, i32, vp]
+            lib.vqref_conv_specular_taps.argtypes = [vp, i32, i32, i32, i32, f32, f32, f32, i32, i32, i32, i32, vp, i32, vp]
             lib.vqref_brdf_lut_texels.argtypes = [vp, vp, i32, vp]
             lib.vqref_blur_pass.argtypes = [vp, i32, i32, i32, vp]
             lib.vqref_tonemap.argtypes = [vp, i32, i32, vp, vp]
@@ -193,6 +194,16 @@ def conv_specular_texels(chain, w0, h0, n_mips, res, roughness, mip, faces, xs, 
     assert load().vqref_conv_specular_texels(chain.ctypes.data, w0, h0, n_mips, res, roughness, float(w0), float(h0), mip,
                                              faces.ctypes.data, xs.ctypes.data, ys.ctypes.data, len(xs), out.ctypes.data) == 0
     return out
+
+
+def conv_specular_taps(chain, w0, h0, n_mips, res, roughness, mip, face, x, y):
+    """(taps float32 [n, 3] = (uv.x, uv.y, lod) of every SampleLevel call of the texel as the reference's code formed them, rgba float32 [4])"""
+    chain = np.ascontiguousarray(chain, np.float32)
+    taps = np.zeros((512, 3), np.float32)
+    out = np.zeros(4, np.float32)
+    n = load().vqref_conv_specular_taps(chain.ctypes.data, w0, h0, n_mips, res, roughness, float(w0), float(h0), mip, face, x, y, taps.ctypes.data, 512, out.ctypes.data)
+    assert 0 <= n <= 512, n
+    return taps[:n], out
 
 
 def brdf_lut_texels(xs, ys):
