@@ -933,6 +933,33 @@ def _pcf_engine_case():
 
 CASES.append(_pcf_engine_case())
 
+# ---- the two caster workloads bench.py times (round 6, benchlib/casters.py): every caster with its OWN view-projection matrix as the engine builds it
+# (Light::GetViewProjectionMatrix: 90-degree perspective frusta for the spots, w != 1; the 256 x 256 orthographic volume of the directional light), shadow maps at the
+# engine's sizes — scene colour of bands of the frames vs the reference's PSMain
+def _caster_workload_cases():
+    def make(tag, frame_fn, W, H, row0, rows, seed, frac):
+        def build():
+            gb_raw, gb = band_gbuffer(W, H, row0, rows, seed)
+            pf, maps = frame_fn()
+            return {"gb": gb, "gb_raw": gb_raw, "pf": pf, "pv": synth.per_view(W, H), "shadow": maps}
+
+        def ref(i):
+            from tests import ref_lib as R
+            return R.forward_from_gbuffer(i["gb_raw"], i["pf"], i["pv"], shadow=host_shadow_dims(i["shadow"]))[..., :3]
+
+        def oracle(i):
+            return O.forward_lighting(i["gb"], i["pf"], i["pv"], F16, shadow=host_shadow_dims(i["shadow"]))[..., :3]
+
+        def product(ctx, i):
+            keep = []
+            return ctx.forward_lighting([_dev(g) for g in i["gb"]], i["pf"], i["pv"], out_fmt=F16, shadow=dev_shadow_dims(i["shadow"], keep)).cpu().numpy()[..., :3]
+        CASES.append(Case(tag, build, ref, oracle, product, ("ulp16", 1, frac), store="f16"))
+    make("cfg1_engine_views_1280x12", scene_mod.default_scene_frame, 1280, 720, 352, 12, 0xC0FFEE, 1e-3)
+    make("engine_max_3840x4", scene_mod.engine_max_frame, 3840, 2160, 1080, 4, 0x6400, 1e-3)
+
+
+_caster_workload_cases()
+
 # ---- BASELINE cfg4 at FULL SIZE against the reference's own HLSL: the load-time passes on the bench's 2048^2 equirect ----
 _CFG4_IN = {}
 
