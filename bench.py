@@ -111,6 +111,21 @@ def load_pmc_constants(config, fresnel_pow):
     return entry, dict(meta, stale=False)
 
 
+def load_time_kernel_counters():
+    """SQ_INSTS_VALU / TCP accesses per launch of the cfg4 load-time kernels (profiles/pmc_constants.json `load_time_kernels`), or None when conv.hip and its headers
+    changed since they were counted: lets the line price those kernels against the ISSUE ceiling instead of a flop model that ignores what a tap really costs."""
+    try:
+        d = json.load(open(PMC_FILE)).get("load_time_kernels")
+    except (OSError, ValueError):
+        return None
+    if not d:
+        return None
+    h = hashlib.sha256()
+    for f in d["sources"]:
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return d if h.hexdigest()[:16] == d["sources_sha256"] else None
+
+
 def _ev():
     return torch.cuda.Event(enable_timing=True)
 
@@ -1015,15 +1030,27 @@ def main():
                            "valu_issue_frac": c2x.get("valu_issue", {}).get("frac")})
         for key, label in (("cfg1", "k_forward_lighting<noenv,casters> cfg1 (1280x720, Default scene lights, PCF)"), ("engine_max", "k_forward_lighting<noenv,casters> engine_max (4K, 100+20 lights, 5+5+1 casters)")):
             if key in extras:
-                others.append({"kernel": label, "ms": extras[key]["shade_ms"], "bytes": SHADE_BYTES_PER_PX * extras[key]["shade_Mpix_s"] * extras[key]["shade_ms"] * 1e3, "frac": extras[key]["hbm_frac"]})
+                others.append({"kernel": label, "ms": extras[key]["shade_ms"], "bytes": SHADE_BYTES_PER_PX * extras[key]["pixels"], "frac": extras[key]["hbm_frac"]})
         if "ibl_load" in extras:
             ib = extras["ibl_load"]
-            others.append({"kernel": "k_conv_diffuse_ordered (cfg4: 6x64^2 texels x 99 382 taps; VALU / L1-bound, no HBM stream)", "ms": ib["conv_diffuse_ms"], "bytes": None, "frac": None,
-                           "valu_frac_model": ib.get("conv_diffuse_valu_frac_model")})
-            others.append({"kernel": "k_conv_specular_ordered (cfg4: 128^2 x 7)", "ms": ib["conv_specular_ms"], "bytes": None, "frac": None, "valu_frac_model": ib.get("conv_specular_valu_frac_model")})
+            ltk = load_time_kernel_counters()
+
+            def issue(kernel, ms):                           # PMC wave-instruction count x 64 lanes / live time / the fast issue rate; L1 tag lookups per clock per CU at 2.1 GHz
+                c = ltk.get(kernel) if ltk else None
+                if not c:
+                    return {}
+                r = {"valu_issue_frac": round(c["valu_wave_instr_per_launch"] * 64 / (ms * 1e-3) / 1e12 / VALU_ISSUE_CEILING_TLIS, 4)}
+                if "tcp_accesses_per_launch" in c:
+                    r["l1_lookups_per_clock_per_cu"] = round(c["tcp_accesses_per_launch"] / (ms * 1e-3) / 2.1e9 / 256, 3)
+                return r
+            others.append({"kernel": "k_conv_diffuse_ordered (cfg4: 6x64^2 texels x 99 382 taps; L1-tag / VALU-bound, no HBM stream)", "ms": ib["conv_diffuse_ms"], "bytes": None, "frac": None,
+                           "valu_frac_model": ib.get("conv_diffuse_valu_frac_model"), **issue("k_conv_diffuse_ordered", ib["conv_diffuse_ms"])})
+            others.append({"kernel": "k_conv_specular_ordered (cfg4: 128^2 x 7)", "ms": ib["conv_specular_ms"], "bytes": None, "frac": None, "valu_frac_model": ib.get("conv_specular_valu_frac_model"),
+                           **issue("k_conv_specular_ordered", ib["conv_specular_ms"])})
             if "engine_default" in ib:
                 others.append({"kernel": "k_conv_specular_ordered (engine default: 512^2 x 9)", "ms": ib["engine_default"]["conv_specular_ms"], "bytes": None, "frac": None})
-            others.append({"kernel": "k_brdf_lut (1024^2 x 2048)", "ms": ib["brdf_lut_warm_ms"], "bytes": 4 * 1024 * 1024, "frac": None, "valu_frac_model": ib.get("brdf_lut_warm_valu_frac_model")})
+            others.append({"kernel": "k_brdf_lut (1024^2 x 2048)", "ms": ib["brdf_lut_warm_ms"], "bytes": 4 * 1024 * 1024, "frac": None, "valu_frac_model": ib.get("brdf_lut_warm_valu_frac_model"),
+                           **issue("k_brdf_lut", ib["brdf_lut_warm_ms"])})
         out["roofline"]["others"] = others
         out["roofline"]["valu"] = {"frac_spec": out["valu"]["frac"], "frac_issue": out.get("valu_issue", {}).get("frac"), "frac_issue_slot_weighted": out.get("valu_issue", {}).get("frac_slot_weighted"),
                                    "note": "the roof that binds the headline kernel: flop model / 157.3 TFLOP/s, and PMC instruction count x live time / 66.7 T lane-instructions/s"}

@@ -87,7 +87,7 @@ def casters_report(ctx, stage_stats, hbm_peak_gbps, gb_4k=None, cores=None):
         img = torch.empty((H, W, 4), dtype=torch.float16, device="cuda")
         st = stage_stats(lambda: ctx.forward_lighting(gb, pf, pv, out=img, out_fmt=F16, shadow=sm))
         px, ms = W * H, st["ms"]
-        out[name] = {"workload": w["workload"], "lights": light_counts(pf), "shade_ms": round(ms, 4), "shade_ms_min": round(st["ms_min"], 4), "shade_ms_max": round(st["ms_max"], 4),
+        out[name] = {"workload": w["workload"], "lights": light_counts(pf), "pixels": px, "shade_ms": round(ms, 4), "shade_ms_min": round(st["ms_min"], 4), "shade_ms_max": round(st["ms_max"], 4),
                      "shade_Mpix_s": round(px / ms / 1e3, 1), "bytes_per_px": BYTES_PER_PX, "hbm_GBps": round(BYTES_PER_PX * px / ms / 1e6, 1),
                      "hbm_frac": round(BYTES_PER_PX * px / ms / 1e6 / hbm_peak_gbps, 4),
                      "kernel": "k_forward_lighting<noenv,casters,RGBA16F>"}
