@@ -131,6 +131,40 @@ def test_conv_specular_all_mips_in_one_launch(ctx, w, h, res0, fmt, order):
     assert_bits(one, ref, f"specular {res0}^2 from {w}x{h}, order {order} vs oracle")
 
 
+@pytest.mark.parametrize("order", [abi.CONV_SEQUENTIAL, abi.CONV_WAVE64])
+@pytest.mark.parametrize("w,h,res0", [(2048, 2048, 128), (512, 256, 64), (64, 32, 8), (100, 50, 8)])
+def test_conv_specular_forms_identical(ctx, set_opt, order, w, h, res0):
+    """Round 6: the branch-free specular sample (unchecked reciprocals + one validity flag, log2 without special cases, branch-free DirectionToEquirectUV, table-driven
+    power-of-two trilinear fetch) == the same kernel with every sample in the general form (option specular_form = general), whole cubes, both summation orders: the BASELINE
+    cfg4 chain, a 2:1 chain, the smallest cube, and a chain that is no power of two (the fast sample is off: both runs are the general form)."""
+    _, _, chain_g, n = _chain(w, h, seed=0x55)
+    set_opt("specular_form", None)
+    fast, _ = ctx.conv_specular(chain_g, w, h, n, res0, order, abi.FMT_RGBA32F)
+    set_opt("specular_form", "general")
+    gen, _ = ctx.conv_specular(chain_g, w, h, n, res0, order, abi.FMT_RGBA32F)
+    _same(fast, gen, f"specular {res0}^2 from {w}x{h}, order {order}: fast vs general sample")
+
+
+def test_conv_specular_fast_sample_special_cases(ctx):
+    """Inputs that raise the fast sample's validity flag or its rare selects, against the CPU oracle: inf / NaN / zero / denormal texels (NaN filtered colours, not NaN
+    addresses), a 1-level chain (lod clamps to 0 everywhere), texel directions on the axes (cube face centres of an odd-free 2^k cube hit x = 0 / z = 0 exactly at res 2)."""
+    eq = synth.equirect(256, 128, seed=0x56)
+    eq[30:34, 60:70, 0] = np.inf
+    eq[80, 200, 1] = np.nan
+    eq[100:104, :, 2] = 0.0
+    eq[110, 10:20, :3] = 1e-42
+    chain_o, n = O.mip_chain(eq)
+    for res0 in (16, 4):
+        with np.errstate(all="ignore"):
+            ref, _ = O.conv_specular(chain_o, 256, 128, n, res0, abi.CONV_SEQUENTIAL, abi.FMT_RGBA32F)
+        got, _ = ctx.conv_specular(dev(chain_o), 256, 128, n, res0, abi.CONV_SEQUENTIAL, abi.FMT_RGBA32F)
+        assert_bits(got, ref, f"specular {res0}^2 over inf / NaN / zero texels")
+    one = synth.equirect(1, 1, seed=0x57)
+    c1, n1 = O.mip_chain(one)
+    ref, _ = O.conv_specular(c1, 1, 1, n1, 4, abi.CONV_SEQUENTIAL, abi.FMT_RGBA32F)
+    assert_bits(ctx.conv_specular(dev(c1), 1, 1, n1, 4, abi.CONV_SEQUENTIAL, abi.FMT_RGBA32F)[0], ref, "specular from a 1 x 1 chain")
+
+
 def test_conv_diffuse_records_across_streams_and_chains(ctx):
     """The footprint records live in one buffer of the context and are rewritten by every call: calls for DIFFERENT chains on different streams must
     not read each other's records (the second call's stream waits for the first call's kernel)."""

@@ -614,6 +614,7 @@ int vqhip_set_option(vqhip_ctx* ctx, const char* key, const char* value) {
     if (k == "post_form") return pick(&o.postForm, { "two", "chain" });
     if (k == "post_strips") return num(&o.postStrips, {});
     if (k == "lut_form") return pick(&o.lutForm, { "general" });
+    if (k == "specular_form") return pick(&o.specularForm, { "general" });
     if (k == "diffuse_form") { if (v == "records") { o.diffuseForm = 0; return VQHIP_OK; } return pick(&o.diffuseForm, { "texels", "general" }); }
     if (k == "diffuse_seq_form") { if (v == "ordered") { o.diffuseSeqForm = 0; return VQHIP_OK; } return pick(&o.diffuseSeqForm, { "lane" }); }
     return fail(ctx, VQHIP_ERR_INVALID_ARG, "set_option: unknown key '" + k + "'");
@@ -1121,7 +1122,7 @@ int vqhip_conv_specular(vqhip_ctx* ctx, void* stream, const void* equirect_mips,
     if (!isImageFmt(fmt)) return fail(ctx, VQHIP_ERR_UNSUPPORTED, "conv_specular: fmt must be RGBA32F or RGBA16F");
     if (order != VQHIP_CONV_SEQUENTIAL && order != VQHIP_CONV_WAVE64) return fail(ctx, VQHIP_ERR_INVALID_ARG, "conv_specular: bad order");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    hipError_t e = launch_conv_specular_all((hipStream_t)stream, (const float4*)equirect_mips, w0, h0, nMips, specRes0, MIPS, order, outCubeMips, fmt);
+    hipError_t e = launch_conv_specular_all((hipStream_t)stream, (const float4*)equirect_mips, w0, h0, nMips, specRes0, MIPS, order, outCubeMips, fmt, ctx->opt);
     return e == hipSuccess ? VQHIP_OK : failHip(ctx, e, "conv_specular launch");
 }
 

@@ -194,13 +194,10 @@ VQD f3 diffuse_tap_general(f3 sv, const float4* chain, int w0, int h0, int nMips
 // diffuse_tap_general (tests/test_gpu_conv_forms.py compares whole cubes of the two forms).
 constexpr float kInvNegTwoPi = 1.0f / -TWO_PI_;                  // == rcp(-TWO_PI_): rcp is the correctly rounded quotient, as is the constant division
 constexpr float kInvPi       = 1.0f / PI_;
-struct DiffuseLevel { const char* tex; int W, H, rowShift; float W256, H256; const char* rec; };   // the sampled level: base, size, log2(W) + 4 (byte offset of a row), 256 W, 256 H
-// the tap in two halves: address arithmetic + the four gathers, then the blend (a loop that requests tap t+1 before it blends tap t was measured: 93
-// VGPRs, 5 waves per SIMD instead of 7, 7.74 against 7.61 ms — the gathers are throughput-, not latency-bound; profiles/r3i_conv_kernels.md)
-struct TapTexels { float4 c00, c10, c01, c11; float wx, wy; };
-template <bool REC = false>
-VQD TapTexels diffuse_tap_fetch(f3 sv, const DiffuseLevel& lv, bool& special) {
-    { float r; (void)sqrt_rcp_newton(dot(sv, sv), &r); sv = mul(sv, r); }                                         // normalize: v * rcp(sqrt(dot)), one quarter-rate instruction
+// DirectionToEquirectUV (ShadingMath.hlsl:70-80) of a direction of length ~1, branch-free: the SAME operations as atan2_ / asin_ / div_ with their branches turned into
+// selects around ONE reciprocal / square root (see diffuse_tap_fetch). What the selects cannot express sets `special` (the caller redoes the tap in the general form): a zero
+// or sub-2^-100 x or a zero z (atan2_'s axis cases; keeps y * rcp(x) finite with rcp(x) normal), |y| >= 1 or NaN (asin_'s pole / NaN cases).
+VQD void equirect_uv_fast(f3 sv, float& u, float& v, bool& special) {
     // atan2_(sv.z, sv.x)
     const float ay = sv.z, axx = sv.x;
     special |= !(abs_(axx) >= 0x1p-100f) | (ay == 0.0f);
@@ -229,7 +226,17 @@ VQD TapTexels diffuse_tap_fetch(f3 sv, const DiffuseLevel& lv, bool& special) {
     const float st = asin_poly(ss, sz);
     float uy = sbig ? 1.5707963267948966192f - (st + st) : st;
     uy = (sx < 0.0f) ? -uy : uy;
-    const float u = ux * kInvNegTwoPi + 0.5f, v = uy * kInvPi + 0.5f;                                             // ShadingMath.hlsl:76-79
+    u = ux * kInvNegTwoPi + 0.5f; v = uy * kInvPi + 0.5f;                                             // ShadingMath.hlsl:76-79
+}
+struct DiffuseLevel { const char* tex; int W, H, rowShift; float W256, H256; const char* rec; };   // the sampled level: base, size, log2(W) + 4 (byte offset of a row), 256 W, 256 H
+// the tap in two halves: address arithmetic + the four gathers, then the blend (a loop that requests tap t+1 before it blends tap t was measured: 93
+// VGPRs, 5 waves per SIMD instead of 7, 7.74 against 7.61 ms — the gathers are throughput-, not latency-bound; profiles/r3i_conv_kernels.md)
+struct TapTexels { float4 c00, c10, c01, c11; float wx, wy; };
+template <bool REC = false>
+VQD TapTexels diffuse_tap_fetch(f3 sv, const DiffuseLevel& lv, bool& special) {
+    { float r; (void)sqrt_rcp_newton(dot(sv, sv), &r); sv = mul(sv, r); }                                         // normalize: v * rcp(sqrt(dot)), one quarter-rate instruction
+    float u, v;
+    equirect_uv_fast(sv, u, v, special);
     // sample_2d_rgba32f_wrap_t<POT = true> on the resolved level; u, v in [-0.01, 1.01]: the float -> int conversions are in range
     // fixed8 (vq_sampling.h): floor((u * W - 0.5) * 256 + 0.5). W is a power of two: u * (256 W) is exact and scaling by 256 commutes with the
     // rounding of the subtraction, so RN(u * W - 0.5) * 256 == fma(u, 256 W, -128) — one operation instead of three, the same value
@@ -453,6 +460,139 @@ __global__ __launch_bounds__(256) void k_conv_diffuse_ordered(const float4* __re
     }
 }
 
+// One executed sample of PSMain_SpecularIrradiance (CubemapConvolution.hlsl:197-215) behind `NdotL > 0`: the filtered environment colour at L.
+// General form: every operation with its range tests and special cases.
+VQD float4 specular_tap_general(f3 L, float NdotH, float HdotV, float Roughness, float fOmegaP, const float4* chain, int w0, int h0, int nMips) {
+    const float D = NormalDistributionGGX(NdotH, Roughness);
+    const float pdf = div_(D * NdotH, 4.0f * HdotV);
+    const float fOmegaS = rcp(max_(512.0f * pdf, 0.00001f));
+    const float fMipLevel = (Roughness == 0.0f) ? 0.0f : max_(0.5f * log2_(div_(fOmegaS, fOmegaP)) + -1.0f, 0.0f);
+    const float2 uv = DirectionToEquirectUV(L);
+    return sample_equirect_lod(chain, w0, h0, nMips, uv.x, uv.y, fMipLevel);
+}
+// Fast form (round 6; the kernel issued ~304 VALU per sample, 0.75 of the issue ceiling: profiles/r6n_pmc_conv.txt): the SAME operations on the same values with
+//   * the three reciprocals unchecked (rcp_newton) and log2 without its special cases (log2_normal_bits), one validity flag: a reciprocal that is not a normal number, a
+//     log2 operand that is not a positive normal number -> `special`;
+//   * DirectionToEquirectUV branch-free (equirect_uv_fast);
+//   * the trilinear WRAP fetch for a power-of-two chain (wave-uniform precondition): level offsets from a table built once per block (LDS), rows by shifts,
+//     fixed8(u * W - 0.5) as floor(fma(u, 256 W, -128) + 0.5) (exact for a power-of-two W: diffuse_tap_fetch), 32-bit byte offsets from the scalar chain base.
+// The caller redoes the sample of the whole wave in the general form when any lane raised `special`; where both apply they give identical bits
+// (tests/test_gpu_conv_forms.py compares whole cubes of the two forms; the oracle comparisons run the fast form).
+struct SpecChain { const char* chain; int lw0, lh0, nMips; float rOmegaP; const uint32_t* lvOff; };    // log2 of the level-0 size; rcp(fOmegaP); byte offsets of the levels (LDS)
+VQD float4 spec_bilinear_pot(const SpecChain& sc, int level, float u, float v) {
+    const int lw = max(sc.lw0 - level, 0), lh = max(sc.lh0 - level, 0);
+    const int W = 1 << lw, H = 1 << lh;
+    const int fx = (int)__builtin_floorf(fma_(u, (float)(W << 8), -128.0f) + 0.5f);
+    const int fy = (int)__builtin_floorf(fma_(v, (float)(H << 8), -128.0f) + 0.5f);
+    const int ix = fx >> 8, iy = fy >> 8;
+    const float wx = (float)(fx & 255) * 0.00390625f, wy = (float)(fy & 255) * 0.00390625f;
+    const uint32_t x0 = (uint32_t)(ix & (W - 1)) << 4, x1 = (uint32_t)((ix + 1) & (W - 1)) << 4;
+    const uint32_t r0 = sc.lvOff[level] + ((uint32_t)(iy & (H - 1)) << (lw + 4)), r1 = sc.lvOff[level] + ((uint32_t)((iy + 1) & (H - 1)) << (lw + 4));
+    return blend4(*(const float4*)(sc.chain + (r0 + x0)), *(const float4*)(sc.chain + (r0 + x1)), *(const float4*)(sc.chain + (r1 + x0)), *(const float4*)(sc.chain + (r1 + x1)), wx, wy);
+}
+VQD float4 specular_tap_fast(f3 L, float NdotH, float HdotV, float Roughness, const SpecChain& sc, bool& special) {
+    // NormalDistributionGGX :65-79
+    const float a = Roughness * Roughness, a2 = a * a, nh2 = NdotH * NdotH;
+    const float t = fma_(nh2, a2 - 1.0f, 1.0f);
+    const float denom = PI_ * (t * t);
+    const bool eps = denom < EPSILON_;
+    const float rd = rcp_newton(denom);
+    special |= !eps & !is_normal(rd);
+    const float D = eps ? 1.0f : a2 * rd;
+    const float rv = rcp_newton(4.0f * HdotV);
+    const float pdf = (D * NdotH) * rv;
+    const float rs = rcp_newton(max_(512.0f * pdf, 0.00001f));           // fOmegaS
+    special |= !(is_normal(rv) && is_normal(rs));
+    const float x = rs * sc.rOmegaP;                                      // div_(fOmegaS, fOmegaP)
+    special |= !((x >= 0x1p-126f) & (x <= 3.4028234663852886e38f));
+    const float lod = (Roughness == 0.0f) ? 0.0f : max_(0.5f * log2_normal_bits(__float_as_uint(x), 0) + -1.0f, 0.0f);
+    float u, v;
+    equirect_uv_fast(L, u, v, special);
+    // sample_equirect_lod_t<POT = true>
+    const float maxl = (float)(sc.nMips - 1);
+    const float l = (lod > 0.0f) ? ((lod < maxl) ? lod : maxl) : 0.0f;
+    const int fl = (int)__builtin_floorf(l * 256.0f + 0.5f);             // l in [0, nMips - 1]: in range
+    int lo = fl >> 8;
+    float f = (float)(fl & 255) * 0.00390625f;
+    if (lo >= sc.nMips - 1) { lo = sc.nMips - 1; f = 0.0f; }
+    const float4 c0 = spec_bilinear_pot(sc, lo, u, v);
+    if (f == 0.0f) return c0;
+    const float4 c1 = spec_bilinear_pot(sc, lo + 1, u, v);
+    const float g = 1.0f - f;
+    return make_float4(fma_(f, c1.x, g * c0.x), fma_(f, c1.y, g * c0.y), fma_(f, c1.z, g * c0.z), fma_(f, c1.w, g * c0.w));
+}
+// ---- the one-sample form of a block (round 6) ---------------------------------------------------------------------------------------------------------
+// At roughness 0 (mip 0: three quarters of the cube's texels) ImportanceSampleGGX returns the SAME half vector for every one of the 512 samples: cosTheta = sqrt((1 - y) /
+// (1 - y)) = 1 exactly (IEEE quotient, BRDF.hlsl:222), sinTheta = 0, so the tangent-space vector is (+-0, +-0, 1) and tangent_to_world forms
+// (t.c * +-0 + b.c * +-0) + N.c * 1 = N.c for every component with a finite frame and N.c != 0 — whatever the signs of the zeros. All 512 samples then fetch the same
+// texels with the same weights, and `prefilteredColor += c * NdotL; totalWeight += NdotL` adds the same four values 512 times. Checked, not assumed: the block verifies that
+// every entry of its table is (+-0, +-0, 1) (spec_table_is_axis: the polar half of every entry evaluated as written, without the 512 sincos) and every texel has a finite
+// frame and no zero component of N; it then evaluates ONE sample per texel and performs the 512 additions in the reference's order on registers (identical operands, identical
+// order: identical bits). cfg4's specular pass 0.409 -> 0.206 ms, the engine default's (512^2 x 9) 6.2 -> 3.06 ms (profiles/r6o_specular_one_sample.md); what
+// remains is the 25 % of the texels with roughness > 0 (8 gathers per sample: two levels) and, per mip-0 block, the chain of 512 dependent additions.
+VQD bool spec_axis_entry(float4 ht) { return (ht.x == 0.0f) & (ht.y == 0.0f) & (ht.z == 1.0f); }
+VQD bool spec_texel_allows_one_sample(f3 N, const TangentFrame& fr) {
+    const float m = (abs_(fr.tangent.x) + abs_(fr.tangent.y) + abs_(fr.tangent.z)) + (abs_(fr.bitangent.x) + abs_(fr.bitangent.y) + abs_(fr.bitangent.z));
+    return (m < __builtin_inff()) & (N.x != 0.0f) & (N.y != 0.0f) & (N.z != 0.0f) & (abs_(N.x) + abs_(N.y) + abs_(N.z) < __builtin_inff());   // false for NaN
+}
+// the 512 tangent-space half vectors of (sample, roughness) into LDS (k_conv_specular_all / _ordered: once per block)
+VQD void spec_build_table(float4* sHt, float Roughness) {
+    for (uint32_t i = threadIdx.x; i < 512u; i += 256) {
+        const float Xix = div_((float)i, 512.0f);
+        float sp, cp; sincos_((2.0f * PI_) * Xix, &sp, &cp);
+        const f3 Ht = ggx_sample_tangent(RadicalInverse_VdC(i), sp, cp, Roughness);
+        sHt[i] = make_float4(Ht.x, Ht.y, Ht.z, 0.0f);
+    }
+}
+// Roughness == 0: is every entry of that table (+-0, +-0, 1)? Only the polar half of ggx_sample_tangent is evaluated, as written — cosTheta = sqrt((1 - y) / (1 + (a^2 - 1) y)),
+// sinTheta = sqrt(1 - cosTheta^2) — and compared with 1 and 0: (cos, sin)(phi) are finite for an argument in [0, 2 pi) (sincos_), so cos(phi) * 0 and sin(phi) * 0 are zeros.
+// Entry 0 is built in full (the one-sample form evaluates it). Returns this lane's verdict over its two entries.
+VQD bool spec_table_is_axis(float4* sHt, float Roughness) {
+    bool axis = true;
+    const float a = Roughness * Roughness;
+    for (uint32_t i = threadIdx.x; i < 512u; i += 256) {
+        const float Xiy = RadicalInverse_VdC(i);
+        const float cosTheta = sqrt_(fdiv_(1.0f - Xiy, 1.0f + (a * a - 1.0f) * Xiy));
+        const float sinTheta = sqrt_(1.0f - cosTheta * cosTheta);
+        axis &= (cosTheta == 1.0f) & (sinTheta == 0.0f);
+    }
+    if (threadIdx.x == 0) {
+        float sp, cp; sincos_((2.0f * PI_) * div_(0.0f, 512.0f), &sp, &cp);
+        const f3 Ht = ggx_sample_tangent(RadicalInverse_VdC(0u), sp, cp, Roughness);
+        sHt[0] = make_float4(Ht.x, Ht.y, Ht.z, 0.0f);
+        axis &= spec_axis_entry(sHt[0]);
+    }
+    return axis;
+}
+constexpr int kSpecMaxLevels = 16;
+// level offsets (bytes) of a power-of-two chain into LDS; returns whether the fast tap may run (power-of-two level 0, <= 16 levels, below 4 GB) — block-uniform
+VQD bool spec_chain_setup(uint32_t* lvOff, int w0, int h0, int nMips) {
+    const bool pot = is_pot2(w0, h0) && nMips <= kSpecMaxLevels && nMips >= 1 && (size_t)w0 * h0 <= ((size_t)1 << 26);
+    if (pot && threadIdx.x < (unsigned)nMips) lvOff[threadIdx.x] = chain_level_offset<true>(w0, h0, (int)threadIdx.x) << 4;
+    return pot;
+}
+
+// One sample of the specular pass for a texel with normal N (= V) and tangent frame fr, from the tangent-space half vector ht: (c * NdotL, NdotL), or zeros for a
+// sample the shader skips (NdotL <= 0). The wave-level choice between the fast and the general form is taken over the lanes active at the call.
+VQD float4 spec_sample(float4 ht, f3 N, const TangentFrame& fr, float Roughness, bool fastOK, const SpecChain& sc, float fOmegaP, const float4* chain, int w0, int h0, int nMips) {
+    const f3 V = N;                                          // PSMain_SpecularIrradiance :172-174
+    const f3 H = tangent_to_world(mk3(ht.x, ht.y, ht.z), fr, N);
+    const f3 L = reflect(neg(V), H);
+    const float NdotL = saturate(dot(N, L));
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (NdotL > 0.0f) {
+        const float NdotH = saturate(dot(N, H));
+        const float HdotV = saturate(dot(H, V));
+        float4 c;
+        if (fastOK) {
+            bool special = false;
+            c = specular_tap_fast(L, NdotH, HdotV, Roughness, sc, special);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) c = specular_tap_general(L, NdotH, HdotV, Roughness, fOmegaP, chain, w0, h0, nMips);
+        } else c = specular_tap_general(L, NdotH, HdotV, Roughness, fOmegaP, chain, w0, h0, nMips);
+        v = make_float4(c.x * NdotL, c.y * NdotL, c.z * NdotL, NdotL);
+    }
+    return v;
+}
 // ---- specular prefilter -------------------------------------------------------------------------------
 // All mips of the prefiltered cube in ONE launch, WAVE64 order (one wave per texel): the 7 launches of the per-mip form leave the chip almost
 // empty for the five small mips (24 ... 1 536 waves). Block = 4 consecutive texels of the mip-major cube; every mip holds a multiple of 4 texels
@@ -460,21 +600,19 @@ __global__ __launch_bounds__(256) void k_conv_diffuse_ordered(const float4* __re
 // reversal, an IEEE division and two square roots per sample — are built once per block into LDS (2 per lane instead of 8 per lane and texel)
 // and the tangent frame of N once per texel. Everything else is the per-mip kernel's arithmetic on the same values: identical bits.
 template <int FMT>
-__global__ __launch_bounds__(256) void k_conv_specular_all(const float4* __restrict__ chain, int w0, int h0, int nMips, int res0, int MIPS, void* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_conv_specular_all(const float4* __restrict__ chain, int w0, int h0, int nMips, int res0, int MIPS, void* __restrict__ out, int allowFast) {
     __shared__ float4 sHt[512];
+    __shared__ uint32_t sLvOff[kSpecMaxLevels];
+    const bool fastOK = spec_chain_setup(sLvOff, w0, h0, nMips) && allowFast;
     const uint32_t NUM_SAMPLES = 512;
     const int lane = threadIdx.x & 63;
     const long T0 = (long)blockIdx.x * 4;
     int mip = 0, res = res0; long base = 0;
     while (mip < MIPS - 1 && T0 >= base + 6L * res * res) { base += 6L * res * res; ++mip; res >>= 1; }
     const float Roughness = div_((float)mip, (float)(MIPS - 1));                       // EnvironmentMapRendering.cpp:432
-    for (uint32_t i = threadIdx.x; i < NUM_SAMPLES; i += 256) {
-        const float Xix = div_((float)i, (float)NUM_SAMPLES);
-        float sp, cp; sincos_((2.0f * PI_) * Xix, &sp, &cp);
-        const f3 Ht = ggx_sample_tangent(RadicalInverse_VdC(i), sp, cp, Roughness);
-        sHt[i] = make_float4(Ht.x, Ht.y, Ht.z, 0.0f);
-    }
-    __syncthreads();
+    // Roughness == 0 (mip 0): the cheap proof that the table is (+-0, +-0, 1) throughout; everything else, and a block that fails it: the table itself
+    const bool axisTable = (Roughness == 0.0f && allowFast) ? (__syncthreads_and(spec_table_is_axis(sHt, Roughness)) != 0) : false;
+    if (!axisTable) { __syncthreads(); spec_build_table(sHt, Roughness); __syncthreads(); }
     const long texel = T0 + (threadIdx.x >> 6) - base;                                  // within the mip
     if (texel >= 6L * res * res) return;
     const int f = (int)(texel / ((long)res * res)), y = (int)((texel / res) % res), x = (int)(texel % res);
@@ -482,21 +620,28 @@ __global__ __launch_bounds__(256) void k_conv_specular_all(const float4* __restr
     const f3 V = N;
     const TangentFrame fr = tangent_frame(N);
     const float fOmegaP = div_(4.0f * PI_, (6.0f * (float)w0) * (float)h0);            // :203 with TextureDimensionsLOD0 = equirect dims (:433-434)
+    const SpecChain sc = { (const char*)chain, 31 - __builtin_clz(w0 | 1), 31 - __builtin_clz(h0 | 1), nMips, rcp(fOmegaP), sLvOff };
     float ax = 0.0f, ay = 0.0f, az = 0.0f, aw = 0.0f;
+    const bool oneSample = axisTable && spec_texel_allows_one_sample(N, fr);            // wave-uniform: a wave is one texel
     for (uint32_t i = (uint32_t)lane; i < NUM_SAMPLES; i += 64u) {
-        const float4 ht = sHt[i];
+        if (oneSample && i >= 64u) {                                                     // the lane's other seven samples are its first one again: add it seven more times
+            const float px = ax, py = ay, pz = az, pw = aw;
+            for (int k = 0; k < 7; ++k) { ax = ax + px; ay = ay + py; az = az + pz; aw = aw + pw; }
+            break;
+        }
+        const float4 ht = sHt[oneSample ? 0u : i];               // one-sample form: only entry 0 of the table was built (every entry is the same vector up to the signs of its zeros)
         const f3 H = tangent_to_world(mk3(ht.x, ht.y, ht.z), fr, N);
         const f3 L = reflect(neg(V), H);
         const float NdotL = saturate(dot(N, L));
         if (NdotL > 0.0f) {
             const float NdotH = saturate(dot(N, H));
             const float HdotV = saturate(dot(H, V));
-            const float D = NormalDistributionGGX(NdotH, Roughness);
-            const float pdf = div_(D * NdotH, 4.0f * HdotV);
-            const float fOmegaS = rcp(max_((float)NUM_SAMPLES * pdf, 0.00001f));
-            const float fMipLevel = (Roughness == 0.0f) ? 0.0f : max_(0.5f * log2_(div_(fOmegaS, fOmegaP)) + -1.0f, 0.0f);
-            const float2 uv = DirectionToEquirectUV(L);
-            const float4 c = sample_equirect_lod(chain, w0, h0, nMips, uv.x, uv.y, fMipLevel);
+            float4 c;
+            if (fastOK) {
+                bool special = false;
+                c = specular_tap_fast(L, NdotH, HdotV, Roughness, sc, special);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(special) != 0, 0)) c = specular_tap_general(L, NdotH, HdotV, Roughness, fOmegaP, chain, w0, h0, nMips);
+            } else c = specular_tap_general(L, NdotH, HdotV, Roughness, fOmegaP, chain, w0, h0, nMips);
             ax = ax + c.x * NdotL; ay = ay + c.y * NdotL; az = az + c.z * NdotL; aw = aw + NdotL;
         }
     }
@@ -513,10 +658,12 @@ __global__ __launch_bounds__(256) void k_conv_specular_all(const float4* __restr
 // 32 consecutive samples of each texel into LDS, a sample the shader skips (NdotL <= 0) parks +0 (x + 0 == x for every accumulator value that can occur:
 // the sums start at +0 and never become -0), and after a round of 64 samples one wave — lane = (texel, channel), 32 lanes — adds them in sample order.
 template <int FMT>
-__global__ __launch_bounds__(256) void k_conv_specular_ordered(const float4* __restrict__ chain, int w0, int h0, int nMips, int res0, int MIPS, void* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_conv_specular_ordered(const float4* __restrict__ chain, int w0, int h0, int nMips, int res0, int MIPS, void* __restrict__ out, int allowFast) {
     constexpr int S = 2, TPR = 32 * S;
     constexpr uint32_t NUM_SAMPLES = 512;
     __shared__ float4 sHt[512];
+    __shared__ uint32_t sLvOff[kSpecMaxLevels];
+    const bool fastOK = spec_chain_setup(sLvOff, w0, h0, nMips) && allowFast;
     __shared__ float4 buf[2][TPR * 8];
     __shared__ float acc[32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -526,44 +673,45 @@ __global__ __launch_bounds__(256) void k_conv_specular_ordered(const float4* __r
     int mip = 0, res = res0; long base = 0;
     while (mip < MIPS - 1 && T0 >= base + 6L * res * res) { base += 6L * res * res; ++mip; res >>= 1; }
     const float Roughness = div_((float)mip, (float)(MIPS - 1));                       // EnvironmentMapRendering.cpp:432
-    for (uint32_t i = threadIdx.x; i < NUM_SAMPLES; i += 256) {
-        const float Xix = div_((float)i, (float)NUM_SAMPLES);
-        float sp, cp; sincos_((2.0f * PI_) * Xix, &sp, &cp);
-        const f3 Ht = ggx_sample_tangent(RadicalInverse_VdC(i), sp, cp, Roughness);
-        sHt[i] = make_float4(Ht.x, Ht.y, Ht.z, 0.0f);
-    }
     if (threadIdx.x < 32) acc[threadIdx.x] = 0.0f;
-    __syncthreads();
     const long texel = T0 + xi - base;                                                  // within the mip
     const bool live = texel < 6L * res * res;
     const long tx = live ? texel : 0;
     const int f = (int)(tx / ((long)res * res)), y = (int)((tx / res) % res), x = (int)(tx % res);
     const f3 N = normalize(cube_texel_dir(f, x, y, res));
-    const f3 V = N;
     const TangentFrame fr = tangent_frame(N);
     const float fOmegaP = div_(4.0f * PI_, (6.0f * (float)w0) * (float)h0);            // :203 with TextureDimensionsLOD0 = equirect dims (:433-434)
+    const SpecChain sc = { (const char*)chain, 31 - __builtin_clz(w0 | 1), 31 - __builtin_clz(h0 | 1), nMips, rcp(fOmegaP), sLvOff };
+    auto sample = [&](uint32_t i) { return spec_sample(sHt[i], N, fr, Roughness, fastOK, sc, fOmegaP, chain, w0, h0, nMips); };
+    // block-uniform: every entry of the table is (+-0, +-0, 1) and every texel of the block qualifies -> one sample per texel, 512 additions on registers (see above)
+    // Roughness == 0 (mip 0): the cheap proof that the table is (+-0, +-0, 1) throughout (spec_table_is_axis); everything else, and a block that fails it: the table itself
+    const bool oneSample = (Roughness == 0.0f && allowFast) &&
+                           __syncthreads_and(spec_table_is_axis(sHt, Roughness) && (!live || spec_texel_allows_one_sample(N, fr))) != 0;
+    if (!oneSample) { __syncthreads(); spec_build_table(sHt, Roughness); __syncthreads(); }
+    if (oneSample) {
+        if (wave != 0) return;
+        if ((lane & 7) == 0) buf[0][xi] = sample(0);             // lane 8 xi: texel xi
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (lane < 32) {                                         // lane = 4 * texel + channel
+            const float p = ((const float*)buf[0])[lane];
+            float a = 0.0f;
+            for (int j = 0; j < (int)NUM_SAMPLES; ++j) a = a + p;
+            acc[lane] = a;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const long to = T0 + (lane >> 2);
+        if (lane < 32 && (lane & 3) == 0 && to - base < 6L * res * res) {
+            const float rw = rcp(max_(acc[lane + 3], 0.0001f));
+            store_px<FMT>(out, (size_t)to, make_float4(acc[lane] * rw, acc[lane + 1] * rw, acc[lane + 2] * rw, 1.0f));
+        }
+        return;
+    }
     for (int r = 0; r < (int)NUM_SAMPLES / TPR; ++r) {
         float4* b = buf[r & 1];
         #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const uint32_t i = (uint32_t)(r * TPR + s * 32 + j32);
-            const float4 ht = sHt[i];
-            const f3 H = tangent_to_world(mk3(ht.x, ht.y, ht.z), fr, N);
-            const f3 L = reflect(neg(V), H);
-            const float NdotL = saturate(dot(N, L));
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (NdotL > 0.0f) {
-                const float NdotH = saturate(dot(N, H));
-                const float HdotV = saturate(dot(H, V));
-                const float D = NormalDistributionGGX(NdotH, Roughness);
-                const float pdf = div_(D * NdotH, 4.0f * HdotV);
-                const float fOmegaS = rcp(max_((float)NUM_SAMPLES * pdf, 0.00001f));
-                const float fMipLevel = (Roughness == 0.0f) ? 0.0f : max_(0.5f * log2_(div_(fOmegaS, fOmegaP)) + -1.0f, 0.0f);
-                const float2 uv = DirectionToEquirectUV(L);
-                const float4 c = sample_equirect_lod(chain, w0, h0, nMips, uv.x, uv.y, fMipLevel);
-                v = make_float4(c.x * NdotL, c.y * NdotL, c.z * NdotL, NdotL);
-            }
-            b[(s * 32 + j32) * 8 + xi] = v;
+            b[(s * 32 + j32) * 8 + xi] = sample((uint32_t)(r * TPR + s * 32 + j32));
         }
         __syncthreads();
         if (wave == (r & 3) && lane < 32) {                      // this round's adder: lane = 4 * texel + channel
@@ -711,17 +859,18 @@ hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0
 }
 
 // every mip of the res0 cube (res0 a power of two >= 4: mips res0 ... 2) in one launch, either order; `out` = the mip-major cube
-hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, int order, void* out, int fmt) {
+hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, int order, void* out, int fmt, const Options& opt) {
+    const int allowFast = opt.specularForm != 1;               // option "specular_form" = "general": every sample with its range tests and branches
     long total = 0;
     for (int m = 0; m < MIPS; ++m) { const long r = res0 >> m; total += 6 * r * r; }
     if (order == VQHIP_CONV_WAVE64) {
         dim3 grid((unsigned)((total + 3) / 4));
-        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular_all<0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
-        else                          hipLaunchKernelGGL((k_conv_specular_all<1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
+        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular_all<0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out, allowFast);
+        else                          hipLaunchKernelGGL((k_conv_specular_all<1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out, allowFast);
     } else {
         dim3 grid((unsigned)((total + 7) / 8));
-        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular_ordered<0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
-        else                          hipLaunchKernelGGL((k_conv_specular_ordered<1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out);
+        if (fmt == VQHIP_FMT_RGBA32F) hipLaunchKernelGGL((k_conv_specular_ordered<0>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out, allowFast);
+        else                          hipLaunchKernelGGL((k_conv_specular_ordered<1>), grid, dim3(256), 0, s, chain, w0, h0, nMips, res0, MIPS, out, allowFast);
     }
     return hipGetLastError();
 }

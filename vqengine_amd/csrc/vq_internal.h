@@ -28,6 +28,7 @@ struct Options {
     int postStrips = 0;         // "post_strips"       : row strips per column strip of k_post_chain (default: CUs / column strips — one workgroup per CU)
     int lutForm = 0;            // "lut_form"          : 1 "general" (every range test left in)
     int diffuseForm = 0;        // "diffuse_form"      : 1 "texels", 2 "general" (default: footprint records)
+    int specularForm = 0;       // "specular_form"     : 1 "general" (default: the branch-free sample with one validity flag)
     int diffuseSeqForm = 0;     // "diffuse_seq_form"  : 1 "lane" (default: k_conv_diffuse_ordered)
 };
 
@@ -161,6 +162,6 @@ hipError_t launch_mip_min(hipStream_t s, const float4* src, float4* dst, int sw,
 size_t conv_diffuse_record_bytes(int w0, int h0, int nMips);
 hipError_t launch_conv_diffuse_tables(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res,
                                       const float* phis, int nPhi, const float* thetas, int nTheta, int order, void* out, int fmt, void* recBuf, const Options& opt);
-hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, int order, void* out, int fmt);
+hipError_t launch_conv_specular_all(hipStream_t s, const float4* chain, int w0, int h0, int nMips, int res0, int MIPS, int order, void* out, int fmt, const Options& opt);
 
 } // namespace vqk
