@@ -330,7 +330,7 @@ VQHIP_API int  vqhip_set_fresnel_pow(vqhip_ctx* ctx, vqhip_fresnel_pow mode);
  * undefined behaviour, and VQEngine records on many threads, SceneRendering.cpp:563-706). value NULL, "" or "default" restores the default. Every
  * form selected here gives the bits of the default form (tests/test_gpu_conv_forms.py, tests/test_gpu_round3.py); unknown keys / values: VQHIP_ERR_INVALID_ARG.
  *   shade_wg 64|128|256 · psmain_waves 4|5|6 · blur_y_wgs n · post_form two|chain · post_strips n · lut_form general ·
- *   diffuse_form records|texels|general · diffuse_seq_form ordered|lane
+ *   specular_form general · diffuse_form records|texels|general · diffuse_seq_form ordered|lane
  * (the non-default values are the general / fallback forms of the same kernels; the measured-and-rejected kernel forms of rounds 2-5 — the compact tonemap
  * tables, the per-sample LUT and per-mip specular kernels, the persistent X pass, the rolling-ring Y pass — are not in the library: docs/HISTORY.md).
  * psmain_waves applies to the literal reading only (the DXC-reading instantiation of the fused PSMain kernel has one register cap). post_form: "two" = vqhip_post_process[_tile] always runs blur X, then blur Y + tonemap (two kernels); "chain" = the one-kernel chain whatever the frame size
