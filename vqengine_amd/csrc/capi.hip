@@ -304,6 +304,10 @@ static int validateLighting(vqhip_ctx* ctx, const char* who, const VQ_PerFrameDa
         if ((L.numPointCasters > 0 && (!sm->point || sm->point_dim <= 0)) || (L.numSpotCasters > 0 && (!sm->spot || sm->spot_dim <= 0)) ||
             (L.directional.enabled && L.directional.shadowing && (!sm->directional || sm->dir_dim <= 0)))
             return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": missing shadow map for a caster");
+        // the PCF kernels address a slice with 32-bit byte / texel offsets (vq_shade.h: pcf_2d, omni_pcf): 2-D maps up to 32768^2, cube faces up to 16384^2
+        if ((L.numPointCasters > 0 && sm->point_dim > 16384) || (L.numSpotCasters > 0 && sm->spot_dim > 32768) ||
+            (L.directional.enabled && L.directional.shadowing && sm->dir_dim > 32768))
+            return fail(ctx, VQHIP_ERR_UNSUPPORTED, w + ": shadow map larger than 32768^2 (2-D) / 16384^2 (cube face)");
     }
     if (env) {
         if (!env->diffuse_cube || env->diffuse_res <= 0) return fail(ctx, VQHIP_ERR_INVALID_ARG, w + ": env->diffuse_cube missing");
