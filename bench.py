@@ -1035,13 +1035,13 @@ def main():
             ib = extras["ibl_load"]
             ltk = load_time_kernel_counters()
 
-            def issue(kernel, ms):                           # PMC wave-instruction count x 64 lanes / live time / the fast issue rate; L1 tag lookups per clock per CU at 2.1 GHz
+            def issue(kernel, ms):                           # PMC wave-instruction count x 64 lanes / live time / the fast issue rate; L1 tag lookups per clock per CU at 2.4 GHz
                 c = ltk.get(kernel) if ltk else None
                 if not c:
                     return {}
                 r = {"valu_issue_frac": round(c["valu_wave_instr_per_launch"] * 64 / (ms * 1e-3) / 1e12 / VALU_ISSUE_CEILING_TLIS, 4)}
                 if "tcp_accesses_per_launch" in c:
-                    r["l1_lookups_per_clock_per_cu"] = round(c["tcp_accesses_per_launch"] / (ms * 1e-3) / 2.1e9 / 256, 3)
+                    r["l1_lookups_per_clock_per_cu"] = round(c["tcp_accesses_per_launch"] / (ms * 1e-3) / 2.4e9 / 256, 3)      # at the 2.4 GHz peak clock; the L1 does one tag lookup per clock
                 return r
             others.append({"kernel": "k_conv_diffuse_ordered (cfg4: 6x64^2 texels x 99 382 taps; L1-tag / VALU-bound, no HBM stream)", "ms": ib["conv_diffuse_ms"], "bytes": None, "frac": None,
                            "valu_frac_model": ib.get("conv_diffuse_valu_frac_model"), **issue("k_conv_diffuse_ordered", ib["conv_diffuse_ms"])})
