@@ -23,6 +23,7 @@ constexpr int R = 10;    // KERNEL_RANGE_MINUS1
 
 // two adjacent pixels with ONE 16-byte store (RGBA16F; idx even) / two float4 stores
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 template <int FMT> VQD void store_px2(void* base, size_t idx, float4 a, float4 b) {
     if (FMT == 1) {
         h8 v;
@@ -52,28 +53,28 @@ __global__ __launch_bounds__(256) void k_blur_x4(const void* __restrict__ in, vo
     __syncthreads();
     const int xb = x0 + 4 * t;
     if (xb >= W) return;                                    // early out :129
-    float wx[24], wy[24], wz[24];
+    v2f wxy[24]; float wz[24];                               // (x, y) as a register pair: one v_pk_fma_f32 per tap for the two channels (round 6, as in k_post_chain)
     #pragma unroll
     for (int k = 0; k < 24; ++k) {
         const int p = 4 * t + k;
         const float4 s = load_px<FMT>(tile, (size_t)(p + (p >> 2)));
-        wx[k] = s.x; wy[k] = s.y; wz[k] = s.z;
+        wxy[k] = v2f{ s.x, s.y }; wz[k] = s.z;
         // the converted texel as three fp32 registers: left alone, the compiler folds each conversion into the four mads that use it (v_fma_mix_f32, 252 per lane), and
         // v_fma_mix_f32 issues no faster than v_cvt_f32_f16 on gfx950 while v_fmac_f32 with a literal weight issues faster (scripts/ubench/mix_rate.hip): 72 conversions +
-        // 252 v_fmac_f32 — 31.6 against 33.1 us at 4K on one box (profiles/r5g_post_forms.md)
-        if (FMT == 1) asm("" : "+v"(wx[k]), "+v"(wy[k]), "+v"(wz[k]));
+        // 252 v_fmac_f32 — 31.6 against 33.1 us at 4K on one box (profiles/r5g_post_forms.md); round 6: (x, y) as a register pair, 84 v_pk_fma_f32 + 84 v_fmac_f32: 29.6 us
+        if (FMT == 1) asm("" : "+v"(wxy[k]), "+v"(wz[k]));
     }
     float4 res[4];
     #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float ax = 0.0f, ay = 0.0f, az = 0.0f;
+        v2f a = { 0.0f, 0.0f }; float az = 0.0f;
         #pragma unroll
         for (int it = 0; it < 21; ++it) {
             const int off = it - R;
             const float w = kW[off < 0 ? -off : off];
-            ax = fma_(wx[j + it], w, ax); ay = fma_(wy[j + it], w, ay); az = fma_(wz[j + it], w, az);
+            a = __builtin_elementwise_fma(wxy[j + it], v2f{ w, w }, a); az = fma_(wz[j + it], w, az);
         }
-        res[j] = make_float4(ax, ay, az, 1.0f);
+        res[j] = make_float4(a.x, a.y, az, 1.0f);
     }
     if (xb + 3 < W && ((row + xb) & 1) == 0) {               // the lane's 4 pixels are 32 contiguous bytes (RGBA16F): two 16-byte stores
         #pragma unroll
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restri
         const int x = tx * 64 + (threadIdx.x & 63);
         const int yBase = (ty * 8 + wv) * ROWS;
         if (x >= W || yBase >= H) continue;
-        float wx[ROWS + 2 * R], wy[ROWS + 2 * R], wz[ROWS + 2 * R];
+        float wx[ROWS + 2 * R], wy[ROWS + 2 * R], wz[ROWS + 2 * R];     // (the (x, y)-pair / v_pk_fma_f32 form of k_blur_x4 costs this kernel its occupancy: 115 VGPRs, 41.3 against 27.0 us)
         #pragma unroll
         for (int i = 0; i < ROWS + 2 * R; ++i) {
             int sy = yBase - R + i;
@@ -352,7 +353,6 @@ __global__ __launch_bounds__(512) void k_blur_y_tonemap_lut(const void* __restri
 // v_add_u32 per window pair before), and tracks their completion itself (s_waitcnt lgkmcnt(n) as the data is needed). Round 5 issued the reads from inline asm whose
 // results the compiler believed ready at once and waited in a separate asm: correct only as long as the register allocator moved none of them in between.
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
-typedef float v2f __attribute__((ext_vector_type(2)));
 #define LDS_AS __attribute__((address_space(3)))
 // `a` is a byte address in the LDS aperture (lds_addr() of a __shared__ pointer + offsets); it is laundered IN PLACE, so consecutive reads from one base register cost no copy
 template <class T, int OFF> VQD T lds_load(uint32_t& a) {
