@@ -445,13 +445,29 @@ VQD float pcf_2d(const float* slice, int dim, float2 smDims, float4 lsp, float b
         row[k] = (uint32_t)wy * (uint32_t)dim * 4u;          // a slice is at most 2^32 bytes (dim <= 32768)
     }
     int count = 0;
-    #pragma unroll
-    for (int x = 0; x < 5; ++x)
+    // The five columns are five CONSECUTIVE texels unless the kernel straddles the map's wrap or a rounding of u + x * tx skips one: then a row of the kernel is 20
+    // contiguous bytes and goes out as one 16-byte + one 4-byte load (4-byte aligned: the hardware's unaligned-access mode) instead of five — the pass is bound by L1 tag
+    // lookups on incoherent positions (every lane's tap is its own cache line: 25 lookups per pixel and caster; now ~11), profiles/r6t_pcf_rows.md. Wave-uniform choice.
+    const bool rowsContiguous = (col[1] == col[0] + 4u) & (col[2] == col[0] + 8u) & (col[3] == col[0] + 12u) & (col[4] == col[0] + 16u);
+    if (__builtin_amdgcn_ballot_w64(!rowsContiguous) == 0) {
+        typedef float fl4 __attribute__((ext_vector_type(4)));
+        struct __attribute__((packed, aligned(4))) U4 { fl4 v; };
         #pragma unroll
         for (int y = 0; y < 5; ++y) {
-            const float closest = *(const float*)((const char*)slice + (row[y] + col[x]));
-            count += (ref > closest) ? 1 : 0;
+            const char* r = (const char*)slice + (row[y] + col[0]);
+            const fl4 a = ((const U4*)r)->v;
+            const float b = *(const float*)(r + 16);
+            count += ((ref > a.x) ? 1 : 0) + ((ref > a.y) ? 1 : 0) + ((ref > a.z) ? 1 : 0) + ((ref > a.w) ? 1 : 0) + ((ref > b) ? 1 : 0);
         }
+    } else {
+        #pragma unroll
+        for (int x = 0; x < 5; ++x)
+            #pragma unroll
+            for (int y = 0; y < 5; ++y) {
+                const float closest = *(const float*)((const char*)slice + (row[y] + col[x]));
+                count += (ref > closest) ? 1 : 0;
+            }
+    }
     return 1.0f - fdiv_rcp((float)count, 25.0f, 0.04f);
 }
 
