@@ -185,6 +185,7 @@ VQD float4 sample_cube_rgba16f(const void* cube, int N, f3 dir) {
     // the two columns of a footprint can only leave the face on the same side (ix < 0: left, else right), likewise the rows:
     // two table entries per sample serve all four taps
     const uint32_t enx = cube_edge_entry(f, ix < 0 ? 0 : 1), eny = cube_edge_entry(f, iy < 0 ? 2 : 3);
+    uint32_t idx[4];
     #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int i = ix + (t & 1), j = iy + (t >> 1);
@@ -196,7 +197,23 @@ VQD float4 sample_cube_rgba16f(const void* cube, int N, f3 dir) {
         ni = one ? ni : min(max(i, 0), N - 1);                        // identity inside the face; any valid address for a corner
         nj = one ? nj : min(max(j, 0), N - 1);
         if (ox & oy) missing = t;
-        c[t] = load_rgba16f(cube, (size_t)((nf * N + nj) * N + ni));
+        idx[t] = (uint32_t)((nf * N + nj) * N + ni);
+    }
+    // Round 6: the two texels of a footprint row are neighbours in memory unless the row crosses a face edge — then they are ONE 16-byte load (8-byte aligned: the hardware's
+    // unaligned-access mode) instead of two 8-byte gathers. On incoherent directions every lane's gather is its own cache line, and the pass costs L1 tag lookups, not bytes.
+    typedef _Float16 h8u __attribute__((ext_vector_type(8)));
+    struct __attribute__((packed, aligned(8))) H8 { h8u v; };
+    #pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const uint32_t a = idx[2 * r], b = idx[2 * r + 1];
+        if (b == a + 1u) {
+            const h8u v = ((const H8*)((const h4*)cube + a))->v;
+            c[2 * r] = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+            c[2 * r + 1] = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+        } else {
+            c[2 * r] = load_rgba16f(cube, (size_t)a);
+            c[2 * r + 1] = load_rgba16f(cube, (size_t)b);
+        }
     }
     if (missing >= 0) {                                               // corner: mean of the other three, in tap order
         const float4 a = missing == 0 ? c[1] : c[0], b = missing <= 1 ? c[2] : c[1], d = missing <= 2 ? c[3] : c[2];
@@ -241,7 +258,15 @@ VQD float2 sample_2d_rg16f_clamp(const void* tex, int W, int H, float u, float v
     int x0 = min(max(ix, 0), W - 1), x1 = min(max(ix + 1, 0), W - 1);
     int y0 = min(max(iy, 0), H - 1), y1 = min(max(iy + 1, 0), H - 1);
     const h2* t = (const h2*)tex;
-    h2 a = t[(size_t)y0 * W + x0], b = t[(size_t)y0 * W + x1], c = t[(size_t)y1 * W + x0], d = t[(size_t)y1 * W + x1];
+    h2 a, b, c, d;
+    if (x1 == x0 + 1) {                                        // not clamped at a border: the two texels of a row as one 8-byte load (see sample_cube_rgba16f)
+        typedef _Float16 h4u __attribute__((ext_vector_type(4)));
+        struct __attribute__((packed, aligned(4))) H4 { h4u v; };
+        const h4u r0 = ((const H4*)(t + (size_t)y0 * W + x0))->v, r1 = ((const H4*)(t + (size_t)y1 * W + x0))->v;
+        a.x = r0[0]; a.y = r0[1]; b.x = r0[2]; b.y = r0[3]; c.x = r1[0]; c.y = r1[1]; d.x = r1[2]; d.y = r1[3];
+    } else {
+        a = t[(size_t)y0 * W + x0]; b = t[(size_t)y0 * W + x1]; c = t[(size_t)y1 * W + x0]; d = t[(size_t)y1 * W + x1];
+    }
     float4 r = blend4(make_float4((float)a.x, (float)a.y, 0, 0), make_float4((float)b.x, (float)b.y, 0, 0),
                       make_float4((float)c.x, (float)c.y, 0, 0), make_float4((float)d.x, (float)d.y, 0, 0), wx, wy);
     return make_float2(r.x, r.y);
