@@ -27,10 +27,12 @@ Every invocation (N = 1 included) ALSO times, outside the headline's timed regio
 
 Every byte that crosses GPUs goes through the C ABI (include/vqhip.h, vqengine_amd/csrc/mgpu.hip); torch.distributed is the control
 plane only (communicator-id broadcast, barriers, the max-over-ranks reduction of the wall time).
-`value` = pixels of the whole frame * steps / max-over-ranks wall time. Prints ONE JSON line on rank 0."""
+`value` = pixels of the whole frame * steps / max-over-ranks wall time. Prints ONE JSON line on rank 0.
+
+This file holds the workload (CONFIGS, Pipeline.step), the ranks (Dist, Comms) and main(); the reporting parts live in benchlib/: consts (peaks), timing (the stage
+timer), pmc (counter constants), cpu (the CPU legs: the only code here that runs oracle/), casters / ibl / widened / tiles (the extra objects), line (key order + digest)."""
 import argparse
 import ctypes as C
-import hashlib
 import json
 import os
 import sys
@@ -45,6 +47,14 @@ sys.path.insert(0, ROOT)
 
 from benchlib import casters as bl_casters, ibl as bl_ibl  # noqa: E402
 from vqengine_amd import abi, capi, synth, tiling  # noqa: E402
+from benchlib.consts import F16, HBM_PEAK_GBPS, R8, SHADE_BYTES_PER_PX, VALU_ISSUE_CEILING_TLIS, VALU_PEAK_TFLOPS  # noqa: E402
+from benchlib.cpu import cpu_baseline, cpu_reference_source, host_cores  # noqa: E402
+from benchlib.ibl import ibl_load_report  # noqa: E402
+from benchlib.line import finish_line  # noqa: E402
+from benchlib.pmc import PMC_FILE, PMC_SOURCES, kernel_source_hash, load_pmc_constants, load_time_kernel_counters  # noqa: E402,F401
+from benchlib.tiles import tile_curve  # noqa: E402
+from benchlib.timing import _ev, _stage_ms, _stage_stats, _time_loop  # noqa: E402,F401
+from benchlib.widened import widened_report  # noqa: E402
 
 CONFIGS = {
     "cfg2": dict(width=1920, height=1080, lights=16, env=False, seed=0xC0FFEE, light_seed=0x1600, scaling="weak",
@@ -57,77 +67,11 @@ CONFIGS = {
                  metric="Mpixels/s forward-PBR @8K,256 lights (BASELINE cfg5, one frame row-tiled over the GPUs)",
                  workload="BASELINE cfg5: ONE 7680x4320 float4 G-buffer, 256 point lights (100 cbuffer + 156 extension) -> RGBA16F, 21-tap blur X/Y, Reinhard+sRGB tonemap -> RGBA8"),
 }
-HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md:35 (spec); 6290 measured copy ceiling
-VALU_PEAK_TFLOPS = 157.3        # :40
-SHADE_BYTES_PER_PX = 64 + 8     # 4 float4 G-buffer planes in + RGBA16F out
 SPINUP_STEPS = int(os.environ.get("VQ_BENCH_SPINUP", "200"))     # untimed steady-state spin-up before the W warm-up steps (~0.25 s of GPU work)
 COLD_STEPS = 20                 # the first steps after the idle set-up phase, timed on their own ("cold_start")
-VALU_ISSUE_CEILING_TLIS = 66.7  # T lane-instructions/s: the FAST issue rate of the chip at steady-state clocks — plain fp32 add / mul / fma on registers, or v_pk_fma_f32 counted as two
-                                # (scripts/ubench/valu_ceiling.hip is the packed form; scripts/ubench/mix_rate.hip, profiles/r5f_issue_classes.md: instructions with an SGPR source,
-                                # conversions, compares, min / max and integer operations issue at 35 T, v_rcp / v_rsq at 17 T)
-XGMI_LINK_GBPS = 153.0          # per direct GPU-GPU link, peak; the tile-curve model also quotes half of it
 WATCHDOG_S = float(os.environ.get("VQ_BENCH_WATCHDOG_S", "30"))
 SUSTAINED_S = float(os.environ.get("VQ_BENCH_SUSTAINED_S", "2.0"))   # length of the `sustained` companion run (0: off)
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
 # Test hooks live OUTSIDE this file: tests/bench_fault_harness.py subclasses Pipeline (a dropped stream wait, a forced watchdog timeout) and runs main() with it
-PMC_SOURCES = ["vqengine_amd/csrc/shade.hip", "vqengine_amd/csrc/vq_shade.h", "vqengine_amd/csrc/vq_devmath.h", "vqengine_amd/csrc/vq_sampling.h", "vqengine_amd/csrc/Makefile"]
-F16, R8 = abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
-
-
-def kernel_source_hash():
-    """sha256 over the shade kernel's sources and over the lines of the Makefile that decide its code generation (the HIPFLAGS assignments and their
-    continuation lines) — a change of prerequisites or comments in the Makefile does not make the counters stale, a change of flags does."""
-    h = hashlib.sha256()
-    for f in PMC_SOURCES:
-        data = open(os.path.join(ROOT, f), "rb").read()
-        if f.endswith("Makefile"):
-            keep, cont = [], False
-            for ln in data.splitlines():
-                if cont or (b"HIPFLAGS" in ln and not ln.lstrip().startswith(b"#") and not ln.startswith(b"\t")):
-                    keep.append(ln.strip())
-                    cont = ln.rstrip().endswith(b"\\")
-                else:
-                    cont = False
-            data = b"\n".join(keep)
-        h.update(data)
-    return h.hexdigest()[:16]
-
-
-def load_pmc_constants(config, fresnel_pow):
-    """Counter-derived constants of the shade kernel (HBM bytes per launch, VALU instructions per wave) cannot be measured from inside
-    bench.py: they are read from profiles/pmc_constants.json, which records the sha256 of the kernel sources they were measured on
-    (scripts/pmc_refresh.sh). If the sources changed since, the constants are NOT used: the fields they feed are null and `stale` is set."""
-    try:
-        d = json.load(open(PMC_FILE))
-    except (OSError, ValueError):
-        return None, {"stale": True, "why": "profiles/pmc_constants.json missing"}
-    entry = d.get(f"{config}/{fresnel_pow}")
-    meta = {"file": "profiles/pmc_constants.json", "kernel_sources_sha256": d.get("kernel_sources_sha256"), "measured_at_commit": d.get("measured_at_commit"),
-            "profile": d.get("profile")}
-    if entry is None:
-        return None, dict(meta, stale=True, why=f"no entry for {config}/{fresnel_pow}")
-    if d.get("kernel_sources_sha256") != kernel_source_hash():
-        return None, dict(meta, stale=True, why="shade.hip / vq_shade.h / vq_devmath.h / vq_sampling.h / Makefile changed since the counters were collected", now=kernel_source_hash())
-    return entry, dict(meta, stale=False)
-
-
-def load_time_kernel_counters():
-    """SQ_INSTS_VALU / TCP accesses per launch of the cfg4 load-time kernels (profiles/pmc_constants.json `load_time_kernels`), or None when conv.hip and its headers
-    changed since they were counted: lets the line price those kernels against the ISSUE ceiling instead of a flop model that ignores what a tap really costs."""
-    try:
-        d = json.load(open(PMC_FILE)).get("load_time_kernels")
-    except (OSError, ValueError):
-        return None
-    if not d:
-        return None
-    h = hashlib.sha256()
-    for f in d["sources"]:
-        h.update(open(os.path.join(ROOT, f), "rb").read())
-    return d if h.hexdigest()[:16] == d["sources_sha256"] else None
-
-
-def _ev():
-    return torch.cuda.Event(enable_timing=True)
 
 
 def build_ibl(ctx, timings=None):
@@ -169,91 +113,6 @@ def upload_tile(cfg, frame_h, row0, row1, coherent=False):
         for k in range(4):
             gb[k][r - row0:r - row0 + part[k].shape[0]].copy_(torch.from_numpy(part[k]))
     return gb
-
-
-def host_cores():
-    cores = len(os.sched_getaffinity(0))
-    try:                                                     # honour a cgroup CPU quota if the box has one
-        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
-        if q != "max":
-            cores = max(1, min(cores, int(float(q) / float(p))))
-    except (OSError, ValueError):
-        pass
-    return cores
-
-
-def cpu_baseline(cfg, env_np, pf, extra, pv, frame_h, target_s=10.0):
-    """The CPU oracle (a scalar C++ port of the HLSL, OpenMP over rows) timed on the host cores on a bounded row
-    band of the SAME workload. Reported baseline only — never the thing measured as `value`."""
-    from tests import oracle_lib as O
-    O.load()
-    cores = host_cores()
-    W = cfg["width"]
-    env = O.host_envmap(*env_np) if env_np is not None else None
-    band = 540 if cfg["lights"] <= 64 else 135               # bands of the SAME synthetic frame
-
-    def run(row0, rows):
-        gb = synth.gbuffer_rows(W, frame_h, row0, row0 + rows, seed=cfg["seed"])
-        t0 = time.perf_counter()
-        sc = O.forward_lighting(gb, pf, pv, abi.FMT_RGBA16F, extra_point=extra, env=env, nthreads=cores)
-        x = O.blur_pass(sc, abi.FMT_RGBA16F, 0, nthreads=cores)
-        y = O.blur_pass(x, abi.FMT_RGBA16F, 1, nthreads=cores)
-        O.tonemap(y, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM, nthreads=cores)
-        return time.perf_counter() - t0
-    run(0, 64)                                               # warm-up (thread pool, page faults)
-    t, rows, k = 0.0, 0, 0
-    while t < target_s and k < 64:
-        t += run((k % 4) * band, band)
-        rows += band
-        k += 1
-    return {"value": round(W * rows / t / 1e6, 4), "unit": "Mpix/s", "cores": int(cores), "kind": "port",
-            "sample": f"oracle (scalar C++ port of the HLSL, OpenMP static over rows, {cores} threads) on {k} bands of {W}x{band} rows of the same "
-                      f"frame ({W * rows / 1e6:.1f} Mpix): shade {cfg['lights']} lights{' + IBL' if env is not None else ''}, blur X/Y, tonemap; {t:.1f} s"}
-
-
-def cpu_reference_source(cfg, env_np, pf, extra, pv, frame_h, target_s=6.0):
-    """The REFERENCE'S OWN shader source (ForwardLighting.hlsl:PSMain, GaussianBlur.hlsl, Tonemapper.hlsl) run on ALL host cores through oracle/_ref
-    (oracle/ref_src/hlsl_shim.h) on bands of rows of the same frame, when that library travelled with the tree. A second reported baseline next to
-    `cpu_baseline`: scalar, literal IEEE; one band per worker thread at a time, every thread on its own copy of the library (the translated shaders keep
-    their cbuffers in globals; ctypes releases the GIL inside the calls)."""
-    from concurrent.futures import ThreadPoolExecutor
-    from tests import oracle_lib as O, ref_lib as R
-    if not R.available("shaders") or (extra is not None and not R.available("shaders_l256")):
-        return None
-    W = cfg["width"]
-    env = O.host_envmap(*env_np) if env_np is not None else None
-    cores = host_cores()
-    rows_per = 22 if cfg["lights"] <= 64 else 4              # one blur kernel height: the band is a (small) image of its own
-
-    def band(job):
-        worker, k = job
-        R.use_private_copy(f"w{worker}")
-        r0 = (k * 97) % (frame_h - rows_per)
-        gb = synth.gbuffer_rows(W, frame_h, r0, r0 + rows_per, seed=cfg["seed"])
-        t0 = time.perf_counter()
-        sc = R.forward_from_gbuffer(gb, pf, pv, env=env, extra=extra).astype(np.float16).astype(np.float32)
-        x = R.blur_pass(sc, 0).astype(np.float16).astype(np.float32)
-        y = R.blur_pass(x, 1).astype(np.float16).astype(np.float32)
-        R.tonemap(y, abi.TonemapperParams.default())
-        return time.perf_counter() - t0
-
-    def worker_loop(worker):                                 # each worker runs bands until the wall-clock budget is spent
-        n, busy = 0, 0.0
-        while time.perf_counter() - start < target_s and n < 64:
-            busy += band((worker, worker * 64 + n))
-            n += 1
-        return n, busy
-    band((0, 0))                                             # load + first-touch outside the timed window
-    start = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=cores) as ex:
-        res = list(ex.map(worker_loop, range(cores)))
-    wall = time.perf_counter() - start
-    bands = sum(n for n, _ in res)
-    rows = bands * rows_per
-    return {"value": round(W * rows / wall / 1e6, 4), "unit": "Mpix/s", "cores": int(cores), "kind": "reference",
-            "sample": f"the reference's HLSL (PSMain {cfg['lights']} lights{' + IBL' if env is not None else ''}, CSMain_X/_Y, tonemapper CSMain) compiled to C++ through "
-                      f"oracle/ref_src/hlsl_shim.h, {cores} threads (one private copy of the library each), {bands} bands of {W}x{rows_per} rows of the same frame "
-                      f"({W * rows / 1e6:.2f} Mpix); {wall:.1f} s wall, {sum(b for _, b in res):.1f} thread-seconds"}
 
 
 def launch_ranks(n):
@@ -1079,62 +938,7 @@ def main():
     ctx.close()
 
 
-def finish_line(out):
-    """Key order of the one JSON line. The driver's record keeps `roofline`, `cpu_baseline` and `config` whole plus the LAST ~2 000 characters of the line: the long objects go
-    first, and the line ends with the second-tier figures a reader needs to recompute the fractions — `valu_issue`, `cfg5_strong`, `stages` without their
-    prose (the notes move to `notes`), then `digest`, a flat summary."""
-    tail_keys = ("valu_issue", "cfg5_strong", "stages")
-    notes = {}
-
-    def strip(obj, path):
-        if not isinstance(obj, dict):
-            return obj
-        res = {}
-        for k, v in obj.items():
-            if isinstance(v, str) and (k.endswith("note") or k in ("workload", "post_chain_co_runs_with")):
-                notes[path + "." + k] = v
-            else:
-                res[k] = strip(v, path + "." + k)
-        return res
-    ordered = {k: v for k, v in out.items() if k not in tail_keys}
-    tail = {k: strip(out[k], k) for k in tail_keys if k in out}
-    ordered["notes"] = notes
-    ordered.update(tail)
-    g = lambda *ks: _dig(out, ks)                            # noqa: E731
-    ordered["digest"] = {
-        "shade_ms": g("roofline", "ms"), "shade_hbm_frac": g("roofline", "frac"), "shade_valu_frac_spec": g("valu", "frac"), "shade_valu_issue_frac": g("valu_issue", "frac"),
-        "post_chain_alone_ms": g("stages", "isolated", "post_chain_ms"), "post_chain_hbm_frac_at_12_B_px": g("stages", "isolated", "post_chain_frac_of_hbm_peak"),
-        "cfg2_shade_ms": g("cfg2", "shade_ms"), "cfg2_hbm_frac": g("cfg2", "hbm_frac"), "cfg2_valu_issue_frac": g("cfg2", "valu_issue", "frac"),
-        "cfg1_shade_ms": g("cfg1", "shade_ms"), "cfg1_Mpix_s": g("cfg1", "shade_Mpix_s"), "cfg1_cpu_Mpix_s": g("cfg1", "cpu_baseline", "value"),
-        "engine_max_shade_ms": g("engine_max", "shade_ms"), "engine_max_coherent_ms": g("engine_max", "coherent_content", "shade_ms"),
-        "cfg5_strong_Mpix_s": g("cfg5_strong", "value"), "cfg5_strong_shade_ms": g("cfg5_strong", "shade_ms"),
-        "conv_diffuse_ms": g("ibl_load", "conv_diffuse_ms"), "conv_specular_ms": g("ibl_load", "conv_specular_ms"), "brdf_lut_ms": g("ibl_load", "brdf_lut_warm_ms"),
-        "engine_default_prefilter_ms": g("ibl_load", "engine_default", "prefilter_ms"), "engine_default_specular_ms": g("ibl_load", "engine_default", "conv_specular_ms"),
-        "psmain_fused_ms": g("widened", "psmain_fused", "ms"), "sustained_Mpix_s": g("sustained", "value"), "cpu_baseline_Mpix_s": g("cpu_baseline", "value"),
-        "bytes_per_px": {"shade": SHADE_BYTES_PER_PX, "post_chain": 12}, "hbm_peak_GBps": HBM_PEAK_GBPS, "px_4k": 3840 * 2160}
-    return ordered
-
-
-def _dig(d, keys):
-    for k in keys:
-        if not isinstance(d, dict) or k not in d:
-            return None
-        d = d[k]
-    return d
-
-
 # ---- the extra objects ------------------------------------------------------------------------------------------------------------------
-def _time_loop(fn, n, spin):
-    for i in range(spin):
-        fn(i)
-    a, b = _ev(), _ev()
-    a.record()
-    for i in range(n):
-        fn(i)
-    b.record(); b.synchronize()
-    return a.elapsed_time(b) / n
-
-
 def shade_only(ctx, d, comms, args, cfg, env, max_env_lod, coherent=False):
     """The shade kernel of `cfg` alone (N = 1): back-to-back launches between two events after a spin-up, with both roofs."""
     p = Pipeline(ctx, d, comms, cfg, args, env=env, max_env_lod=max_env_lod, coherent=coherent)
@@ -1161,183 +965,6 @@ def coherent_scene(ctx, d, comms, args, cfg, env, spec_mips):
     res = shade_only(ctx, d, comms, args, cfg, env, spec_mips, coherent=True)
     res["note"] = ("the cfg3 shade kernel on synth.gbuffer_rows_coherent; slow_path_pixel_fraction_round2 = pixels with roughness < 0.04, which round 2 sent "
                    "through the IEEE light loop wave by wave; now whole waves choose the EPSILON-select / back-facing-skip forms (shade.hip)")
-    return res
-
-
-STAGE_SPIN_S = float(os.environ.get("VQ_BENCH_STAGE_SPIN_S", "0.25"))     # the chip needs ~0.25 s of sustained load to reach its clocks
-STAGE_BATCHES = 7
-STAGE_BATCH_S = 0.03
-
-
-def _stage_stats(fn, spin_s=None, batches=STAGE_BATCHES, batch_s=STAGE_BATCH_S):
-    """THE timer of every per-stage figure of the line (widened.*, ibl_load.*_warm_ms, cfg2, coherent_scene, stages.isolated): a spin-up sized by TIME
-    (>= STAGE_SPIN_S of back-to-back calls of the same fn), then `batches` back-to-back timed batches of ~batch_s each, every batch between its own
-    two HIP events with no host synchronisation in between (all events are recorded first, read afterwards). The figure is the MEDIAN batch; the
-    spread (min / max batch) is reported with it."""
-    spin_s = STAGE_SPIN_S if spin_s is None else spin_s
-    probe = _time_loop(lambda i: fn(), 3, 2)                                   # ms per call, cold: only sizes the loops
-    spin = int(min(20000, max(3, spin_s * 1e3 / probe)))
-    n = int(min(4000, max(2, batch_s * 1e3 / probe)))
-    for _ in range(spin):
-        fn()
-    ev = [_ev() for _ in range(batches + 1)]
-    ev[0].record()
-    for b in range(batches):
-        for _ in range(n):
-            fn()
-        ev[b + 1].record()
-    ev[-1].synchronize()
-    per = sorted(ev[b].elapsed_time(ev[b + 1]) / n for b in range(batches))
-    return {"ms": per[len(per) // 2], "ms_min": per[0], "ms_max": per[-1], "batches": batches, "launches_per_batch": n, "spinup_launches": spin}
-
-
-def _stage_ms(fn):
-    return _stage_stats(fn)["ms"]
-
-
-def widened_report(ctx, env, spec_mips):
-    """The kernels of SURVEY.md 8f (the callers and data formats either side of the hot path) at 4K on this GPU, each with its algorithmic HBM bytes
-    per pixel and the fraction of the 8 TB/s spec they amount to; VALU-bound ones say so. Inputs: 540-row synthetic bands tiled to 2160 rows."""
-    W, H, NM, BAND = 3840, 2160, 12, 540
-    px = W * H
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
-    tile = lambda a: np.tile(a, (H // BAND,) + (1,) * (a.ndim - 1))   # noqa: E731
-    res = {"frame": [W, H], "note": "every figure: >= 0.25 s spin-up of the one call, then the median of 7 back-to-back batches of ~30 ms (ms_min / ms_max = the fastest / slowest batch); *_hbm_frac = algorithmic bytes / time / 8 TB/s. producer / "
-                                    "skydome / RCAS / SSR fallback are HBM-shaped; the fused PSMain and EASU are VALU-bound (see their notes)"}
-
-    def entry(st, bytes_px, **kw):
-        ms = st["ms"]
-        return dict(ms=round(ms, 4), ms_min=round(st["ms_min"], 4), ms_max=round(st["ms_max"], 4), batches=st["batches"], launches_per_batch=st["launches_per_batch"],
-                    Mpix_s=round(px / ms / 1e3, 1), bytes_per_px=bytes_px, GBps=round(px * bytes_px / ms / 1e6, 1),
-                    hbm_frac=round(px * bytes_px / ms / 1e6 / HBM_PEAK_GBPS, 4), **kw)
-    # ---- 8f.1: G-buffer producer, alone and fused with the lighting (PSMain as one kernel)
-    ipd = [dev(tile(p_)) for p_ in synth.interpolants(W, BAND, NM)]
-    ssao = dev(tile(synth.ssao_image(W, BAND)))
-    datas, texsets = synth.material_set(NM, max_dim=1024, same_size=False)
-    dmats, dm0, keep, nmaps = (abi.MaterialDesc * NM)(), (abi.MaterialDesc * NM)(), [], 0
-    for i, (dd, ts) in enumerate(zip(datas, texsets)):
-        dmats[i].data = dd
-        dm0[i].data = dd
-        dm0[i].data.textureConfig = 0.0
-        for slot, img in ts.items():
-            chain_g, nm = ctx.mip_chain_rgba8(dev(img))
-            keep.append(chain_g)
-            setattr(dmats[i], slot, abi.Texture2D(chain_g.data_ptr(), img.shape[1], img.shape[0], nm, 0))
-            nmaps += 1
-    gb = tuple(torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(4))
-    res["gbuffer_producer_textured"] = entry(_stage_stats(lambda: ctx.gbuffer_from_materials(ipd, dmats, 0.055, ssao, out=gb)), 113,
-                                             what=f"vqhip_gbuffer_from_materials: 3 interpolant planes + SSAO -> 4 float4 planes, {NM} materials, {nmaps} RGBA8 mip-chained maps (cache resident)")
-    res["gbuffer_producer_textureless"] = entry(_stage_stats(lambda: ctx.gbuffer_from_materials(ipd, dm0, 0.055, None, out=gb)), 112,
-                                                what="the same call with texture-less materials: the streaming floor of the kernel")
-    pf, extra = synth.per_frame(points=synth.point_lights(64, seed=0x6400), hdri_offset=0.3)
-    pv = synth.per_view(W, H, max_env_lod=spec_mips)
-    scene = capi.empty_image(H, W, F16, ctx.device)
-    st_f = _stage_stats(lambda: ctx.forward_lighting_from_materials(ipd, dmats, pf, pv, ssao=ssao, out=scene, out_fmt=F16, extra_point=extra, env=env))
-    ms = st_f["ms"]
-    res["psmain_fused"] = entry(st_f, 57, valu_frac_model=round((170 * 64 + 160) * px / ms / 1e9 / VALU_PEAK_TFLOPS, 4),
-                                what="vqhip_forward_lighting_from_materials: PSMain as ONE kernel (producer + 64 point lights + IBL), 48 + 1 B in, 8 B out; VALU-bound like the headline's shade kernel")
-    # the same draw with its other render targets bound (OUTPUT_ALBEDO + OUTPUT_MOTION_VECTORS, ForwardLighting.hlsl:382-389), and the Z pre-pass's normals
-    svc, svp = (dev(tile(a_)) for a_ in synth.clip_positions(W, BAND))
-    tg, _alb, _mv = ctx._psmain_targets(H, W, F16, abi.FMT_RG16F, svc, svp)
-    st_m = _stage_stats(lambda: ctx.forward_lighting_from_materials(ipd, dmats, pf, pv, ssao=ssao, out=scene, out_fmt=F16, extra_point=extra, env=env, _targets=tg))
-    ms_mrt = st_m["ms"]
-    res["psmain_fused_mrt"] = entry(st_m, 101, extra_ms_over_psmain_fused=round(ms_mrt - ms, 4),
-                                    extra_ms_spread=[round(st_m["ms_min"] - st_f["ms_max"], 4), round(st_m["ms_max"] - st_f["ms_min"], 4)],
-                                    what="vqhip_forward_lighting_from_materials_mrt: the same kernel also writing SV_TARGET1 (albedo, metalness: RGBA16F) and the motion "
-                                         "vectors (RG16F, from two float4 clip-position planes): + 32 B in, + 12 B out per pixel")
-    nrm = torch.empty((H, W), dtype=torch.int32, device="cuda")
-    res["scene_normals_prepass"] = entry(_stage_stats(lambda: ctx.scene_normals_from_materials(ipd, dmats, out=nrm)), 52,
-                                         what="vqhip_scene_normals_from_materials (DepthPrePass.hlsl:PSMain): 3 interpolant planes -> Tex_SceneNormals R10G10B10A2, normal maps "
-                                              "(+ diffuse alpha of masked materials) cache resident: 48 B in, 4 B out")
-    del gb, ipd, ssao, keep, svc, svp, _alb, _mv, nrm
-    # ---- 8f.2: skydome, all-sky frame (worst case), RGBA16F target, 2048^2 equirect
-    import math
-    from vqengine_amd import scene as scene_mod
-    eq = dev(synth.equirect(2048, 2048))
-    sp = scene_mod.skydome_params(0.9, -0.2, 0.5, 60.0 * math.pi / 180.0, W, H)
-    res["skydome_all_sky"] = entry(_stage_stats(lambda: ctx.skydome(eq, sp, scene, F16)), 8, what="vqhip_skydome over a frame without geometry: 8 B/px written, equirect taps cache resident")
-    # ---- 8f.3: Radiance .hdr ingest, 2048^2 (256 run-length coded rows, repeated): host header parse + walk of the run headers, device run expansion + RGBE -> RGBA32F
-    rgbe = synth.float_to_rgbe(synth.equirect(2048, 256)[..., :3])
-    part = synth.hdr_file_bytes(rgbe)
-    body = part[part.index(b"+X 2048\n") + 8:]
-    data = part[:part.index(b"-Y ")] + b"-Y 2048 +X 2048\n" + body * 8
-    ctx.load_hdr(data)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
-        ctx.load_hdr(data)
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 3 * 1e3
-    res["hdr_decode_2048"] = {"ms": round(ms, 3), "file_bytes": len(data), "Mpix_s": round(2048 * 2048 / ms / 1e3, 1),
-                              "kernel_ms": None,
-                              "what": "vqhip_hdr_decode_rgba32f, wall time of the call + stream sync: host walk of the run headers (count bytes only), upload of the encoded file from "
-                                      "pageable memory, ONE kernel that expands the runs (a workgroup per scanline, a wave per byte plane, through LDS) and converts RGBE -> RGBA32F"}
-    # ---- 8f.4: FSR 1.0 (2560x1440 -> 3840x2160, RGBA8), SSR environment fallback
-    iw, ih = 2560, 1440
-    src = torch.randint(0, 256, (ih, iw, 4), dtype=torch.uint8, device="cuda")
-    up, fin = torch.empty((H, W, 4), dtype=torch.uint8, device="cuda"), torch.empty((H, W, 4), dtype=torch.uint8, device="cuda")
-    econ, rcon = capi.fsr_easu_con(iw, ih, W, H), capi.fsr_rcas_con(0.2)
-    res["fsr_easu_1440p_to_4k"] = entry(_stage_stats(lambda: ctx.fsr_easu(src, R8, W, H, con=econ, out=up)), round(4 + iw * ih * 4 / px, 2),
-                                        what="vqhip_fsr_easu RGBA8 -> RGBA8; VALU-bound: ~700 VALU per output pixel (profiles/r3i_conv_kernels.md addendum)")
-    res["fsr_rcas_4k"] = entry(_stage_stats(lambda: ctx.fsr_rcas(up, R8, con=rcon, out=fin)), 8, what="vqhip_fsr_rcas RGBA8 -> RGBA8; VALU-bound: ~300 VALU per pixel")
-    sc, depth, packed, _ = synth.ssr_surfaces(W, BAND)
-    scd, dpd, nmd = dev(tile(sc.astype(np.float16))), dev(tile(depth)), dev(tile(packed.view(np.int32)))
-    cb = synth.ssr_constants(W, H, spec_mips)
-    rad = capi.empty_image(H, W, F16, ctx.device)
-    res["ssr_env_fallback_4k"] = entry(_stage_stats(lambda: ctx.ssr_environment_fallback(scd, F16, dpd, nmd, abi.FMT_R10G10B10A2_UNORM, cb, env, F16, out=rad)), 24,
-                                       what="vqhip_ssr_environment_fallback on white-noise surfaces (72 % of the pixels take the fallback): 8 + 4 + 4 B in, 8 B out; "
-                                            "fractional-LOD seamless cube fetch + LUT per pixel, cache resident")
-    return res
-
-
-def ibl_load_report(t):
-    """BASELINE config 4 as the engine runs it at load time (EnvironmentMapRendering.cpp:139-486, Renderer.cpp:871-909), with the flop models
-    of SURVEY.md 8d: diffuse 6x64^2 texels x 99 382 taps x ~60 flop, specular 67 M taps x ~80, LUT 1024^2 x 2048 samples x ~80."""
-    model = {"conv_diffuse_ms": 6 * 64 * 64 * 99382 * 60.0, "conv_specular_ms": 67.1e6 * 80.0, "brdf_lut_warm_ms": 1024 * 1024 * 2048 * 80.0}
-    out = dict(t)
-    out["total_ms"] = round(t["mip_chain_ms"] + t["prefilter_ms"] + t["brdf_lut_ms"], 4)
-    out["warm_total_ms"] = round(t["mip_chain_warm_ms"] + t["prefilter_warm_ms"] + t["brdf_lut_warm_ms"], 4)
-    for k, fl in model.items():
-        out[k.replace("_ms", "_valu_frac_model")] = round(fl / (t[k] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)
-    out["mip_chain_hbm_frac"] = round((2048 * 2048 * 16 * 5.0 / 3.0) / (t["mip_chain_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)   # each level read once, written once
-    out["workload"] = "BASELINE cfg4: 2048^2 RGBA32F equirect -> 12-level min-filter chain, diffuse irradiance 6x64^2 at step 0.010 (99 382 taps/texel) + blur, 7-mip GGX specular 128^2, BRDF LUT 1024^2 x 2048"
-    out["note"] = ("mip_chain / prefilter (diffuse + face blur + specular) / brdf_lut are the product calls as build_ibl() issues them, first use of each kernel "
-                   "(code load and cold clocks included: total_ms); conv_diffuse / conv_specular / brdf_lut_warm / mip_chain_warm / prefilter_warm are the stage on its "
-                   "own in back-to-back calls after a >= 0.25 s spin-up (median of 7 batches, *_ms_spread = [min, max]), like every other per-stage figure (warm_total_ms = mip chain + prefilter + "
-                   "LUT of those); *_single_call_ms = ONE call without a spin-up (what these keys meant in rounds 1-3). The convolutions run in the reference's "
-                   "summation order (wave-parallel taps parked in LDS, added in order: profiles/r4a_conv_ordered.md); the diffuse one is bound by L1 tag lookups")
-    return out
-
-
-def tile_curve(ctx, d, comms, args, p5, strong):
-    """One GPU can say how the cfg5 tile step shrinks with the tile: step time for the top 4320/N rows, N = 1, 2, 4, 8 (same frame, same lights).
-    The speed-up line is a MODEL, labelled as such: tile step + halo bytes / link + (composite bytes into the root over its N-1 links when it
-    is not overlapped). It bounds compute efficiency and tail effects; RCCL latency and launch skew are not in it."""
-    W, H = p5.W, p5.frame_h
-    res = {"frame": [W, H], "lights": p5.cfg["lights"], "tiles": [], "t1_ms": None,
-           "model": "speedup(N) = t_step(4320 rows) / (t_step(4320/N rows) + halo + composite_if_not_overlapped); halo = 2 x 10 rows x 7680 px x 8 B over one link, "
-                    "composite = (N-1)/N x 132.7 MB into the root over N-1 links; link = 153 GB/s peak (76 GB/s in the conservative column). MODELLED, not measured."}
-    t1 = None
-    for n in (1, 2, 4, 8):
-        rows = H // n
-        gb = [g[:rows] for g in p5.gb]
-        sc, xb, sd = p5.scene[0][:rows], p5.xblur[:rows], p5.sdr[0][:rows]
-
-        def step(i):
-            ctx.forward_lighting(gb, p5.pf, p5.pv, out=sc, out_fmt=F16, extra_point=p5.extra)
-            ctx.gaussian_blur_x(sc, F16, out=xb)
-            ctx.gaussian_blur_y_tonemap(xb, F16, R8, out=sd)
-        ms = _time_loop(step, 8 * n if n < 8 else 40, 3 * n)
-        t1 = t1 or ms
-        halo_b, comp_b = 2 * 10 * W * 8, (n - 1) / n * W * H * 4
-        row = {"gpus_modelled": n, "tile_rows": rows, "workgroups_shade": ((W + 255) // 256) * rows, "step_ms": round(ms, 4), "compute_speedup": round(t1 / ms, 3)}
-        for tag, bw in (("peak_link", XGMI_LINK_GBPS), ("half_link", XGMI_LINK_GBPS / 2)):
-            halo_ms = 0.0 if n == 1 else halo_b / bw / 1e6
-            comp_ms = 0.0 if n == 1 else comp_b / (bw * (n - 1)) / 1e6
-            row[f"modelled_speedup_overlapped_{tag}"] = round(t1 / (ms + halo_ms), 3)
-            row[f"modelled_speedup_serial_{tag}"] = round(t1 / (ms + halo_ms + comp_ms), 3)
-        res["tiles"].append(row)
-    res["t1_ms"] = round(t1, 4)
     return res
 
 

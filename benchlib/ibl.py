@@ -8,6 +8,8 @@ import torch
 
 from vqengine_amd import abi, synth
 
+from .consts import HBM_PEAK_GBPS, VALU_PEAK_TFLOPS
+
 W0, H0, SPEC_RES0, DIFF_RES, DIFF_STEP = 4096, 2048, 512, 64, 0.010
 
 
@@ -46,4 +48,23 @@ def engine_default_report(ctx, stage_stats):
                    "one expansion kernel). The specular pass is 16x cfg4's texels (ibl_load.conv_specular_ms); the BRDF LUT does not depend on the environment (ibl_load.brdf_lut_warm_ms)")
     del img, chain
     torch.cuda.empty_cache()
+    return out
+
+
+def ibl_load_report(t):
+    """BASELINE config 4 as the engine runs it at load time (EnvironmentMapRendering.cpp:139-486, Renderer.cpp:871-909), with the flop models
+    of SURVEY.md 8d: diffuse 6x64^2 texels x 99 382 taps x ~60 flop, specular 67 M taps x ~80, LUT 1024^2 x 2048 samples x ~80."""
+    model = {"conv_diffuse_ms": 6 * 64 * 64 * 99382 * 60.0, "conv_specular_ms": 67.1e6 * 80.0, "brdf_lut_warm_ms": 1024 * 1024 * 2048 * 80.0}
+    out = dict(t)
+    out["total_ms"] = round(t["mip_chain_ms"] + t["prefilter_ms"] + t["brdf_lut_ms"], 4)
+    out["warm_total_ms"] = round(t["mip_chain_warm_ms"] + t["prefilter_warm_ms"] + t["brdf_lut_warm_ms"], 4)
+    for k, fl in model.items():
+        out[k.replace("_ms", "_valu_frac_model")] = round(fl / (t[k] * 1e-3) / 1e12 / VALU_PEAK_TFLOPS, 4)
+    out["mip_chain_hbm_frac"] = round((2048 * 2048 * 16 * 5.0 / 3.0) / (t["mip_chain_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)   # each level read once, written once
+    out["workload"] = "BASELINE cfg4: 2048^2 RGBA32F equirect -> 12-level min-filter chain, diffuse irradiance 6x64^2 at step 0.010 (99 382 taps/texel) + blur, 7-mip GGX specular 128^2, BRDF LUT 1024^2 x 2048"
+    out["note"] = ("mip_chain / prefilter (diffuse + face blur + specular) / brdf_lut are the product calls as build_ibl() issues them, first use of each kernel "
+                   "(code load and cold clocks included: total_ms); conv_diffuse / conv_specular / brdf_lut_warm / mip_chain_warm / prefilter_warm are the stage on its "
+                   "own in back-to-back calls after a >= 0.25 s spin-up (median of 7 batches, *_ms_spread = [min, max]), like every other per-stage figure (warm_total_ms = mip chain + prefilter + "
+                   "LUT of those); *_single_call_ms = ONE call without a spin-up (what these keys meant in rounds 1-3). The convolutions run in the reference's "
+                   "summation order (wave-parallel taps parked in LDS, added in order: profiles/r4a_conv_ordered.md); the diffuse one is bound by L1 tag lookups")
     return out

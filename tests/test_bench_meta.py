@@ -34,10 +34,12 @@ def test_every_invocation_reports_the_other_baseline_configs():
     """the default invocation times cfg5 strong scaling (every N) and cfg2 / cfg4 / the coherent frame / the tile curve (N = 1)
     next to the cfg3 headline; source-level check of the wiring (the values need a GPU: tests/test_gpu_bench_flow.py)."""
     src = open(os.path.join(ROOT, "bench.py")).read()
+    wid = open(os.path.join(ROOT, "benchlib", "widened.py")).read()         # extras["widened"] = widened_report(...)
+    assert "from benchlib.widened import widened_report" in src
     for key in ('extras["cfg5_strong"]', 'extras["tile_curve"]', 'extras["cfg2"]', 'extras["ibl_load"]', 'extras["coherent_scene"]', 'extras["widened"]', '"rccl": comms.info()'):
         assert key in src, key
     # VERDICT r3 #4: every SURVEY 8f kernel rides in the driver-run line
     for key in ("gbuffer_producer_textured", "gbuffer_producer_textureless", "psmain_fused", "skydome_all_sky", "hdr_decode_2048", "fsr_easu_1440p_to_4k", "fsr_rcas_4k", "ssr_env_fallback_4k",
                 "psmain_fused_mrt", "scene_normals_prepass"):
-        assert f'res["{key}"]' in src, key
+        assert f'res["{key}"]' in wid, key
     assert 'default="auto"' in src and "completes_within" in src          # the overlapped composite runs under a watchdog by default
