@@ -522,6 +522,13 @@ int vqo_forward_lighting(const vqhip_gbuffer* gb, const VQ_PerFrameData* perFram
                          void* out, int out_pitch, int outFmt, int nthreads) {
     if (!gb || !perFrame || !perView || !out) return -1;
     if (outFmt != VQHIP_FMT_RGBA32F && outFmt != VQHIP_FMT_RGBA16F) return -3;
+    {   // casters without their maps: refused like the product refuses them (capi.hip: "shadow casters present but sm is NULL"), not dereferenced
+        const auto& L = perFrame->Lights;
+        const bool dirCaster = L.directional.enabled && L.directional.shadowing;
+        if ((L.numPointCasters > 0 || L.numSpotCasters > 0 || dirCaster) && !sm) return -1;
+        if (sm && ((L.numPointCasters > 0 && (!sm->point || sm->point_dim <= 0)) || (L.numSpotCasters > 0 && (!sm->spot || sm->spot_dim <= 0)) ||
+                   (dirCaster && (!sm->directional || sm->dir_dim <= 0)))) return -1;
+    }
     const int W = gb->width, H = gb->height, pitch = gb->row_pitch_px;
     const f4* g0 = (const f4*)gb->gb0; const f4* g1 = (const f4*)gb->gb1; const f4* g2 = (const f4*)gb->gb2; const f4* g3 = (const f4*)gb->gb3;
     if (nthreads <= 0) nthreads = omp_get_max_threads();

@@ -146,3 +146,46 @@ def test_casters_dxc_reading_and_exp2_pow(ctx):
         finally:
             ctx.set_arithmetic(False); O.load().vqo_set_arithmetic(0)
             ctx.set_fresnel_pow(False); O.load().vqo_set_fresnel_pow(0)
+
+
+FUZZ_SEEDS_THAT_FAILED_ONCE = [1001926, 1003254, 1003275, 1003389, 1003901, 1004453, 1004987, 1005360]       # an albedo of 1e25: F0 and kA finite, their product not (px.skipOK)
+
+
+@pytest.mark.parametrize("seed", FUZZ_SEEDS_THAT_FAILED_ONCE + [1000003, 1000040, 1000085])
+def test_fuzz_cases_that_failed_once(ctx, seed):
+    """scripts/fuzz_casters.py draws light counts, map sizes, matrices, biases, lattice positions and special values per case; the seeds that ever differed are replayed here
+    (and three ordinary ones, among them a frame with casters and NO maps, which both sides refuse)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import fuzz_casters
+    bad, idx, what, got, ref = fuzz_casters.run_case(ctx, seed, dev)
+    assert bad == 0, f"{what}: {bad} channels, first at {np.asarray(idx).tolist()}"
+
+
+@pytest.mark.parametrize("arith_dxc", [False, True])
+def test_huge_albedo_in_a_wave_that_skips_lights(ctx, arith_dxc):
+    """Finite F0 and kA whose PRODUCT overflows (albedo 1e25, metalness between 0 and 1): the BRDF of such a lane is -inf, the reference's b * (cb * +0) is NaN for a light that
+    faces away or whose cone misses the pixel — the lane must keep its wave out of the back-facing skip of the point-light loop and of the idle-wave exit of the spot lights."""
+    W, H = 512, 6
+    gb = [np.array(g, copy=True) for g in synth.gbuffer(W, H, seed=0xA1BE, coherent=True)]
+    gb[1][..., :3] = np.float32((0.0, 1.0, 0.0))                          # one surface: every wave is eligible for the skip
+    gb[1][..., 3] = 0.5
+    for y, x, ch in ((0, 5, 0), (1, 70, 1), (2, 200, 2), (3, 300, 0), (4, 450, 1)):
+        gb[2][y, x, ch] = 1e25
+        gb[2][y, x, 3] = 0.4
+    gb[2][5, 100, :3] = 3e19; gb[2][5, 100, 3] = 0.5                      # just below the overflow: finite b, the skip's result and the full evaluation agree
+    points = synth.point_lights(24, seed=0xA1BE)
+    for i in range(0, 24, 2):
+        points[i].position.y = -30.0                                      # below the surface: NdotL = +0 in every lane
+    pf, _ = synth.per_frame(points=points, spots=synth.spot_lights(8, seed=0xA1BE), ambient=0.055)
+    pv = synth.per_view(W, H)
+    ctx.set_arithmetic(arith_dxc); O.load().vqo_set_arithmetic(1 if arith_dxc else 0)
+    try:
+        with np.errstate(all="ignore"):
+            ref = O.forward_lighting(gb, pf, pv, F32)
+        got = ctx.forward_lighting([dev(g) for g in gb], pf, pv, out_fmt=F32)
+        assert_bits(got, ref, f"huge albedo dxc={arith_dxc}")
+        assert np.isnan(ref[0, 5, :3]).any() and np.isfinite(ref[0, 6, :3]).all()
+    finally:
+        ctx.set_arithmetic(False); O.load().vqo_set_arithmetic(0)

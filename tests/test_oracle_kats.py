@@ -286,3 +286,18 @@ def test_oracle_reproduces_golden_fixtures(name):
     for k in fx.files:
         n, idx = O.bits_equal(np.asarray(now[k]), fx[k])
         assert n == 0, (name, k, n, idx)
+
+
+def test_oracle_refuses_casters_without_maps():
+    """the checker refuses what the product refuses (capi.hip validateLighting: "shadow casters present but sm is NULL") instead of dereferencing the missing maps"""
+    from vqengine_amd import scene, synth
+    pf, maps = scene.engine_max_frame(map_dims=(8, 8, 8))
+    gb = synth.gbuffer(64, 2, seed=1)
+    pv = synth.per_view(64, 2)
+    with pytest.raises(AssertionError):
+        O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F, shadow=None)
+    sm = scene.shadow_maps_struct(maps, lambda a: a.ctypes.data)
+    assert O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F, shadow=sm).shape == (2, 64, 4)
+    sm.spot_dim = 0
+    with pytest.raises(AssertionError):
+        O.forward_lighting(gb, pf, pv, abi.FMT_RGBA32F, shadow=sm)

@@ -42,7 +42,7 @@ struct Pixel {
                                           // flag on purpose: with the mode as a template parameter (no branch in the light loop) the same arithmetic ran
                                           // 9 % slower on the same box (profiles/r2c_shade_variants.md) — the scheduler's choice for the longer block
     bool fastOK;                          // roughness in [0,1] and a finite Wo: precondition of the unchecked fast reciprocals (add_point_light)
-    bool skipOK;                          // finite F0 / kA and a normal close to the wave's first one: this lane may take part in the back-facing-light skip
+    bool skipOK;                          // F0 / kA below 2^40 (a finite BRDF whatever the light): this lane may take part in the skips of lights that add b * 0
 };
 
 VQD f3 ld3(const VQ_float3& v) { return mk3(v.x, v.y, v.z); }
@@ -98,9 +98,12 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam, int neg
         }
         px.fastOK &= ok;
     }
-    // the skip of back-facing lights (add_point_light<.., true>) needs a finite BRDF whatever the light: finite F0 (hence 1 - F0) and kA
+    // the skip of lights that add b * (cb * +0) (add_point_light<.., true>, spot_light) needs a FINITE BRDF whatever the light. b = fma(F, sG - kA, kA) with
+    // |F| <= 2 |F0| + 1 and sG = D G / denom <= 1e12 * 4 / 1e-4 < 2^56 for roughness in [0, 1] (D <= 1 / EPSILON, each G1 <= 2, denom >= 1e-4): with
+    // |F0| and |kA| below 2^40 the product stays under 2^98. Finite F0 and kA alone are NOT enough — an albedo of 1e25 keeps both finite and overflows F * kA
+    // (found by scripts/fuzz_casters.py: the reference's inf * 0 = NaN against a skipped light)
     px.skipOK = ((__builtin_fabsf(px.F0.x) + __builtin_fabsf(px.F0.y) + __builtin_fabsf(px.F0.z)) +
-                 (__builtin_fabsf(px.kA.x) + __builtin_fabsf(px.kA.y) + __builtin_fabsf(px.kA.z))) < __builtin_inff();
+                 (__builtin_fabsf(px.kA.x) + __builtin_fabsf(px.kA.y) + __builtin_fabsf(px.kA.z))) < 0x1p40f;
 }
 
 // BRDF(s, Wi, V), BRDF.hlsl:163-194. As written: H = normalize(Wo + Wi) (IEEE quotients through rc.div), NdotH, nh2*(a2-1)+1.
