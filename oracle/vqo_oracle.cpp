@@ -678,8 +678,10 @@ int vqo_mip_chain_min_rgba32f(float* chain, int w0, int h0, int nMips) {
                 for (int ch = 0; ch < 3; ++ch) {
                     const float a = src[((size_t)y0 * sw + x0) * 4 + ch], b = src[((size_t)y0 * sw + x1) * 4 + ch],
                                 c = src[((size_t)y1 * sw + x0) * 4 + ch], d = src[((size_t)y1 * sw + x1) * 4 + ch];
-                    const float cd = c < d ? c : d, bcd = b < cd ? b : cd;     // min(a, min(b, min(c, d))) as std::min
-                    dst[((size_t)y * dw + x) * 4 + ch] = a < bcd ? a : bcd;    // std::min(a,b) = (b < a) ? b : a; equal for non-NaN
+                    // min(a, min(b, min(c, d))) with std::min(p, q) = (q < p) ? q : p, literally: a NaN or a zero in FIRST position wins (NaN: no comparison is true;
+                    // +0 against -0: neither is less). Rounds 1-5 wrote (p < q) ? p : q, which differs exactly there (scripts/fuzz_ibl.py, round 6)
+                    const float cd = d < c ? d : c, bcd = cd < b ? cd : b;
+                    dst[((size_t)y * dw + x) * 4 + ch] = bcd < a ? bcd : a;
                 }
                 dst[((size_t)y * dw + x) * 4 + 3] = 1.0f;
             }
