@@ -103,8 +103,20 @@ def case(seed):
             gb[2][..., :3] = -0.0
     pf.fAmbientLightingFactor = float(r.choice([0.0, 0.055]))
     pv = synth.per_view(W, H)
-    return dict(W=W, H=H, dims=dims, pf=pf, pv=pv, maps=maps, gb=gb, fmt=int(r.choice([F32, F16])), dxc=bool(r.integers(0, 2)), exp2=bool(r.integers(0, 2)),
-                no_maps=r.random() < 0.05)
+    res = dict(W=W, H=H, dims=dims, pf=pf, pv=pv, maps=maps, gb=gb, fmt=int(r.choice([F32, F16])), dxc=bool(r.integers(0, 2)), exp2=bool(r.integers(0, 2)),
+               no_maps=r.random() < 0.05, env=None, extra=None)
+    # drawn AFTER everything above, so that a seed of the first runs (tests/test_gpu_casters.py replays them) still means the same frame
+    if r.random() < 0.3:                                             # the <env, casters> instantiation: random fp16 cubes (scripts/fuzz_shade.py draws more of their corners)
+        import fuzz_shade
+        dres, sres, lsz = int(r.choice([1, 4, 16])), int(r.choice([1, 8, 64])), int(r.choice([2, 16, 64]))
+        smips = int(r.integers(1, int(np.log2(sres)) + 2))
+        spec = np.concatenate([fuzz_shade.rand_f16(r, (6, max(1, sres >> m), max(1, sres >> m), 4), 0.0).reshape(-1) for m in range(smips)])
+        res["env"] = dict(diffuse=fuzz_shade.rand_f16(r, (6, dres, dres, 4), 0.0), spec=spec, sres=sres, smips=smips, lut=fuzz_shade.rand_f16(r, (lsz, lsz, 2), 0.0))
+        pv.MaxEnvMapLODLevels = float(smips - int(r.integers(0, 2)))
+        pf.fHDRIOffsetInRadians = float(r.choice([0.0, 0.3, -2.0]))
+    if r.random() < 0.15:                                            # the extension array behind the cbuffer's lights
+        res["extra"] = synth.point_lights(int(r.choice([3, 40])), seed=(seed >> 3) & 0xFFFFF)
+    return res
 
 
 def run_case(ctx, seed, dev):
@@ -113,7 +125,7 @@ def run_case(ctx, seed, dev):
     lib = O.load()
     L = c["pf"].Lights
     what = (f"seed {seed}: {c['W']}x{c['H']} dims {c['dims']} fmt {c['fmt']} dxc {c['dxc']} exp2 {c['exp2']} lights p{L.numPointLights} s{L.numSpotLights} "
-            f"pc{L.numPointCasters} sc{L.numSpotCasters} dir {L.directional.enabled}/{L.directional.shadowing} maps {not c['no_maps']}")
+            f"pc{L.numPointCasters} sc{L.numSpotCasters} dir {L.directional.enabled}/{L.directional.shadowing} maps {not c['no_maps']} env {c['env'] is not None} extra {0 if c['extra'] is None else len(c['extra'])}")
     ctx.set_arithmetic(c["dxc"]); lib.vqo_set_arithmetic(1 if c["dxc"] else 0)
     ctx.set_fresnel_pow(c["exp2"]); lib.vqo_set_fresnel_pow(1 if c["exp2"] else 0)
     try:
@@ -123,6 +135,12 @@ def run_case(ctx, seed, dev):
         sm_o = None if c["no_maps"] else scene.shadow_maps_struct(m, lambda a: a.ctypes.data)
         casters = L.numPointCasters > 0 or L.numSpotCasters > 0 or (L.directional.enabled and L.directional.shadowing)
         gb_d = [dev(g) for g in c["gb"]]
+        env_o = env_g = None
+        if c["env"] is not None:
+            e = c["env"]
+            env_o = O.host_envmap(e["diffuse"], e["spec"], e["sres"], e["smips"], e["lut"])
+            keep += [dev(e["diffuse"]), dev(e["spec"]), dev(e["lut"])]
+            env_g = abi.EnvMap(keep[-3].data_ptr(), e["diffuse"].shape[1], keep[-2].data_ptr(), e["sres"], e["smips"], keep[-1].data_ptr(), e["lut"].shape[0])
         if c["no_maps"] and casters:                                 # casters without maps: both sides refuse (capi.hip validateLighting, vqo_forward_lighting)
             refused = [False, False]
             try:
@@ -135,8 +153,8 @@ def run_case(ctx, seed, dev):
                 refused[1] = True
             return (0 if all(refused) else 1), [], what + f" refused {refused}", None, None
         with np.errstate(all="ignore"):
-            ref = O.forward_lighting(c["gb"], c["pf"], c["pv"], c["fmt"], shadow=sm_o)
-        got = ctx.forward_lighting(gb_d, c["pf"], c["pv"], out_fmt=c["fmt"], shadow=sm_g).cpu().numpy()
+            ref = O.forward_lighting(c["gb"], c["pf"], c["pv"], c["fmt"], shadow=sm_o, env=env_o, extra_point=c["extra"])
+        got = ctx.forward_lighting(gb_d, c["pf"], c["pv"], out_fmt=c["fmt"], shadow=sm_g, env=env_g, extra_point=c["extra"]).cpu().numpy()
     finally:
         ctx.set_arithmetic(False); lib.vqo_set_arithmetic(0)
         ctx.set_fresnel_pow(False); lib.vqo_set_fresnel_pow(0)
