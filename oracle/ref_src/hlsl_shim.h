@@ -258,21 +258,25 @@ VQ_HLSL_OPS(float4, 4)
 #undef VQ_HLSL_OPS
 
 // ---- scalar intrinsics --------------------------------------------------------------------------------------------------
-inline float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
-inline float max(float a, float b) { return fmaxf(a, b); }
-inline float min(float a, float b) { return fminf(a, b); }
+// FMax / FMin: a NaN operand is dropped; of two zeros max returns +0 and min -0 whatever their order (IEEE 754-2019 maximum / minimum, what a GPU's v_max_f32 / v_min_f32 do).
+// libm's fmaxf / fminf return their FIRST operand on that tie — an artefact of the host library, not of the shader (round 6)
+inline float vq_fmax(float a, float b) { if (a != a) return b; if (b != b) return a; if (a == b) return __builtin_signbit(a) ? b : a; return a > b ? a : b; }
+inline float vq_fmin(float a, float b) { if (a != a) return b; if (b != b) return a; if (a == b) return __builtin_signbit(a) ? a : b; return a < b ? a : b; }
+inline float saturate(float x) { return vq_fmin(vq_fmax(x, 0.0f), 1.0f); }
+inline float max(float a, float b) { return vq_fmax(a, b); }
+inline float min(float a, float b) { return vq_fmin(a, b); }
 inline int max(int a, int b) { return a > b ? a : b; }
 inline int min(int a, int b) { return a < b ? a : b; }
 inline uint max(uint a, uint b) { return a > b ? a : b; }
 inline uint min(uint a, uint b) { return a < b ? a : b; }
-inline float max(float a, int b) { return fmaxf(a, (float)b); }      // HLSL promotes the int: max(L.z, 0)
-inline float min(float a, int b) { return fminf(a, (float)b); }
-inline float max(int a, float b) { return fmaxf((float)a, b); }
-inline float min(int a, float b) { return fminf((float)a, b); }
+inline float max(float a, int b) { return vq_fmax(a, (float)b); }      // HLSL promotes the int: max(L.z, 0)
+inline float min(float a, int b) { return vq_fmin(a, (float)b); }
+inline float max(int a, float b) { return vq_fmax((float)a, b); }
+inline float min(int a, float b) { return vq_fmin((float)a, b); }
 inline int abs(int x) { return x < 0 ? -x : x; }
 inline int clamp(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
 inline float trunc(float x) { return truncf(x); }
-inline float clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+inline float clamp(float x, float lo, float hi) { return vq_fmin(vq_fmax(x, lo), hi); }
 inline float abs(float x) { return fabsf(x); }
 inline float sqrt(float x) { return sqrtf(x); }
 #ifdef VQ_SHIM_DXC

@@ -26,7 +26,9 @@
 //   reflect(i,n)             i - (2*dot(n,i))*n           written as i - n*(2*dot(n,i)) per component
 //   cross(a,b)               (ay*bz - az*by, az*bx - ax*bz, ax*by - ay*bx), no FMA
 //   saturate(x)              min(max(x,0),1) with NaN -> 0
-//   max/min                  IEEE maxNum/minNum (fmaxf/fminf)
+//   max/min                  a NaN operand is dropped (maxNum / minNum, DXIL FMax / FMin); of two zeros min returns -0, max returns +0 whatever their order —
+//                            IEEE 754-2019 minimum / maximum, what v_min_f32 / v_max_f32 do (libm's fminf / fmaxf return the FIRST operand on that tie:
+//                            rounds 1-5 called them, scripts/fuzz_wide.py found FSR frames where the order shows)
 //   pow(x, 2)                x*x          (DXC HLOperationLower: only the literal exponent 2 becomes a mul
 //                                          outside FXC-compat mode — recalled from DXC sources, unverifiable here)
 //   pow(x, y)                exp2(y * log2(x))   => pow(0,y>0) = 0, pow(neg,y) = NaN
@@ -64,8 +66,8 @@ static inline float div_(float a, float b) { return a * rcp(b); }
 static inline float fdiv_(float a, float b) { return a / b; }          // IEEE-754 correctly rounded quotient (load-time passes, see below)
 static inline float sqrt_(float x) { return __builtin_sqrtf(x); }
 static inline float rsqrt(float x) { return rcp(sqrt_(x)); }
-static inline float max_(float a, float b) { return __builtin_fmaxf(a, b); }
-static inline float min_(float a, float b) { return __builtin_fminf(a, b); }
+static inline float max_(float a, float b) { if (a != a) return b; if (b != b) return a; if (a == b) return __builtin_signbit(a) ? b : a; return a > b ? a : b; }
+static inline float min_(float a, float b) { if (a != a) return b; if (b != b) return a; if (a == b) return __builtin_signbit(a) ? a : b; return a < b ? a : b; }
 static inline float saturate(float x) { return (x > 0.0f) ? ((x < 1.0f) ? x : 1.0f) : 0.0f; }   // NaN -> 0
 static inline float abs_(float x) { return __builtin_fabsf(x); }
 

@@ -1,4 +1,4 @@
-"""-m gpu: a slice of the randomised parity runs of scripts/fuzz_shade.py, fuzz_post.py, fuzz_casters.py and fuzz_ibl.py (each draws sizes, counts, formats, arithmetic readings, options and
+"""-m gpu: a slice of the randomised parity runs of scripts/fuzz_shade.py, fuzz_post.py, fuzz_casters.py, fuzz_ibl.py and fuzz_wide.py (each draws sizes, counts, formats, arithmetic readings, options and
 special values per case from its seed and demands the HIP product's bits == the oracle's). The long runs are the scripts themselves (round 6: 9 862 shade cases, 10 087 post
 cases, 16 195 caster cases, 9 567 load-time IBL cases on the GPU, profiles/r6w_fuzz.md); the seeds that ever failed are replayed in tests/test_gpu_casters.py."""
 import os
@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,first,count", [("fuzz_shade", 7000021, 60), ("fuzz_post", 7000021, 60), ("fuzz_casters", 7000021, 60), ("fuzz_ibl", 7000021, 60)])
+@pytest.mark.parametrize("name,first,count", [("fuzz_shade", 7000021, 60), ("fuzz_post", 7000021, 60), ("fuzz_casters", 7000021, 60), ("fuzz_ibl", 7000021, 60), ("fuzz_wide", 7000021, 60)])
 def test_fuzz_slice(ctx, name, first, count):
     mod = __import__(name)
     bad = []
