@@ -8,6 +8,8 @@ One of, per case:
   fsr       EASU (random source / target sizes, ratios from 1x to 4x, both RGBA8 and RGBA16F) followed by RCAS at a random sharpness
   skydome   random cameras, fields of view, equirect sizes and coverage planes
   hdr       run-length coded / flat .hdr files of random sizes, cut at a random byte in a third of the cases: the same image, or the same refusal
+  ssr       the environment fallback of SSR's tile classification on random surfaces / cubes / thresholds, packed or float normals (seeds >= 2 000 000)
+  reflect   the reflections composite, with and without the bounding-volume image;  viz: every Visualization.hlsl draw mode on every colour format
 The HIP product's bits must equal the oracle's. Exit status 1 if a case differed."""
 import argparse
 import os
@@ -75,7 +77,7 @@ def run_case(ctx, seed, dev):
     import torch
     from vqengine_amd import capi
     r = np.random.Generator(np.random.Philox(key=[int(seed), 0xF4]))
-    kind = str(r.choice(["psmain", "psmain", "producer", "fsr", "fsr", "skydome", "hdr", "hdr"]))
+    kind = str(r.choice(["psmain", "psmain", "producer", "fsr", "fsr", "skydome", "hdr", "hdr"] + (["ssr", "ssr", "viz", "reflect"] if seed >= 2000000 else [])))   # seeds below 2 000 000 keep their first meaning
     with np.errstate(all="ignore"):
         if kind in ("psmain", "producer"):
             W, H, NM = int(r.choice([1, 64, 130, 200, 333])), int(r.integers(1, 9)), int(r.choice([1, 3, 6, 16]))
@@ -169,6 +171,56 @@ def run_case(ctx, seed, dev):
             ref = O.skydome(eq, sp, base.copy(), fmt, cov[2] if cov is not None else None)
             got = ctx.skydome(dev(eq), sp, dev(base), fmt, [dev(p) for p in cov] if cov is not None else None)
             return _cmp([(got, ref)]) + (f"seed {seed}: skydome {W}x{H} equirect {ew}x{eh} fmt {fmt} coverage {cov is not None}",)
+        if kind == "ssr":
+            import fuzz_shade
+            W, H = int(r.choice([1, 64, 130, 333])), int(r.integers(1, 9))
+            sc, depth, packed, nf = synth.ssr_surfaces(W, H, seed=int(r.integers(0, 1 << 20)), sky_fraction=float(r.choice([0.0, 0.1, 0.9])))
+            dres, sres, lsz = int(r.choice([1, 4, 16])), int(r.choice([2, 8, 64])), int(r.choice([2, 16, 64]))
+            smips = int(r.integers(1, int(np.log2(sres)) + 2))
+            spec = np.concatenate([fuzz_shade.rand_f16(r, (6, max(1, sres >> m), max(1, sres >> m), 4), 0.0).reshape(-1) for m in range(smips)])
+            dif, lut = fuzz_shade.rand_f16(r, (6, dres, dres, 4), 0.0), fuzz_shade.rand_f16(r, (lsz, lsz, 2), 0.0)
+            env_o = O.host_envmap(dif, spec, sres, smips, lut)
+            kd = [dev(dif), dev(spec), dev(lut)]
+            env_g = abi.EnvMap(kd[0].data_ptr(), dres, kd[1].data_ptr(), sres, smips, kd[2].data_ptr(), lsz)
+            cb = synth.ssr_constants(W, max(H, 1), smips, hdri_yaw=float(r.choice([0.0, 0.3, -2.0])), roughness_threshold=float(r.choice([0.0, 0.2, 1.0])))
+            sfmt = int(r.choice([F32, F16]))
+            sc = sc.astype(np.float16) if sfmt == F16 else sc
+            if r.random() < 0.4:
+                n = int(r.integers(1, 6))
+                sc[r.integers(0, H, n), r.integers(0, W, n), 3] = r.choice(np.array([0.0, 1.0, -0.0, 2.0, np.nan, 0.2, 0.19995], np.float32), n).astype(sc.dtype)
+                depth[r.integers(0, H, n), r.integers(0, W, n)] = r.choice(np.array([0.0, 1.0, 0.5, np.nan, 1.0000001], np.float32), n)
+            packed_normals = bool(r.integers(0, 2))
+            nfmt = abi.FMT_R10G10B10A2_UNORM if packed_normals else F32
+            nrm_o = packed if packed_normals else nf
+            nrm_g = dev(packed.view(np.int32)) if packed_normals else dev(nf)
+            ofmt = int(r.choice([F32, F16]))
+            ref, rr = O.ssr_environment_fallback(sc, sfmt, depth, nrm_o, nfmt, cb, env_o, ofmt, extract_roughness=True)
+            got = ctx.ssr_environment_fallback(dev(sc), sfmt, dev(depth), nrm_g, nfmt, cb, env_g, ofmt, extract_roughness=True)
+            return _cmp([(got[0], ref), (got[1], rr)]) + (f"seed {seed}: ssr {W}x{H} scene fmt {sfmt} normals {nfmt} out {ofmt} env {(dres, sres, smips, lsz)}",)
+        if kind == "reflect":
+            W, H, fmt = int(r.choice([1, 64, 333])), int(r.integers(1, 9)), int(r.choice([F32, F16]))
+            dt = np.float16 if fmt == F16 else np.float32
+            mk = lambda: (r.random((H, W, 4), dtype=np.float32) * np.float32(r.choice([1.0, 100.0, 6e4]))).astype(dt)  # noqa: E731
+            refl, scn, bv = mk(), mk(), (mk() if r.random() < 0.5 else None)
+            if bv is not None:
+                bv[..., 3] = r.choice(np.array([0.0, 1.0, 0.5, 0.25], np.float32), (H, W)).astype(dt)
+            if r.random() < 0.4:
+                n = int(r.integers(1, 6))
+                refl[r.integers(0, H, n), r.integers(0, W, n), r.integers(0, 4, n)] = r.choice(np.array([np.inf, -np.inf, np.nan, -0.0, 0.0], np.float32), n).astype(dt)
+            want = O.composite_reflections(refl, scn, fmt, bv)
+            got = ctx.composite_reflections(dev(refl), dev(scn), fmt, dev(bv) if bv is not None else None)
+            return _cmp([(got, want)]) + (f"seed {seed}: reflections composite {W}x{H} fmt {fmt} bounding volumes {bv is not None}",)
+        if kind == "viz":
+            W, H = int(r.choice([1, 64, 333])), int(r.integers(1, 9))
+            fmt = int(r.choice([F32, F16, R8]))
+            if fmt == R8:
+                img = r.integers(0, 256, (H, W, 4), dtype=np.uint8)
+            else:
+                img = (r.random((H, W, 4), dtype=np.float32) * np.float32(r.choice([1.0, 5.0, 2000.0])) - np.float32(r.choice([0.0, 0.5]))).astype(np.float16 if fmt == F16 else np.float32)
+            vp = abi.VizParams(int(r.integers(0, 12)), int(r.integers(0, 2)), float(r.choice([0.0, 1.0, 10.0, 100.0])))
+            want = O.visualize(img, fmt, vp)
+            got = ctx.visualize(dev(img), fmt, vp)
+            return _cmp([(got, want)]) + (f"seed {seed}: visualize {W}x{H} fmt {fmt} mode {vp.iDrawMode} unpack {vp.iUnpackNormals} strength {vp.fInputStrength}",)
         # hdr
         w, h = int(r.choice([1, 7, 8, 9, 64, 300, 32767 // 40])), int(r.integers(1, 12))
         rgbe = synth.float_to_rgbe((r.random((h, w, 3), dtype=np.float32) * np.float32(r.choice([1.0, 100.0, 6e4]))).astype(np.float32))
