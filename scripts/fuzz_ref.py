@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Randomised check of the ORACLE against the REFERENCE'S OWN SHADER SOURCE (oracle/_ref: the HLSL compiled for the CPU through oracle/ref_src/hlsl_shim.h) — CPU only, runs
+where /root/reference was available to build oracle/_ref:   python scripts/fuzz_ref.py [--seconds 120] [--seed 1]
+
+The cases are the GPU fuzzers' own (scripts/fuzz_shade.py, fuzz_casters.py, fuzz_post.py: same seeds, same frames). The bar is the pinning tests' (tests/ref_cases.py): the
+oracle's RGBA16F / RGBA8 output within ONE unit of the storage format of what the reference's HLSL writes, wherever the reference's value is finite and the frame is not
+saturated by a non-finite light; a NaN / infinity in one and a finite value in the other is reported too (the arithmetic contract regroups a few products — DESIGN.md 3 — so an
+overflow may surface as inf in one and NaN in the other: those are counted, not failed). Exit status 1 if a finite channel differs by more than one unit."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+from tests import oracle_lib as O, ref_lib as R  # noqa: E402
+from tests.ref_cases import at_boundary, ulp16_distance  # noqa: E402
+from vqengine_amd import abi, scene  # noqa: E402
+
+F32, F16, R8 = abi.FMT_RGBA32F, abi.FMT_RGBA16F, abi.FMT_RGBA8_UNORM
+
+
+def compare16(ref, got16, strict_px):
+    """ref: float32 values the HLSL wrote; got16: the oracle's RGBA16F output; strict_px: [H,W] pixels where more than one unit is a FAILURE.
+    -> (finite channels compared, channels above one unit, of those in strict pixels, worst, channels finite in one and not in the other, first strict offenders)"""
+    ref, got = np.asarray(ref, np.float32)[..., :3], np.asarray(got16)[..., :3].astype(np.float32)
+    with np.errstate(all="ignore"):
+        r16 = ref.astype(np.float16).astype(np.float32)
+    both = np.isfinite(r16) & np.isfinite(got)
+    d = ulp16_distance(np.where(both, got, 0), np.where(both, ref, 0))
+    cls = (np.isnan(r16) != np.isnan(got)) | (np.isinf(r16) != np.isinf(got))
+    strict = (d > 1) & strict_px[..., None]
+    return int(both.sum()), int((d > 1).sum()), int(strict.sum()), int(d.max()) if both.any() else 0, int(cls.sum()), np.argwhere(strict)[:3].tolist()
+
+
+def run_shade(seed, casters):
+    """Where more than one unit FAILS: the literal reading (the oracle writes the HLSL's own expression trees there, contract v5: the two sides perform the same IEEE operations)
+    on pixels inside the domain the C++ shim defines — `int(roughness * MaxEnvMapLODLevels)` of a NaN / out-of-range product is undefined behaviour in C++ (D3D: NaN -> 0,
+    saturating), so such pixels are only counted. The DXC reading regroups quotients into a * rcp(b) and the BRDF into fma(F, sG - kA, kA) (contract v2-v4): one-ulp differences
+    that the GGX lobe of a polished pixel amplifies by up to 1 / a^2 — counted below roughness 0.3, failed above it (without environment cubes: a white-noise cube turns an ulp
+    of uv into a different 1/256 filter step)."""
+    import fuzz_casters
+    import fuzz_shade
+    c = (fuzz_casters if casters else fuzz_shade).case(seed)
+    if casters and c["no_maps"]:
+        return None
+    lib = O.load()
+    lib.vqo_set_arithmetic(1 if c["dxc"] else 0); lib.vqo_set_fresnel_pow(1)      # the shim's pow is exp2(y * log2 x): the engine-faithful lowering on both sides
+    try:
+        env_o = None
+        if c["env"] is not None:
+            e = c["env"]
+            env_o = O.host_envmap(e["diffuse"], e["spec"], e["sres"], e["smips"], e["lut"])
+        sm = scene.shadow_maps_struct(c["maps"], lambda a: a.ctypes.data) if casters else None
+        with np.errstate(all="ignore"):
+            # the reference harness takes the rasterised normal and normalises it itself (PSMain :264-266); the oracle, like the product, starts behind that line
+            got = O.forward_lighting(at_boundary(c["gb"]), c["pf"], c["pv"], F16, extra_point=c["extra"], env=env_o, shadow=sm)
+            try:
+                ref = R.forward_from_gbuffer(c["gb"], c["pf"], c["pv"], env=env_o, shadow=sm, extra=c["extra"], reading="dxc" if c["dxc"] else "literal")
+            except AssertionError:                                   # more extension lights than the reference build's raised cap (256 in all)
+                return None
+            rough = c["gb"][1][..., 3]
+            mipf = rough * np.float32(c["pv"].MaxEnvMapLODLevels)
+            defined = np.isfinite(rough) & ((env_o is None) | (np.isfinite(mipf) & (np.abs(mipf) < 2.0 ** 30)))
+            strict = defined & ((rough >= 0.3) & (env_o is None) if c["dxc"] else True)
+    finally:
+        lib.vqo_set_arithmetic(0); lib.vqo_set_fresnel_pow(0)
+    return compare16(ref, got, strict) + ("dxc" if c["dxc"] else "literal",)
+
+
+def run_post(seed):
+    import fuzz_post
+    c = fuzz_post.case(seed)
+    if c["w"] * c["h"] > 300000 or c["params"].OutputDisplayCurveEnum not in (0, 1, 2):
+        return None
+    img = c["img"][c["hr"]:c["hr"] + c["h"]].astype(np.float32)
+    with np.errstate(all="ignore"):
+        x = R.blur_pass(img, 0).astype(np.float16).astype(np.float32)
+        y = R.blur_pass(x, 1).astype(np.float16).astype(np.float32)
+        ref = R.tonemap(y, c["params"])
+        got = O.tonemap(O.gaussian_blur(img.astype(np.float16), F16), F16, R8, params=c["params"])
+    from tests.ref_cases import to_unorm8
+    r8 = to_unorm8(np.nan_to_num(ref[..., :3], nan=0.0))
+    ok = np.isfinite(ref[..., :3])
+    d = np.abs(got[..., :3].astype(np.int32) - r8.astype(np.int32)) * ok
+    return int(ok.sum()), int((d > 1).sum()), int((d > 1).sum()), int(d.max()), 0, np.argwhere(d > 1)[:3].tolist(), "post"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120.0)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    if not (R.available("shaders") and R.available("shaders_dxc") and R.available("shaders_l256")):
+        raise SystemExit("fuzz_ref: oracle/_ref is not built (needs /root/reference: make -C oracle ref)")
+    t0, n, fails, skipped = time.time(), 0, [], 0
+    tot = {}
+    while time.time() - t0 < a.seconds:
+        seed = a.seed * 1000003 + n
+        kind = ("shade", "casters", "post")[n % 3]
+        res = run_post(seed) if kind == "post" else run_shade(seed, kind == "casters")
+        n += 1
+        if res is None:
+            skipped += 1
+            continue
+        ch, above, strict, worst, cls, where, reading = res
+        t = tot.setdefault(reading, {"cases": 0, "channels": 0, "above_one_unit": 0, "of_those_failures": 0, "worst": 0, "finite_in_one_only": 0})
+        t["cases"] += 1; t["channels"] += ch; t["above_one_unit"] += above; t["of_those_failures"] += strict; t["finite_in_one_only"] += cls; t["worst"] = max(t["worst"], worst)
+        if strict:
+            fails.append((kind, seed))
+            print(f"FAIL {kind} ({reading}) seed {seed}: {strict} channels above one unit where the two sides perform the same operations, first at {where}", flush=True)
+    for reading, t in sorted(tot.items()):
+        print(f"fuzz_ref {reading}: {t}", flush=True)
+    print(f"fuzz_ref: {n} cases ({skipped} skipped), failures: {fails[:20]}", flush=True)
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
