@@ -28,7 +28,7 @@
 //   saturate(x)              min(max(x,0),1) with NaN -> 0
 //   max/min                  a NaN operand is dropped (maxNum / minNum, DXIL FMax / FMin); of two zeros min returns -0, max returns +0 whatever their order —
 //                            IEEE 754-2019 minimum / maximum, what v_min_f32 / v_max_f32 do (libm's fminf / fmaxf return the FIRST operand on that tie:
-//                            rounds 1-5 called them, scripts/fuzz_wide.py found FSR frames where the order shows)
+//                            rounds 1-5 called them, tests/fuzz/fuzz_wide.py found FSR frames where the order shows)
 //   pow(x, 2)                x*x          (DXC HLOperationLower: only the literal exponent 2 becomes a mul
 //                                          outside FXC-compat mode — recalled from DXC sources, unverifiable here)
 //   pow(x, y)                exp2(y * log2(x))   => pow(0,y>0) = 0, pow(neg,y) = NaN

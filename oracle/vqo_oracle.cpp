@@ -679,7 +679,7 @@ int vqo_mip_chain_min_rgba32f(float* chain, int w0, int h0, int nMips) {
                     const float a = src[((size_t)y0 * sw + x0) * 4 + ch], b = src[((size_t)y0 * sw + x1) * 4 + ch],
                                 c = src[((size_t)y1 * sw + x0) * 4 + ch], d = src[((size_t)y1 * sw + x1) * 4 + ch];
                     // min(a, min(b, min(c, d))) with std::min(p, q) = (q < p) ? q : p, literally: a NaN or a zero in FIRST position wins (NaN: no comparison is true;
-                    // +0 against -0: neither is less). Rounds 1-5 wrote (p < q) ? p : q, which differs exactly there (scripts/fuzz_ibl.py, round 6)
+                    // +0 against -0: neither is less). Rounds 1-5 wrote (p < q) ? p : q, which differs exactly there (tests/fuzz/fuzz_ibl.py, round 6)
                     const float cd = d < c ? d : c, bcd = cd < b ? cd : b;
                     dst[((size_t)y * dw + x) * 4 + ch] = bcd < a ? bcd : a;
                 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity of the light / shadow-caster path: python scripts/fuzz_casters.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
+"""Randomised parity of the light / shadow-caster path: python tests/fuzz/fuzz_casters.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
 
 Every case draws its own light counts (0 .. the cbuffer's limits), shadow-map sizes (powers of two and not, 1 .. 300), view-projection matrices (the engine's
 own, lattice-aligned orthographic ones that put taps EXACTLY on texel borders, degenerate ones), depth biases (0, negative, huge, non-finite), depth maps
@@ -13,8 +13,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))          # the fuzzers import each other
 
 from tests import oracle_lib as O  # noqa: E402
 from vqengine_amd import abi, scene, synth  # noqa: E402
@@ -106,7 +107,7 @@ def case(seed):
     res = dict(W=W, H=H, dims=dims, pf=pf, pv=pv, maps=maps, gb=gb, fmt=int(r.choice([F32, F16])), dxc=bool(r.integers(0, 2)), exp2=bool(r.integers(0, 2)),
                no_maps=r.random() < 0.05, env=None, extra=None)
     # drawn AFTER everything above, so that a seed of the first runs (tests/test_gpu_casters.py replays them) still means the same frame
-    if r.random() < 0.3:                                             # the <env, casters> instantiation: random fp16 cubes (scripts/fuzz_shade.py draws more of their corners)
+    if r.random() < 0.3:                                             # the <env, casters> instantiation: random fp16 cubes (tests/fuzz/fuzz_shade.py draws more of their corners)
         import fuzz_shade
         dres, sres, lsz = int(r.choice([1, 4, 16])), int(r.choice([1, 8, 64])), int(r.choice([2, 16, 64]))
         smips = int(r.integers(1, int(np.log2(sres)) + 2))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity of the load-time IBL path (min-filter mip chain, diffuse irradiance, GGX specular prefilter, face blur, BRDF LUT):
-python scripts/fuzz_ibl.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
+python tests/fuzz/fuzz_ibl.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
 
 Every case draws the equirect's size (2:1, square, tall; 8 .. 512 wide), its content (smooth sky, white noise, a few suns of 1e4 .. 6e4, zeros, a few non-finite texels), the cube
 sizes (diffuse 1 .. 16, specular 4 .. 64 (the product takes powers of two >= 4) with every mip), the integration step, the summation order (the reference's / wave-parallel), the kernel-form options
@@ -13,8 +13,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))          # the fuzzers import each other
 
 from tests import oracle_lib as O  # noqa: E402
 from vqengine_amd import abi, synth  # noqa: E402

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity of the post chain (21-tap blur X, blur Y, tonemapper): python scripts/fuzz_post.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
+"""Randomised parity of the post chain (21-tap blur X, blur Y, tonemapper): python tests/fuzz/fuzz_post.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
 
 Every case draws the image size (1 x 1 .. a few hundred squared for the two-kernel forms, and frames of >= 2^20 pixels with widths that are no multiple of the 64-column strips
 for the one-kernel chain), the content (smooth, white noise, constant blocks; magnitudes up to the fp16 maximum; a few non-finite, negative, zero and subnormal channels — the
@@ -13,8 +13,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))          # the fuzzers import each other
 
 from tests import oracle_lib as O  # noqa: E402
 from vqengine_amd import abi  # noqa: E402

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised check of the ORACLE against the REFERENCE'S OWN SHADER SOURCE (oracle/_ref: the HLSL compiled for the CPU through oracle/ref_src/hlsl_shim.h) — CPU only, runs
-where /root/reference was available to build oracle/_ref:   python scripts/fuzz_ref.py [--seconds 120] [--seed 1]
+where /root/reference was available to build oracle/_ref:   python tests/fuzz/fuzz_ref.py [--seconds 120] [--seed 1]
 
-The cases are the GPU fuzzers' own (scripts/fuzz_shade.py, fuzz_casters.py, fuzz_post.py: same seeds, same frames). The bar is the pinning tests' (tests/ref_cases.py): the
+The cases are the GPU fuzzers' own (tests/fuzz/fuzz_shade.py, fuzz_casters.py, fuzz_post.py: same seeds, same frames). The bar is the pinning tests' (tests/ref_cases.py): the
 oracle's RGBA16F / RGBA8 output within ONE unit of the storage format of what the reference's HLSL writes, wherever the reference's value is finite and the frame is not
 saturated by a non-finite light; a NaN / infinity in one and a finite value in the other is reported too (the arithmetic contract regroups a few products — DESIGN.md 3 — so an
 overflow may surface as inf in one and NaN in the other: those are counted, not failed). Exit status 1 if a finite channel differs by more than one unit."""
@@ -13,9 +13,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from tests import oracle_lib as O, ref_lib as R  # noqa: E402
 from tests.ref_cases import at_boundary, ulp16_distance  # noqa: E402

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity of the headline path's shade kernel (point lights + extension array + spot lights + directional light + IBL sample), no casters:
-python scripts/fuzz_shade.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
+python tests/fuzz/fuzz_shade.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
 
 Every case draws the frame size, white-noise or surface-coherent content, light counts up to the cbuffer's 100 + an extension array, lights AT pixels, on an axis above a pixel,
 with -0.0 coordinates, zero / huge / non-finite ranges and colours, the camera (also AT a pixel), environment cubes of random sizes filled with random fp16 texels (a few of them
@@ -13,8 +13,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))          # the fuzzers import each other
 
 from tests import oracle_lib as O  # noqa: E402
 from vqengine_amd import abi, synth  # noqa: E402

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised parity of the kernels either side of the hot path: python scripts/fuzz_wide.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
+"""Randomised parity of the kernels either side of the hot path: python tests/fuzz/fuzz_wide.py [--seconds 120] [--seed 1] (needs a GPU; the oracle is the checker).
 
 One of, per case:
   psmain    PSMain as ONE kernel (vqhip_forward_lighting_from_materials, with or without the other render targets): random interpolants (a share of them arbitrary bit
@@ -18,8 +18,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))          # the fuzzers import each other
 
 from tests import oracle_lib as O  # noqa: E402
 from vqengine_amd import abi, scene, synth  # noqa: E402

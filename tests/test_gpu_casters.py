@@ -153,11 +153,11 @@ FUZZ_SEEDS_THAT_FAILED_ONCE = [1001926, 1003254, 1003275, 1003389, 1003901, 1004
 
 @pytest.mark.parametrize("seed", FUZZ_SEEDS_THAT_FAILED_ONCE + [1000003, 1000040, 1000085])
 def test_fuzz_cases_that_failed_once(ctx, seed):
-    """scripts/fuzz_casters.py draws light counts, map sizes, matrices, biases, lattice positions and special values per case; the seeds that ever differed are replayed here
+    """tests/fuzz/fuzz_casters.py draws light counts, map sizes, matrices, biases, lattice positions and special values per case; the seeds that ever differed are replayed here
     (and three ordinary ones, among them a frame with casters and NO maps, which both sides refuse)."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
     import fuzz_casters
     bad, idx, what, got, ref = fuzz_casters.run_case(ctx, seed, dev)
     assert bad == 0, f"{what}: {bad} channels, first at {np.asarray(idx).tolist()}"

@@ -1,4 +1,4 @@
-"""-m gpu: a slice of the randomised parity runs of scripts/fuzz_shade.py, fuzz_post.py, fuzz_casters.py, fuzz_ibl.py and fuzz_wide.py (each draws sizes, counts, formats, arithmetic readings, options and
+"""-m gpu: a slice of the randomised parity runs of tests/fuzz/fuzz_shade.py, fuzz_post.py, fuzz_casters.py, fuzz_ibl.py and fuzz_wide.py (each draws sizes, counts, formats, arithmetic readings, options and
 special values per case from its seed and demands the HIP product's bits == the oracle's). The long runs are the scripts themselves (round 6: 9 862 shade cases, 10 087 post
 cases, 16 195 caster cases, 9 567 load-time IBL cases on the GPU, profiles/r6w_fuzz.md); the seeds that ever failed are replayed in tests/test_gpu_casters.py."""
 import os
@@ -9,7 +9,7 @@ import pytest
 
 from tests.test_gpu_parity import dev
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
 pytestmark = pytest.mark.gpu
 
 

@@ -1,4 +1,4 @@
-"""A slice of scripts/fuzz_ref.py in the CPU suite: the ORACLE against the reference's own HLSL (oracle/_ref, built where /root/reference is available) on the random frames
+"""A slice of tests/fuzz/fuzz_ref.py in the CPU suite: the ORACLE against the reference's own HLSL (oracle/_ref, built where /root/reference is available) on the random frames
 the GPU fuzzers draw — PSMain in both readings with and without casters, the post chain, FSR, the skydome, the reflections composite. Skipped where oracle/_ref is absent."""
 import os
 import sys
@@ -7,7 +7,7 @@ import pytest
 
 from tests import ref_lib as R
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "fuzz"))
 pytestmark = pytest.mark.skipif(not (R.available("shaders") and R.available("shaders_dxc") and R.available("shaders_l256") and R.available("fsr")),
                                 reason="oracle/_ref is not built here (needs /root/reference)")
 

@@ -408,7 +408,7 @@ def test_mip_chains_equal_the_reference_mipimage(shape):
     l0[0, 0, :3] = (np.inf, 0.0, -3.0)
     if h >= 8 and w >= 8:
         # std::min(p, q) = (q < p) ? q : p keeps its FIRST argument when nothing compares less: a NaN, or +0 against -0, wins or loses by its position in the 2 x 2 block
-        # (min(a, min(b, min(c, d))), DXGIUtils.cpp:305-307). Every position of a block, for NaN and for both zeros (round 6: scripts/fuzz_ibl.py found the oracle
+        # (min(a, min(b, min(c, d))), DXGIUtils.cpp:305-307). Every position of a block, for NaN and for both zeros (round 6: tests/fuzz/fuzz_ibl.py found the oracle
         # writing (p < q) ? p : q, which differs exactly here)
         for k, (dy, dx) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
             l0[2 + dy, 2 * k + dx, 0] = np.nan

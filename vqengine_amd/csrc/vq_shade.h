@@ -101,7 +101,7 @@ VQD void setup_pixel(Pixel& px, float4 g0, float4 g1, float4 g2, f3 cam, int neg
     // the skip of lights that add b * (cb * +0) (add_point_light<.., true>, spot_light) needs a FINITE BRDF whatever the light. b = fma(F, sG - kA, kA) with
     // |F| <= 2 |F0| + 1 and sG = D G / denom <= 1e12 * 4 / 1e-4 < 2^56 for roughness in [0, 1] (D <= 1 / EPSILON, each G1 <= 2, denom >= 1e-4): with
     // |F0| and |kA| below 2^40 the product stays under 2^98. Finite F0 and kA alone are NOT enough — an albedo of 1e25 keeps both finite and overflows F * kA
-    // (found by scripts/fuzz_casters.py: the reference's inf * 0 = NaN against a skipped light)
+    // (found by tests/fuzz/fuzz_casters.py: the reference's inf * 0 = NaN against a skipped light)
     px.skipOK = ((__builtin_fabsf(px.F0.x) + __builtin_fabsf(px.F0.y) + __builtin_fabsf(px.F0.z)) +
                  (__builtin_fabsf(px.kA.x) + __builtin_fabsf(px.kA.y) + __builtin_fabsf(px.kA.z))) < 0x1p40f;
 }
