@@ -141,6 +141,39 @@ def run_wide(seed):
         return _cmp16(got, ref) + ("reflections",)
 
 
+def run_ibl(seed):
+    """The load-time passes on random small equirects: diffuse irradiance (the shader's default step 0.010: 99 382 taps per texel), GGX specular mips, BRDF LUT texels.
+    Diffuse and LUT: within one unit, failed otherwise. Specular: counted — a tap whose uv / LOD lands an ulp to the other side of a 1/256 filter step (polynomial atan2 / asin /
+    log2 against libm) moves a 512-tap mean by more (tests/golden/specular_filterstep_tail.json is that class at cfg4's size); failed beyond 0.5 % of the channels or 16 units."""
+    from vqengine_amd import synth
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0xF6]))
+    kind = str(r.choice(["diffuse", "specular", "specular", "lut"]))
+    with np.errstate(all="ignore"):
+        if kind == "lut":
+            n = 24
+            xs, ys = r.integers(0, 1024, n), r.integers(0, 1024, n)
+            ref = R.brdf_lut_texels(xs, ys)
+            rows = {int(y): O.brdf_lut(1024, 2048, abi.FMT_RG16F, rows=(int(y), int(y) + 1))[0] for y in set(int(v) for v in ys)}
+            got = np.stack([rows[int(y)][int(x)] for x, y in zip(xs, ys)]).astype(np.float32)
+            g3, r3 = np.concatenate([got, got[:, :1]], 1), np.concatenate([ref, ref[:, :1]], 1)
+            return _cmp16(g3.astype(np.float16), r3) + ("brdf_lut",)
+        w, h = [(16, 8), (32, 16), (64, 32), (64, 64), (32, 64)][int(r.integers(0, 5))]
+        eq = synth.equirect(w, h, seed=int(r.integers(0, 1 << 20))) if r.random() < 0.6 else (r.random((h, w, 4), dtype=np.float32) * np.float32(r.choice([1.0, 50.0]))).astype(np.float32)
+        eq[..., 3] = 1.0
+        chain, n = O.mip_chain(eq)
+        if kind == "diffuse":
+            res = int(r.choice([1, 2]))
+            got = O.conv_diffuse(chain, w, h, n, res, 0.010, abi.CONV_SEQUENTIAL, F16)
+            return _cmp16(got, R.conv_diffuse(chain, w, h, n, res)) + ("conv_diffuse",)
+        res0 = int(r.choice([4, 8, 16]))
+        mips = abi.specular_mip_count(res0)
+        got = O.conv_specular(chain, w, h, n, res0, abi.CONV_SEQUENTIAL, F16)[0]
+        ref = np.concatenate([R.conv_specular_mip(chain, w, h, n, res0 >> m, float(np.float32(m) / np.float32(mips - 1)), m).reshape(-1, 4) for m in range(mips)])
+        c = _cmp16(got, ref)
+        fail = c[1] if (c[1] > 0.005 * max(1, c[0]) or c[3] > 16) else 0
+        return c[:2] + (fail,) + c[3:] + ("conv_specular",)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
@@ -152,8 +185,8 @@ def main():
     tot = {}
     while time.time() - t0 < a.seconds:
         seed = a.seed * 1000003 + n
-        kind = ("shade", "casters", "post", "wide")[n % 4]
-        res = run_post(seed) if kind == "post" else run_wide(seed) if kind == "wide" else run_shade(seed, kind == "casters")
+        kind = ("shade", "casters", "post", "wide", "ibl")[n % 5]
+        res = run_post(seed) if kind == "post" else run_wide(seed) if kind == "wide" else run_ibl(seed) if kind == "ibl" else run_shade(seed, kind == "casters")
         n += 1
         if res is None:
             skipped += 1

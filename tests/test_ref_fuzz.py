@@ -1,5 +1,5 @@
 """A slice of tests/fuzz/fuzz_ref.py in the CPU suite: the ORACLE against the reference's own HLSL (oracle/_ref, built where /root/reference is available) on the random frames
-the GPU fuzzers draw — PSMain in both readings with and without casters, the post chain, FSR, the skydome, the reflections composite. Skipped where oracle/_ref is absent."""
+the GPU fuzzers draw — PSMain in both readings with and without casters, the post chain, FSR, the skydome, the reflections composite, the load-time IBL passes. Skipped where oracle/_ref is absent."""
 import os
 import sys
 
@@ -12,12 +12,13 @@ pytestmark = pytest.mark.skipif(not (R.available("shaders") and R.available("sha
                                 reason="oracle/_ref is not built here (needs /root/reference)")
 
 
-@pytest.mark.parametrize("kind,first,count", [("shade", 9000001, 24), ("casters", 9000001, 24), ("post", 9000001, 40), ("wide", 9000001, 40)])
+@pytest.mark.parametrize("kind,first,count", [("shade", 9000001, 24), ("casters", 9000001, 24), ("post", 9000001, 40), ("wide", 9000001, 40), ("ibl", 9000001, 10)])
 def test_oracle_against_the_reference_hlsl_on_random_frames(kind, first, count):
     import fuzz_ref
     compared = 0
     for seed in range(first, first + count):
-        res = fuzz_ref.run_post(seed) if kind == "post" else fuzz_ref.run_wide(seed) if kind == "wide" else fuzz_ref.run_shade(seed, kind == "casters")
+        res = (fuzz_ref.run_post(seed) if kind == "post" else fuzz_ref.run_wide(seed) if kind == "wide" else fuzz_ref.run_ibl(seed) if kind == "ibl"
+               else fuzz_ref.run_shade(seed, kind == "casters"))
         if res is None:
             continue
         ch, above, strict, worst, cls, where, reading = res
