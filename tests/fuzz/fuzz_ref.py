@@ -141,6 +141,42 @@ def run_wide(seed):
         return _cmp16(got, ref) + ("reflections",)
 
 
+def run_psmain(seed):
+    """PSMain from interpolants + a material table over mip-chained RGBA8 maps (texture sampling, uv transform, normal mapping, SSAO, alpha-masked permutation in some cases)
+    and the Z pre-pass's normals: the oracle's producer + shade / scene normals against the reference's HLSL, valid pixels only. The texture sampler both sides call is the
+    same statement of D3D's rules (oracle/vqo_sampling.h through ref_hooks): what is compared is everything around it."""
+    from vqengine_amd import synth
+    r = np.random.Generator(np.random.Philox(key=[int(seed), 0xF7]))
+    W, H, NM = int(r.choice([16, 48, 96])), int(r.integers(2, 12)), int(r.choice([1, 3, 6]))
+    am = bool(r.random() < 0.3)
+    ip = [p.copy() for p in synth.interpolants(W, H, NM, seed=int(r.integers(0, 1 << 20)))]
+    datas, texsets = synth.material_set(NM, seed=int(r.integers(0, 1 << 20)), max_dim=int(r.choice([8, 64])))
+    hc = []
+    for ts in texsets:
+        hc.append({slot: (O.mip_chain_rgba8(img)[0], img.shape[1], img.shape[0], O.mip_chain_rgba8(img)[1]) for slot, img in ts.items()})
+    mats = O.host_materials(datas, hc)
+    for k in range(NM):
+        mats[k].texDiffuse.reserved = abi.MATERIAL_ALPHA_MASKED if am else 0
+    ssao = synth.ssao_image(W, H) if r.random() < 0.5 else None
+    pf, _ = synth.per_frame(points=synth.point_lights(int(r.choice([1, 4, 12])), seed=seed & 0xFFFF), spots=synth.spot_lights(int(r.choice([1, 2])), seed=seed & 0xFFF),
+                            directional=synth.directional_light() if r.random() < 0.5 else None, ambient=float(r.choice([0.0, 0.055])))
+    pv = synth.per_view(W, H)
+    idx0 = np.ascontiguousarray(ip[2][..., 3]).view(np.int32)
+    valid = (idx0 >= 0) & (idx0 < NM)
+    with np.errstate(all="ignore"):
+        ipo = [p.copy() for p in ip]
+        gb = O.gbuffer_from_materials(ipo, mats, pf.fAmbientLightingFactor, ssao=ssao)
+        lit = O.forward_lighting(gb, pf, pv, F16).astype(np.float32)
+        gone = valid & (np.ascontiguousarray(ipo[2][..., 3]).view(np.int32) == -1)
+        lit[gone] = -1.0                                             # discarded fragments: the sentinel the reference harness writes
+        ref = R.forward_psmain([p.copy() for p in ip], mats, pf, pv, ssao=ssao, alpha_masked=am)
+        a = _cmp16(lit[valid][None].astype(np.float16), ref[valid][None])
+        nr = R.prepass_normals([p.copy() for p in ip], mats, alpha_masked=am)
+        no = O.scene_normals_from_materials([p.copy() for p in ip], mats, F32)
+        same = int((no[valid][..., :3].view(np.uint32) != nr[valid][..., :3].view(np.uint32)).sum())
+    return (a[0] + int(valid.sum()) * 3, a[1] + same, a[2] + same, a[3], a[4], a[5], "psmain_materials")
+
+
 def run_ibl(seed):
     """The load-time passes on random small equirects: diffuse irradiance (the shader's default step 0.010: 99 382 taps per texel), GGX specular mips, BRDF LUT texels.
     Diffuse and LUT: within one unit, failed otherwise. Specular: counted — a tap whose uv / LOD lands an ulp to the other side of a 1/256 filter step (polynomial atan2 / asin /
@@ -185,8 +221,9 @@ def main():
     tot = {}
     while time.time() - t0 < a.seconds:
         seed = a.seed * 1000003 + n
-        kind = ("shade", "casters", "post", "wide", "ibl")[n % 5]
-        res = run_post(seed) if kind == "post" else run_wide(seed) if kind == "wide" else run_ibl(seed) if kind == "ibl" else run_shade(seed, kind == "casters")
+        kind = ("shade", "casters", "post", "wide", "ibl", "psmain")[n % 6]
+        res = (run_post(seed) if kind == "post" else run_wide(seed) if kind == "wide" else run_ibl(seed) if kind == "ibl" else run_psmain(seed) if kind == "psmain"
+               else run_shade(seed, kind == "casters"))
         n += 1
         if res is None:
             skipped += 1

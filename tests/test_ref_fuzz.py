@@ -12,12 +12,12 @@ pytestmark = pytest.mark.skipif(not (R.available("shaders") and R.available("sha
                                 reason="oracle/_ref is not built here (needs /root/reference)")
 
 
-@pytest.mark.parametrize("kind,first,count", [("shade", 9000001, 24), ("casters", 9000001, 24), ("post", 9000001, 40), ("wide", 9000001, 40), ("ibl", 9000001, 10)])
+@pytest.mark.parametrize("kind,first,count", [("shade", 9000001, 24), ("casters", 9000001, 24), ("post", 9000001, 40), ("wide", 9000001, 40), ("ibl", 9000001, 10), ("psmain", 9000001, 20)])
 def test_oracle_against_the_reference_hlsl_on_random_frames(kind, first, count):
     import fuzz_ref
     compared = 0
     for seed in range(first, first + count):
-        res = (fuzz_ref.run_post(seed) if kind == "post" else fuzz_ref.run_wide(seed) if kind == "wide" else fuzz_ref.run_ibl(seed) if kind == "ibl"
+        res = (fuzz_ref.run_post(seed) if kind == "post" else fuzz_ref.run_wide(seed) if kind == "wide" else fuzz_ref.run_ibl(seed) if kind == "ibl" else fuzz_ref.run_psmain(seed) if kind == "psmain"
                else fuzz_ref.run_shade(seed, kind == "casters"))
         if res is None:
             continue
